@@ -1,0 +1,195 @@
+// ORACLE — test infrastructure only (see field.hpp header).
+// C ABI over the CPU restatement so that tests/ and bench.py's cpu_baseline leg can
+// drive it through ctypes.  Conventions (identical to the product's Seam B so the
+// same buffers can be handed to both): limbs little-endian u64; field elements in
+// Montgomery form, R = 2^384 (BLS12-377 Fq) / 2^768 (BW6-761 Fq); scalars canonical;
+// affine points x||y with a separate infinity byte array (NULL = none infinite);
+// Jacobian results X||Y||Z with Z == 0 for the identity.
+#include "pairing.hpp"
+#include <chrono>
+
+using namespace orc;
+
+namespace {
+template <class F> constexpr int limbs_of();
+template <> constexpr int limbs_of<Fq377>() { return 6; }
+template <> constexpr int limbs_of<Fq761>() { return 12; }
+template <> constexpr int limbs_of<Fq2_377>() { return 12; }
+
+template <class F> void load_f(F& f, const u64* p);
+template <> void load_f<Fq377>(Fq377& f, const u64* p) { memcpy(f.v, p, 48); }
+template <> void load_f<Fq761>(Fq761& f, const u64* p) { memcpy(f.v, p, 96); }
+template <> void load_f<Fq2_377>(Fq2_377& f, const u64* p) { memcpy(f.c0.v, p, 48); memcpy(f.c1.v, p + 6, 48); }
+template <class F> void store_f(const F& f, u64* p);
+template <> void store_f<Fq377>(const Fq377& f, u64* p) { memcpy(p, f.v, 48); }
+template <> void store_f<Fq761>(const Fq761& f, u64* p) { memcpy(p, f.v, 96); }
+template <> void store_f<Fq2_377>(const Fq2_377& f, u64* p) { memcpy(p, f.c0.v, 48); memcpy(p + 6, f.c1.v, 48); }
+
+template <class F> std::vector<Affine<F>> load_affine(const u64* xy, const uint8_t* inf, size_t n) {
+  constexpr int L = limbs_of<F>();
+  std::vector<Affine<F>> v(n);
+  for (size_t i = 0; i < n; i++) {
+    load_f(v[i].x, xy + i * 2 * L);
+    load_f(v[i].y, xy + i * 2 * L + L);
+    v[i].inf = inf ? inf[i] != 0 : false;
+  }
+  return v;
+}
+template <class F> void store_jac(const Jac<F>& j, u64* out) {
+  constexpr int L = limbs_of<F>();
+  store_f(j.x, out);
+  store_f(j.y, out + L);
+  store_f(j.z, out + 2 * L);
+}
+template <class F> Jac<F> load_jac(const u64* in) {
+  constexpr int L = limbs_of<F>();
+  Jac<F> j;
+  load_f(j.x, in);
+  load_f(j.y, in + L);
+  load_f(j.z, in + 2 * L);
+  return j;
+}
+
+template <class F, int SL>
+int msm_impl(const u64* xy, const uint8_t* inf, const u64* sc, size_t n, int bits, int threads, int naive, u64* out) {
+  auto b = load_affine<F>(xy, inf, n);
+  Jac<F> r = naive ? msm_naive<F, SL>(b.data(), sc, n) : msm_pippenger<F, SL>(b.data(), sc, n, bits, threads);
+  store_jac(r, out);
+  return 0;
+}
+template <class F, int SL> int mul_impl(const u64* xy, const u64* k, u64* out) {
+  auto b = load_affine<F>(xy, nullptr, 1);
+  store_jac(Jac<F>::from_affine(b[0]).template mul<SL>(k), out);
+  return 0;
+}
+template <class F> int normalize_impl(const u64* jac, size_t n, u64* xy, uint8_t* inf) {
+  constexpr int L = limbs_of<F>();
+  std::vector<Jac<F>> in(n);
+  std::vector<Affine<F>> o(n);
+  for (size_t i = 0; i < n; i++) in[i] = load_jac<F>(jac + i * 3 * L);
+  batch_normalize(in.data(), o.data(), n);
+  for (size_t i = 0; i < n; i++) {
+    store_f(o[i].x, xy + i * 2 * L);
+    store_f(o[i].y, xy + i * 2 * L + L);
+    inf[i] = o[i].inf;
+  }
+  return 0;
+}
+template <class F> int sum_impl(const u64* jac, size_t n, u64* out) {  // Signature::aggregate / PublicKey::aggregate
+  constexpr int L = limbs_of<F>();
+  Jac<F> acc = Jac<F>::identity();
+  for (size_t i = 0; i < n; i++) acc = acc.add(load_jac<F>(jac + i * 3 * L));
+  store_jac(acc, out);
+  return 0;
+}
+void store_gt377(const Fq12_377& g, u64* out) {
+  const Fq2_377* c[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
+  for (int i = 0; i < 6; i++) store_f(*c[i], out + 12 * i);
+}
+Fq12_377 load_gt377(const u64* in) {
+  Fq12_377 g;
+  Fq2_377* c[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
+  for (int i = 0; i < 6; i++) load_f(*c[i], in + 12 * i);
+  return g;
+}
+void store_gt761(const Fq6_761& g, u64* out) {
+  const Fq761* c[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
+  for (int i = 0; i < 6; i++) store_f(*c[i], out + 12 * i);
+}
+}  // namespace
+
+extern "C" {
+
+// ---- Montgomery conversion (count field elements)
+int orc_to_mont_377(const u64* in, u64* out, size_t count) {
+  for (size_t i = 0; i < count; i++) { Fq377 f = Fq377::from_canonical(in + 6 * i); memcpy(out + 6 * i, f.v, 48); }
+  return 0;
+}
+int orc_from_mont_377(const u64* in, u64* out, size_t count) {
+  for (size_t i = 0; i < count; i++) { Fq377 f; memcpy(f.v, in + 6 * i, 48); f.to_canonical(out + 6 * i); }
+  return 0;
+}
+int orc_to_mont_761(const u64* in, u64* out, size_t count) {
+  for (size_t i = 0; i < count; i++) { Fq761 f = Fq761::from_canonical(in + 12 * i); memcpy(out + 12 * i, f.v, 96); }
+  return 0;
+}
+int orc_from_mont_761(const u64* in, u64* out, size_t count) {
+  for (size_t i = 0; i < count; i++) { Fq761 f; memcpy(f.v, in + 12 * i, 96); f.to_canonical(out + 12 * i); }
+  return 0;
+}
+
+// ---- MSM: naive != 0 selects the sum-of-scalar-muls definition instead of Pippenger
+int orc_msm_bls12_377_g1(const u64* xy, const uint8_t* inf, const u64* sc, size_t n, int threads, int naive, u64* out18) {
+  return msm_impl<Fq377, 4>(xy, inf, sc, n, 253, threads, naive, out18);
+}
+int orc_msm_bls12_377_g2(const u64* xy, const uint8_t* inf, const u64* sc, size_t n, int threads, int naive, u64* out36) {
+  return msm_impl<Fq2_377, 4>(xy, inf, sc, n, 253, threads, naive, out36);
+}
+int orc_msm_bw6_761_g1(const u64* xy, const uint8_t* inf, const u64* sc, size_t n, int threads, int naive, u64* out36) {
+  return msm_impl<Fq761, 6>(xy, inf, sc, n, 377, threads, naive, out36);
+}
+// BW6-761 G2 has the same coordinate field (Fq) and the same a = 0 formulas; only b differs, which
+// the group law never uses, so the same routine serves both groups.
+int orc_msm_bw6_761_g2(const u64* xy, const uint8_t* inf, const u64* sc, size_t n, int threads, int naive, u64* out36) {
+  return msm_impl<Fq761, 6>(xy, inf, sc, n, 377, threads, naive, out36);
+}
+
+// ---- single scalar mul (k canonical, 4 / 6 limbs), Jacobian out
+int orc_mul_bls12_377_g1(const u64* xy, const u64* k, u64* out18) { return mul_impl<Fq377, 4>(xy, k, out18); }
+int orc_mul_bls12_377_g2(const u64* xy, const u64* k, u64* out36) { return mul_impl<Fq2_377, 4>(xy, k, out36); }
+int orc_mul_bw6_761(const u64* xy, const u64* k, u64* out36) { return mul_impl<Fq761, 6>(xy, k, out36); }
+
+// ---- Jacobian -> affine (Montgomery batch inversion), and plain sums
+int orc_normalize_bls12_377_g1(const u64* jac, size_t n, u64* xy, uint8_t* inf) { return normalize_impl<Fq377>(jac, n, xy, inf); }
+int orc_normalize_bls12_377_g2(const u64* jac, size_t n, u64* xy, uint8_t* inf) { return normalize_impl<Fq2_377>(jac, n, xy, inf); }
+int orc_normalize_bw6_761(const u64* jac, size_t n, u64* xy, uint8_t* inf) { return normalize_impl<Fq761>(jac, n, xy, inf); }
+int orc_sum_bls12_377_g1(const u64* jac, size_t n, u64* out) { return sum_impl<Fq377>(jac, n, out); }
+int orc_sum_bls12_377_g2(const u64* jac, size_t n, u64* out) { return sum_impl<Fq2_377>(jac, n, out); }
+
+// ---- pairings.  GT layout: 6 Fq2 (BLS12-377) or 6 Fq (BW6-761) coefficients in tower order
+//      c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 ; 72 u64 either way.
+int orc_miller_loop_bls12_377(const u64* g1, const uint8_t* inf1, const u64* g2, const uint8_t* inf2, size_t k, u64* gt72) {
+  auto p = load_affine<Fq377>(g1, inf1, k);
+  auto q = load_affine<Fq2_377>(g2, inf2, k);
+  std::vector<Bls12_377::G2Prepared> prep(k);
+  for (size_t i = 0; i < k; i++) prep[i] = Bls12_377::prepare(q[i]);
+  store_gt377(Bls12_377::miller_loop(p.data(), prep.data(), k), gt72);
+  return 0;
+}
+int orc_final_exp_bls12_377(const u64* in72, u64* out72) {
+  store_gt377(Bls12_377::final_exponentiation(load_gt377(in72)), out72);
+  return 0;
+}
+int orc_pairing_product_bls12_377(const u64* g1, const uint8_t* inf1, const u64* g2, const uint8_t* inf2, size_t k, u64* gt72, int* is_one) {
+  auto p = load_affine<Fq377>(g1, inf1, k);
+  auto q = load_affine<Fq2_377>(g2, inf2, k);
+  Fq12_377 g = Bls12_377::product_of_pairings(p.data(), q.data(), k);
+  if (gt72) store_gt377(g, gt72);
+  if (is_one) *is_one = g.is_one();
+  return 0;
+}
+int orc_pairing_product_bw6_761(const u64* g1, const uint8_t* inf1, const u64* g2, const uint8_t* inf2, size_t k, u64* gt72, int* is_one) {
+  auto p = load_affine<Fq761>(g1, inf1, k);
+  auto q = load_affine<Fq761>(g2, inf2, k);
+  Fq6_761 g = Bw6_761::product_of_pairings(p.data(), q.data(), k);
+  if (gt72) store_gt761(g, gt72);
+  if (is_one) *is_one = (g == Fq6_761::one());
+  return 0;
+}
+int orc_miller_loop_bw6_761(const u64* g1, const uint8_t* inf1, const u64* g2, const uint8_t* inf2, size_t k, u64* gt72) {
+  auto p = load_affine<Fq761>(g1, inf1, k);
+  auto q = load_affine<Fq761>(g2, inf2, k);
+  std::vector<Bw6_761::G2Prepared> prep(k);
+  for (size_t i = 0; i < k; i++) prep[i] = Bw6_761::prepare(q[i]);
+  store_gt761(Bw6_761::miller_loop(p.data(), prep.data(), k), gt72);
+  return 0;
+}
+
+// ---- timing helpers for bench.py's cpu_baseline leg (seconds of wall time)
+double orc_time_msm_bls12_377_g1(const u64* xy, const u64* sc, size_t n, int threads, u64* out18) {
+  auto t0 = std::chrono::steady_clock::now();
+  msm_impl<Fq377, 4>(xy, nullptr, sc, n, 253, threads, 0, out18);
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+int orc_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
+}

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Extracts the reference's own golden VECTORS (hex data literals held by its tests)
+into tests/golden/reference_vectors.json.  Run in the build container only
+(/root/reference does not exist on the GPU box); the JSON it writes is committed.
+
+Only data is taken — hex strings and the scalar parameters of the test that
+holds them — never source text.  Sources (paths relative to /root/reference):
+  crates/bls-crypto/src/hash_to_curve/mod.rs:412-513   hash-to-G1/G2 outputs (compressed points)
+  crates/bls-snark-sys/src/snark/mod.rs:52-119         Groth16/BW6-761 accept vector
+  crates/epoch-snark/src/epoch_block.rs:243-246        epoch encodings (embed the G2 generator)
+"""
+import json, os, re, sys
+
+REF = "/root/reference/crates"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
+
+
+def hex_lists_by_fn(path):
+    """map test-fn name -> list of hex string literals inside its expected_hashes vec."""
+    txt = open(path).read()
+    out = {}
+    for m in re.finditer(r"fn (test_hash_to_curve\w*)\(\)", txt):
+        body = txt[m.end():]
+        end = body.find("].into_iter()")
+        out[m.group(1)] = re.findall(r'"([0-9a-f]{96,})"', body[:end])
+    return out
+
+
+def consts(path):
+    txt = open(path).read()
+    return {m.group(1): m.group(2) for m in re.finditer(r'(?:const|static) (\w+): &str\s*=\s*"([0-9a-f]*)"', txt)}
+
+
+def main():
+    h = hex_lists_by_fn(f"{REF}/bls-crypto/src/hash_to_curve/mod.rs")
+    # the file holds two functions named test_hash_to_curve_g1 (compat / non-compat modules);
+    # regex dict keeps the last; re-scan in order to keep both
+    txt = open(f"{REF}/bls-crypto/src/hash_to_curve/mod.rs").read()
+    ordered = []
+    for m in re.finditer(r"fn (test_hash_to_curve\w*)\(\)", txt):
+        body = txt[m.end():]
+        end = body.find("].into_iter()")
+        ordered.append((m.group(1), re.findall(r'"([0-9a-f]{96,})"', body[:end])))
+    names = ["g1_compat_before_donut_dup", "g1_compat", "g1_compat_cip22", "g1_noncompat", "g2_noncompat"]
+    vec = {}
+    k = 0
+    for name, lst in ordered:
+        if not lst:
+            continue
+        vec[names[k] if k < len(names) else f"extra{k}"] = {"fn": name, "points": lst}
+        k += 1
+    g = consts(f"{REF}/bls-snark-sys/src/snark/mod.rs")
+    e = consts(f"{REF}/epoch-snark/src/epoch_block.rs")
+    out = {
+        "_source": "celo-org/celo-bls-snark-rs test vectors (data literals only); see extract_reference_vectors.py",
+        "hash_to_curve": vec,
+        "groth16_bw6_761": {
+            "vk": g["ENTROPY_VK"], "proof": g["ENTROPY_PROOF"],
+            "first_pubkeys": g["ENTROPY_FIRST_PUBKEYS"], "last_pubkeys": g["ENTROPY_LAST_PUBKEYS"],
+            "first_epoch_entropy": g["FIRST_EPOCH_ENTROPY"], "first_parent_entropy": g["FIRST_PARENT_ENTROPY"],
+            "last_epoch_entropy": g["LAST_EPOCH_ENTROPY"], "last_parent_entropy": g["LAST_PARENT_ENTROPY"],
+            "first": {"index": 0, "round": 0, "maximum_non_signers": 1, "pubkeys_num": 4, "maximum_validators": 4},
+            "last": {"index": 2, "round": 0, "maximum_non_signers": 1, "pubkeys_num": 4, "maximum_validators": 4},
+            "expected": True,
+        },
+        "epoch_encoding": {k: v for k, v in e.items() if k.startswith("EXPECTED_")},
+    }
+    json.dump(out, open(OUT, "w"), indent=1)
+    print("wrote", OUT, {k: len(v["points"]) for k, v in vec.items()})
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("reference not present (build container only)")
+    main()

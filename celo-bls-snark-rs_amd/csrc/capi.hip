@@ -1,0 +1,79 @@
+// extern "C" boundary of the gfx950 hot path (include/celo_bls_amd.h).
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <cstdio>
+#include "../../include/celo_bls_amd.h"
+
+namespace celo {
+std::mutex& api_mutex() { static std::mutex m; return m; }
+static bool g_inited = false;
+int api_ensure_init() {
+  if (g_inited) return 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    fprintf(stderr, "[celo-amd] no HIP device: the MSM/pairing path has no CPU fallback\n");
+    return 100;
+  }
+  g_inited = true;
+  return 0;
+}
+#define DECL(TAG)                                                                                     \
+  int msm_host_##TAG(const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*);            \
+  int msm_dev_##TAG(const void*, const void*, const void*, size_t, uint64_t*, void*);                 \
+  int msm_timings_##TAG(float*, int*);                                                                \
+  int msm_set_c_##TAG(int);                                                                           \
+  int gen_points_##TAG(void*, size_t, uint64_t, const uint64_t*, void*);                              \
+  int sum_jac_##TAG(const uint64_t*, size_t, uint64_t*);
+DECL(g1_377) DECL(g2_377) DECL(761)
+}  // namespace celo
+using namespace celo;
+
+extern "C" {
+int celo_amd_init(int device) {
+  std::lock_guard<std::mutex> lk(api_mutex());
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return 100;
+  if (device < 0 || device >= n) return 101;
+  if (hipSetDevice(device) != hipSuccess) return 102;
+  g_inited = true;
+  return 0;
+}
+int celo_amd_device_name(char* buf, size_t buflen) {
+  hipDeviceProp_t p;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 100;
+  snprintf(buf, buflen, "%s", p.gcnArchName);
+  return 0;
+}
+int msm_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { return msm_host_g1_377(b, inf, s, n, out); }
+int msm_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { return msm_host_g2_377(b, inf, s, n, out); }
+int msm_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { return msm_host_761(b, inf, s, n, out); }
+int msm_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { return msm_host_761(b, inf, s, n, out); }
+int msm_bls12_377_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_g1_377(b, inf, s, n, out, st); }
+int msm_bls12_377_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_g2_377(b, inf, s, n, out, st); }
+int msm_bw6_761_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_761(b, inf, s, n, out, st); }
+int msm_bw6_761_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_761(b, inf, s, n, out, st); }
+int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]) {
+  switch (group) {
+    case 0: return msm_timings_g1_377(ms, cfg);
+    case 1: return msm_timings_g2_377(ms, cfg);
+    case 2: return msm_timings_761(ms, cfg);
+    default: return 1;
+  }
+}
+int celo_amd_msm_set_window_bits(int group, int c) {
+  if (c != 0 && (c < 4 || c > 16)) return 1;
+  switch (group) {
+    case 0: return msm_set_c_g1_377(c);
+    case 1: return msm_set_c_g2_377(c);
+    case 2: return msm_set_c_761(c);
+    default: return 1;
+  }
+}
+int celo_amd_sum_jacobian_bls12_377_g1(const uint64_t* j, size_t k, uint64_t* out) { return sum_jac_g1_377(j, k, out); }
+int celo_amd_sum_jacobian_bls12_377_g2(const uint64_t* j, size_t k, uint64_t* out) { return sum_jac_g2_377(j, k, out); }
+int celo_amd_sum_jacobian_bw6_761(const uint64_t* j, size_t k, uint64_t* out) { return sum_jac_761(j, k, out); }
+int celo_amd_gen_points_bls12_377_g1_dev(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) { return gen_points_g1_377(d, n, seed, g, st); }
+int celo_amd_gen_points_bls12_377_g2_dev(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) { return gen_points_g2_377(d, n, seed, g, st); }
+int celo_amd_gen_points_bw6_761_dev(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) { return gen_points_761(d, n, seed, g, st); }
+}

@@ -1,0 +1,131 @@
+// Short-Weierstrass (a = 0) point arithmetic in extended-Jacobian "XYZZ" coordinates
+// (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2), generic over the coordinate field F
+// (Fp<P377> for BLS12-377 G1, Fp2 for G2, Fp<P761> for both BW6-761 groups).
+//
+// Replaces ark-ec's GroupProjective::{add_assign_mixed, add_assign, double_in_place}
+//  underneath VariableBaseMSM (crates/bls-crypto/src/bls/signature.rs:85,
+// public.rs:61).  The reference uses Jacobian madd-2007-bl (7M+4S); on the GPU the bucket
+// accumulators use XYZZ (madd-2008-s: 8M+2S, no field additions on the critical multiplication
+// inputs and cheaper general adds for the bucket reduction).  Group elements are unique, so the
+// affine-normalised result is bit-identical to the reference's.
+//
+// Every formula is annotated with the [lb, vb] bounds of fp.h's contract.
+#pragma once
+#include "fp.h"
+
+namespace celo {
+
+template <class F> struct Affine {
+  F x, y;  // normalised limbs (lb<=1), vb<=2
+};
+
+template <class F> struct Xyzz {
+  F X, Y, ZZ, ZZZ;  // stored normalised: lb 1; vb(X) <= 19, vb(Y) <= 7, vb(ZZ), vb(ZZZ) <= 3 (Fp2 products are < 3p)
+  HD static Xyzz identity() { return {F::zero(), F::zero(), F::zero(), F::zero()}; }
+  HD bool is_identity() const { return ZZ.limbs_all_zero(); }
+  HD static Xyzz from_affine(const Affine<F>& p) { return {p.x, p.y, F::one(), F::one()}; }
+};
+
+// 2*(x,y) for an affine point (mdbl-2008-s-1, a = 0).  y == 0 cannot occur on prime-order-cofactor
+// curves' r-torsion; handled anyway (result identity).
+template <class F> HD Xyzz<F> xyzz_dbl_affine(const Affine<F>& p) {
+  if (p.y.is_zero_mod_p()) return Xyzz<F>::identity();
+  F U = F::dbl(p.y);                                  // [2, 4]
+  F V = F::sqr(U);                                    // [1, 2]
+  F W = F::mul(U, V);                                 // [1, 2]
+  F S = F::mul(p.x, V);                               // [1, 2]
+  F xx = F::sqr(p.x);
+  F M = F::add(F::add(xx, xx), xx);                   // [3, 6]
+  F M2 = F::sqr(M);                                   // 9 ok
+  F X3 = F::norm(F::template sub<16, 3>(M2, F::dbl(S)));   // [1, 10]
+  F t = F::template sub<32, 1>(S, X3);                // [3, 18]
+  F Y3 = F::norm(F::template sub<4, 1>(F::mul(M, t), F::mul(W, p.y)));  // [1, 6]
+  return {X3, Y3, V, W};
+}
+
+template <class F> HD Xyzz<F> xyzz_dbl(const Xyzz<F>& a) {
+  if (a.is_identity()) return a;
+  if (a.Y.is_zero_mod_p()) return Xyzz<F>::identity();
+  F U = F::dbl(a.Y);                                  // [2, 12]
+  F V = F::sqr(U);
+  F W = F::mul(U, V);
+  F S = F::mul(a.X, V);
+  F xx = F::sqr(a.X);
+  F M = F::add(F::add(xx, xx), xx);                   // [3, 6]
+  F M2 = F::sqr(M);
+  F X3 = F::norm(F::template sub<16, 3>(M2, F::dbl(S)));
+  F t = F::template sub<32, 1>(S, X3);
+  F Y3 = F::norm(F::template sub<4, 1>(F::mul(M, t), F::mul(W, a.Y)));
+  return {X3, Y3, F::mul(V, a.ZZ), F::mul(W, a.ZZZ)};
+}
+
+// acc += (x2, y2) affine (madd-2008-s).  acc may be the identity.
+template <class F> HD void xyzz_madd(Xyzz<F>& a, const Affine<F>& p) {
+  if (a.is_identity()) { a = Xyzz<F>::from_affine(p); return; }
+  F U2 = F::mul(p.x, a.ZZ);                           // [1, 2]
+  F S2 = F::mul(p.y, a.ZZZ);
+  F Pd = F::template sub<32, 1>(U2, a.X);             // [3, 18]
+  F R = F::template sub<16, 1>(S2, a.Y);              // [3, 18]
+  if (Pd.is_zero_mod_p()) {
+    if (R.is_zero_mod_p()) a = xyzz_dbl_affine(p);
+    else a = Xyzz<F>::identity();
+    return;
+  }
+  F PP = F::sqr(Pd);                                  // 9 ok -> [1, 2]
+  F PPP = F::mul(Pd, PP);
+  F Q = F::mul(a.X, PP);
+  F R2 = F::sqr(R);
+  F s = F::add(F::add(PPP, Q), Q);                    // [3, 6]
+  F X3 = F::norm(F::template sub<16, 3>(R2, s));       // [1, 10]
+  F t = F::template sub<32, 1>(Q, X3);                // [3, 18]
+  F Y3 = F::norm(F::template sub<4, 1>(F::mul(R, t), F::mul(a.Y, PPP)));  // [1, 6]
+  a.ZZ = F::mul(a.ZZ, PP);
+  a.ZZZ = F::mul(a.ZZZ, PPP);
+  a.X = X3;
+  a.Y = Y3;
+}
+
+// a += b (add-2008-s), both XYZZ, either may be the identity
+template <class F> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& b) {
+  if (b.is_identity()) return;
+  if (a.is_identity()) { a = b; return; }
+  F U1 = F::mul(a.X, b.ZZ);
+  F U2 = F::mul(b.X, a.ZZ);
+  F S1 = F::mul(a.Y, b.ZZZ);
+  F S2 = F::mul(b.Y, a.ZZZ);
+  F Pd = F::template sub<4, 1>(U2, U1);               // [3, 6]
+  F R = F::template sub<4, 1>(S2, S1);
+  if (Pd.is_zero_mod_p()) {
+    if (R.is_zero_mod_p()) a = xyzz_dbl(a);
+    else a = Xyzz<F>::identity();
+    return;
+  }
+  F PP = F::sqr(Pd);
+  F PPP = F::mul(Pd, PP);
+  F Q = F::mul(U1, PP);
+  F R2 = F::sqr(R);
+  F s = F::add(F::add(PPP, Q), Q);
+  F X3 = F::norm(F::template sub<16, 3>(R2, s));
+  F t = F::template sub<32, 1>(Q, X3);
+  F Y3 = F::norm(F::template sub<4, 1>(F::mul(R, t), F::mul(S1, PPP)));
+  a.ZZ = F::mul(F::mul(a.ZZ, b.ZZ), PP);
+  a.ZZZ = F::mul(F::mul(a.ZZZ, b.ZZZ), PPP);
+  a.X = X3;
+  a.Y = Y3;
+}
+
+template <class F> HD Affine<F> affine_neg(const Affine<F>& p) {
+  return {p.x, F::norm(F::template neg<4, 1>(p.y))};
+}
+
+// k * a for a small non-negative k (bucket-reduction fix-ups), MSB-first double-and-add
+template <class F> HD Xyzz<F> xyzz_mul_small(const Xyzz<F>& a, uint32_t k) {
+  Xyzz<F> r = Xyzz<F>::identity();
+  for (int i = 31; i >= 0; i--) {
+    r = xyzz_dbl(r);
+    if ((k >> i) & 1) xyzz_add(r, a);
+  }
+  return r;
+}
+
+}  // namespace celo

@@ -1,0 +1,393 @@
+// Reduced-radix Montgomery prime-field arithmetic for gfx950 (and the host epilogues).
+//
+// Replaces ark-ff's Fp384 / Fp768 Montgomery arithmetic that the reference reaches through
+// VariableBaseMSM::multi_scalar_mul and PairingEngine::product_of_pairings
+// (crates/bls-crypto/src/bls/public.rs:61,102; signature.rs:85,149).
+//
+// MI355X design notes (measured with tools/ubench_valu.hip):
+//  * v_mad_u64_u32 issues at ~the cost of any other 3-operand VALU op, and the carry chain of a
+//    full-radix (2^32) multiply needs ~2 extra VALU ops per product.  So limbs are W = 28 bits
+//    in 32-bit registers: a whole product column (<= 2L terms of < 2^58) is accumulated into
+//    ONE 64-bit register pair by back-to-back v_mad_u64_u32 with NO carry handling; one shift
+//    per column propagates.  (FIPS: finely integrated product scanning.)
+//  * Values are kept loosely reduced (value < ~64p, limbs < ~3*2^W): additions are plain limb
+//    adds, subtractions add a redundant multiple of p whose limbs dominate the subtrahend's,
+//    and carries are only propagated ("norm") where a bound below requires it.
+//  * Montgomery radix is R_d = 2^(W*L) (2^392 / 2^784), not arkworks' 2^384 / 2^768; one
+//    multiplication by a constant converts on the way in and out (from_ark / to_ark).
+//
+// Bounds contract (checked at run time in host builds with -DCELO_FP_TRACK):
+//   lb = max limb / 2^W   (limb bound),  vb = value / p  (value bound)
+//   mul(a,b), sqr(a):  L*(lb_a*lb_b + 1) <= 255  and  vb_a*vb_b <= 2^15  ->  lb = 1, vb < 2
+//   add(a,b):          lb = lb_a + lb_b,  vb = vb_a + vb_b
+//   sub<K,M>(a,b):     needs lb_b <= M, vb_b <= K                -> lb = lb_a + M + 1, vb = vb_a + K
+//   norm(a):           lb = 1 (top limb keeps the excess), vb unchanged
+#pragma once
+#include <cstdint>
+#include "fp_consts.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HD __host__ __device__ __forceinline__
+#else
+#define HD inline
+struct uint4 { uint32_t x, y, z, w; };  // host-only builds (bounds-tracking unit tests)
+#endif
+
+#ifdef CELO_FP_TRACK
+#include <cassert>
+#include <cstdio>
+#define TRK(x) x
+#else
+#define TRK(x)
+#endif
+
+namespace celo {
+
+template <class P> struct Fp {
+  static constexpr int L = P::L;
+  static constexpr int W = P::W;
+  static constexpr uint32_t MASK = P::MASK;
+  uint32_t l[L];
+  TRK(double lb = 1; double vb = 2;)
+
+  HD static Fp zero() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = 0;
+    TRK(r.lb = 0; r.vb = 0;)
+    return r;
+  }
+  HD static Fp from_limbs(const uint32_t* c) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = c[i];
+    TRK(r.lb = 1; r.vb = 2;)
+    return r;
+  }
+  HD static Fp one() { return from_limbs(P::ONE); }
+
+  // ---- Montgomery multiplication, product scanning with interleaved reduction.
+  // For L > 25 (BW6-761: 28 limbs) a column of 2L products only fits 64 bits when lb_a*lb_b <= 8, so the
+  // un-normalised subtraction results (lb 3) the curve formulas feed in are normalised on entry there.
+  static constexpr bool NORM_IN = (L * 10 > 255);
+  HD static Fp mul(const Fp& a_, const Fp& b) {
+    const Fp a = NORM_IN ? norm(a_) : a_;
+    TRK(assert(L * (a.lb * b.lb + 1) <= 255.5); assert(a.vb * b.vb <= 32768.0);)
+    Fp r;
+    uint32_t m[L];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      uint32_t lo = (uint32_t)acc;
+      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      acc += (uint64_t)m[k] * P::P[0];
+      acc >>= W;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      r.l[k - L] = (uint32_t)acc & MASK;
+      acc >>= W;
+    }
+    r.l[L - 1] = (uint32_t)acc;
+    TRK(r.lb = 1; r.vb = 2;)
+    return r;
+  }
+  HD static Fp sqr(const Fp& a_) {
+    const Fp a = NORM_IN ? norm(a_) : a_;
+    TRK(assert(L * (a.lb * a.lb + 1) <= 255.5); assert(a.vb * a.vb <= 32768.0);)
+    Fp r;
+    uint32_t m[L], a2[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) a2[i] = a.l[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+      for (int i = 0; 2 * i < k; i++) acc += (uint64_t)a2[i] * a.l[k - i];
+      if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      uint32_t lo = (uint32_t)acc;
+      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      acc += (uint64_t)m[k] * P::P[0];
+      acc >>= W;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+      for (int i = k - L + 1; 2 * i < k; i++) acc += (uint64_t)a2[i] * a.l[k - i];
+      if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      r.l[k - L] = (uint32_t)acc & MASK;
+      acc >>= W;
+    }
+    r.l[L - 1] = (uint32_t)acc;
+    TRK(r.lb = 1; r.vb = 2;)
+    return r;
+  }
+  HD static Fp add(const Fp& a, const Fp& b) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = a.l[i] + b.l[i];
+    TRK(r.lb = a.lb + b.lb; r.vb = a.vb + b.vb; assert(r.lb <= 15);)
+    return r;
+  }
+  HD static Fp dbl(const Fp& a) { return add(a, a); }
+  // a - b + K*p  (K*p in redundant form dominating limbs of b up to M*(2^W-1))
+  template <int K, int M> HD static const uint32_t* kp() {
+    if constexpr (K == 4 && M == 1) return P::KP4_M1;
+    else if constexpr (K == 8 && M == 1) return P::KP8_M1;
+    else if constexpr (K == 16 && M == 1) return P::KP16_M1;
+    else if constexpr (K == 32 && M == 1) return P::KP32_M1;
+    else if constexpr (K == 64 && M == 1) return P::KP64_M1;
+    else if constexpr (K == 8 && M == 3) return P::KP8_M3;
+    else if constexpr (K == 16 && M == 3) return P::KP16_M3;
+    else if constexpr (K == 32 && M == 3) return P::KP32_M3;
+    else return nullptr;
+  }
+  template <int K, int M = 1> HD static Fp sub(const Fp& a, const Fp& b) {
+    TRK(assert(b.lb <= M + 1e-9); assert(b.vb <= K);)
+    Fp r;
+    if constexpr (K == 4 && M == 1) {
+#pragma unroll
+      for (int i = 0; i < L; i++) r.l[i] = a.l[i] + P::KP4_M1[i] - b.l[i];
+    } else if constexpr (K == 8 && M == 1) {
+#pragma unroll
+      for (int i = 0; i < L; i++) r.l[i] = a.l[i] + P::KP8_M1[i] - b.l[i];
+    } else if constexpr (K == 16 && M == 1) {
+#pragma unroll
+      for (int i = 0; i < L; i++) r.l[i] = a.l[i] + P::KP16_M1[i] - b.l[i];
+    } else if constexpr (K == 32 && M == 1) {
+#pragma unroll
+      for (int i = 0; i < L; i++) r.l[i] = a.l[i] + P::KP32_M1[i] - b.l[i];
+    } else if constexpr (K == 64 && M == 1) {
+#pragma unroll
+      for (int i = 0; i < L; i++) r.l[i] = a.l[i] + P::KP64_M1[i] - b.l[i];
+    } else if constexpr (K == 8 && M == 3) {
+#pragma unroll
+      for (int i = 0; i < L; i++) r.l[i] = a.l[i] + P::KP8_M3[i] - b.l[i];
+    } else if constexpr (K == 16 && M == 3) {
+#pragma unroll
+      for (int i = 0; i < L; i++) r.l[i] = a.l[i] + P::KP16_M3[i] - b.l[i];
+    } else {
+      static_assert(K == 32 && M == 3, "unsupported sub<K,M>");
+#pragma unroll
+      for (int i = 0; i < L; i++) r.l[i] = a.l[i] + P::KP32_M3[i] - b.l[i];
+    }
+    TRK(r.lb = a.lb + M + 1; r.vb = a.vb + K; assert(r.lb <= 15);)
+    return r;
+  }
+  template <int K, int M = 1> HD static Fp neg(const Fp& b) { return sub<K, M>(zero(), b); }
+  // carry propagation: limbs 0..L-2 < 2^W, the top limb keeps whatever is left (value < 2^(W*L) assumed)
+  HD static Fp norm(const Fp& a) {
+    Fp r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) {
+      uint32_t t = a.l[i] + c;
+      r.l[i] = t & MASK;
+      c = t >> W;
+    }
+    r.l[L - 1] = a.l[L - 1] + c;
+    TRK(r.lb = 1; r.vb = a.vb;)
+    return r;
+  }
+  // ---- canonical reduction to [0, p): value must be < 128p.  Slow path only (equality tests, export).
+  HD static Fp reduce(const Fp& a) {
+    Fp r = norm(a);
+    cond_sub(r, P::NP64);
+    cond_sub(r, P::NP32);
+    cond_sub(r, P::NP16);
+    cond_sub(r, P::NP8);
+    cond_sub(r, P::NP4);
+    cond_sub(r, P::NP2);
+    cond_sub(r, P::NP1);
+    TRK(r.lb = 1; r.vb = 1;)
+    return r;
+  }
+  HD static void cond_sub(Fp& r, const uint32_t* kp) {
+    // r (normalised) >= kp ? r - kp : r
+    uint32_t t[L];
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) {
+      int32_t d = (int32_t)r.l[i] - (int32_t)kp[i] + borrow;
+      t[i] = (uint32_t)d & MASK;
+      borrow = d >> W;  // arithmetic shift: 0 or -1
+    }
+    int64_t dt = (int64_t)r.l[L - 1] - (int64_t)kp[L - 1] + borrow;
+    bool ge = dt >= 0;
+    t[L - 1] = (uint32_t)dt;
+    if (ge) {
+#pragma unroll
+      for (int i = 0; i < L; i++) r.l[i] = t[i];
+    }
+  }
+  // exact zero test (mod p).  Fast filter on the low limb: x == j*p for small j requires
+  // (x0 * p0^-1) mod 2^W == j; only then pay for the canonical reduction.
+  HD bool is_zero_mod_p() const {
+    uint32_t lo = l[0] & MASK;
+    uint32_t t = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);  // = -j mod 2^W
+    uint32_t j = (0u - t) & MASK;
+    if (j > 130) return false;
+    Fp r = reduce(*this);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) o |= r.l[i];
+    return o == 0;
+  }
+  HD bool limbs_all_zero() const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) o |= l[i];
+    return o == 0;
+  }
+  HD static bool eq_mod_p(const Fp& a, const Fp& b) {  // a, b normalised (lb<=1), vb <= 64
+    return sub<64, 1>(a, b).is_zero_mod_p();
+  }
+
+
+  // ---- device memory layout: L limbs padded to a multiple of 4 words (16-byte vector accesses)
+  static constexpr int WORDS = (L + 3) / 4 * 4;
+  static constexpr int ARK64 = P::N64;
+  HD static Fp load(const uint32_t* p) {
+    Fp r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int k = 0; k < WORDS / 4; k++) {
+      uint4 v = q[k];
+      if (4 * k < L) r.l[4 * k] = v.x;
+      if (4 * k + 1 < L) r.l[4 * k + 1] = v.y;
+      if (4 * k + 2 < L) r.l[4 * k + 2] = v.z;
+      if (4 * k + 3 < L) r.l[4 * k + 3] = v.w;
+    }
+    TRK(r.lb = 1; r.vb = 64;)
+    return r;
+  }
+  HD void store(uint32_t* p) const {
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int k = 0; k < WORDS / 4; k++) {
+      uint4 v;
+      v.x = 4 * k < L ? l[4 * k] : 0u;
+      v.y = 4 * k + 1 < L ? l[4 * k + 1] : 0u;
+      v.z = 4 * k + 2 < L ? l[4 * k + 2] : 0u;
+      v.w = 4 * k + 3 < L ? l[4 * k + 3] : 0u;
+      q[k] = v;
+    }
+  }
+
+  // ---- sum of two products in one reduction pass:  (a*b + c*d)/R   or, with SUB5,  (a*b - 5*c*d)/R + p
+  // Inputs must be normalised (lb <= 1).  Used by Fp2 (u^2 = -5): two passes per Fp2 product
+  // instead of three full multiplications' worth of carries/adds.
+  template <bool SUB5> HD static Fp mul2(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+    TRK(assert(a.lb <= 1 && b.lb <= 1 && c.lb <= 1 && d.lb <= 1); assert(a.vb * b.vb + 5 * c.vb * d.vb <= 32768.0);)
+    Fp r;
+    uint32_t m[L], cc[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) cc[i] = SUB5 ? c.l[i] * 5u : c.l[i];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc += (uint64_t)a.l[i] * b.l[k - i];
+        if (SUB5) acc -= (uint64_t)cc[i] * d.l[k - i];
+        else acc += (uint64_t)cc[i] * d.l[k - i];
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      uint32_t lo = (uint32_t)acc;
+      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      acc += (uint64_t)m[k] * P::P[0];
+      acc = (uint64_t)((int64_t)acc >> W);
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) {
+        acc += (uint64_t)a.l[i] * b.l[k - i];
+        if (SUB5) acc -= (uint64_t)cc[i] * d.l[k - i];
+        else acc += (uint64_t)cc[i] * d.l[k - i];
+      }
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      if (SUB5) acc += P::P[k - L];  // + p after the division by R keeps the result positive
+      r.l[k - L] = (uint32_t)acc & MASK;
+      acc = (uint64_t)((int64_t)acc >> W);
+    }
+    if (SUB5) acc += P::P[L - 1];
+    r.l[L - 1] = (uint32_t)acc;
+    TRK(r.lb = 1; r.vb = SUB5 ? 3 : 2;)
+    return r;
+  }
+
+  // ---- arkworks Montgomery (R = 2^(64*N64), 64-bit limbs) <-> device form
+  HD static Fp repack_from64(const uint64_t* s) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int bit = i * W;
+      int w = bit >> 6, off = bit & 63;
+      uint64_t v = (w < P::N64) ? (s[w] >> off) : 0;
+      if (off + W > 64 && w + 1 < P::N64) v |= s[w + 1] << (64 - off);
+      r.l[i] = (uint32_t)v & MASK;
+    }
+    TRK(r.lb = 1; r.vb = 2;)
+    return r;
+  }
+  HD void repack_to64(uint64_t* d) const {  // *this canonical & normalised
+#pragma unroll
+    for (int w = 0; w < P::N64; w++) d[w] = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      int bit = i * W;
+      int w = bit >> 6, off = bit & 63;
+      if (w < P::N64) {
+        d[w] |= (uint64_t)l[i] << off;
+        if (off + W > 64 && w + 1 < P::N64) d[w + 1] |= (uint64_t)l[i] >> (64 - off);
+      }
+    }
+  }
+  HD static Fp from_ark(const uint64_t* s) { return mul(repack_from64(s), from_limbs(P::C_IN)); }
+  HD void to_ark(uint64_t* d) const { reduce(mul(*this, from_limbs(P::C_OUT))).repack_to64(d); }
+  // canonical integer (64-bit limbs) <-> device form
+  HD static Fp from_canonical(const uint64_t* s) { return mul(repack_from64(s), from_limbs(P::R2)); }
+  HD void to_canonical(uint64_t* d) const { reduce(mul(*this, from_limbs(P::RAW_ONE))).repack_to64(d); }
+
+  // ---- exponentiation / inversion (slow paths: host epilogues, final exponentiation easy part)
+  HD static Fp pow64(const Fp& a, const uint64_t* e, int nlimbs) {
+    Fp r = one();
+    bool started = false;
+    for (int i = nlimbs * 64 - 1; i >= 0; i--) {
+      if (started) r = sqr(r);
+      if ((e[i >> 6] >> (i & 63)) & 1) {
+        r = started ? mul(r, a) : a;
+        started = true;
+      }
+    }
+    return r;
+  }
+  HD static Fp inv(const Fp& a) {  // a^(p-2); a must have lb<=1... (normalise first)
+    uint64_t e[P::N64];
+#pragma unroll
+    for (int i = 0; i < P::N64; i++) e[i] = P::P64[i];
+    e[0] -= 2;
+    return pow64(norm(a), e, P::N64);
+  }
+};
+
+typedef Fp<P377> Fq377d;
+typedef Fp<P761> Fq761d;
+
+}  // namespace celo

@@ -1,0 +1,108 @@
+"""ctypes binding of the gfx950 C-ABI library (include/celo_bls_amd.h).
+
+There is NO CPU fallback: if build/libcelo_bls_amd.so is missing, import of `lib()` raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "build", "libcelo_bls_amd.so")
+
+GROUP_ID = {"bls12_377_g1": 0, "bls12_377_g2": 1, "bw6_761_g1": 2, "bw6_761_g2": 2}
+# (u64 limbs per affine point, u64 limbs per scalar, u64 limbs of the Jacobian result)
+GROUP_SHAPE = {"bls12_377_g1": (12, 4, 18), "bls12_377_g2": (24, 4, 36), "bw6_761_g1": (24, 6, 36), "bw6_761_g2": (24, 6, 36)}
+
+EXPORTS = [
+    "celo_amd_init", "celo_amd_device_name",
+    "msm_bls12_377_g1", "msm_bls12_377_g2", "msm_bw6_761_g1", "msm_bw6_761_g2",
+    "msm_bls12_377_g1_dev", "msm_bls12_377_g2_dev", "msm_bw6_761_g1_dev", "msm_bw6_761_g2_dev",
+    "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
+    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits",
+    "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with __graft_entry__.build() "
+                "(make -C celo-bls-snark-rs_amd/csrc). There is no CPU fallback for the MSM/pairing path.")
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def init(device=0):
+    rc = lib().celo_amd_init(C.c_int(device))
+    if rc != 0:
+        raise RuntimeError(f"celo_amd_init({device}) failed rc={rc} (no gfx950 device?)")
+
+
+def msm(group, bases_xy, inf, scalars):
+    """Host-buffer MSM. bases_xy: uint64 [n, A]; inf: uint8 [n] or None; scalars: uint64 [n, S]. Returns Jacobian limbs."""
+    A, S, O = GROUP_SHAPE[group]
+    n = int(bases_xy.shape[0]) if bases_xy.ndim == 2 else int(bases_xy.size // A)
+    bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    assert bases_xy.size == n * A and scalars.size == n * S, "bases / scalars length mismatch"
+    out = np.zeros(O, dtype=np.uint64)
+    rc = getattr(lib(), "msm_" + group)(_p(bases_xy), _p(inf), _p(scalars), C.c_size_t(n), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"msm_{group} failed rc={rc}")
+    return out
+
+
+def msm_dev(group, d_bases, d_inf, d_scalars, n, stream=0):
+    """Device-pointer MSM: d_* are integer device addresses (e.g. torch tensor .data_ptr())."""
+    O = GROUP_SHAPE[group][2]
+    out = np.zeros(O, dtype=np.uint64)
+    rc = getattr(lib(), "msm_" + group + "_dev")(C.c_void_p(d_bases), C.c_void_p(d_inf or 0), C.c_void_p(d_scalars),
+                                                 C.c_size_t(n), _p(out), C.c_void_p(stream or 0))
+    if rc != 0:
+        raise RuntimeError(f"msm_{group}_dev failed rc={rc}")
+    return out
+
+
+def msm_timings(group):
+    ms = (C.c_float * 5)()
+    cfg = (C.c_int * 3)()
+    rc = lib().celo_amd_msm_last_timings(C.c_int(GROUP_ID[group]), ms, cfg)
+    assert rc == 0
+    return {"convert_ms": ms[0], "sort_ms": ms[1], "accumulate_ms": ms[2], "reduce_ms": ms[3], "total_ms": ms[4],
+            "window_bits": cfg[0], "windows": cfg[1], "buckets": cfg[2]}
+
+
+def set_window_bits(group, c):
+    rc = lib().celo_amd_msm_set_window_bits(C.c_int(GROUP_ID[group]), C.c_int(c))
+    if rc != 0:
+        raise ValueError(f"window bits {c} not supported")
+
+
+def gen_points_dev(group, d_out, n, seed, gen_xy, stream=0):
+    name = {"bls12_377_g1": "celo_amd_gen_points_bls12_377_g1_dev", "bls12_377_g2": "celo_amd_gen_points_bls12_377_g2_dev",
+            "bw6_761_g1": "celo_amd_gen_points_bw6_761_dev", "bw6_761_g2": "celo_amd_gen_points_bw6_761_dev"}[group]
+    gen_xy = np.ascontiguousarray(gen_xy, dtype=np.uint64)
+    rc = getattr(lib(), name)(C.c_void_p(d_out), C.c_size_t(n), C.c_uint64(seed), _p(gen_xy), C.c_void_p(stream or 0))
+    if rc != 0:
+        raise RuntimeError(f"{name} failed rc={rc}")
+
+
+def sum_jacobian(group, jac):
+    """Plain sum of k Jacobian points (uint64 [k, O]) -> Jacobian limbs."""
+    O = GROUP_SHAPE[group][2]
+    jac = np.ascontiguousarray(jac, dtype=np.uint64).reshape(-1, O)
+    out = np.zeros(O, dtype=np.uint64)
+    name = {"bls12_377_g1": "celo_amd_sum_jacobian_bls12_377_g1", "bls12_377_g2": "celo_amd_sum_jacobian_bls12_377_g2",
+            "bw6_761_g1": "celo_amd_sum_jacobian_bw6_761", "bw6_761_g2": "celo_amd_sum_jacobian_bw6_761"}[group]
+    rc = getattr(lib(), name)(_p(jac), C.c_size_t(jac.shape[0]), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"{name} failed rc={rc}")
+    return out

@@ -1,0 +1,73 @@
+/* celo_bls_amd.h — C ABI of the MI355X (gfx950) MSM / pairing hot path.
+ *
+ * "Seam B" of SURVEY.md §8b: the thin extern "C" shim that replaces the arkworks call sites
+ * of celo-bls-snark-rs.  Each entry cites the reference interface it stands in for.
+ *
+ * Conventions (identical to what a Rust shim over arkworks 0.1 types would hand over):
+ *   - limbs little-endian u64; base-field elements in arkworks Montgomery form
+ *     (R = 2^384 for BLS12-377 Fq, 2^768 for BW6-761 Fq); Fq2 = c0 || c1;
+ *   - scalars canonical (Fr::into_repr()): 4 x u64 (BLS12-377 Fr) / 6 x u64 (BW6-761 Fr), must be < r;
+ *   - affine bases x || y, with an optional byte-per-point infinity array (NULL = none);
+ *   - results: Jacobian (X, Y, Z) in Montgomery form, identity encoded Z = 0 — the in-memory
+ *     layout of GroupProjective{x,y,z};
+ *   - return 0 = ok, non-zero = device/runtime error (a caller maps it to `false` like
+ *     crates/bls-snark-sys/src/lib.rs:21-27 convert_result_to_bool);
+ *   - *_dev variants take DEVICE pointers (inputs already resident in HBM) and a hipStream_t
+ *     (as void*; NULL = default stream); the result still lands in host memory.
+ * All functions are synchronous and may be called from any host thread (internally serialised).
+ */
+#ifndef CELO_BLS_AMD_H
+#define CELO_BLS_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Selects the HIP device for this process (one process per GPU). Returns 0, or non-zero if no gfx950 device. */
+int celo_amd_init(int device);
+/* "gfx950:..." string of the active device into buf; returns 0. */
+int celo_amd_device_name(char* buf, size_t buflen);
+
+/* ---- MSM.  Replaces VariableBaseMSM::multi_scalar_mul(&[GAffine], &[BigInt]) at
+ *   crates/bls-crypto/src/bls/signature.rs:85  (G1, Signature::batch)
+ *   crates/bls-crypto/src/bls/public.rs:61     (G2, PublicKey::batch)
+ *   ark_groth16::create_proof_no_zk via crates/epoch-snark/src/api/prover.rs:78,112 (BW6-761 / BLS12-377 prover MSMs) */
+int msm_bls12_377_g1(const uint64_t* bases_xy /* n*12 */, const uint8_t* inf, const uint64_t* scalars /* n*4 */, size_t n,
+                     uint64_t out_xyz[18]);
+int msm_bls12_377_g2(const uint64_t* bases_xy /* n*24 */, const uint8_t* inf, const uint64_t* scalars /* n*4 */, size_t n,
+                     uint64_t out_xyz[36]);
+int msm_bw6_761_g1(const uint64_t* bases_xy /* n*24 */, const uint8_t* inf, const uint64_t* scalars /* n*6 */, size_t n,
+                   uint64_t out_xyz[36]);
+int msm_bw6_761_g2(const uint64_t* bases_xy /* n*24 */, const uint8_t* inf, const uint64_t* scalars /* n*6 */, size_t n,
+                   uint64_t out_xyz[36]);
+int msm_bls12_377_g1_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[18], void* stream);
+int msm_bls12_377_g2_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
+int msm_bw6_761_g1_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
+int msm_bw6_761_g2_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
+
+/* ---- plain sums of k Jacobian points (host pointers, arkworks layout; host-side, for small k): the fold of per-GPU
+ * partial MSM results and small aggregates — Signature::aggregate / PublicKey::aggregate
+ * (crates/bls-crypto/src/bls/signature.rs:61-67, public.rs:38-44). */
+int celo_amd_sum_jacobian_bls12_377_g1(const uint64_t* jac /* k*18 */, size_t k, uint64_t out_xyz[18]);
+int celo_amd_sum_jacobian_bls12_377_g2(const uint64_t* jac /* k*36 */, size_t k, uint64_t out_xyz[36]);
+int celo_amd_sum_jacobian_bw6_761(const uint64_t* jac /* k*36 */, size_t k, uint64_t out_xyz[36]);
+
+/* ---- instrumentation (bench.py / tests).  group: 0 = bls12_377_g1, 1 = bls12_377_g2, 2 = bw6_761.
+ * ms[5] = {convert, sort, accumulate, reduce, total} of the last MSM on that engine, from HIP events recorded on the
+ * MSM's own stream; cfg[3] = {window bits c, windows, buckets}. */
+int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]);
+/* Forces the Pippenger window size (0 = automatic) — tuning and test hook. */
+int celo_amd_msm_set_window_bits(int group, int c);
+
+/* ---- synthetic-workload generators (bench / tests only): writes n affine points
+ * P_i = k_i * G into DEVICE memory in the arkworks layout, k_i = 64-bit splitmix64(seed, i) | 1.
+ * gen_xy: the generator G, affine, HOST pointer, arkworks layout. */
+int celo_amd_gen_points_bls12_377_g1_dev(void* d_out_xy, size_t n, uint64_t seed, const uint64_t* gen_xy, void* stream);
+int celo_amd_gen_points_bls12_377_g2_dev(void* d_out_xy, size_t n, uint64_t seed, const uint64_t* gen_xy, void* stream);
+int celo_amd_gen_points_bw6_761_dev(void* d_out_xy, size_t n, uint64_t seed, const uint64_t* gen_xy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,43 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports every symbol include/celo_bls_amd.h declares.
+No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "celo_bls_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(\w+)\s*\(", txt)))
+
+
+def test_header_declares_expected_entry_points():
+    from celo_bls_snark_rs_amd import ffi
+    decl = declared_symbols()
+    for name in ffi.EXPORTS:
+        assert name in decl, name
+
+
+def test_library_exports_every_declared_symbol():
+    from celo_bls_snark_rs_amd import ffi
+    if not os.path.exists(ffi.LIB_PATH):
+        pytest.fail(f"{ffi.LIB_PATH} missing — run __graft_entry__.build()")
+    lib = C.CDLL(ffi.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"missing export {name}"
+
+
+def test_no_device_fails_loudly():
+    """Without a GPU the product must refuse, not fall back to a CPU path."""
+    import numpy as np
+    import torch
+    from celo_bls_snark_rs_amd import ffi
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    xy = np.zeros((2, 12), dtype=np.uint64)
+    sc = np.ones((2, 4), dtype=np.uint64)
+    with pytest.raises(RuntimeError):
+        ffi.msm("bls12_377_g1", xy, None, sc)

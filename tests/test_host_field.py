@@ -1,0 +1,123 @@
+"""CPU (-m "not gpu"): the product's own field / curve templates (celo-bls-snark-rs_amd/csrc/{fp,fp2,curve}.h)
+compiled for the host with run-time bounds tracking (-DCELO_FP_TRACK asserts every lazy-reduction bound),
+checked against the Python oracle."""
+import ctypes as C
+import os
+import random
+import subprocess
+import numpy as np
+import pytest
+from oracle.py import ecc
+from oracle import cpu_oracle as co
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "celo-bls-snark-rs_amd", "csrc")
+LIB = os.path.join(ROOT, "celo-bls-snark-rs_amd", "build", "libcelo_hosttest.so")
+
+
+@pytest.fixture(scope="module")
+def ht():
+    if not os.path.exists(LIB):
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB,
+                               os.path.join(CSRC, "host_test.cpp")])
+    return C.CDLL(LIB)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("prime,fn,n64", [(ecc.Q377, "ht_fq377", 6), (ecc.Q761, "ht_fq761", 12)])
+def test_fp_ops(ht, prime, fn, n64):
+    random.seed(7)
+    f = getattr(ht, fn)
+
+    def op(o, a, b):
+        A = co.to_mont([a], prime).reshape(-1)
+        B = co.to_mont([b], prime).reshape(-1)
+        out = np.zeros(n64, dtype=np.uint64)
+        f(o, _p(A), _p(B), _p(out))
+        return co.from_mont(out, prime)[0]
+
+    cases = [(0, 0), (prime - 1, prime - 1), (1, prime - 1), (prime - 1, 1), (2, (prime + 1) // 2)]
+    cases += [(random.randrange(prime), random.randrange(prime)) for _ in range(150)]
+    for i, (a, b) in enumerate(cases):
+        assert op(0, a, b) == a * b % prime
+        assert op(1, a, b) == a * a % prime
+        assert op(2, a, b) == (a + b) % prime
+        assert op(3, a, b) == (a - b) % prime
+        assert op(5, a, b) == a
+        if i < 8 and a:
+            assert op(4, a, b) == pow(a, -1, prime)
+
+
+def test_fp2_ops(ht):
+    random.seed(8)
+    p, f2 = ecc.Q377, ecc.F2_377
+
+    def op(o, a, b):
+        A = co.to_mont(list(a), p).reshape(-1)
+        B = co.to_mont(list(b), p).reshape(-1)
+        out = np.zeros(12, dtype=np.uint64)
+        ht.ht_fq2_377(o, _p(A), _p(B), _p(out))
+        return tuple(co.from_mont(out, p))
+
+    cases = [((p - 1, p - 1), (p - 1, p - 1)), ((0, 1), (0, 1)), ((1, 0), (0, 0))]
+    cases += [((random.randrange(p), random.randrange(p)), (random.randrange(p), random.randrange(p))) for _ in range(150)]
+    for i, (a, b) in enumerate(cases):
+        assert op(0, a, b) == f2.mul(a, b)
+        assert op(1, a, b) == f2.sqr(a)
+        assert op(2, a, b) == f2.add(a, b)
+        assert op(3, a, b) == f2.sub(a, b)
+        if i < 6 and a != (0, 0):
+            assert op(4, a, b) == f2.inv(a)
+
+
+@pytest.mark.parametrize("kind", ["g1_377", "g2_377"])
+def test_point_ops(ht, kind):
+    cur, gen, fn, pack, nw = {
+        "g1_377": (ecc.E1_377, ecc.G1_377, ht.ht_g1_377, co.pack_g1_377, 18),
+        "g2_377": (ecc.E2_377, ecc.G2_377, ht.ht_g2_377, co.pack_g2_377, 36),
+    }[kind]
+
+    def op(o, P1, P2, k=0):
+        a, _ = pack([P1])
+        b, _ = pack([P2])
+        out = np.zeros(nw, dtype=np.uint64)
+        fn(o, _p(a), _p(b), C.c_uint32(k), _p(out))
+        return co.jac_to_affine(out, kind)
+
+    rng = ecc.SplitMix64(5)
+    for _ in range(4):
+        A = cur.mul(gen, rng.next())
+        B = cur.mul(gen, rng.next())
+        assert op(0, A, B) == cur.add(A, B)
+        assert op(1, A, B) == cur.add(A, A)
+        assert op(2, A, B) == cur.add(A, cur.add(cur.add(B, B), A))
+        k = rng.next() & 0xFFFF
+        assert op(3, A, B, k) == cur.mul(A, k)
+        assert op(4, A, B) is None                 # P + (-P): cancellation branch
+        assert op(5, A, B) == cur.add(A, A)        # madd hitting the doubling branch
+        assert op(6, A, B, 37) == cur.add(A, cur.mul(B, 37))
+        assert op(7, A, B) == cur.add(A, A)        # add-with-self
+
+
+def test_point_ops_bw6(ht, golden):
+    from oracle.py import epoch as ep
+    vk = ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))
+    A, B = vk["alpha_g1"], vk["gamma_abc_g1"][1]
+    cur = ecc.E1_761
+
+    def op(o, P1, P2, k=0):
+        a, _ = co.pack_761([P1])
+        b, _ = co.pack_761([P2])
+        out = np.zeros(36, dtype=np.uint64)
+        ht.ht_g_761(o, _p(a), _p(b), C.c_uint32(k), _p(out))
+        return co.jac_to_affine(out, "761")
+
+    assert op(0, A, B) == cur.add(A, B)
+    assert op(1, A, B) == cur.add(A, A)
+    assert op(3, A, B, 1000003) == cur.mul(A, 1000003)
+    assert op(4, A, B) is None
+    assert op(6, A, B, 9) == cur.add(A, cur.mul(B, 9))

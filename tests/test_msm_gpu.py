@@ -1,0 +1,185 @@
+"""GPU (-m gpu): MSM parity — the HIP pipeline through the C ABI vs the oracle on the same seeded inputs.
+
+Reference call sites: crates/bls-crypto/src/bls/signature.rs:85 (G1), public.rs:61 (G2),
+ark_groth16 prover MSMs via crates/epoch-snark/src/api/prover.rs:78.  Parity = equality of the affine-normalised
+group element (bit-exact; SURVEY.md §7 "Bit-exactness must be defined on canonical forms")."""
+import numpy as np
+import pytest
+import torch
+from oracle.py import ecc
+from oracle import cpu_oracle as co
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _affine(out, kind):
+    return co.jac_to_affine(out, kind)
+
+
+def _gen_points_gpu(gpu, group, n, seed, gen_xy_limbs, words_per_point):
+    t = torch.empty(n * words_per_point, dtype=torch.int64, device="cuda")
+    gpu.gen_points_dev(group, t.data_ptr(), n, seed, gen_xy_limbs)
+    torch.cuda.synchronize()
+    return t
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 256, 1024])
+def test_g1_small_vs_python(gpu, n):
+    """Small sizes incl. edge scalars (0, 1, r-1, 2^64, 136-bit), an infinity base and a repeated base;
+    expected value from the Python big-int definition (sum of scalar muls)."""
+    pts = H.seeded_points(ecc.E1_377, ecc.G1_377, n, 100 + n)
+    sc = H.seeded_scalars(n, 200 + n, ecc.R377)
+    if n >= 33:
+        pts[7] = None
+        pts[12] = pts[13]
+        sc[12] = sc[13]          # identical (point, scalar) pairs land in the same bucket: doubling branch
+        pts[20] = ecc.E1_377.neg(pts[21])
+        sc[20] = sc[21]          # P and -P with equal digits: cancellation branch
+    xy, inf = co.pack_g1_377(pts)
+    s = H.scalars_np(sc, 4)
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, inf, s, threads=4), "g1_377")
+    if n <= 256:
+        assert exp == ecc.E1_377.msm(pts, sc)
+    got = _affine(gpu.msm("bls12_377_g1", xy, inf, s), "g1_377")
+    assert got == exp
+
+
+def test_g1_empty_and_all_zero(gpu):
+    out = gpu.msm("bls12_377_g1", np.zeros((0, 12), dtype=np.uint64), None, np.zeros((0, 4), dtype=np.uint64))
+    assert _affine(out, "g1_377") is None
+    pts = H.seeded_points(ecc.E1_377, ecc.G1_377, 40, 5)
+    xy, inf = co.pack_g1_377(pts)
+    out = gpu.msm("bls12_377_g1", xy, inf, np.zeros((40, 4), dtype=np.uint64))
+    assert _affine(out, "g1_377") is None
+    # all scalars 1 == plain aggregate (Signature::aggregate, crates/bls-crypto/src/bls/signature.rs:61-67)
+    ones = np.zeros((40, 4), dtype=np.uint64)
+    ones[:, 0] = 1
+    agg = None
+    for P in pts:
+        agg = ecc.E1_377.add(agg, P)
+    assert _affine(gpu.msm("bls12_377_g1", xy, inf, ones), "g1_377") == agg
+
+
+def test_g1_skewed_scalars(gpu):
+    """Bucket skew: every scalar equal (one bucket per window gets all points) and witness-like 0/1-heavy scalars."""
+    n = 512
+    pts = H.seeded_points(ecc.E1_377, ecc.G1_377, n, 77)
+    xy, inf = co.pack_g1_377(pts)
+    k = 0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789AB % ecc.R377
+    s = H.scalars_np([k] * n, 4)
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, inf, s, threads=4), "g1_377")
+    assert _affine(gpu.msm("bls12_377_g1", xy, inf, s), "g1_377") == exp
+    rng = ecc.SplitMix64(9)
+    sc = [(0 if (rng.next() % 10) < 4 else 1 if (rng.next() % 10) < 5 else ecc.random_scalar(rng, ecc.R377)) for _ in range(n)]
+    s = H.scalars_np(sc, 4)
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, inf, s, threads=4), "g1_377")
+    assert _affine(gpu.msm("bls12_377_g1", xy, inf, s), "g1_377") == exp
+
+
+@pytest.mark.parametrize("c", [4, 7, 11, 13, 16])
+def test_g1_window_sizes(gpu, c):
+    n = 700
+    pts = H.seeded_points(ecc.E1_377, ecc.G1_377, n, 31)
+    sc = H.seeded_scalars(n, 32, ecc.R377)
+    xy, inf = co.pack_g1_377(pts)
+    s = H.scalars_np(sc, 4)
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, inf, s, threads=4), "g1_377")
+    gpu.set_window_bits("bls12_377_g1", c)
+    try:
+        assert _affine(gpu.msm("bls12_377_g1", xy, inf, s), "g1_377") == exp
+        assert gpu.msm_timings("bls12_377_g1")["window_bits"] == c
+    finally:
+        gpu.set_window_bits("bls12_377_g1", 0)
+
+
+@pytest.mark.parametrize("logn", [14, 17, 20])
+def test_g1_large_device_resident(gpu, logn):
+    """BASELINE config 2 shape: bases generated on the device (P_i = k_i*G), uniform scalars < r, inputs resident in
+    HBM; the C++ oracle (arkworks Pippenger restatement, all host threads) runs on the same buffers.  Also checks the
+    generator kernel against the oracle on a sample and the linearity property MSM(2s) == 2*MSM(s)."""
+    n = 1 << logn
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    bases = _gen_points_gpu(gpu, "bls12_377_g1", n, 0x5EED0002, gen.reshape(-1), 12)
+    rng = np.random.default_rng(0x5EED0001)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    sc ^= rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)   # < 2^252 < r: uniform 252-bit scalars
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = gpu.msm_dev("bls12_377_g1", bases.data_ptr(), 0, d_sc.data_ptr(), n)
+    h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 12)
+    # sample-check the generated bases: P_i = (splitmix64(seed, i) | 1) * G
+    for i in (0, 1, n // 2, n - 1):
+        k = H.splitmix64_at(0x5EED0002, i) | 1
+        exp_pt = ecc.E1_377.mul(ecc.G1_377, k)
+        got_pt = tuple(co.from_mont(h_bases[i].reshape(2, 6), ecc.Q377))
+        assert got_pt == exp_pt
+    threads = max(1, min(32, co.lib().orc_hardware_threads()))
+    exp = co.msm("bls12_377_g1", h_bases, None, sc, threads=threads)
+    assert _affine(out, "g1_377") == co.jac_to_affine(exp, "g1_377")
+    if logn <= 17:
+        sc2 = sc.copy()
+        sc2[:, 3] &= np.uint64((1 << 59) - 1)
+        d2 = torch.from_numpy(sc2.view(np.int64)).cuda()
+        a = _affine(gpu.msm_dev("bls12_377_g1", bases.data_ptr(), 0, d2.data_ptr(), n), "g1_377")
+        # doubled scalars: shift left by one bit
+        carry = (sc2 >> np.uint64(63))
+        sc2d = (sc2 << np.uint64(1))
+        sc2d[:, 1:] |= carry[:, :-1]
+        d3 = torch.from_numpy(sc2d.view(np.int64)).cuda()
+        b = _affine(gpu.msm_dev("bls12_377_g1", bases.data_ptr(), 0, d3.data_ptr(), n), "g1_377")
+        assert b == ecc.E1_377.add(a, a)
+
+
+@pytest.mark.parametrize("n", [1, 33, 300])
+def test_g2_vs_oracle(gpu, n):
+    pts = H.seeded_points(ecc.E2_377, ecc.G2_377, n, 300 + n)
+    sc = H.seeded_scalars(n, 400 + n, ecc.R377)
+    if n >= 33:
+        pts[3] = None
+        pts[8] = pts[9]
+        sc[8] = sc[9]
+    xy, inf = co.pack_g2_377(pts)
+    s = H.scalars_np(sc, 4)
+    exp = co.jac_to_affine(co.msm("bls12_377_g2", xy, inf, s, threads=4), "g2_377")
+    assert _affine(gpu.msm("bls12_377_g2", xy, inf, s), "g2_377") == exp
+
+
+def test_g2_large_device_resident(gpu):
+    n = 1 << 14
+    gen, _ = co.pack_g2_377([ecc.G2_377])
+    bases = _gen_points_gpu(gpu, "bls12_377_g2", n, 0x5EED0003, gen.reshape(-1), 24)
+    rng = np.random.default_rng(5)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = gpu.msm_dev("bls12_377_g2", bases.data_ptr(), 0, d_sc.data_ptr(), n)
+    h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 24)
+    k = H.splitmix64_at(0x5EED0003, 5) | 1
+    v = co.from_mont(h_bases[5].reshape(4, 6), ecc.Q377)
+    assert ((v[0], v[1]), (v[2], v[3])) == ecc.E2_377.mul(ecc.G2_377, k)
+    exp = co.msm("bls12_377_g2", h_bases, None, sc, threads=max(1, min(32, co.lib().orc_hardware_threads())))
+    assert _affine(out, "g2_377") == co.jac_to_affine(exp, "g2_377")
+
+
+@pytest.mark.parametrize("n", [1, 40, 2048])
+def test_bw6_761_vs_oracle(gpu, golden, n):
+    """BASELINE config 4 shape (Groth16 prover MSM over BW6-761 G1/G2) at oracle-checkable sizes; base points derived
+    from the reference's Groth16 verifying key (the only BW6-761 points in the tree)."""
+    from oracle.py import epoch as ep
+    vk = ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))
+    for grp, G, cur in (("bw6_761_g1", vk["alpha_g1"], ecc.E1_761), ("bw6_761_g2", vk["beta_g2"], ecc.E2_761)):
+        if n <= 40:
+            rng = ecc.SplitMix64(n)
+            pts = [cur.mul(G, rng.next() | 1) for _ in range(n)]
+            if n == 40:
+                pts[3] = None
+            xy, inf = co.pack_761(pts)
+        else:
+            gen, _ = co.pack_761([G])
+            t = _gen_points_gpu(gpu, grp, n, 0x5EED0004, gen.reshape(-1), 24)
+            xy, inf = t.cpu().numpy().view(np.uint64).reshape(n, 24), None
+        sc = H.seeded_scalars(n, 500 + n, ecc.R761)
+        s = H.scalars_np(sc, 6)
+        exp = co.jac_to_affine(co.msm(grp, xy, inf, s, threads=8), "761")
+        assert _affine(gpu.msm(grp, xy, inf, s), "761") == exp

@@ -1,0 +1,163 @@
+"""CPU (-m "not gpu"): pins the oracle on the reference's own golden vectors and
+cross-checks its three layers (Python big-int  <->  C++ arkworks-style restatement)."""
+import numpy as np
+import pytest
+from oracle.py import ecc, pairing as pp, epoch as ep
+from oracle import cpu_oracle as co
+from tests import helpers as H
+
+
+def test_constants_and_generators():
+    assert ecc.E1_377.on_curve(ecc.G1_377) and ecc.E1_377.mul(ecc.G1_377, ecc.R377) is None
+    assert ecc.E2_377.on_curve(ecc.G2_377) and ecc.E2_377.mul(ecc.G2_377, ecc.R377) is None
+
+
+@pytest.mark.parametrize("key", ["g1_compat", "g1_compat_cip22", "g1_noncompat", "g2_noncompat"])
+def test_reference_hash_vectors_decode(golden, key):
+    """crates/bls-crypto/src/hash_to_curve/mod.rs:412-513: every expected hash is a valid compressed
+    point of the r-torsion and re-encodes to the same bytes (pins moduli, curve b, twist b', sqrt, sign flag)."""
+    cur = ecc.E2_377 if key.startswith("g2") else ecc.E1_377
+    for hx in golden["hash_to_curve"][key]["points"]:
+        b = bytes.fromhex(hx)
+        P = ecc.deser_point(cur, b)
+        assert cur.in_subgroup(P)
+        assert ecc.ser_point(cur, P) == b
+
+
+def test_reference_epoch_encodings(golden):
+    """crates/epoch-snark/src/epoch_block.rs:243-320 (pins the G2 generator and the y-sign convention)."""
+    e = golden["epoch_encoding"]
+    pk10 = [ecc.G2_377] * 10
+    f, g = bytes([255] * 16), bytes([254] * 16)
+    assert ep.EpochBlock(120, 5, f, g, 3, 10, pk10).encode_first_epoch_to_bytes_cip22().hex() == e["EXPECTED_ENCODING_WITH_ENTROPY"]
+    assert ep.EpochBlock(120, 5, None, None, 3, 10, pk10).encode_first_epoch_to_bytes_cip22().hex() == e["EXPECTED_ENCODING_WITHOUT_ENTROPY"]
+    assert ep.EpochBlock(120, 10, None, None, 3, 10, pk10).encode_to_bytes().hex() == e["EXPECTED_ENCODING_BEFORE_DONUT"]
+    assert ep.EpochBlock(120, 5, f, g, 3, 11, pk10).encode_first_epoch_to_bytes_cip22().hex() == e["EXPECTED_ENCODING_WITH_ENTROPY_PADDED"]
+
+
+def _groth16_setup(golden):
+    g = golden["groth16_bw6_761"]
+    vk = ep.parse_vk(bytes.fromhex(g["vk"]))
+    pr = ep.parse_proof(bytes.fromhex(g["proof"]))
+
+    def pks(hx):
+        b = bytes.fromhex(hx)
+        return [ecc.deser_point(ecc.E2_377, b[96 * i:96 * i + 96]) for i in range(len(b) // 96)]
+
+    first = ep.EpochBlock(g["first"]["index"], g["first"]["round"], bytes.fromhex(g["first_epoch_entropy"]),
+                          bytes.fromhex(g["first_parent_entropy"]), g["first"]["maximum_non_signers"],
+                          g["first"]["maximum_validators"], pks(g["first_pubkeys"]))
+    last = ep.EpochBlock(g["last"]["index"], g["last"]["round"], bytes.fromhex(g["last_epoch_entropy"]),
+                         bytes.fromhex(g["last_parent_entropy"]), g["last"]["maximum_non_signers"],
+                         g["last"]["maximum_validators"], pks(g["last_pubkeys"]))
+    inputs = ep.pack(ep.hash_first_last_epoch_block(first, last))
+    return vk, pr, inputs
+
+
+def test_reference_groth16_vector_accepts(golden):
+    """crates/bls-snark-sys/src/snark/mod.rs:52-119 — the only end-to-end pairing known-answer vector:
+    the C++ BW6-761 pairing restatement must ACCEPT it and REJECT any tampering."""
+    vk, pr, inputs = _groth16_setup(golden)
+    for P in [vk["alpha_g1"], pr["a"], pr["c"]] + vk["gamma_abc_g1"]:
+        assert ecc.E1_761.in_subgroup(P)
+    for P in [vk["beta_g2"], vk["gamma_g2"], vk["delta_g2"], pr["b"]]:
+        assert ecc.E2_761.in_subgroup(P)
+    pairs = ep.groth16_pairs(vk, pr, inputs)
+    g1, i1 = co.pack_761([p for p, _ in pairs])
+    g2, i2 = co.pack_761([q for _, q in pairs])
+    _, ok = co.pairing_product_761(g1, i1, g2, i2)
+    assert ok
+    bad = ep.groth16_pairs(vk, pr, [inputs[0] ^ 1, inputs[1]])
+    g1b, _ = co.pack_761([p for p, _ in bad])
+    _, ok = co.pairing_product_761(g1b, i1, g2, i2)
+    assert not ok
+    bad_pr = dict(pr, c=ecc.E1_761.add(pr["c"], pr["c"]))
+    pairs = ep.groth16_pairs(vk, bad_pr, inputs)
+    g1c, _ = co.pack_761([p for p, _ in pairs])
+    _, ok = co.pairing_product_761(g1c, i1, g2, i2)
+    assert not ok
+
+
+def test_cpp_bw6_pairing_value_vs_python_textbook(golden):
+    """C++ optimal-ate value == (Python flat-field optimal ate)^k, k = (R0(x)+q R1(x)) / ((q^2-q+1)/r)."""
+    vk, _, _ = _groth16_setup(golden)
+    P, Q = vk["alpha_g1"], vk["beta_g2"]
+    x, q, r = ecc.X, ecc.Q761, ecc.R761
+    f1 = pp.miller_loop_761(P, Q, loop=x + 1)
+    f2 = pp.miller_loop_761(P, Q, loop=x ** 3 - x ** 2 - x)
+    F = pp.F6_761
+    f = F.mul(f1, F.frob(f2, 1))
+    tb = F.pow(f, (q ** 6 - 1) // r)
+    R0 = -103 * x**7 + 70 * x**6 + 269 * x**5 - 197 * x**4 - 314 * x**3 - 73 * x**2 - 263 * x - 220
+    R1 = 103 * x**9 - 276 * x**8 + 77 * x**7 + 492 * x**6 - 445 * x**5 - 65 * x**4 + 452 * x**3 - 181 * x**2 + 34 * x + 229
+    h = (q * q - q + 1) // r
+    assert (R0 + q * R1) % h == 0
+    k = (R0 + q * R1) // h
+    g1, i1 = co.pack_761([P])
+    g2, i2 = co.pack_761([Q])
+    gt, one = co.pairing_product_761(g1, i1, g2, i2)
+    assert not one
+    assert co.gt761_to_flat(gt) == F.pow(tb, k)
+
+
+def test_cpp_msm_matches_definition():
+    """Pippenger restatement == naive sum of scalar muls == Python, with edge scalars,
+    an infinity base and a repeated base; 1 and several threads."""
+    n = 70
+    pts = H.seeded_points(ecc.E1_377, ecc.G1_377, n, 11)
+    pts[9] = None
+    pts[10] = pts[11]
+    sc = H.seeded_scalars(n, 12, ecc.R377)
+    exp = ecc.E1_377.msm(pts, sc)
+    xy, inf = co.pack_g1_377(pts)
+    s = H.scalars_np(sc, 4)
+    for naive in (False, True):
+        for th in (1, 3):
+            assert co.jac_to_affine(co.msm("bls12_377_g1", xy, inf, s, threads=th, naive=naive), "g1_377") == exp
+    pts2 = H.seeded_points(ecc.E2_377, ecc.G2_377, 33, 13)
+    sc2 = H.seeded_scalars(33, 14, ecc.R377)
+    xy2, inf2 = co.pack_g2_377(pts2)
+    assert co.jac_to_affine(co.msm("bls12_377_g2", xy2, inf2, H.scalars_np(sc2, 4), threads=2), "g2_377") == ecc.E2_377.msm(pts2, sc2)
+
+
+def test_cpp_msm_bw6(golden):
+    vk, pr, _ = _groth16_setup(golden)
+    base_pts = [vk["alpha_g1"], pr["a"], pr["c"]] + vk["gamma_abc_g1"]
+    rng = ecc.SplitMix64(3)
+    pts = [ecc.E1_761.mul(base_pts[i % len(base_pts)], rng.next() | 1) for i in range(20)]
+    sc = H.seeded_scalars(20, 15, ecc.R761)
+    xy, inf = co.pack_761(pts)
+    got = co.jac_to_affine(co.msm("bw6_761_g1", xy, inf, H.scalars_np(sc, 6), threads=2), "761")
+    assert got == ecc.E1_761.msm(pts, sc)
+
+
+def test_cpp_bls12_pairing_is_cube_of_textbook():
+    """arkworks' BLS12 final exponentiation returns the cube of the reduced pairing."""
+    rng = ecc.SplitMix64(21)
+    P = ecc.E1_377.mul(ecc.G1_377, rng.next())
+    Q = ecc.E2_377.mul(ecc.G2_377, rng.next())
+    g1, i1 = co.pack_g1_377([P])
+    g2, i2 = co.pack_g2_377([Q])
+    gt, _ = co.pairing_product_377(g1, i1, g2, i2)
+    tb = pp.pairing_377(P, Q)
+    assert co.gt377_to_flat(gt) == pp.F12_377.pow(tb, 3)
+    # miller loop then final exp separately == product_of_pairings
+    ml = co.miller_loop_377(g1, i1, g2, i2)
+    assert np.array_equal(co.final_exp_377(ml), gt)
+
+
+def test_cpp_pairing_product_accept_reject():
+    """sign -> verify shape of crates/bls-crypto/src/bls/public.rs:94-120: e(sig,-g2) * e(H,pk) == 1."""
+    sk, h = 0x1234567890ABCDEF1234, 0xCAFEBABE
+    Hm = ecc.E1_377.mul(ecc.G1_377, h)
+    sig = ecc.E1_377.mul(Hm, sk)
+    pk = ecc.E2_377.mul(ecc.G2_377, sk)
+    g1, i1 = co.pack_g1_377([sig, Hm])
+    g2, i2 = co.pack_g2_377([ecc.E2_377.neg(ecc.G2_377), pk])
+    assert co.pairing_product_377(g1, i1, g2, i2)[1]
+    g2b, _ = co.pack_g2_377([ecc.E2_377.neg(ecc.G2_377), ecc.E2_377.mul(ecc.G2_377, sk + 1)])
+    assert not co.pairing_product_377(g1, i1, g2b, i2)[1]
+    # pairs with a point at infinity are skipped (ark-ec bls12 miller_loop)
+    g1c, i1c = co.pack_g1_377([sig, Hm, None])
+    g2c, i2c = co.pack_g2_377([ecc.E2_377.neg(ecc.G2_377), pk, pk])
+    assert co.pairing_product_377(g1c, i1c, g2c, i2c)[1]

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of bases per GPU (default 2^20 = BASELINE config)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--balanced", action="store_true", help="diagnostic: scalars whose digits fill every bucket equally (not the headline workload)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -65,6 +66,12 @@ def main():
     sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
     sc ^= rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) << np.uint64(1)
     sc[:, 3] &= np.uint64((1 << 60) - 1)      # uniform 252-bit scalars, all < r
+    if args.balanced:
+        i = np.arange(n, dtype=np.uint64)
+        sc = np.zeros((n, 4), dtype=np.uint64)
+        for w in range(16):
+            d = ((i * np.uint64(2 * w + 1) + np.uint64(977 * w)) % np.uint64(32768)) + np.uint64(1)
+            sc[:, w // 4] |= d << np.uint64(16 * (w % 4))
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
     torch.cuda.synchronize()
 

@@ -158,15 +158,59 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
   }
 }
 
+// ---- longest-first bucket schedule.  Bucket sizes are far from uniform (the top window of a 253-bit scalar
+// only has ~12 significant bits: 4096 buckets of n/4096 points; skewed inputs are worse), and a wave runs as long as
+// its largest bucket.  A counting sort of the buckets by size (descending, sizes clamped to SIZE_BINS-1) makes the
+// lanes of a wave near-equal and puts the big buckets first so no long tail is left at the end of the launch.
+constexpr uint32_t SIZE_BINS = 2048;
+template <class G>
+__global__ void __launch_bounds__(256) k_size_hist(const uint32_t* __restrict__ counts, uint32_t* __restrict__ bins, uint32_t total) {
+  __shared__ uint32_t lh[SIZE_BINS];
+  for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 256) lh[i] = 0;
+  __syncthreads();
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    uint32_t c = counts[t];
+    uint32_t b = SIZE_BINS - 1 - (c < SIZE_BINS ? c : SIZE_BINS - 1);  // descending size
+    atomicAdd(&lh[b], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 256)
+    if (lh[i]) atomicAdd(&bins[i], lh[i]);
+}
+template <class G>
+__global__ void __launch_bounds__(1024) k_size_scan(uint32_t* __restrict__ bins) {  // in-place exclusive scan of SIZE_BINS counters
+  __shared__ uint32_t tmp[SIZE_BINS];
+  for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 1024) tmp[i] = bins[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (uint32_t i = 0; i < SIZE_BINS; i++) { uint32_t v = tmp[i]; tmp[i] = run; run += v; }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 1024) bins[i] = tmp[i];
+}
+template <class G>
+__global__ void __launch_bounds__(256) k_size_scatter(const uint32_t* __restrict__ counts, uint32_t* __restrict__ bins,
+                                                      uint32_t* __restrict__ order, uint32_t total) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  uint32_t c = counts[t];
+  uint32_t b = SIZE_BINS - 1 - (c < SIZE_BINS ? c : SIZE_BINS - 1);
+  uint32_t pos = atomicAdd(&bins[b], 1u);
+  order[pos] = t;
+}
+
 // one lane per bucket: XYZZ sum of its run of (signed) points
 template <class G>
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends,
-                                                    uint32_t* __restrict__ buckets, uint32_t B, uint32_t total, uint32_t n) {
+                                                    const uint32_t* __restrict__ order, uint32_t* __restrict__ buckets,
+                                                    uint32_t B, uint32_t total, uint32_t n) {
   typedef typename G::F F;
   typedef PointIO<F> IO;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= total) return;
+  uint32_t t = order[tid];
   uint32_t w = t / B;
   const uint32_t* run = sorted + (size_t)w * n;
   uint32_t s = starts[t], e = ends[t];
@@ -244,9 +288,9 @@ template <class G> class MsmEngine {
   ~MsmEngine() { release(); }
   void release() {
     for (void* p : {(void*)d_bases, (void*)d_sorted, (void*)d_counts, (void*)d_starts, (void*)d_cursors, (void*)d_buckets,
-                    (void*)d_tmpA, (void*)d_tmpB, (void*)d_in_bases, (void*)d_in_scalars, (void*)d_in_inf})
+                    (void*)d_tmpA, (void*)d_tmpB, (void*)d_order, (void*)d_bins, (void*)d_in_bases, (void*)d_in_scalars, (void*)d_in_inf})
       if (p) (void)hipFree(p);
-    d_bases = d_sorted = d_counts = d_starts = d_cursors = d_buckets = d_tmpA = d_tmpB = nullptr;
+    d_bases = d_sorted = d_counts = d_starts = d_cursors = d_buckets = d_tmpA = d_tmpB = d_order = d_bins = nullptr;
     d_in_bases = nullptr; d_in_scalars = nullptr; d_in_inf = nullptr;
     if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; }
     for (int i = 0; i < 6; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
@@ -279,9 +323,13 @@ template <class G> class MsmEngine {
     if (launch_digits(0, c, d_scalars, d_inf, d_counts, nullptr, (uint32_t)n, stream)) return 3;
     hipLaunchKernelGGL((k_scan<G>), dim3(nw), dim3(1024), 0, stream, d_counts, d_starts, d_cursors, B);
     if (launch_digits(1, c, d_scalars, d_inf, d_cursors, d_sorted, (uint32_t)n, stream)) return 3;
+    HIP_OK(hipMemsetAsync(d_bins, 0, SIZE_BINS * 4, stream));
+    hipLaunchKernelGGL((k_size_hist<G>), dim3(total / 256 < 512 ? (total + 255) / 256 : 512), dim3(256), 0, stream, d_counts, d_bins, total);
+    hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins);
+    hipLaunchKernelGGL((k_size_scatter<G>), dim3((total + 255) / 256), dim3(256), 0, stream, d_counts, d_bins, d_order, total);
     HIP_OK(hipEventRecord(ev[2], stream));
     hipLaunchKernelGGL((k_accumulate<G>), dim3((total + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_starts, d_cursors,
-                       d_buckets, B, total, (uint32_t)n);
+                       d_order, d_buckets, B, total, (uint32_t)n);
     HIP_OK(hipEventRecord(ev[3], stream));
     // bucket reduction
     uint32_t CH = B >= 16 ? 16 : B;
@@ -367,7 +415,7 @@ template <class G> class MsmEngine {
 
  private:
   uint32_t *d_bases = nullptr, *d_sorted = nullptr, *d_counts = nullptr, *d_starts = nullptr, *d_cursors = nullptr;
-  uint32_t *d_buckets = nullptr, *d_tmpA = nullptr, *d_tmpB = nullptr;
+  uint32_t *d_buckets = nullptr, *d_tmpA = nullptr, *d_tmpB = nullptr, *d_order = nullptr, *d_bins = nullptr;
   uint64_t* d_in_bases = nullptr;
   uint64_t* d_in_scalars = nullptr;
   uint8_t* d_in_inf = nullptr;
@@ -380,6 +428,7 @@ template <class G> class MsmEngine {
     if (!ev[0])
       for (int i = 0; i < 6; i++) HIP_OK(hipEventCreate(&ev[i]));
     if (!h_out) HIP_OK(hipHostMalloc(&h_out, (size_t)4 * 128 * IO::XYZZ_WORDS * 4));
+    if (!d_bins) HIP_OK(hipMalloc(&d_bins, SIZE_BINS * 4));
     int c = force_c ? force_c : window_bits(n);
     size_t nw = (G::SCALAR_BITS + c) / c;
     if (n > cap_n) {
@@ -395,9 +444,10 @@ template <class G> class MsmEngine {
       cap_sorted = n * nw;
     }
     if (total > cap_total) {
-      for (void* p : {(void*)d_counts, (void*)d_starts, (void*)d_cursors, (void*)d_buckets, (void*)d_tmpA, (void*)d_tmpB})
+      for (void* p : {(void*)d_counts, (void*)d_starts, (void*)d_cursors, (void*)d_buckets, (void*)d_tmpA, (void*)d_tmpB, (void*)d_order})
         if (p) (void)hipFree(p);
-      d_counts = d_starts = d_cursors = d_buckets = d_tmpA = d_tmpB = nullptr; cap_total = 0;
+      d_counts = d_starts = d_cursors = d_buckets = d_tmpA = d_tmpB = d_order = nullptr; cap_total = 0;
+      HIP_OK(hipMalloc(&d_order, (size_t)total * 4));
       HIP_OK(hipMalloc(&d_counts, (size_t)total * 4));
       HIP_OK(hipMalloc(&d_starts, (size_t)total * 4));
       HIP_OK(hipMalloc(&d_cursors, (size_t)total * 4));

@@ -9,13 +9,18 @@
 // GPU pipeline (all on one HIP stream, no host sync until the window sums come back):
 //   1 k_convert_bases   ark Montgomery (2^384 / 2^768 radix, 64-bit limbs) -> 28-bit-limb device form,
 //                       128 B (G1-377) / 256 B per affine point, coalesced in, 16-B vector stores out
-//   2 k_digits<count>   signed c-bit digits per scalar; per-(window,bucket) histogram (global atomics)
-//   3 k_scan            exclusive prefix sum per window (one workgroup per window, LDS + wave scans)
-//   4 k_digits<scatter> counting-sort scatter of (point index | sign) into per-bucket runs
-//   5 k_accumulate      one lane per bucket: gathers its run of points, XYZZ mixed adds
-//   6 k_reduce_chunks   running-sum over CH consecutive buckets per lane -> (sum, weighted sum)
-//   7 k_fixup / k_tree  weighted fix-up by small scalar, then 8-ary tree sums down to <=4 points/window
-//   8 host              <=4*NW XYZZ points: Horner over windows (c doublings each) -> Jacobian, ark form
+//   2 k_digits          signed c-bit digits per scalar, stored once as u16 per (window, scalar)
+//     k_count           LDS-staged counting sort, pass 1: one workgroup per (chunk, window) histograms its digits in LDS
+//     k_bucket_totals   (up to 2^15 counters = 128 KB of the CU's 160 KB LDS), no global atomics
+//     k_scan            exclusive prefix sums per window (wave shuffles + LDS)
+//     k_scatter         pass 2: LDS cursors, (point index | sign) written into per-bucket runs
+//   3 k_make_pieces     runs are cut into pieces of <= SEG points; counting sort of the pieces by length -> longest-first
+//     k_size_*          schedule, lanes of a wave get equal-length pieces
+//   4 k_accumulate      one lane per piece: gathers its points (128 B each), XYZZ mixed adds      <- dominant kernel
+//   5 k_combine_big     (skewed inputs only) folds buckets that were cut into many pieces
+//     k_reduce_chunks   running-sum over CH consecutive buckets per lane -> (sum, weighted sum)
+//     k_fixup / k_tree  weighted fix-up by small scalar, then 8-ary tree sums down to <=4 points/window
+//   6 host              <=4*NW XYZZ points: Horner over windows (c doublings each) -> Jacobian, ark form
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -81,13 +86,12 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint64_t* __restric
   IO::store_affine(dev + i * IO::AFF_WORDS, a);
 }
 
-// signed-digit recoding; MODE 0 = histogram, MODE 1 = scatter
-template <int SW, int CB, int NW, int MODE>
+// ---- 2a. signed-digit recoding, once per MSM: digits[w*n + i] (u16): 0xFFFF = zero digit, else (|d|-1) | (d<0)<<15.
+template <int SW, int CB, int NW>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
-                                                uint32_t* __restrict__ counters, uint32_t* __restrict__ sorted, uint32_t n) {
+                                                uint16_t* __restrict__ digits, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (inf && inf[i]) return;
   uint32_t s[SW + 1];
   const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * SW);
 #pragma unroll
@@ -96,11 +100,11 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
     s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w;
   }
   s[SW] = 0;
+  const bool skip = inf && inf[i];
   constexpr uint32_t B = 1u << (CB - 1);
   uint32_t carry = 0;
 #pragma unroll
   for (int w = 0; w < NW; w++) {
-    constexpr int dummy = 0; (void)dummy;
     const int bit = w * CB;
     const int wi = bit >> 5, off = bit & 31;
     uint32_t raw = 0;
@@ -112,130 +116,270 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
     uint32_t neg = d > B ? 1u : 0u;
     uint32_t mag = neg ? ((1u << CB) - d) : d;
     carry = neg;
-    if (mag != 0) {
-      uint32_t slot = (uint32_t)w * B + (mag - 1);
-      if (MODE == 0) {
-        atomicAdd(&counters[slot], 1u);
-      } else {
-        uint32_t pos = atomicAdd(&counters[slot], 1u);
-        sorted[(size_t)w * n + pos] = i | (neg << 31);
-      }
-    }
+    digits[(size_t)w * n + i] = (mag == 0 || skip) ? (uint16_t)0xFFFF : (uint16_t)((mag - 1) | (neg << 15));
   }
 }
 
-// exclusive scan of B counters per window; one 1024-thread workgroup per window.
-// counts[] -> starts[] (exclusive prefix) and cursors[] (= starts, consumed by the scatter pass)
+// ---- 2b. per-workgroup LDS histogram: block (j, w) counts chunk j of window w; no global atomics.
+template <class G>
+__global__ void __launch_bounds__(1024) k_count(const uint16_t* __restrict__ digits, uint32_t* __restrict__ blockcnt, uint32_t n,
+                                                uint32_t B, uint32_t chunk) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t j = blockIdx.x, w = blockIdx.y, KB = gridDim.x;
+  for (uint32_t b = threadIdx.x; b < B; b += 1024) lds[b] = 0;
+  __syncthreads();
+  const uint32_t lo = j * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+  const uint16_t* dg = digits + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    uint32_t d = dg[i];
+    if (d != 0xFFFFu) atomicAdd(&lds[d & 0x7FFFu], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = blockcnt + ((size_t)w * KB + j) * B;
+  for (uint32_t b = threadIdx.x; b < B; b += 1024) out[b] = lds[b];
+}
+
+// ---- 2c. per bucket: exclusive prefix of the per-block counts over the blocks (in place) and the bucket total
+template <class G>
+__global__ void __launch_bounds__(256) k_bucket_totals(uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ counts, uint32_t B,
+                                                       uint32_t KB, uint32_t total) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  uint32_t w = t / B, b = t - w * B;
+  uint32_t run = 0;
+  for (uint32_t j = 0; j < KB; j++) {
+    size_t idx = ((size_t)w * KB + j) * B + b;
+    uint32_t v = blockcnt[idx];
+    blockcnt[idx] = run;
+    run += v;
+  }
+  counts[t] = run;
+}
+
+// ---- 2d. exclusive scan per window (one 1024-thread workgroup per window, wave scans + LDS) of the bucket counts
+// (-> starts) and of the piece counts ceil(count/SEG) (-> pfirst, offset by the window's static piece region w*PW).
 template <class G>
 __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
-                                               uint32_t* __restrict__ cursors, uint32_t B) {
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t running;
+                                               uint32_t* __restrict__ pfirst, uint32_t B, uint32_t SEG, uint32_t PW) {
+  __shared__ uint32_t wave_tot[16], wave_tot2[16];
+  __shared__ uint32_t running, running2;
   const uint32_t* c = counts + (size_t)blockIdx.x * B;
   uint32_t* st = starts + (size_t)blockIdx.x * B;
-  uint32_t* cu = cursors + (size_t)blockIdx.x * B;
-  if (threadIdx.x == 0) running = 0;
+  uint32_t* pf = pfirst + (size_t)blockIdx.x * B;
+  if (threadIdx.x == 0) { running = 0; running2 = blockIdx.x * PW; }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (uint32_t base = 0; base < B; base += 1024) {
     uint32_t idx = base + threadIdx.x;
     uint32_t v = idx < B ? c[idx] : 0;
-    uint32_t x = v;  // inclusive wave scan
+    uint32_t p = idx < B ? (v + SEG - 1) / SEG : 0;
+    uint32_t x = v, y = p;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      uint32_t y = __shfl_up(x, o, 64);
-      if (lane >= o) x += y;
+      uint32_t x2 = __shfl_up(x, o, 64), y2 = __shfl_up(y, o, 64);
+      if (lane >= o) { x += x2; y += y2; }
     }
-    if (lane == 63) wave_tot[wv] = x;
+    if (lane == 63) { wave_tot[wv] = x; wave_tot2[wv] = y; }
     __syncthreads();
-    uint32_t pre = running;
-    for (int k = 0; k < wv; k++) pre += wave_tot[k];
-    uint32_t excl = pre + x - v;
-    if (idx < B) { st[idx] = excl; cu[idx] = excl; }
+    uint32_t pre = running, pre2 = running2;
+    for (int k = 0; k < wv; k++) { pre += wave_tot[k]; pre2 += wave_tot2[k]; }
+    if (idx < B) { st[idx] = pre + x - v; pf[idx] = pre2 + y - p; }
     __syncthreads();
-    if (threadIdx.x == 1023) running = pre + x;
+    if (threadIdx.x == 1023) { running = pre + x; running2 = pre2 + y; }
     __syncthreads();
   }
 }
 
-// ---- longest-first bucket schedule.  Bucket sizes are far from uniform (the top window of a 253-bit scalar
-// only has ~12 significant bits: 4096 buckets of n/4096 points; skewed inputs are worse), and a wave runs as long as
-// its largest bucket.  A counting sort of the buckets by size (descending, sizes clamped to SIZE_BINS-1) makes the
-// lanes of a wave near-equal and puts the big buckets first so no long tail is left at the end of the launch.
-constexpr uint32_t SIZE_BINS = 2048;
+// ---- 2e. scatter: block (j, w) owns LDS cursors = bucket start + this block's prefix; positions by LDS atomics
 template <class G>
-__global__ void __launch_bounds__(256) k_size_hist(const uint32_t* __restrict__ counts, uint32_t* __restrict__ bins, uint32_t total) {
+__global__ void __launch_bounds__(1024) k_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ blockcnt,
+                                                  const uint32_t* __restrict__ starts, uint32_t* __restrict__ sorted, uint32_t n,
+                                                  uint32_t B, uint32_t chunk) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t j = blockIdx.x, w = blockIdx.y, KB = gridDim.x;
+  const uint32_t* bc = blockcnt + ((size_t)w * KB + j) * B;
+  const uint32_t* st = starts + (size_t)w * B;
+  for (uint32_t b = threadIdx.x; b < B; b += 1024) lds[b] = st[b] + bc[b];
+  __syncthreads();
+  const uint32_t lo = j * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+  const uint16_t* dg = digits + (size_t)w * n;
+  uint32_t* out = sorted + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    uint32_t d = dg[i];
+    if (d != 0xFFFFu) {
+      uint32_t pos = atomicAdd(&lds[d & 0x7FFFu], 1u);
+      out[pos] = i | ((d >> 15) << 31);
+    }
+  }
+}
+
+// ---- 3. work items.  A bucket's run is cut into pieces of at most SEG points so that no lane works much longer than
+// the average (the top window of a 253-bit scalar has ~12 significant bits -> 16x fewer, 16x longer buckets; skewed
+// inputs are worse).  Piece ids of bucket t: pfirst[t] .. pfirst[t] + ceil(count/SEG) - 1 (a static region per window).
+template <class G>
+__global__ void __launch_bounds__(256) k_make_pieces(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
+                                                     const uint32_t* __restrict__ pfirst, uint32_t* __restrict__ pstart,
+                                                     uint32_t* __restrict__ plen, uint32_t* __restrict__ big, uint32_t* __restrict__ nbig,
+                                                     uint32_t* __restrict__ mid, uint32_t* __restrict__ nmid,
+                                                     uint32_t B, uint32_t SEG, uint32_t n, uint32_t total) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  uint32_t c = counts[t];
+  if (c == 0) return;
+  uint32_t w = t / B;
+  uint32_t pc = (c + SEG - 1) / SEG, pf = pfirst[t], s = w * n + starts[t];
+  for (uint32_t k = 0; k < pc; k++) {
+    pstart[pf + k] = s + k * SEG;
+    plen[pf + k] = (c - k * SEG < SEG) ? c - k * SEG : SEG;
+  }
+  if (pc > 16) big[atomicAdd(nbig, 1u)] = t;
+  else if (pc > 1) mid[atomicAdd(nmid, 1u)] = t;
+}
+
+// longest-first schedule of the pieces: counting sort by length (descending); zero-length slots are dropped
+constexpr uint32_t SIZE_BINS = 2048;  // SEG < SIZE_BINS
+template <class G>
+__global__ void __launch_bounds__(256) k_size_hist(const uint32_t* __restrict__ plen, uint32_t* __restrict__ bins, uint32_t slots) {
   __shared__ uint32_t lh[SIZE_BINS];
   for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 256) lh[i] = 0;
   __syncthreads();
-  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-    uint32_t c = counts[t];
-    uint32_t b = SIZE_BINS - 1 - (c < SIZE_BINS ? c : SIZE_BINS - 1);  // descending size
-    atomicAdd(&lh[b], 1u);
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < slots; t += gridDim.x * 256) {
+    uint32_t c = plen[t];
+    if (c) atomicAdd(&lh[SIZE_BINS - 1 - c], 1u);
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 256)
     if (lh[i]) atomicAdd(&bins[i], lh[i]);
 }
 template <class G>
-__global__ void __launch_bounds__(1024) k_size_scan(uint32_t* __restrict__ bins) {  // in-place exclusive scan of SIZE_BINS counters
-  __shared__ uint32_t tmp[SIZE_BINS];
-  for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 1024) tmp[i] = bins[i];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (uint32_t i = 0; i < SIZE_BINS; i++) { uint32_t v = tmp[i]; tmp[i] = run; run += v; }
+__global__ void __launch_bounds__(1024) k_size_scan(uint32_t* __restrict__ bins, uint32_t* __restrict__ nwork) {
+  // in-place exclusive scan of SIZE_BINS (= 2 per thread) counters; nwork = number of non-empty pieces
+  __shared__ uint32_t wave_tot[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t a = bins[2 * threadIdx.x], b = bins[2 * threadIdx.x + 1];
+  uint32_t x = a + b;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
   }
+  if (lane == 63) wave_tot[wv] = x;
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 1024) bins[i] = tmp[i];
+  uint32_t pre = 0;
+  for (int k = 0; k < wv; k++) pre += wave_tot[k];
+  uint32_t excl = pre + x - (a + b);
+  bins[2 * threadIdx.x] = excl;
+  bins[2 * threadIdx.x + 1] = excl + a;
+  if (threadIdx.x == 1023) *nwork = pre + x;
 }
 template <class G>
-__global__ void __launch_bounds__(256) k_size_scatter(const uint32_t* __restrict__ counts, uint32_t* __restrict__ bins,
-                                                      uint32_t* __restrict__ order, uint32_t total) {
+__global__ void __launch_bounds__(256) k_size_scatter(const uint32_t* __restrict__ plen, uint32_t* __restrict__ bins,
+                                                      uint32_t* __restrict__ order, uint32_t slots) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  uint32_t c = counts[t];
-  uint32_t b = SIZE_BINS - 1 - (c < SIZE_BINS ? c : SIZE_BINS - 1);
-  uint32_t pos = atomicAdd(&bins[b], 1u);
+  if (t >= slots) return;
+  uint32_t c = plen[t];
+  if (!c) return;
+  uint32_t pos = atomicAdd(&bins[SIZE_BINS - 1 - c], 1u);
   order[pos] = t;
 }
 
-// one lane per bucket: XYZZ sum of its run of (signed) points
+// ---- 4. one lane per piece: XYZZ sum of its run of (signed) points
 template <class G>
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                    const uint32_t* __restrict__ starts, const uint32_t* __restrict__ ends,
-                                                    const uint32_t* __restrict__ order, uint32_t* __restrict__ buckets,
-                                                    uint32_t B, uint32_t total, uint32_t n) {
+                                                    const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ plen,
+                                                    const uint32_t* __restrict__ order, const uint32_t* __restrict__ nwork,
+                                                    uint32_t* __restrict__ partials) {
   typedef typename G::F F;
   typedef PointIO<F> IO;
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= total) return;
-  uint32_t t = order[tid];
-  uint32_t w = t / B;
-  const uint32_t* run = sorted + (size_t)w * n;
-  uint32_t s = starts[t], e = ends[t];
+  if (tid >= *nwork) return;
+  uint32_t pid = order[tid];
+  const uint32_t* run = sorted + pstart[pid];
+  uint32_t len = plen[pid];
   Xyzz<F> acc = Xyzz<F>::identity();
-  for (uint32_t k = s; k < e; k++) {
+  for (uint32_t k = 0; k < len; k++) {
     uint32_t v = run[k];
     Affine<F> p = IO::load_affine(bases + (size_t)(v & 0x7fffffffu) * IO::AFF_WORDS);
     if (v >> 31) p = affine_neg(p);
     xyzz_madd(acc, p);
   }
-  IO::store_xyzz(buckets + (size_t)t * IO::XYZZ_WORDS, acc);
+  IO::store_xyzz(partials + (size_t)pid * IO::XYZZ_WORDS, acc);
+}
+
+// ---- 5a. buckets cut into 2..16 pieces (e.g. every bucket of a short top window): one lane folds the pieces
+template <class G>
+__global__ void __launch_bounds__(128) k_combine_mid(const uint32_t* __restrict__ mid, const uint32_t* __restrict__ nmid,
+                                                     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ pfirst,
+                                                     uint32_t* __restrict__ partials, uint32_t* __restrict__ pieces_of, uint32_t SEG) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < *nmid; q += gridDim.x * blockDim.x) {
+    uint32_t t = mid[q];
+    uint32_t pc = (counts[t] + SEG - 1) / SEG, pf = pfirst[t];
+    Xyzz<F> acc = IO::load_xyzz(partials + (size_t)pf * IO::XYZZ_WORDS);
+    for (uint32_t k = 1; k < pc; k++) {
+      Xyzz<F> v = IO::load_xyzz(partials + (size_t)(pf + k) * IO::XYZZ_WORDS);
+      xyzz_add(acc, v);
+    }
+    IO::store_xyzz(partials + (size_t)pf * IO::XYZZ_WORDS, acc);
+    pieces_of[t] = 1;
+  }
+}
+
+// ---- 5b. buckets cut into many pieces (skewed inputs): one workgroup per such bucket folds its pieces into the first
+template <class G>
+__global__ void __launch_bounds__(256) k_combine_big(const uint32_t* __restrict__ big, const uint32_t* __restrict__ nbig,
+                                                     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ pfirst,
+                                                     uint32_t* __restrict__ partials, uint32_t* __restrict__ pieces_of, uint32_t SEG) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  __shared__ uint32_t stage[64 * IO::XYZZ_WORDS];
+  for (uint32_t q = blockIdx.x; q < *nbig; q += gridDim.x) {
+    uint32_t t = big[q];
+    uint32_t pc = (counts[t] + SEG - 1) / SEG, pf = pfirst[t];
+    Xyzz<F> acc = Xyzz<F>::identity();
+    for (uint32_t k = threadIdx.x; k < pc; k += 256) {
+      Xyzz<F> v = IO::load_xyzz(partials + (size_t)(pf + k) * IO::XYZZ_WORDS);
+      xyzz_add(acc, v);
+    }
+    // fold 256 -> 64 -> 1 through LDS (64 slots)
+    for (uint32_t width = 256; width > 1; width >>= 2) {
+      uint32_t q4 = width >> 2;
+      for (uint32_t r = 1; r < 4; r++) {
+        __syncthreads();
+        if (threadIdx.x >= r * q4 && threadIdx.x < (r + 1) * q4) IO::store_xyzz(stage + (threadIdx.x - r * q4) * IO::XYZZ_WORDS, acc);
+        __syncthreads();
+        if (threadIdx.x < q4) { Xyzz<F> v = IO::load_xyzz(stage + threadIdx.x * IO::XYZZ_WORDS); xyzz_add(acc, v); }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { IO::store_xyzz(partials + (size_t)pf * IO::XYZZ_WORDS, acc); pieces_of[t] = 1; }
+    __syncthreads();
+  }
+}
+
+template <class G> HD Xyzz<typename G::F> load_bucket(const uint32_t* partials, const uint32_t* counts, const uint32_t* pfirst,
+                                                       const uint32_t* pieces_of, uint32_t t, uint32_t SEG) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  uint32_t c = counts[t];
+  if (c == 0) return Xyzz<F>::identity();
+  (void)pieces_of; (void)SEG;  // k_combine_mid / k_combine_big have folded multi-piece buckets into their first piece
+  return IO::load_xyzz(partials + (size_t)pfirst[t] * IO::XYZZ_WORDS);
 }
 
 // running sums over CH consecutive buckets (descending): out[2*t] = sum_{j} (j - lo + 1) * B_j, out[2*t+1] = sum_j B_j
 template <class G>
-__global__ void __launch_bounds__(128) k_reduce_chunks(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out,
-                                                       uint32_t CH, uint32_t nchunks) {
+__global__ void __launch_bounds__(128) k_reduce_chunks(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
+                                                       const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ pieces_of,
+                                                       uint32_t SEG, uint32_t* __restrict__ out, uint32_t CH, uint32_t nchunks) {
   typedef typename G::F F;
   typedef PointIO<F> IO;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nchunks) return;
   Xyzz<F> running = Xyzz<F>::identity(), acc = Xyzz<F>::identity();
-  const uint32_t* b = buckets + (size_t)t * CH * IO::XYZZ_WORDS;
   for (int j = (int)CH - 1; j >= 0; j--) {
-    Xyzz<F> v = IO::load_xyzz(b + (size_t)j * IO::XYZZ_WORDS);
+    Xyzz<F> v = load_bucket<G>(partials, counts, pfirst, pieces_of, t * CH + (uint32_t)j, SEG);
     xyzz_add(running, v);
     xyzz_add(acc, running);
   }
@@ -287,14 +431,12 @@ template <class G> class MsmEngine {
 
   ~MsmEngine() { release(); }
   void release() {
-    for (void* p : {(void*)d_bases, (void*)d_sorted, (void*)d_counts, (void*)d_starts, (void*)d_cursors, (void*)d_buckets,
-                    (void*)d_tmpA, (void*)d_tmpB, (void*)d_order, (void*)d_bins, (void*)d_in_bases, (void*)d_in_scalars, (void*)d_in_inf})
+    if (arena) { (void)hipFree(arena); arena = nullptr; arena_bytes = 0; }
+    for (void* p : {(void*)d_in_bases, (void*)d_in_scalars, (void*)d_in_inf})
       if (p) (void)hipFree(p);
-    d_bases = d_sorted = d_counts = d_starts = d_cursors = d_buckets = d_tmpA = d_tmpB = d_order = d_bins = nullptr;
-    d_in_bases = nullptr; d_in_scalars = nullptr; d_in_inf = nullptr;
+    d_in_bases = nullptr; d_in_scalars = nullptr; d_in_inf = nullptr; cap_in = 0;
     if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; }
     for (int i = 0; i < 6; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
-    cap_n = 0; cap_in = 0; cap_sorted = 0; cap_total = 0;
   }
   static int window_bits(size_t n) {
     int lg = 0;
@@ -307,34 +449,101 @@ template <class G> class MsmEngine {
   int force_c = 0;  // test hook / tuning: 0 = auto
 
   // bases/scalars/inf are DEVICE pointers (ark layout); result: Jacobian in ark Montgomery form (3*ARK64 u64) on host.
-  int run_device(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n, uint64_t* out_jac,
+  int run_device(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, uint64_t* out_jac,
                  hipStream_t stream) {
-    if (n == 0) { write_identity(out_jac); return 0; }
-    if (n >= (size_t(1) << 31)) return 2;
-    int c = force_c ? force_c : window_bits(n);
+    if (n_ == 0) { write_identity(out_jac); return 0; }
+    if (n_ >= (size_t(1) << 31)) return 2;
+    const uint32_t n = (uint32_t)n_;
+    const int c = force_c ? force_c : window_bits(n);
     const int nw = (G::SCALAR_BITS + c) / c;
     const uint32_t B = 1u << (c - 1);
     const uint32_t total = (uint32_t)nw * B;
-    if (ensure(n, total)) return 1;
+    // blocks per window for the LDS counting sort: fill the chip, at least ~4096 digits per block
+    uint32_t KB = 256 / (uint32_t)nw;
+    if (KB < 1) KB = 1;
+    while (KB > 1 && (n + KB - 1) / KB < 4096) KB >>= 1;
+    if (KB > 64) KB = 64;
+    const uint32_t chunk = (n + KB - 1) / KB;
+    // piece length: twice the average bucket, within [32, SIZE_BINS-1]
+    uint32_t SEG = 2 * (n / B + 1);
+    if (SEG < 32) SEG = 32;
+    if (SEG > SIZE_BINS - 1) SEG = SIZE_BINS - 1;
+    const uint32_t PW = B + n / SEG + 1;       // static piece region per window
+    const uint32_t slots = (uint32_t)nw * PW;
+    const uint32_t CH = B >= 16 ? 16 : B;
+    const uint32_t cpw = B / CH, nchunks = cpw * nw;
+
+    // ---- workspace arena
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
+    const size_t o_bases = take((size_t)n * IO::AFF_WORDS * 4);
+    const size_t o_digits = take((size_t)n * nw * 2);
+    const size_t o_sorted = take((size_t)n * nw * 4);
+    const size_t o_blockcnt = take((size_t)nw * KB * B * 4);
+    const size_t o_counts = take((size_t)total * 4);
+    const size_t o_starts = take((size_t)total * 4);
+    const size_t o_pfirst = take((size_t)total * 4);
+    const size_t o_piecesof = take((size_t)total * 4);
+    const size_t o_big = take((size_t)total * 4);
+    const size_t o_mid = take((size_t)total * 4);
+    const size_t o_pstart = take((size_t)slots * 4);
+    const size_t o_plen = take((size_t)slots * 4);
+    const size_t o_order = take((size_t)slots * 4);
+    const size_t o_bins = take((size_t)SIZE_BINS * 4 + 256);  // + nwork, nbig
+    const size_t o_partials = take((size_t)slots * IO::XYZZ_WORDS * 4);
+    const size_t o_tmpA = take(((size_t)2 * nchunks + 64) * IO::XYZZ_WORDS * 4);
+    const size_t o_tmpB = take(((size_t)nchunks + 64) * IO::XYZZ_WORDS * 4);
+    if (ensure(off)) return 1;
+    char* A = arena;
+    uint32_t* d_bases = (uint32_t*)(A + o_bases);
+    uint16_t* d_digits = (uint16_t*)(A + o_digits);
+    uint32_t* d_sorted = (uint32_t*)(A + o_sorted);
+    uint32_t* d_blockcnt = (uint32_t*)(A + o_blockcnt);
+    uint32_t* d_counts = (uint32_t*)(A + o_counts);
+    uint32_t* d_starts = (uint32_t*)(A + o_starts);
+    uint32_t* d_pfirst = (uint32_t*)(A + o_pfirst);
+    uint32_t* d_piecesof = (uint32_t*)(A + o_piecesof);
+    uint32_t* d_big = (uint32_t*)(A + o_big);
+    uint32_t* d_mid = (uint32_t*)(A + o_mid);
+    uint32_t* d_pstart = (uint32_t*)(A + o_pstart);
+    uint32_t* d_plen = (uint32_t*)(A + o_plen);
+    uint32_t* d_order = (uint32_t*)(A + o_order);
+    uint32_t* d_bins = (uint32_t*)(A + o_bins);
+    uint32_t* d_nwork = d_bins + SIZE_BINS;
+    uint32_t* d_nbig = d_bins + SIZE_BINS + 1;
+    uint32_t* d_nmid = d_bins + SIZE_BINS + 2;
+    uint32_t* d_partials = (uint32_t*)(A + o_partials);
+    uint32_t* d_tmpA = (uint32_t*)(A + o_tmpA);
+    uint32_t* d_tmpB = (uint32_t*)(A + o_tmpB);
+
     HIP_OK(hipEventRecord(ev[0], stream));
-    hipLaunchKernelGGL((k_convert_bases<G>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_ark_bases, d_bases, n);
+    hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_ark_bases, d_bases, (size_t)n);
     HIP_OK(hipEventRecord(ev[1], stream));
-    HIP_OK(hipMemsetAsync(d_counts, 0, (size_t)total * 4, stream));
-    if (launch_digits(0, c, d_scalars, d_inf, d_counts, nullptr, (uint32_t)n, stream)) return 3;
-    hipLaunchKernelGGL((k_scan<G>), dim3(nw), dim3(1024), 0, stream, d_counts, d_starts, d_cursors, B);
-    if (launch_digits(1, c, d_scalars, d_inf, d_cursors, d_sorted, (uint32_t)n, stream)) return 3;
-    HIP_OK(hipMemsetAsync(d_bins, 0, SIZE_BINS * 4, stream));
-    hipLaunchKernelGGL((k_size_hist<G>), dim3(total / 256 < 512 ? (total + 255) / 256 : 512), dim3(256), 0, stream, d_counts, d_bins, total);
-    hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins);
-    hipLaunchKernelGGL((k_size_scatter<G>), dim3((total + 255) / 256), dim3(256), 0, stream, d_counts, d_bins, d_order, total);
+    // ---- sort
+    if (launch_digits(c, d_scalars, d_inf, d_digits, n, stream)) return 3;
+    hipLaunchKernelGGL((k_count<G>), dim3(KB, nw), dim3(1024), B * 4, stream, d_digits, d_blockcnt, n, B, chunk);
+    hipLaunchKernelGGL((k_bucket_totals<G>), dim3((total + 255) / 256), dim3(256), 0, stream, d_blockcnt, d_counts, B, KB, total);
+    hipLaunchKernelGGL((k_scan<G>), dim3(nw), dim3(1024), 0, stream, d_counts, d_starts, d_pfirst, B, SEG, PW);
+    hipLaunchKernelGGL((k_scatter<G>), dim3(KB, nw), dim3(1024), B * 4, stream, d_digits, d_blockcnt, d_starts, d_sorted, n, B, chunk);
+    // ---- work items, longest first
+    HIP_OK(hipMemsetAsync(d_plen, 0, (size_t)slots * 4, stream));
+    HIP_OK(hipMemsetAsync(d_bins, 0, (size_t)SIZE_BINS * 4 + 256, stream));
+    HIP_OK(hipMemsetAsync(d_piecesof, 0, (size_t)total * 4, stream));
+    hipLaunchKernelGGL((k_make_pieces<G>), dim3((total + 255) / 256), dim3(256), 0, stream, d_counts, d_starts, d_pfirst, d_pstart,
+                       d_plen, d_big, d_nbig, d_mid, d_nmid, B, SEG, n, total);
+    hipLaunchKernelGGL((k_size_hist<G>), dim3(slots / 256 < 512 ? (slots + 255) / 256 : 512), dim3(256), 0, stream, d_plen, d_bins, slots);
+    hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
+    hipLaunchKernelGGL((k_size_scatter<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_plen, d_bins, d_order, slots);
     HIP_OK(hipEventRecord(ev[2], stream));
-    hipLaunchKernelGGL((k_accumulate<G>), dim3((total + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_starts, d_cursors,
-                       d_order, d_buckets, B, total, (uint32_t)n);
+    // ---- accumulate (grid covers every slot; lanes beyond the number of non-empty pieces exit)
+    hipLaunchKernelGGL((k_accumulate<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order,
+                       d_nwork, d_partials);
     HIP_OK(hipEventRecord(ev[3], stream));
-    // bucket reduction
-    uint32_t CH = B >= 16 ? 16 : B;
-    uint32_t cpw = B / CH, nchunks = cpw * nw;
-    hipLaunchKernelGGL((k_reduce_chunks<G>), dim3((nchunks + 127) / 128), dim3(128), 0, stream, d_buckets, d_tmpA, CH, nchunks);
+    // ---- bucket reduction
+    hipLaunchKernelGGL((k_combine_mid<G>), dim3(256), dim3(128), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
+    hipLaunchKernelGGL((k_combine_big<G>), dim3(256), dim3(256), 0, stream, d_big, d_nbig, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
+    hipLaunchKernelGGL((k_reduce_chunks<G>), dim3((nchunks + 127) / 128), dim3(128), 0, stream, d_partials, d_counts, d_pfirst,
+                       d_piecesof, SEG, d_tmpA, CH, nchunks);
     hipLaunchKernelGGL((k_fixup<G>), dim3((nchunks + 127) / 128), dim3(128), 0, stream, d_tmpA, d_tmpB, CH, cpw, nchunks);
     uint32_t per_window = cpw;
     uint32_t* src = d_tmpB;
@@ -359,7 +568,7 @@ template <class G> class MsmEngine {
     (void)hipEventElapsedTime(&tm.reduce, ev[3], ev[4]);
     (void)hipEventElapsedTime(&tm.total, ev[0], ev[5]);
     last_c = c; last_nw = nw; last_buckets = total;
-    // host epilogue: Horner over windows
+    // ---- host epilogue: Horner over windows (nw * c doublings + <= 4*nw additions)
     Xyzz<F> total_pt = Xyzz<F>::identity();
     for (int w = nw - 1; w >= 0; w--) {
       for (int k = 0; k < c; k++) total_pt = xyzz_dbl(total_pt);
@@ -414,75 +623,53 @@ template <class G> class MsmEngine {
   }
 
  private:
-  uint32_t *d_bases = nullptr, *d_sorted = nullptr, *d_counts = nullptr, *d_starts = nullptr, *d_cursors = nullptr;
-  uint32_t *d_buckets = nullptr, *d_tmpA = nullptr, *d_tmpB = nullptr, *d_order = nullptr, *d_bins = nullptr;
+  char* arena = nullptr;  // one device allocation, carved per call (sizes depend on n and the window size)
+  size_t arena_bytes = 0;
   uint64_t* d_in_bases = nullptr;
   uint64_t* d_in_scalars = nullptr;
   uint8_t* d_in_inf = nullptr;
   uint32_t* h_out = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t cap_n = 0, cap_in = 0;
-  uint32_t cap_total = 0;
+  size_t cap_in = 0;
 
-  int ensure(size_t n, uint32_t total) {
+  int ensure(size_t bytes) {
     if (!ev[0])
       for (int i = 0; i < 6; i++) HIP_OK(hipEventCreate(&ev[i]));
-    if (!h_out) HIP_OK(hipHostMalloc(&h_out, (size_t)4 * 128 * IO::XYZZ_WORDS * 4));
-    if (!d_bins) HIP_OK(hipMalloc(&d_bins, SIZE_BINS * 4));
-    int c = force_c ? force_c : window_bits(n);
-    size_t nw = (G::SCALAR_BITS + c) / c;
-    if (n > cap_n) {
-      if (d_bases) (void)hipFree(d_bases);
-      d_bases = nullptr; cap_n = 0;
-      HIP_OK(hipMalloc(&d_bases, n * IO::AFF_WORDS * 4));
-      cap_n = n;
+    if (!h_out) {
+      HIP_OK(hipHostMalloc(&h_out, (size_t)4 * 128 * IO::XYZZ_WORDS * 4));
+      // the LDS histograms use up to 128 KB of dynamic LDS (2^15 counters)
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_count<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    if (n * nw > cap_sorted) {
-      if (d_sorted) (void)hipFree(d_sorted);
-      d_sorted = nullptr; cap_sorted = 0;
-      HIP_OK(hipMalloc(&d_sorted, n * nw * 4));
-      cap_sorted = n * nw;
-    }
-    if (total > cap_total) {
-      for (void* p : {(void*)d_counts, (void*)d_starts, (void*)d_cursors, (void*)d_buckets, (void*)d_tmpA, (void*)d_tmpB, (void*)d_order})
-        if (p) (void)hipFree(p);
-      d_counts = d_starts = d_cursors = d_buckets = d_tmpA = d_tmpB = d_order = nullptr; cap_total = 0;
-      HIP_OK(hipMalloc(&d_order, (size_t)total * 4));
-      HIP_OK(hipMalloc(&d_counts, (size_t)total * 4));
-      HIP_OK(hipMalloc(&d_starts, (size_t)total * 4));
-      HIP_OK(hipMalloc(&d_cursors, (size_t)total * 4));
-      HIP_OK(hipMalloc(&d_buckets, (size_t)total * IO::XYZZ_WORDS * 4));
-      HIP_OK(hipMalloc(&d_tmpA, ((size_t)total / 4 + 1024) * IO::XYZZ_WORDS * 4));
-      HIP_OK(hipMalloc(&d_tmpB, ((size_t)total / 4 + 1024) * IO::XYZZ_WORDS * 4));
-      cap_total = total;
+    if (bytes > arena_bytes) {
+      if (arena) (void)hipFree(arena);
+      arena = nullptr; arena_bytes = 0;
+      HIP_OK(hipMalloc(&arena, bytes));
+      arena_bytes = bytes;
     }
     return 0;
   }
-  size_t cap_sorted = 0;
 
-  template <int CB> int launch_digits_c(int mode, const uint32_t* sc, const uint8_t* inf, uint32_t* ctr, uint32_t* sorted, uint32_t n,
-                                        hipStream_t st) {
+  template <int CB> int launch_digits_c(const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {
     constexpr int NW = (G::SCALAR_BITS + CB) / CB;
-    dim3 g((n + 255) / 256), b(256);
-    if (mode == 0) hipLaunchKernelGGL((k_digits<SW, CB, NW, 0>), g, b, 0, st, sc, inf, ctr, sorted, n);
-    else hipLaunchKernelGGL((k_digits<SW, CB, NW, 1>), g, b, 0, st, sc, inf, ctr, sorted, n);
+    hipLaunchKernelGGL((k_digits<SW, CB, NW>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);
     return 0;
   }
-  int launch_digits(int mode, int c, const uint32_t* sc, const uint8_t* inf, uint32_t* ctr, uint32_t* sorted, uint32_t n, hipStream_t st) {
+  int launch_digits(int c, const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {
     switch (c) {
-      case 4: return launch_digits_c<4>(mode, sc, inf, ctr, sorted, n, st);
-      case 5: return launch_digits_c<5>(mode, sc, inf, ctr, sorted, n, st);
-      case 6: return launch_digits_c<6>(mode, sc, inf, ctr, sorted, n, st);
-      case 7: return launch_digits_c<7>(mode, sc, inf, ctr, sorted, n, st);
-      case 8: return launch_digits_c<8>(mode, sc, inf, ctr, sorted, n, st);
-      case 9: return launch_digits_c<9>(mode, sc, inf, ctr, sorted, n, st);
-      case 10: return launch_digits_c<10>(mode, sc, inf, ctr, sorted, n, st);
-      case 11: return launch_digits_c<11>(mode, sc, inf, ctr, sorted, n, st);
-      case 12: return launch_digits_c<12>(mode, sc, inf, ctr, sorted, n, st);
-      case 13: return launch_digits_c<13>(mode, sc, inf, ctr, sorted, n, st);
-      case 14: return launch_digits_c<14>(mode, sc, inf, ctr, sorted, n, st);
-      case 15: return launch_digits_c<15>(mode, sc, inf, ctr, sorted, n, st);
-      case 16: return launch_digits_c<16>(mode, sc, inf, ctr, sorted, n, st);
+      case 4: return launch_digits_c<4>(sc, inf, digits, n, st);
+      case 5: return launch_digits_c<5>(sc, inf, digits, n, st);
+      case 6: return launch_digits_c<6>(sc, inf, digits, n, st);
+      case 7: return launch_digits_c<7>(sc, inf, digits, n, st);
+      case 8: return launch_digits_c<8>(sc, inf, digits, n, st);
+      case 9: return launch_digits_c<9>(sc, inf, digits, n, st);
+      case 10: return launch_digits_c<10>(sc, inf, digits, n, st);
+      case 11: return launch_digits_c<11>(sc, inf, digits, n, st);
+      case 12: return launch_digits_c<12>(sc, inf, digits, n, st);
+      case 13: return launch_digits_c<13>(sc, inf, digits, n, st);
+      case 14: return launch_digits_c<14>(sc, inf, digits, n, st);
+      case 15: return launch_digits_c<15>(sc, inf, digits, n, st);
+      case 16: return launch_digits_c<16>(sc, inf, digits, n, st);
       default: return 1;
     }
   }

@@ -25,6 +25,8 @@ int api_ensure_init() {
   int gen_points_##TAG(void*, size_t, uint64_t, const uint64_t*, void*);                              \
   int sum_jac_##TAG(const uint64_t*, size_t, uint64_t*);
 DECL(g1_377) DECL(g2_377) DECL(761)
+int pairing_run_377(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
+int pairing_timings_377(float*);
 }  // namespace celo
 using namespace celo;
 
@@ -53,6 +55,22 @@ int msm_bls12_377_g1_dev(const void* b, const void* inf, const void* s, size_t n
 int msm_bls12_377_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_g2_377(b, inf, s, n, out, st); }
 int msm_bw6_761_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_761(b, inf, s, n, out, st); }
 int msm_bw6_761_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_761(b, inf, s, n, out, st); }
+int pairing_product_is_one_bls12_377(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2, size_t k, int* is_one) {
+  uint32_t offs[2] = {0, (uint32_t)k};
+  uint8_t one = 0;
+  int rc = pairing_run_377(g1, inf1, g2, inf2, offs, 1, &one, nullptr, 0);
+  if (rc == 0 && is_one) *is_one = one;
+  return rc;
+}
+int pairing_product_is_one_batch_bls12_377(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2,
+                                           const uint32_t* offsets, size_t m, uint8_t* is_one) {
+  return pairing_run_377(g1, inf1, g2, inf2, offsets, m, is_one, nullptr, 0);
+}
+int celo_amd_pairing_gt_bls12_377(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2, const uint32_t* offsets,
+                                  size_t m, int miller_only, uint64_t* gt72) {
+  return pairing_run_377(g1, inf1, g2, inf2, offsets, m, nullptr, gt72, miller_only ? 1 : 0);
+}
+int celo_amd_pairing_last_timings(float ms[4]) { return pairing_timings_377(ms); }
 int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]) {
   switch (group) {
     case 0: return msm_timings_g1_377(ms, cfg);

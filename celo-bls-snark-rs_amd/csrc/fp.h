@@ -244,6 +244,30 @@ template <class P> struct Fp {
     TRK(r.lb = 1; r.vb = a.vb;)
     return r;
   }
+
+  // ---- weak reduction: value < ~300p (normalised limbs)  ->  value < 1.05p.  Quotient estimate from the top limb
+  // (p's top limb has >= 13 bits for BLS12-377), one multiply-subtract sweep, ~60 VALU ops: used by the pairing tower
+  // to stop the value growth of lazy additions without paying a full Montgomery multiplication.
+  HD static Fp wred(const Fp& a_) {
+    static_assert(P::P[L - 1] >= 4096, "wred needs a wide top limb of p (BLS12-377); BW6-761 uses reduce()");
+    const Fp a = norm(a_);
+    TRK(assert(a.vb <= 300);)
+    constexpr uint64_t D = (uint64_t)P::P[L - 1] + 1;
+    constexpr uint64_t M = ((1ull << 34) + D - 1) / D;      // ceil(2^34 / D); exact floor(t/D) for t < 2^21
+    const uint32_t q = (uint32_t)(((uint64_t)a.l[L - 1] * M) >> 34);
+    Fp r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) {
+      int64_t t = (int64_t)a.l[i] - (int64_t)((uint64_t)q * P::P[i]) + carry;
+      r.l[i] = (uint32_t)t & MASK;
+      carry = t >> W;
+    }
+    r.l[L - 1] = (uint32_t)((int64_t)a.l[L - 1] - (int64_t)((uint64_t)q * P::P[L - 1]) + carry);
+    TRK(r.lb = 1; r.vb = 2;)
+    return r;
+  }
+
   // ---- canonical reduction to [0, p): value must be < 128p.  Slow path only (equality tests, export).
   HD static Fp reduce(const Fp& a) {
     Fp r = norm(a);

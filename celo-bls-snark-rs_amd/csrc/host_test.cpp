@@ -3,6 +3,7 @@
 // Driven by tests/test_host_field.py through ctypes; never shipped.
 #include "curve.h"
 #include "fp2.h"
+#include "pairing.h"
 #include <cstring>
 using namespace celo;
 
@@ -46,7 +47,44 @@ template <class F> static void point_op(int op, const uint64_t* p1, const uint64
   xyzz_to_jac(acc, out);
 }
 
+// pairing tower on the host with bounds tracking.  mode 0: product of pairings (GT), 1: Miller-loop product only,
+// 2: final exponentiation of the given GT (in72), 3: Fq12 mul (in72 * in72b), 4: Fq12 inverse, 5: cyclotomic square,
+// 6: frobenius 1, 7: frobenius 2, 8: frobenius 3, 9: Fq12 square
+static void pairing_op(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
+                       uint64_t* out72, int* is_one) {
+  Fq12 r;
+  if (mode <= 1) {
+    Fq12 acc = f12_one();
+    for (size_t i = 0; i < k; i++) {
+      Fq px = Fq::from_ark(g1 + i * 12), py = Fq::from_ark(g1 + i * 12 + 6);
+      Fq2 qx = Fq2::from_ark(g2 + i * 24), qy = Fq2::from_ark(g2 + i * 24 + 12);
+      Fq12 f, t;
+      miller_loop_single(f, px, py, qx, qy);
+      f12_mul(t, acc, f);
+      acc = t;
+    }
+    if (mode == 0) final_exponentiation(r, acc);
+    else r = acc;
+  } else {
+    Fq12 a = f12_from_ark(in72);
+    switch (mode) {
+      case 2: final_exponentiation(r, a); break;
+      case 3: { Fq12 b = f12_from_ark(in72b); f12_mul(r, a, b); } break;
+      case 4: f12_inv(r, a); break;
+      case 5: f12_cyclotomic_sqr(r, a); break;
+      case 6: f12_frob<1>(r, a); break;
+      case 7: f12_frob<2>(r, a); break;
+      case 8: f12_frob<3>(r, a); break;
+      default: f12_sqr(r, a); break;
+    }
+  }
+  f12_to_ark(r, out72);
+  if (is_one) *is_one = f12_is_one(r) ? 1 : 0;
+}
+
 extern "C" {
+void ht_pairing_377(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
+                    uint64_t* out72, int* is_one) { pairing_op(mode, g1, g2, k, in72, in72b, out72, is_one); }
 void ht_fq377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp<P377>>(op, a, b, out); }
 void ht_fq761(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp<P761>>(op, a, b, out); }
 void ht_fq2_377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp2<P377>>(op, a, b, out); }

@@ -273,14 +273,28 @@ __global__ void __launch_bounds__(1024) k_size_scan(uint32_t* __restrict__ bins,
   if (threadIdx.x == 1023) *nwork = pre + x;
 }
 template <class G>
-__global__ void __launch_bounds__(256) k_size_scatter(const uint32_t* __restrict__ plen, uint32_t* __restrict__ bins,
-                                                      uint32_t* __restrict__ order, uint32_t slots) {
-  uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= slots) return;
-  uint32_t c = plen[t];
-  if (!c) return;
-  uint32_t pos = atomicAdd(&bins[SIZE_BINS - 1 - c], 1u);
-  order[pos] = t;
+__global__ void __launch_bounds__(1024) k_size_scatter(const uint32_t* __restrict__ plen, uint32_t* __restrict__ bins,
+                                                       uint32_t* __restrict__ order, uint32_t slots) {
+  // workgroup-aggregated: local ranks from LDS atomics, ONE global atomic per (workgroup, non-empty bin)
+  __shared__ uint32_t lcnt[SIZE_BINS], lbase[SIZE_BINS];
+  constexpr uint32_t PER = 4;
+  for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 1024) lcnt[i] = 0;
+  __syncthreads();
+  uint32_t c[PER], r[PER];
+  const uint32_t base = blockIdx.x * (1024 * PER);
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    uint32_t t = base + k * 1024 + threadIdx.x;
+    c[k] = t < slots ? plen[t] : 0;
+    r[k] = c[k] ? atomicAdd(&lcnt[SIZE_BINS - 1 - c[k]], 1u) : 0;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < SIZE_BINS; i += 1024)
+    if (lcnt[i]) lbase[i] = atomicAdd(&bins[i], lcnt[i]);
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++)
+    if (c[k]) order[lbase[SIZE_BINS - 1 - c[k]] + r[k]] = base + k * 1024 + threadIdx.x;
 }
 
 // ---- 4. one lane per piece: XYZZ sum of its run of (signed) points
@@ -319,7 +333,7 @@ __global__ void __launch_bounds__(128) k_combine_mid(const uint32_t* __restrict_
     Xyzz<F> acc = IO::load_xyzz(partials + (size_t)pf * IO::XYZZ_WORDS);
     for (uint32_t k = 1; k < pc; k++) {
       Xyzz<F> v = IO::load_xyzz(partials + (size_t)(pf + k) * IO::XYZZ_WORDS);
-      xyzz_add(acc, v);
+      xyzz_add_fn(acc, v);
     }
     IO::store_xyzz(partials + (size_t)pf * IO::XYZZ_WORDS, acc);
     pieces_of[t] = 1;
@@ -340,7 +354,7 @@ __global__ void __launch_bounds__(256) k_combine_big(const uint32_t* __restrict_
     Xyzz<F> acc = Xyzz<F>::identity();
     for (uint32_t k = threadIdx.x; k < pc; k += 256) {
       Xyzz<F> v = IO::load_xyzz(partials + (size_t)(pf + k) * IO::XYZZ_WORDS);
-      xyzz_add(acc, v);
+      xyzz_add_fn(acc, v);
     }
     // fold 256 -> 64 -> 1 through LDS (64 slots)
     for (uint32_t width = 256; width > 1; width >>= 2) {
@@ -349,7 +363,7 @@ __global__ void __launch_bounds__(256) k_combine_big(const uint32_t* __restrict_
         __syncthreads();
         if (threadIdx.x >= r * q4 && threadIdx.x < (r + 1) * q4) IO::store_xyzz(stage + (threadIdx.x - r * q4) * IO::XYZZ_WORDS, acc);
         __syncthreads();
-        if (threadIdx.x < q4) { Xyzz<F> v = IO::load_xyzz(stage + threadIdx.x * IO::XYZZ_WORDS); xyzz_add(acc, v); }
+        if (threadIdx.x < q4) { Xyzz<F> v = IO::load_xyzz(stage + threadIdx.x * IO::XYZZ_WORDS); xyzz_add_fn(acc, v); }
       }
     }
     __syncthreads();
@@ -380,30 +394,30 @@ __global__ void __launch_bounds__(128) k_reduce_chunks(const uint32_t* __restric
   Xyzz<F> running = Xyzz<F>::identity(), acc = Xyzz<F>::identity();
   for (int j = (int)CH - 1; j >= 0; j--) {
     Xyzz<F> v = load_bucket<G>(partials, counts, pfirst, pieces_of, t * CH + (uint32_t)j, SEG);
-    xyzz_add(running, v);
-    xyzz_add(acc, running);
+    xyzz_add_fn(running, v);
+    xyzz_add_fn(acc, running);
   }
   IO::store_xyzz(out + (size_t)(2 * t) * IO::XYZZ_WORDS, acc);
   IO::store_xyzz(out + (size_t)(2 * t + 1) * IO::XYZZ_WORDS, running);
 }
 
-// contribution of chunk t (within its window): acc_t + (t_in_window * CH) * running_t
+// weighted part of chunk t (within its window): t_in_window * running_t.  The window sum is
+//   sum_t acc_t + CH * sum_t (t * running_t);  the factor CH (log2 CH doublings) is applied once per window on the host.
 template <class G>
-__global__ void __launch_bounds__(128) k_fixup(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t CH,
-                                               uint32_t chunks_per_window, uint32_t nchunks) {
+__global__ void __launch_bounds__(128) k_fixup(const uint32_t* __restrict__ in, uint32_t* __restrict__ out_acc,
+                                               uint32_t* __restrict__ out_w, uint32_t chunks_per_window, uint32_t nchunks) {
   typedef typename G::F F;
   typedef PointIO<F> IO;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nchunks) return;
   Xyzz<F> acc = IO::load_xyzz(in + (size_t)(2 * t) * IO::XYZZ_WORDS);
   Xyzz<F> run = IO::load_xyzz(in + (size_t)(2 * t + 1) * IO::XYZZ_WORDS);
-  uint32_t k = (t % chunks_per_window) * CH;
-  Xyzz<F> m = xyzz_mul_small(run, k);
-  xyzz_add(acc, m);
-  IO::store_xyzz(out + (size_t)t * IO::XYZZ_WORDS, acc);
+  IO::store_xyzz(out_acc + (size_t)t * IO::XYZZ_WORDS, acc);
+  Xyzz<F> m = xyzz_mul_small(run, t % chunks_per_window);
+  IO::store_xyzz(out_w + (size_t)t * IO::XYZZ_WORDS, m);
 }
 
-// out[t] = sum of in[t*G .. t*G+G-1]
+// out[t] = sum of in[t*grp .. t*grp+grp-1]
 template <class G>
 __global__ void __launch_bounds__(128) k_tree(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t grp, uint32_t nout) {
   typedef typename G::F F;
@@ -413,7 +427,7 @@ __global__ void __launch_bounds__(128) k_tree(const uint32_t* __restrict__ in, u
   Xyzz<F> acc = IO::load_xyzz(in + (size_t)t * grp * IO::XYZZ_WORDS);
   for (uint32_t j = 1; j < grp; j++) {
     Xyzz<F> v = IO::load_xyzz(in + ((size_t)t * grp + j) * IO::XYZZ_WORDS);
-    xyzz_add(acc, v);
+    xyzz_add_fn(acc, v);
   }
   IO::store_xyzz(out + (size_t)t * IO::XYZZ_WORDS, acc);
 }
@@ -470,7 +484,7 @@ template <class G> class MsmEngine {
     if (SEG > SIZE_BINS - 1) SEG = SIZE_BINS - 1;
     const uint32_t PW = B + n / SEG + 1;       // static piece region per window
     const uint32_t slots = (uint32_t)nw * PW;
-    const uint32_t CH = B >= 16 ? 16 : B;
+    const uint32_t CH = B >= 8 ? 8 : B;
     const uint32_t cpw = B / CH, nchunks = cpw * nw;
 
     // ---- workspace arena
@@ -492,7 +506,7 @@ template <class G> class MsmEngine {
     const size_t o_bins = take((size_t)SIZE_BINS * 4 + 256);  // + nwork, nbig
     const size_t o_partials = take((size_t)slots * IO::XYZZ_WORDS * 4);
     const size_t o_tmpA = take(((size_t)2 * nchunks + 64) * IO::XYZZ_WORDS * 4);
-    const size_t o_tmpB = take(((size_t)nchunks + 64) * IO::XYZZ_WORDS * 4);
+    const size_t o_tmpB = take(((size_t)2 * nchunks + 64) * IO::XYZZ_WORDS * 4);
     if (ensure(off)) return 1;
     char* A = arena;
     uint32_t* d_bases = (uint32_t*)(A + o_bases);
@@ -533,7 +547,7 @@ template <class G> class MsmEngine {
                        d_plen, d_big, d_nbig, d_mid, d_nmid, B, SEG, n, total);
     hipLaunchKernelGGL((k_size_hist<G>), dim3(slots / 256 < 512 ? (slots + 255) / 256 : 512), dim3(256), 0, stream, d_plen, d_bins, slots);
     hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
-    hipLaunchKernelGGL((k_size_scatter<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_plen, d_bins, d_order, slots);
+    hipLaunchKernelGGL((k_size_scatter<G>), dim3((slots + 4095) / 4096), dim3(1024), 0, stream, d_plen, d_bins, d_order, slots);
     HIP_OK(hipEventRecord(ev[2], stream));
     // ---- accumulate (grid covers every slot; lanes beyond the number of non-empty pieces exit)
     hipLaunchKernelGGL((k_accumulate<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order,
@@ -544,20 +558,22 @@ template <class G> class MsmEngine {
     hipLaunchKernelGGL((k_combine_big<G>), dim3(256), dim3(256), 0, stream, d_big, d_nbig, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
     hipLaunchKernelGGL((k_reduce_chunks<G>), dim3((nchunks + 127) / 128), dim3(128), 0, stream, d_partials, d_counts, d_pfirst,
                        d_piecesof, SEG, d_tmpA, CH, nchunks);
-    hipLaunchKernelGGL((k_fixup<G>), dim3((nchunks + 127) / 128), dim3(128), 0, stream, d_tmpA, d_tmpB, CH, cpw, nchunks);
+    // d_tmpB: [0, nchunks) = acc_t, [nchunks, 2 nchunks) = t * running_t; binary trees (depth log2) down to <= 2 per window
+    uint32_t* accs = d_tmpB;
+    uint32_t* wts = d_tmpB + (size_t)nchunks * IO::XYZZ_WORDS;
+    hipLaunchKernelGGL((k_fixup<G>), dim3((nchunks + 127) / 128), dim3(128), 0, stream, d_tmpA, accs, wts, cpw, nchunks);
+    // both arrays have the same shape, so one launch per level handles them as 2*nw "windows" of per_window items
     uint32_t per_window = cpw;
     uint32_t* src = d_tmpB;
     uint32_t* dst = d_tmpA;
-    while (per_window > 4) {
-      uint32_t grp = per_window >= 8 ? 8 : per_window;
-      while (per_window % grp) grp--;  // per_window is a power of two, so grp stays a power of two
-      uint32_t nout = per_window / grp * nw;
-      hipLaunchKernelGGL((k_tree<G>), dim3((nout + 127) / 128), dim3(128), 0, stream, src, dst, grp, nout);
-      per_window /= grp;
+    while (per_window > 2) {
+      uint32_t nout = per_window / 2 * 2 * nw;
+      hipLaunchKernelGGL((k_tree<G>), dim3((nout + 127) / 128), dim3(128), 0, stream, src, dst, 2u, nout);
+      per_window /= 2;
       uint32_t* t = src; src = dst; dst = t;
     }
     HIP_OK(hipEventRecord(ev[4], stream));
-    size_t out_words = (size_t)per_window * nw * IO::XYZZ_WORDS;
+    size_t out_words = (size_t)per_window * 2 * nw * IO::XYZZ_WORDS;
     HIP_OK(hipMemcpyAsync(h_out, src, out_words * 4, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ev[5], stream));
     HIP_OK(hipStreamSynchronize(stream));
@@ -568,10 +584,19 @@ template <class G> class MsmEngine {
     (void)hipEventElapsedTime(&tm.reduce, ev[3], ev[4]);
     (void)hipEventElapsedTime(&tm.total, ev[0], ev[5]);
     last_c = c; last_nw = nw; last_buckets = total;
-    // ---- host epilogue: Horner over windows (nw * c doublings + <= 4*nw additions)
+    // ---- host epilogue: window sum = A_w + CH * T_w, then Horner over windows (c doublings each)
+    int log_ch = 0;
+    while ((1u << log_ch) < CH) log_ch++;
     Xyzz<F> total_pt = Xyzz<F>::identity();
     for (int w = nw - 1; w >= 0; w--) {
       for (int k = 0; k < c; k++) total_pt = xyzz_dbl(total_pt);
+      Xyzz<F> tw = Xyzz<F>::identity();
+      for (uint32_t j = 0; j < per_window; j++) {
+        Xyzz<F> v = IO::load_xyzz(h_out + ((size_t)(nw + w) * per_window + j) * IO::XYZZ_WORDS);
+        xyzz_add(tw, v);
+      }
+      for (int k = 0; k < log_ch; k++) tw = xyzz_dbl(tw);
+      xyzz_add(total_pt, tw);
       for (uint32_t j = 0; j < per_window; j++) {
         Xyzz<F> v = IO::load_xyzz(h_out + ((size_t)w * per_window + j) * IO::XYZZ_WORDS);
         xyzz_add(total_pt, v);

@@ -17,6 +17,8 @@ EXPORTS = [
     "celo_amd_init", "celo_amd_device_name",
     "msm_bls12_377_g1", "msm_bls12_377_g2", "msm_bw6_761_g1", "msm_bw6_761_g2",
     "msm_bls12_377_g1_dev", "msm_bls12_377_g2_dev", "msm_bw6_761_g1_dev", "msm_bw6_761_g2_dev",
+    "pairing_product_is_one_bls12_377", "pairing_product_is_one_batch_bls12_377", "celo_amd_pairing_gt_bls12_377",
+    "celo_amd_pairing_last_timings",
     "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
     "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
@@ -106,3 +108,47 @@ def sum_jacobian(group, jac):
     if rc != 0:
         raise RuntimeError(f"{name} failed rc={rc}")
     return out
+
+
+def pairing_product_is_one(g1_xy, inf1, g2_xy, inf2):
+    """One product of k pairings == 1 ?  g1_xy uint64 [k,12], g2_xy uint64 [k,24]."""
+    g1_xy = np.ascontiguousarray(g1_xy, dtype=np.uint64)
+    g2_xy = np.ascontiguousarray(g2_xy, dtype=np.uint64)
+    k = g1_xy.size // 12
+    one = C.c_int(0)
+    rc = lib().pairing_product_is_one_bls12_377(_p(g1_xy), _p(inf1), _p(g2_xy), _p(inf2), C.c_size_t(k), C.byref(one))
+    if rc != 0:
+        raise RuntimeError(f"pairing_product_is_one_bls12_377 failed rc={rc}")
+    return bool(one.value)
+
+
+def pairing_product_is_one_batch(g1_xy, inf1, g2_xy, inf2, offsets):
+    """m independent products; offsets uint32 [m+1]. Returns uint8 [m]."""
+    g1_xy = np.ascontiguousarray(g1_xy, dtype=np.uint64)
+    g2_xy = np.ascontiguousarray(g2_xy, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    m = offsets.size - 1
+    out = np.zeros(m, dtype=np.uint8)
+    rc = lib().pairing_product_is_one_batch_bls12_377(_p(g1_xy), _p(inf1), _p(g2_xy), _p(inf2), _p(offsets), C.c_size_t(m), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"pairing_product_is_one_batch_bls12_377 failed rc={rc}")
+    return out
+
+
+def pairing_gt(g1_xy, inf1, g2_xy, inf2, offsets, miller_only=False):
+    g1_xy = np.ascontiguousarray(g1_xy, dtype=np.uint64)
+    g2_xy = np.ascontiguousarray(g2_xy, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    m = offsets.size - 1
+    out = np.zeros((m, 72), dtype=np.uint64)
+    rc = lib().celo_amd_pairing_gt_bls12_377(_p(g1_xy), _p(inf1), _p(g2_xy), _p(inf2), _p(offsets), C.c_size_t(m),
+                                             C.c_int(1 if miller_only else 0), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"celo_amd_pairing_gt_bls12_377 failed rc={rc}")
+    return out
+
+
+def pairing_timings():
+    ms = (C.c_float * 4)()
+    assert lib().celo_amd_pairing_last_timings(ms) == 0
+    return {"miller_ms": ms[0], "product_ms": ms[1], "final_exp_ms": ms[2], "total_ms": ms[3]}

@@ -46,6 +46,25 @@ int msm_bls12_377_g2_dev(const void* d_bases_xy, const void* d_inf, const void* 
 int msm_bw6_761_g1_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
 int msm_bw6_761_g2_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
 
+/* ---- pairing product check.  Replaces `Bls12_377::product_of_pairings(&pairs) == Fq12::one()` at
+ *   crates/bls-crypto/src/bls/public.rs:102    (PublicKey::verify_sig: 2 pairs)
+ *   crates/bls-crypto/src/bls/signature.rs:149 (Signature::batch_verify_hashes: n+1 pairs, one final exponentiation)
+ * g1_xy: k affine G1 points (k*12 u64), g2_xy: k affine G2 points (k*24 u64), optional infinity byte arrays (a pair with
+ * an infinite point contributes 1, as in ark-ec).  *is_one = 1 iff the product of the k pairings is the identity of GT.
+ * The batch form checks m independent products in one launch: product p covers pairs [offsets[p], offsets[p+1]),
+ * offsets has m+1 entries — the per-batch checks of Batch::verify (crates/bls-crypto/src/bls/batch.rs:83) for many
+ * batches at once (crates/bls-snark-sys/src/signatures.rs:358 loops over them serially). */
+int pairing_product_is_one_bls12_377(const uint64_t* g1_xy, const uint8_t* inf1, const uint64_t* g2_xy, const uint8_t* inf2, size_t k,
+                                     int* is_one);
+int pairing_product_is_one_batch_bls12_377(const uint64_t* g1_xy, const uint8_t* inf1, const uint64_t* g2_xy, const uint8_t* inf2,
+                                           const uint32_t* offsets, size_t m, uint8_t* is_one);
+/* Test/inspection hook: the GT value itself (72 u64 per product: the arkworks in-memory Fq12, Montgomery form);
+ * miller_only != 0 skips the final exponentiation (product of Miller-loop values). */
+int celo_amd_pairing_gt_bls12_377(const uint64_t* g1_xy, const uint8_t* inf1, const uint64_t* g2_xy, const uint8_t* inf2,
+                                  const uint32_t* offsets, size_t m, int miller_only, uint64_t* gt72);
+/* ms[4] = {miller loops, GT products, final exponentiations, total} of the last pairing call (HIP events). */
+int celo_amd_pairing_last_timings(float ms[4]);
+
 /* ---- plain sums of k Jacobian points (host pointers, arkworks layout; host-side, for small k): the fold of per-GPU
  * partial MSM results and small aggregates — Signature::aggregate / PublicKey::aggregate
  * (crates/bls-crypto/src/bls/signature.rs:61-67, public.rs:38-44). */

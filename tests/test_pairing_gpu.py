@@ -1,0 +1,118 @@
+"""GPU (-m gpu): BLS12-377 pairing product check through the C ABI vs the oracle.
+
+Reference call sites: crates/bls-crypto/src/bls/public.rs:102 (verify, 2 pairs), signature.rs:149 (batch_verify_hashes,
+n+1 pairs), batch.rs:83 (strict batches).  The reference only exposes `== Fq12::one()`; here the GT value itself and the
+Miller-loop product are additionally compared bit-for-bit with the oracle's arkworks restatement."""
+import numpy as np
+import pytest
+from oracle.py import ecc
+from oracle import cpu_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def _signed_pairs(rng, npairs, bad=None):
+    """(n aggregates) -> n+1 pairs of Signature::batch_verify_hashes: (asig, -g2), (H_i, apk_i)...; product == 1."""
+    sks = [ecc.random_scalar(rng, ecc.R377) for _ in range(npairs - 1)]
+    hs = [ecc.E1_377.mul(ecc.G1_377, rng.next() | 1) for _ in range(npairs - 1)]
+    pks = [ecc.E2_377.mul(ecc.G2_377, sk) for sk in sks]
+    asig = None
+    for sk, h in zip(sks, hs):
+        asig = ecc.E1_377.add(asig, ecc.E1_377.mul(h, sk))
+    if bad is not None:
+        pks[bad] = ecc.E2_377.mul(ecc.G2_377, sks[bad] + 1)
+    g1 = [asig] + hs
+    g2 = [ecc.E2_377.neg(ecc.G2_377)] + pks
+    return g1, g2
+
+
+def test_gt_values_bit_exact(gpu):
+    rng = ecc.SplitMix64(41)
+    P = [ecc.E1_377.mul(ecc.G1_377, rng.next()) for _ in range(3)]
+    Q = [ecc.E2_377.mul(ecc.G2_377, rng.next()) for _ in range(3)]
+    g1, _ = co.pack_g1_377(P)
+    g2, _ = co.pack_g2_377(Q)
+    # three independent single-pair products: Miller values and GT values
+    offs = np.array([0, 1, 2, 3], dtype=np.uint32)
+    ml = gpu.pairing_gt(g1, None, g2, None, offs, miller_only=True)
+    gt = gpu.pairing_gt(g1, None, g2, None, offs)
+    for i in range(3):
+        assert np.array_equal(ml[i], co.miller_loop_377(g1[i:i + 1], None, g2[i:i + 1], None))
+        assert np.array_equal(gt[i], co.pairing_product_377(g1[i:i + 1], None, g2[i:i + 1], None)[0])
+    # one 3-pair product: equals the oracle's shared-squaring multi-Miller loop + one final exponentiation
+    gt3 = gpu.pairing_gt(g1, None, g2, None, np.array([0, 3], dtype=np.uint32))
+    assert np.array_equal(gt3[0], co.pairing_product_377(g1, None, g2, None)[0])
+
+
+def test_bilinearity(gpu):
+    a, b = 0x1234567890ABCDEF, 0xFEDCBA0987654321
+    P, Q = ecc.G1_377, ecc.G2_377
+    g1, _ = co.pack_g1_377([ecc.E1_377.mul(P, a), ecc.E1_377.neg(ecc.E1_377.mul(P, a * b % ecc.R377))])
+    g2, _ = co.pack_g2_377([ecc.E2_377.mul(Q, b), Q])
+    assert gpu.pairing_product_is_one(g1, None, g2, None)          # e(aP,bQ) * e(-abP,Q) == 1
+    g1b, _ = co.pack_g1_377([ecc.E1_377.mul(P, a), ecc.E1_377.neg(ecc.E1_377.mul(P, (a * b + 1) % ecc.R377))])
+    assert not gpu.pairing_product_is_one(g1b, None, g2, None)
+
+
+def test_verify_and_infinity(gpu):
+    """crates/bls-crypto/src/bls/public.rs:94-120: e(sig,-g2) * e(H(m),pk) == 1; pairs with an infinite point are skipped."""
+    sk = 0x1234567890ABCDEF1234
+    Hm = ecc.E1_377.mul(ecc.G1_377, 0xCAFEBABE)
+    sig = ecc.E1_377.mul(Hm, sk)
+    pk = ecc.E2_377.mul(ecc.G2_377, sk)
+    ng2 = ecc.E2_377.neg(ecc.G2_377)
+    g1, i1 = co.pack_g1_377([sig, Hm])
+    g2, i2 = co.pack_g2_377([ng2, pk])
+    assert gpu.pairing_product_is_one(g1, i1, g2, i2)
+    assert co.pairing_product_377(g1, i1, g2, i2)[1]
+    g2b, _ = co.pack_g2_377([ng2, ecc.E2_377.mul(ecc.G2_377, sk + 1)])
+    assert not gpu.pairing_product_is_one(g1, i1, g2b, i2)
+    g1c, i1c = co.pack_g1_377([sig, Hm, None])
+    g2c, i2c = co.pack_g2_377([ng2, pk, pk])
+    assert gpu.pairing_product_is_one(g1c, i1c, g2c, i2c)
+    g1d, i1d = co.pack_g1_377([sig, Hm, Hm])
+    g2d, i2d = co.pack_g2_377([ng2, pk, None])
+    assert gpu.pairing_product_is_one(g1d, i1d, g2d, i2d)
+    # empty product is 1
+    assert gpu.pairing_product_is_one(np.zeros((0, 12), dtype=np.uint64), None, np.zeros((0, 24), dtype=np.uint64), None)
+
+
+@pytest.mark.parametrize("npairs", [2, 8, 33])
+def test_batch_verify_shape(gpu, npairs):
+    """Signature::batch_verify_hashes (signature.rs:125-155): n+1-pair product, accept; corrupt one key, reject; same
+    verdicts as the oracle."""
+    rng = ecc.SplitMix64(500 + npairs)
+    g1p, g2p = _signed_pairs(rng, npairs)
+    g1, _ = co.pack_g1_377(g1p)
+    g2, _ = co.pack_g2_377(g2p)
+    assert gpu.pairing_product_is_one(g1, None, g2, None) and co.pairing_product_377(g1, None, g2, None)[1]
+    g1p, g2p = _signed_pairs(ecc.SplitMix64(500 + npairs), npairs, bad=(npairs - 2) // 2)
+    g2, _ = co.pack_g2_377(g2p)
+    assert not gpu.pairing_product_is_one(g1, None, g2, None)
+    assert not co.pairing_product_377(g1, None, g2, None)[1]
+
+
+def test_many_independent_products(gpu):
+    """BASELINE config 3 shape: many independent 2-pair checks in ONE launch, 1-in-8 corrupted; the accept vector must equal
+    the oracle's."""
+    m = 192
+    rng = ecc.SplitMix64(77)
+    g1l, g2l, expect = [], [], []
+    ng2 = ecc.E2_377.neg(ecc.G2_377)
+    for i in range(m):
+        sk = ecc.random_scalar(rng, ecc.R377)
+        Hm = ecc.E1_377.mul(ecc.G1_377, rng.next() | 1)
+        sig = ecc.E1_377.mul(Hm, sk)
+        bad = (i % 8) == 3
+        pk = ecc.E2_377.mul(ecc.G2_377, sk + (1 if bad else 0))
+        g1l += [sig, Hm]
+        g2l += [ng2, pk]
+        expect.append(0 if bad else 1)
+    g1, _ = co.pack_g1_377(g1l)
+    g2, _ = co.pack_g2_377(g2l)
+    offs = np.arange(0, 2 * m + 1, 2, dtype=np.uint32)
+    got = gpu.pairing_product_is_one_batch(g1, None, g2, None, offs)
+    assert got.tolist() == expect
+    for i in (0, 3, 100):
+        assert co.pairing_product_377(g1[2 * i:2 * i + 2], None, g2[2 * i:2 * i + 2], None)[1] == bool(expect[i])
+    print("pairing timings:", gpu.pairing_timings())

@@ -121,8 +121,18 @@ template <class F> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& b) {
 #else
 #define CURVE_FN inline
 #endif
-template <class F> CURVE_FN void xyzz_add_fn(Xyzz<F>& a, const Xyzz<F>& b) { xyzz_add(a, b); }
-template <class F> CURVE_FN void xyzz_dbl_fn(Xyzz<F>& a) { a = xyzz_dbl(a); }
+template <class F> CURVE_FN void xyzz_add_outline(Xyzz<F>& a, const Xyzz<F>& b) { xyzz_add(a, b); }
+template <class F> CURVE_FN void xyzz_dbl_outline(Xyzz<F>& a) { a = xyzz_dbl(a); }
+// 14-limb fields (BLS12-377 G1, the headline path) keep the inlined bodies: out-of-line calls pass the points through
+// private memory and doubled the per-addition latency of the (latency-bound) reduction kernels.
+template <class F> HD void xyzz_add_fn(Xyzz<F>& a, const Xyzz<F>& b) {
+  if constexpr (sizeof(F) <= 64) xyzz_add(a, b);
+  else xyzz_add_outline(a, b);
+}
+template <class F> HD void xyzz_dbl_fn(Xyzz<F>& a) {
+  if constexpr (sizeof(F) <= 64) a = xyzz_dbl(a);
+  else xyzz_dbl_outline(a);
+}
 
 template <class F> HD Affine<F> affine_neg(const Affine<F>& p) {
   return {p.x, F::norm(F::template neg<4, 1>(p.y))};

@@ -115,6 +115,16 @@ def main():
         value = world * n * args.steps / elapsed
         acc_avg = float(np.mean(acc_ms))
         achieved = n * ALG_BYTES_PER_SMUL / (acc_avg * 1e-3) / 1e9
+        traffic, traffic_src = None, "no committed PMC profile found"
+        try:
+            import glob
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            if cand:
+                tj = json.load(open(cand[-1]))
+                traffic = tj["kernels"]["k_accumulate<G1_377>"]["hbm_bytes_per_launch"] if args.log_n == 20 else None
+                traffic_src = os.path.basename(cand[-1])
+        except Exception:
+            pass
         line = {
             "metric": "BLS12-377 G1 MSM scalar-muls/sec",
             "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -124,13 +134,16 @@ def main():
                        "bases_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"], "buckets": tm["buckets"],
                        "sharding": "index-range shards + all_gather of 144-B partial sums" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate<G1_377>", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "note": "integer-VALU bound, not HBM bound (SURVEY.md §8d); algorithmic bytes = n*128 B per launch; "
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "integer-VALU bound, not HBM bound (SURVEY.md §8d); algorithmic bytes = n*128 B per launch; traffic = PMC bytes of the "
+                                 "same launch shape from the committed profile (each base is gathered once per window: 16x re-read, served by the 256 MB Infinity Cache); "
                                  "kernel ms from HIP events on the MSM stream: accumulate=%.3f of total=%.3f (convert=%.3f sort=%.3f reduce=%.3f)"
                                  % (acc_avg, float(np.mean(tot_ms)), tm["convert_ms"], tm["sort_ms"], tm["reduce_ms"])},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(bases, sc, n, result if world == 1 else None)
+            if world == 1:
+                line["pairing"] = pairing_leg(ffi, codec)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -161,6 +174,47 @@ def cpu_baseline(bases, sc, n, gpu_result):
             "sample": "full 2^%d-term MSM once, arkworks windowing c=%d (%d windows), one thread per window (%d of %d hw threads); "
                       "C++ restatement of ark-ec VariableBaseMSM, not the Rust binary (no Rust toolchain)" % (lg, c, windows, threads, hw),
             "seconds": secs, "parity_with_gpu": ok}
+
+
+def pairing_leg(ffi, codec):
+    """Secondary metric of BASELINE.json ("+ pairings/sec"): m independent 2-pair checks e(sig,-g2)*e(H,pk) == 1
+    (the shape of PublicKey::verify / Batch::verify's final check) in one launch; Miller loops/s with one final
+    exponentiation per 2 loops.  The oracle runs a sample of the same products on one host core and the accept
+    vectors are compared."""
+    from oracle import cpu_oracle as co
+    from oracle.py import ecc
+    import time as _t
+    m = 2048
+    rng = ecc.SplitMix64(0x5EED0005)
+    base = []
+    ng2 = ecc.E2_377.neg(ecc.G2_377)
+    for i in range(16):                      # 16 distinct signed messages, tiled (big-int signing in Python is slow)
+        sk = ecc.random_scalar(rng, ecc.R377)
+        Hm = ecc.E1_377.mul(ecc.G1_377, rng.next() | 1)
+        bad = (i % 8) == 5
+        base.append((ecc.E1_377.mul(Hm, sk), Hm, ecc.E2_377.mul(ecc.G2_377, sk + (1 if bad else 0)), 0 if bad else 1))
+    g1l, g2l, expect = [], [], []
+    for i in range(m):
+        sig, Hm, pk, ok = base[i % 16]
+        g1l += [sig, Hm]; g2l += [ng2, pk]; expect.append(ok)
+    g1, _ = co.pack_g1_377(g1l[:32]); g2, _ = co.pack_g2_377(g2l[:32])
+    g1 = np.tile(g1, (m // 16, 1)); g2 = np.tile(g2, (m // 16, 1))
+    offs = np.arange(0, 2 * m + 1, 2, dtype=np.uint32)
+    ffi.pairing_product_is_one_batch(g1, None, g2, None, offs)          # warm-up
+    t0 = _t.perf_counter()
+    got = ffi.pairing_product_is_one_batch(g1, None, g2, None, offs)
+    dt = _t.perf_counter() - t0
+    tm = ffi.pairing_timings()
+    ok = got.tolist() == expect
+    t0 = _t.perf_counter()
+    cpu_ok = [co.pairing_product_377(g1[2 * i:2 * i + 2], None, g2[2 * i:2 * i + 2], None)[1] for i in range(16)]
+    cdt = (_t.perf_counter() - t0) / 16
+    ok = ok and [int(x) for x in cpu_ok] == expect[:16]
+    if not ok:
+        raise SystemExit("PARITY FAILURE: GPU pairing accept vector != oracle")
+    return {"metric": "BLS12-377 Miller loops/s (2-pair products, 1 final exponentiation per product)", "value": 2 * m / dt,
+            "products": m, "wall_ms": dt * 1e3, "miller_ms": tm["miller_ms"], "final_exp_ms": tm["final_exp_ms"],
+            "bytes_per_miller_loop": 288, "cpu_port_miller_loops_per_s_1core": 2 / cdt, "accept_vector_matches_oracle": ok}
 
 
 if __name__ == "__main__":

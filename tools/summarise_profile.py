@@ -47,5 +47,13 @@ for k in sorted(sa):
         v = sa[k].get(c, [0]); return sum(v) / max(1, len(v))
     waves = a("SQ_WAVES")
     lines.append(f"| `{k}` | {waves:.0f} | {a('SQ_INSTS_VALU'):.3g} | {a('SQ_WAVE_CYCLES'):.3g} | {a('SQ_BUSY_CYCLES'):.3g} | {a('SQ_WAIT_INST_ANY'):.3g} | {a('SQ_ACTIVE_INST_VALU'):.3g} | {a('SQ_INSTS_VMEM_RD'):.3g} | {a('SQ_INSTS_VALU')/max(1,waves):.0f} |")
+import json
+traffic = {}
+for k in sorted(set(fa) | set(wa)):
+    f = sum(fa[k].get("FETCH_SIZE", [0])) / max(1, len(fa[k].get("FETCH_SIZE", [0])))
+    w = sum(wa[k].get("WRITE_SIZE", [0])) / max(1, len(wa[k].get("WRITE_SIZE", [0])))
+    traffic[k] = {"fetch_bytes_x2_corrected": 2 * f * 1024, "write_bytes": w * 1024, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
+json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tag {tag}; FETCH_SIZE doubled per MI355X_MICROARCH.md",
+           "kernels": traffic}, open(os.path.join(root, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
 open(out, "w").write("\n".join(lines) + "\n")
 print(open(out).read())

@@ -20,6 +20,7 @@ int api_ensure_init() {
 #define DECL(TAG)                                                                                     \
   int msm_host_##TAG(const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*);            \
   int msm_dev_##TAG(const void*, const void*, const void*, size_t, uint64_t*, void*);                 \
+  int msm_batch_host_##TAG(const uint64_t*, const uint8_t*, const uint64_t*, const uint32_t*, size_t, uint64_t*); \
   int msm_timings_##TAG(float*, int*);                                                                \
   int msm_set_c_##TAG(int);                                                                           \
   int gen_points_##TAG(void*, size_t, uint64_t, const uint64_t*, void*);                              \
@@ -55,6 +56,10 @@ int msm_bls12_377_g1_dev(const void* b, const void* inf, const void* s, size_t n
 int msm_bls12_377_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_g2_377(b, inf, s, n, out, st); }
 int msm_bw6_761_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_761(b, inf, s, n, out, st); }
 int msm_bw6_761_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_761(b, inf, s, n, out, st); }
+int msm_batch_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g1_377(b, inf, s, off, m, out); }
+int msm_batch_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g2_377(b, inf, s, off, m, out); }
+int msm_batch_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_761(b, inf, s, off, m, out); }
+int msm_batch_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_761(b, inf, s, off, m, out); }
 int pairing_product_is_one_bls12_377(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2, size_t k, int* is_one) {
   uint32_t offs[2] = {0, (uint32_t)k};
   uint8_t one = 0;

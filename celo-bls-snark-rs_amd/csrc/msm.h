@@ -432,6 +432,139 @@ __global__ void __launch_bounds__(128) k_tree(const uint32_t* __restrict__ in, u
   IO::store_xyzz(out + (size_t)t * IO::XYZZ_WORDS, acc);
 }
 
+// =====================================================================================================================
+// Batched small MSMs: m independent instances (instance p owns points [offsets[p], offsets[p+1])), the shape of
+// bls-crypto's Batch::verify (crates/bls-crypto/src/bls/batch.rs:69,76: one n-term G2 MSM + one n-term G1 MSM per batch,
+// n = number of signers, a few hundred) when bls-snark-sys' batch_verify_strict (crates/bls-snark-sys/src/signatures.rs:358)
+// hands over thousands of batches.  Per-instance Pippenger with a small window; the instances are the parallel axis.
+//   k_batch_sort      one workgroup per instance: signed digits, per-window LDS counting sort, runs written to HBM
+//   k_size_* + k_accumulate (shared with the big path): every (instance, window, bucket) run is a work item, longest first
+//   k_batch_reduce    one lane per (instance, window): running sum over its <= 64 buckets
+//   k_batch_horner    one lane per instance: Horner over the windows, Jacobian result in arkworks form
+template <int SW, int CB, int NW, int PT>
+__global__ void __launch_bounds__(256) k_batch_sort(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
+                                                    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted,
+                                                    uint32_t* __restrict__ pstart, uint32_t* __restrict__ plen) {
+  constexpr uint32_t B = 1u << (CB - 1);
+  static_assert(B <= 64, "batch path supports window sizes up to 7 bits");
+  __shared__ uint32_t cnt[B], cur[B];
+  const uint32_t inst = blockIdx.x;
+  const uint32_t lo = offsets[inst], n = offsets[inst + 1] - lo;
+  const size_t entry_base = (size_t)lo * NW;
+  uint32_t s[PT][SW + 1];
+  uint32_t carry[PT];
+  bool live[PT];
+#pragma unroll
+  for (int q = 0; q < PT; q++) {
+    uint32_t i = q * 256 + threadIdx.x;
+    live[q] = i < n && !(inf && inf[lo + i]);
+    carry[q] = 0;
+#pragma unroll
+    for (int k = 0; k <= SW; k++) s[q][k] = 0;
+    if (i < n) {
+      const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)(lo + i) * SW);
+#pragma unroll
+      for (int k = 0; k < SW / 4; k++) {
+        uint4 v = sp[k];
+        s[q][4 * k] = v.x; s[q][4 * k + 1] = v.y; s[q][4 * k + 2] = v.z; s[q][4 * k + 3] = v.w;
+      }
+    }
+  }
+#pragma unroll 1
+  for (int w = 0; w < NW; w++) {
+    if (threadIdx.x < B) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mag[PT], neg[PT];
+    const int bit = w * CB;
+    const int wi = bit >> 5, off = bit & 31;
+#pragma unroll
+    for (int q = 0; q < PT; q++) {
+      uint32_t raw = 0;
+      if (wi < SW) {
+        // dynamic word index: select from the register array (SW <= 12)
+        uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+        for (int k = 0; k <= SW; k++) { if (k == wi) w0 = s[q][k]; if (k == wi + 1) w1 = s[q][k]; }
+        uint64_t two = ((uint64_t)w1 << 32) | w0;
+        raw = (uint32_t)(two >> off) & ((1u << CB) - 1);
+      }
+      uint32_t d = raw + carry[q];
+      neg[q] = d > B ? 1u : 0u;
+      mag[q] = neg[q] ? ((1u << CB) - d) : d;
+      carry[q] = neg[q];
+      if (!live[q]) mag[q] = 0;
+      if (mag[q]) atomicAdd(&cnt[mag[q] - 1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan of B <= 64 counters by the first wave
+      uint32_t v = threadIdx.x < B ? cnt[threadIdx.x] : 0, x = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o, 64);
+        if ((int)threadIdx.x >= o) x += y;
+      }
+      if (threadIdx.x < B) {
+        uint32_t excl = x - v;
+        cur[threadIdx.x] = excl;
+        size_t bucket = ((size_t)inst * NW + w) * B + threadIdx.x;
+        pstart[bucket] = (uint32_t)(entry_base + (size_t)w * n + excl);
+        plen[bucket] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PT; q++) {
+      if (mag[q]) {
+        uint32_t pos = atomicAdd(&cur[mag[q] - 1], 1u);
+        sorted[entry_base + (size_t)w * n + pos] = (lo + q * 256 + threadIdx.x) | (neg[q] << 31);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <class G>
+__global__ void __launch_bounds__(128) k_batch_reduce(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ plen,
+                                                      uint32_t* __restrict__ wsum, uint32_t B, uint32_t nvw) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  uint32_t vw = blockIdx.x * blockDim.x + threadIdx.x;
+  if (vw >= nvw) return;
+  Xyzz<F> running = Xyzz<F>::identity(), acc = Xyzz<F>::identity();
+  for (int b = (int)B - 1; b >= 0; b--) {
+    size_t bucket = (size_t)vw * B + b;
+    if (plen[bucket]) {
+      Xyzz<F> v = IO::load_xyzz(partials + bucket * IO::XYZZ_WORDS);
+      xyzz_add_fn(running, v);
+    }
+    xyzz_add_fn(acc, running);
+  }
+  IO::store_xyzz(wsum + (size_t)vw * IO::XYZZ_WORDS, acc);
+}
+
+template <class G>
+__global__ void __launch_bounds__(128) k_batch_horner(const uint32_t* __restrict__ wsum, uint64_t* __restrict__ out, uint32_t nw,
+                                                      uint32_t c, uint32_t m) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= m) return;
+  Xyzz<F> acc = Xyzz<F>::identity();
+  for (int w = (int)nw - 1; w >= 0; w--) {
+    for (uint32_t k = 0; k < c; k++) xyzz_dbl_fn(acc);
+    Xyzz<F> v = IO::load_xyzz(wsum + ((size_t)inst * nw + w) * IO::XYZZ_WORDS);
+    xyzz_add_fn(acc, v);
+  }
+  uint64_t* o = out + (size_t)inst * 3 * IO::ARK64;
+  if (acc.is_identity() || acc.ZZ.is_zero_mod_p()) {
+    F::zero().to_ark(o); F::one().to_ark(o + IO::ARK64); F::zero().to_ark(o + 2 * IO::ARK64);
+  } else {
+    F::mul(acc.X, acc.ZZ).to_ark(o);
+    F::mul(acc.Y, acc.ZZZ).to_ark(o + IO::ARK64);
+    acc.ZZ.to_ark(o + 2 * IO::ARK64);
+  }
+}
+
 // ---------------------------------------------------------------- host driver
 struct MsmTimings {  // milliseconds, HIP events on the MSM's stream (last call)
   float convert = 0, sort = 0, accumulate = 0, reduce = 0, total = 0;
@@ -625,6 +758,85 @@ template <class G> class MsmEngine {
     return run_device(d_in_bases, inf ? d_in_inf : nullptr, (const uint32_t*)d_in_scalars, n, out_jac, stream);
   }
 
+  // ---- batched small MSMs (host pointers).  offsets[m+1]; every instance must have <= 1024 points (larger instances go
+  // through run_host one by one).  out: m Jacobian results (arkworks form).
+  static constexpr uint32_t BATCH_MAX_N = 1024;
+  MsmTimings tm_batch;
+  int run_batch_host(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m,
+                     uint64_t* out, hipStream_t stream) {
+    if (m == 0) return 0;
+    const uint32_t total_pts = offsets[m];
+    uint32_t max_n = 0;
+    for (size_t p = 0; p < m; p++) {
+      uint32_t k = offsets[p + 1] - offsets[p];
+      if (k > max_n) max_n = k;
+    }
+    if (max_n > BATCH_MAX_N || total_pts == 0) {  // fall back to instance-at-a-time on the big pipeline (still the GPU)
+      for (size_t p = 0; p < m; p++) {
+        uint32_t lo = offsets[p], k = offsets[p + 1] - lo;
+        int rc = run_host(bases + (size_t)lo * 2 * IO::ARK64, inf ? inf + lo : nullptr, scalars + (size_t)lo * (SW / 2), k,
+                          out + p * 3 * IO::ARK64, stream);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+    int c = force_c ? force_c : 3;
+    if (!force_c) { while (c < 7 && (2u << c) <= max_n / 2) c++; }   // ~ log2(n) - 2
+    if (c > 7) c = 7;
+    if (c < 3) c = 3;
+    const int nw = (G::SCALAR_BITS + c) / c;
+    const uint32_t B = 1u << (c - 1);
+    const size_t nvw = m * (size_t)nw, nbuckets = nvw * B, entries = (size_t)total_pts * nw;
+    if (nbuckets >= (size_t(1) << 31) || entries >= (size_t(1) << 32)) return 2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
+    const size_t o_in_b = take((size_t)total_pts * 2 * IO::ARK64 * 8), o_in_s = take((size_t)total_pts * SW * 4), o_in_i = take(total_pts + 8);
+    const size_t o_off = take((m + 1) * 4);
+    const size_t o_bases = take((size_t)total_pts * IO::AFF_WORDS * 4), o_sorted = take(entries * 4 + 16);
+    const size_t o_pstart = take(nbuckets * 4), o_plen = take(nbuckets * 4), o_order = take(nbuckets * 4);
+    const size_t o_bins = take((size_t)SIZE_BINS * 4 + 256), o_partials = take(nbuckets * IO::XYZZ_WORDS * 4);
+    const size_t o_wsum = take(nvw * IO::XYZZ_WORDS * 4), o_out = take(m * 3 * IO::ARK64 * 8);
+    if (ensure(off)) return 1;
+    char* A = arena;
+    uint64_t* d_in_b = (uint64_t*)(A + o_in_b); uint32_t* d_in_s = (uint32_t*)(A + o_in_s); uint8_t* d_in_i = (uint8_t*)(A + o_in_i);
+    uint32_t* d_off = (uint32_t*)(A + o_off);
+    uint32_t* d_bases = (uint32_t*)(A + o_bases); uint32_t* d_sorted = (uint32_t*)(A + o_sorted);
+    uint32_t* d_pstart = (uint32_t*)(A + o_pstart); uint32_t* d_plen = (uint32_t*)(A + o_plen); uint32_t* d_order = (uint32_t*)(A + o_order);
+    uint32_t* d_bins = (uint32_t*)(A + o_bins); uint32_t* d_nwork = d_bins + SIZE_BINS;
+    uint32_t* d_partials = (uint32_t*)(A + o_partials); uint32_t* d_wsum = (uint32_t*)(A + o_wsum); uint64_t* d_out = (uint64_t*)(A + o_out);
+    HIP_OK(hipMemcpyAsync(d_in_b, bases, (size_t)total_pts * 2 * IO::ARK64 * 8, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(d_in_s, scalars, (size_t)total_pts * SW * 4, hipMemcpyHostToDevice, stream));
+    if (inf) HIP_OK(hipMemcpyAsync(d_in_i, inf, total_pts, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(d_off, offsets, (m + 1) * 4, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipEventRecord(ev[0], stream));
+    hipLaunchKernelGGL((k_convert_bases<G>), dim3((total_pts + 255) / 256), dim3(256), 0, stream, d_in_b, d_bases, (size_t)total_pts);
+    HIP_OK(hipEventRecord(ev[1], stream));
+    HIP_OK(hipMemsetAsync(d_bins, 0, (size_t)SIZE_BINS * 4 + 256, stream));
+    if (launch_batch_sort(c, max_n, d_in_s, inf ? d_in_i : nullptr, d_off, d_sorted, d_pstart, d_plen, (uint32_t)m, stream)) return 3;
+    const uint32_t slots = (uint32_t)nbuckets;
+    hipLaunchKernelGGL((k_size_hist<G>), dim3(slots / 256 < 2048 ? (slots + 255) / 256 : 2048), dim3(256), 0, stream, d_plen, d_bins, slots);
+    hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
+    hipLaunchKernelGGL((k_size_scatter<G>), dim3((slots + 4095) / 4096), dim3(1024), 0, stream, d_plen, d_bins, d_order, slots);
+    HIP_OK(hipEventRecord(ev[2], stream));
+    hipLaunchKernelGGL((k_accumulate<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order,
+                       d_nwork, d_partials);
+    HIP_OK(hipEventRecord(ev[3], stream));
+    hipLaunchKernelGGL((k_batch_reduce<G>), dim3(((uint32_t)nvw + 127) / 128), dim3(128), 0, stream, d_partials, d_plen, d_wsum, B, (uint32_t)nvw);
+    hipLaunchKernelGGL((k_batch_horner<G>), dim3(((uint32_t)m + 127) / 128), dim3(128), 0, stream, d_wsum, d_out, (uint32_t)nw, (uint32_t)c, (uint32_t)m);
+    HIP_OK(hipEventRecord(ev[4], stream));
+    HIP_OK(hipMemcpyAsync(out, d_out, m * 3 * IO::ARK64 * 8, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipEventRecord(ev[5], stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipGetLastError());
+    (void)hipEventElapsedTime(&tm_batch.convert, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&tm_batch.sort, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&tm_batch.accumulate, ev[2], ev[3]);
+    (void)hipEventElapsedTime(&tm_batch.reduce, ev[3], ev[4]);
+    (void)hipEventElapsedTime(&tm_batch.total, ev[0], ev[5]);
+    tm = tm_batch; last_c = c; last_nw = nw; last_buckets = (uint32_t)nbuckets;
+    return 0;
+  }
+
   MsmTimings tm;
   int last_c = 0, last_nw = 0;
   uint32_t last_buckets = 0;
@@ -675,6 +887,29 @@ template <class G> class MsmEngine {
     return 0;
   }
 
+  template <int CB, int PT> int launch_batch_sort_cp(const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
+                                                     uint32_t* pstart, uint32_t* plen, uint32_t m, hipStream_t st) {
+    constexpr int NW = (G::SCALAR_BITS + CB) / CB;
+    hipLaunchKernelGGL((k_batch_sort<SW, CB, NW, PT>), dim3(m), dim3(256), 0, st, sc, inf, off, sorted, pstart, plen);
+    return 0;
+  }
+  template <int CB> int launch_batch_sort_c(uint32_t max_n, const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
+                                            uint32_t* pstart, uint32_t* plen, uint32_t m, hipStream_t st) {
+    if (max_n <= 256) return launch_batch_sort_cp<CB, 1>(sc, inf, off, sorted, pstart, plen, m, st);
+    if (max_n <= 512) return launch_batch_sort_cp<CB, 2>(sc, inf, off, sorted, pstart, plen, m, st);
+    return launch_batch_sort_cp<CB, 4>(sc, inf, off, sorted, pstart, plen, m, st);
+  }
+  int launch_batch_sort(int c, uint32_t max_n, const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
+                        uint32_t* pstart, uint32_t* plen, uint32_t m, hipStream_t st) {
+    switch (c) {
+      case 3: return launch_batch_sort_c<3>(max_n, sc, inf, off, sorted, pstart, plen, m, st);
+      case 4: return launch_batch_sort_c<4>(max_n, sc, inf, off, sorted, pstart, plen, m, st);
+      case 5: return launch_batch_sort_c<5>(max_n, sc, inf, off, sorted, pstart, plen, m, st);
+      case 6: return launch_batch_sort_c<6>(max_n, sc, inf, off, sorted, pstart, plen, m, st);
+      case 7: return launch_batch_sort_c<7>(max_n, sc, inf, off, sorted, pstart, plen, m, st);
+      default: return 1;
+    }
+  }
   template <int CB> int launch_digits_c(const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {
     constexpr int NW = (G::SCALAR_BITS + CB) / CB;
     hipLaunchKernelGGL((k_digits<SW, CB, NW>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);

@@ -90,6 +90,11 @@ template <class F> int sum_jacobian_impl(const uint64_t* jac, size_t k, uint64_t
     if (int rc = api_ensure_init()) return rc;                                                                           \
     return eng_##TAG.run_device((const uint64_t*)b, (const uint8_t*)inf, (const uint32_t*)s, n, out, (hipStream_t)st);   \
   }                                                                                                                      \
+  int msm_batch_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { \
+    std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
+    if (int rc = api_ensure_init()) return rc;                                                                           \
+    return eng_##TAG.run_batch_host(b, inf, s, off, m, out, nullptr);                                                    \
+  }                                                                                                                      \
   int msm_timings_##TAG(float ms[5], int cfg[3]) {                                                                       \
     std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
     const MsmTimings& t = eng_##TAG.tm;                                                                                  \

@@ -16,6 +16,7 @@ GROUP_SHAPE = {"bls12_377_g1": (12, 4, 18), "bls12_377_g2": (24, 4, 36), "bw6_76
 EXPORTS = [
     "celo_amd_init", "celo_amd_device_name",
     "msm_bls12_377_g1", "msm_bls12_377_g2", "msm_bw6_761_g1", "msm_bw6_761_g2",
+    "msm_batch_bls12_377_g1", "msm_batch_bls12_377_g2", "msm_batch_bw6_761_g1", "msm_batch_bw6_761_g2",
     "msm_bls12_377_g1_dev", "msm_bls12_377_g2_dev", "msm_bw6_761_g1_dev", "msm_bw6_761_g2_dev",
     "pairing_product_is_one_bls12_377", "pairing_product_is_one_batch_bls12_377", "celo_amd_pairing_gt_bls12_377",
     "celo_amd_pairing_last_timings",
@@ -152,3 +153,18 @@ def pairing_timings():
     ms = (C.c_float * 4)()
     assert lib().celo_amd_pairing_last_timings(ms) == 0
     return {"miller_ms": ms[0], "product_ms": ms[1], "final_exp_ms": ms[2], "total_ms": ms[3]}
+
+
+def msm_batch(group, bases_xy, inf, scalars, offsets):
+    """m independent MSMs in one call. offsets uint32 [m+1]. Returns uint64 [m, O] Jacobian results."""
+    A, S, O = GROUP_SHAPE[group]
+    bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    m = offsets.size - 1
+    assert bases_xy.size == int(offsets[-1]) * A and scalars.size == int(offsets[-1]) * S
+    out = np.zeros((m, O), dtype=np.uint64)
+    rc = getattr(lib(), "msm_batch_" + group)(_p(bases_xy), _p(inf), _p(scalars), _p(offsets), C.c_size_t(m), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"msm_batch_{group} failed rc={rc}")
+    return out

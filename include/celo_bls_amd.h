@@ -46,6 +46,17 @@ int msm_bls12_377_g2_dev(const void* d_bases_xy, const void* d_inf, const void* 
 int msm_bw6_761_g1_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
 int msm_bw6_761_g2_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
 
+/* ---- batched MSMs: m independent instances in one call; instance p owns points/scalars [offsets[p], offsets[p+1])
+ * (offsets has m+1 entries), out_xyz holds m Jacobian results back to back.  This is the shape of Batch::verify
+ * (crates/bls-crypto/src/bls/batch.rs:69,76 — one G2 and one G1 MSM over the batch's signers) when
+ * batch_verify_strict (crates/bls-snark-sys/src/signatures.rs:343-400) is handed many batches; the reference loops over
+ * them serially (signatures.rs:358).  Instances of up to 1024 points run on the batched kernels; larger ones are
+ * processed one at a time on the large-MSM pipeline. */
+int msm_batch_bls12_377_g1(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*18 */);
+int msm_batch_bls12_377_g2(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*36 */);
+int msm_batch_bw6_761_g1(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*36 */);
+int msm_batch_bw6_761_g2(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*36 */);
+
 /* ---- pairing product check.  Replaces `Bls12_377::product_of_pairings(&pairs) == Fq12::one()` at
  *   crates/bls-crypto/src/bls/public.rs:102    (PublicKey::verify_sig: 2 pairs)
  *   crates/bls-crypto/src/bls/signature.rs:149 (Signature::batch_verify_hashes: n+1 pairs, one final exponentiation)

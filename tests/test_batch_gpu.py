@@ -1,0 +1,90 @@
+"""GPU (-m gpu): batched small MSMs and the Batch::verify / batch_verify_strict flow (BASELINE config 3 shape at
+oracle-checkable sizes).  Reference: crates/bls-crypto/src/bls/batch.rs:44-84, crates/bls-snark-sys/src/signatures.rs:343-400."""
+import numpy as np
+import pytest
+from oracle.py import ecc
+from oracle import cpu_oracle as co
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_batch(gpu, group, kind, curve, gen, packer, sizes, bits, seed):
+    rng = ecc.SplitMix64(seed)
+    offs = np.zeros(len(sizes) + 1, dtype=np.uint32)
+    pts, sc = [], []
+    for i, k in enumerate(sizes):
+        offs[i + 1] = offs[i] + k
+        base = curve.mul(gen, rng.next() | 1)
+        inst = []
+        for j in range(k):
+            inst.append(curve.add(base, inst[-1]) if inst else base)   # cheap distinct points: base, 2base, ...
+        if k >= 8:
+            inst[3] = None
+            inst[5] = inst[6]
+        pts += inst
+        s = [ecc.random_scalar(rng, 1 << bits) for _ in range(k)]
+        if k >= 8:
+            s[0] = 0; s[1] = 1; s[5] = s[6]
+        sc += s
+    xy, inf = packer(pts)
+    s_np = H.scalars_np(sc, 4)
+    got = gpu.msm_batch(group, xy, inf, s_np, offs)
+    for i, k in enumerate(sizes):
+        lo, hi = int(offs[i]), int(offs[i + 1])
+        exp = co.jac_to_affine(co.msm(group, xy[lo:hi], inf[lo:hi], s_np[lo:hi], threads=2), kind) if k else None
+        assert co.jac_to_affine(got[i], kind) == exp, (i, k)
+
+
+def test_batch_g1_mixed_sizes_136bit(gpu):
+    _check_batch(gpu, "bls12_377_g1", "g1_377", ecc.E1_377, ecc.G1_377, co.pack_g1_377, [1, 17, 256, 0, 300, 64], 136, 1)
+
+
+def test_batch_g1_full_scalars(gpu):
+    _check_batch(gpu, "bls12_377_g1", "g1_377", ecc.E1_377, ecc.G1_377, co.pack_g1_377, [33, 256, 700], 252, 2)
+
+
+def test_batch_g2(gpu):
+    _check_batch(gpu, "bls12_377_g2", "g2_377", ecc.E2_377, ecc.G2_377, co.pack_g2_377, [5, 64, 256], 136, 3)
+
+
+def test_batch_verify_strict_flow(gpu):
+    """Vectorised batch_verify_strict: valid batches accept, a batch with one bad signature rejects; the same exponents go
+    through the oracle's MSM + pairing and must give the same accept vector."""
+    from celo_bls_snark_rs_amd import bls
+    rng = ecc.SplitMix64(99)
+    batches, exps, expect = [], [], []
+    for b in range(6):
+        n = [3, 20, 64, 7, 1, 20][b]
+        h = ecc.E1_377.mul(ecc.G1_377, rng.next() | 1)         # synthetic H(m) = h*G1 (hash-to-curve is out of scope)
+        sks = [ecc.random_scalar(rng, ecc.R377) for _ in range(n)]
+        pks = [ecc.E2_377.mul(ecc.G2_377, sk) for sk in sks]
+        sigs = [ecc.E1_377.mul(h, sk) for sk in sks]
+        bad = b in (2, 4)
+        if bad:
+            sigs[n // 2] = ecc.E1_377.mul(h, sks[n // 2] + 1)
+        batches.append((pks, sigs, h))
+        nb = bls.byte_count_from_target_batch_size(n)
+        exps.append([int.from_bytes(bytes((rng.next() >> (8 * (k % 8))) & 0xFF for k in range(nb)), "little") for _ in range(n)])
+        expect.append(not bad)
+    assert bls.byte_count_from_target_batch_size(256) == 17 and bls.byte_count_from_target_batch_size(257) == 18
+    got = bls.batch_verify_strict(batches, exps)
+    assert got == expect
+    # oracle on the same exponents
+    for (pks, sigs, h), ex, want in zip(batches, exps, expect):
+        xy2, i2 = co.pack_g2_377(pks)
+        xy1, i1 = co.pack_g1_377(sigs)
+        s = H.scalars_np(ex, 4)
+        bpk = co.jac_to_affine(co.msm("bls12_377_g2", xy2, i2, s), "g2_377")
+        bsg = co.jac_to_affine(co.msm("bls12_377_g1", xy1, i1, s), "g1_377")
+        g1, j1 = co.pack_g1_377([bsg, h])
+        g2, j2 = co.pack_g2_377([ecc.E2_377.neg(ecc.G2_377), bpk])
+        assert co.pairing_product_377(g1, j1, g2, j2)[1] == want
+    # production path draws its own exponents (OS RNG): verdicts must still be right
+    assert bls.batch_verify_strict(batches) == expect
+    # single verify + aggregate screening mirrors
+    pks, sigs, h = batches[0]
+    bls.verify_hash(pks[0], h, sigs[0])
+    with pytest.raises(bls.BLSError):
+        bls.verify_hash(pks[1], h, sigs[0])
+    assert bls.public_key_batch([1, 2], pks[:1]) is None      # length mismatch -> None (public.rs:53-56)

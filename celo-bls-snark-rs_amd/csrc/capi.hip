@@ -28,6 +28,7 @@ int api_ensure_init() {
 DECL(g1_377) DECL(g2_377) DECL(761)
 int pairing_run_377(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
 int pairing_timings_377(float*);
+int pairing_run_761(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
 }  // namespace celo
 using namespace celo;
 
@@ -74,6 +75,17 @@ int pairing_product_is_one_batch_bls12_377(const uint64_t* g1, const uint8_t* in
 int celo_amd_pairing_gt_bls12_377(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2, const uint32_t* offsets,
                                   size_t m, int miller_only, uint64_t* gt72) {
   return pairing_run_377(g1, inf1, g2, inf2, offsets, m, nullptr, gt72, miller_only ? 1 : 0);
+}
+int pairing_product_is_one_bw6_761(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2, size_t k, int* is_one) {
+  uint32_t offs[2] = {0, (uint32_t)k};
+  uint8_t one = 0;
+  int rc = pairing_run_761(g1, inf1, g2, inf2, offs, 1, &one, nullptr, 0);
+  if (rc == 0 && is_one) *is_one = one;
+  return rc;
+}
+int celo_amd_pairing_gt_bw6_761(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2, const uint32_t* offsets,
+                                size_t m, int miller_only, uint64_t* gt72) {
+  return pairing_run_761(g1, inf1, g2, inf2, offsets, m, nullptr, gt72, miller_only ? 1 : 0);
 }
 int celo_amd_pairing_last_timings(float ms[4]) { return pairing_timings_377(ms); }
 int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]) {

@@ -117,7 +117,7 @@ template <class F> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& b) {
 // Out-of-line variants for the latency-bound reduction kernels (one code copy per translation unit instead of one per
 // call site: the inlined bodies are ~8-17k instructions each and dominated the build time).
 #if defined(__HIPCC__)
-#define CURVE_FN __host__ __device__ __attribute__((noinline))
+#define CURVE_FN __host__ __device__ inline __attribute__((noinline))
 #else
 #define CURVE_FN inline
 #endif

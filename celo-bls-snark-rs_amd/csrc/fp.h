@@ -245,16 +245,23 @@ template <class P> struct Fp {
     return r;
   }
 
-  // ---- weak reduction: value < ~300p (normalised limbs)  ->  value < 1.05p.  Quotient estimate from the top limb
-  // (p's top limb has >= 13 bits for BLS12-377), one multiply-subtract sweep, ~60 VALU ops: used by the pairing tower
+  // ---- weak reduction: value < ~300p (normalised limbs)  ->  value < ~2.1p.  Quotient estimate from the top limb(s),
+  // one multiply-subtract sweep, ~60-110 VALU ops: used by the pairing towers
   // to stop the value growth of lazy additions without paying a full Montgomery multiplication.
   HD static Fp wred(const Fp& a_) {
-    static_assert(P::P[L - 1] >= 4096, "wred needs a wide top limb of p (BLS12-377); BW6-761 uses reduce()");
     const Fp a = norm(a_);
     TRK(assert(a.vb <= 300);)
-    constexpr uint64_t D = (uint64_t)P::P[L - 1] + 1;
-    constexpr uint64_t M = ((1ull << 34) + D - 1) / D;      // ceil(2^34 / D); exact floor(t/D) for t < 2^21
-    const uint32_t q = (uint32_t)(((uint64_t)a.l[L - 1] * M) >> 34);
+    uint32_t q;
+    if constexpr (P::P[L - 1] >= 4096) {                      // BLS12-377: 13-bit top limb, integer reciprocal
+      constexpr uint64_t D = (uint64_t)P::P[L - 1] + 1;
+      constexpr uint64_t M = ((1ull << 34) + D - 1) / D;      // ceil(2^34 / D); exact floor(t/D) for t < 2^21
+      q = (uint32_t)(((uint64_t)a.l[L - 1] * M) >> 34);
+    } else {                                                  // BW6-761: 5-bit top limb -> estimate from the top two limbs
+      constexpr double DINV = 1.0 / (double)((((uint64_t)P::P[L - 1]) << W) + P::P[L - 2] + 1);
+      const uint64_t t2 = (((uint64_t)a.l[L - 1]) << W) + a.l[L - 2];
+      const uint32_t e = (uint32_t)((double)t2 * DINV);
+      q = e ? e - 1 : 0;                                      // never above floor(a/p)
+    }
     Fp r;
     int64_t carry = 0;
 #pragma unroll
@@ -264,7 +271,7 @@ template <class P> struct Fp {
       carry = t >> W;
     }
     r.l[L - 1] = (uint32_t)((int64_t)a.l[L - 1] - (int64_t)((uint64_t)q * P::P[L - 1]) + carry);
-    TRK(r.lb = 1; r.vb = 2;)
+    TRK(r.lb = 1; r.vb = 3;)
     return r;
   }
 

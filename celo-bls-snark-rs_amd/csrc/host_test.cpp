@@ -82,7 +82,23 @@ static void pairing_op(int mode, const uint64_t* g1, const uint64_t* g2, size_t 
   if (is_one) *is_one = f12_is_one(r) ? 1 : 0;
 }
 
+static void pairing_op_761(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out72, int* is_one) {
+  Fw6 acc = quad_one<Base761>();
+  for (size_t i = 0; i < k; i++) {
+    Fw6 f, t;
+    PP761::miller(f, g1 + i * 24, g2 + i * 24);
+    quad_mul(t, acc, f);
+    acc = t;
+  }
+  Fw6 r;
+  if (mode == 0) bw6_final_exponentiation(r, acc);
+  else r = acc;
+  QuadIO<Base761>::to_ark(r, out72);
+  if (is_one) *is_one = quad_is_one(r) ? 1 : 0;
+}
+
 extern "C" {
+void ht_pairing_761(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out72, int* is_one) { pairing_op_761(mode, g1, g2, k, out72, is_one); }
 void ht_pairing_377(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
                     uint64_t* out72, int* is_one) { pairing_op(mode, g1, g2, k, in72, in72b, out72, is_one); }
 void ht_fq377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp<P377>>(op, a, b, out); }

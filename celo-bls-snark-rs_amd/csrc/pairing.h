@@ -152,60 +152,205 @@ TW_FN void final_exponentiation(Fq12& out, const Fq12& f) {
   f12_mul(out, y5, y1);
 }
 
+
+// ================================================================== BW6-761 (Groth16 verify, crates/epoch-snark/src/api/verifier.rs:35)
+// ark-ec models/bw6: two Miller loops (x+1, and the signed-digit expansion of x^3-x^2-x), f1 * frob(f2), then
+// (q^3-1)(q+1) and the hard part m^R0(x) * (m^q)^R1(x) (El Housni-Guillevic, eprint 2020/351 Alg. 6).  G2 coordinates
+// are in Fq (M-type sextic twist y^2 = x^3 + 4).
+struct G2ProjW { Fw x, y, z; };
+struct EllW { Fw c0, c1, c2; };
+typedef Base761 BW;
+
+TW_FN void bw6_double_step(G2ProjW& r, EllW& l) {
+  Fw a, b, c, j, t, g2, e2s;
+  BW::mul(a, r.x, r.y);
+  BW::sqr(b, r.y);
+  BW::sqr(c, r.z);
+  Fw c3 = BW::tpl(c);
+  Fw e = BW::wred(BW::dbl(BW::dbl(c3)));                 // B' * 3c = 12c
+  Fw f = BW::tpl(e);                                     // vb 9
+  Fw g = BW::add(b, f);
+  BW::sqr(t, BW::add(r.y, r.z));
+  Fw h = BW::sub<8>(t, BW::add(b, c));
+  Fw i = BW::sub<4>(e, b);
+  BW::sqr(j, r.x);
+  BW::sqr(e2s, BW::dbl(e));
+  BW::mul(t, BW::dbl(a), BW::sub<16>(b, f));
+  r.x = t;
+  BW::sqr(g2, g);
+  r.y = BW::wred(BW::sub<8>(g2, BW::tpl(e2s)));
+  BW::mul(t, BW::dbl(BW::dbl(b)), h);
+  r.z = t;
+  l.c0 = BW::wred(i);
+  l.c1 = BW::wred(BW::tpl(j));
+  l.c2 = BW::wred(BW::neg<16>(h));
+}
+TW_FN void bw6_add_step(G2ProjW& r, const Fw& qx, const Fw& qy, EllW& l) {
+  Fw t, c, d, e, f, g, u, v;
+  BW::mul(t, qy, r.z);
+  Fw theta = BW::sub<4>(r.y, t);
+  BW::mul(t, qx, r.z);
+  Fw lambda = BW::sub<4>(r.x, t);
+  BW::sqr(c, theta);
+  BW::sqr(d, lambda);
+  BW::mul(e, lambda, d);
+  BW::mul(f, r.z, c);
+  BW::mul(g, r.x, d);
+  Fw h = BW::sub<8>(BW::add(e, f), BW::dbl(g));
+  BW::mul(t, lambda, h);
+  Fw nx = t;
+  BW::mul(u, theta, BW::sub<16>(g, h));
+  BW::mul(v, e, r.y);
+  r.y = BW::wred(BW::sub<4>(u, v));
+  r.x = nx;
+  BW::mul(t, r.z, e);
+  r.z = t;
+  BW::mul(u, theta, qx);
+  BW::mul(v, lambda, qy);
+  l.c0 = BW::wred(BW::sub<4>(u, v));
+  l.c1 = BW::wred(BW::neg<8>(theta));
+  l.c2 = BW::wred(lambda);
+}
+TW_FN void bw6_ell(Fw6& f, const EllW& l, const Fw& px, const Fw& py) {
+  Fw s1, s4;
+  BW::mul(s1, l.c1, px);
+  BW::mul(s4, l.c2, py);
+  fw6_mul_by_014(f, l.c0, s1, s4);
+}
+TW_FN void bw6_miller_loop_single(Fw6& out, const Fw& px, const Fw& py, const Fw& qx, const Fw& qy) {
+  EllW l;
+  // f_{x+1,Q}(P)
+  G2ProjW r = {qx, qy, Fw::one()};
+  Fw6 f1 = quad_one<Base761>(), t;
+  for (int i = 62; i >= 0; i--) {
+    quad_sqr(t, f1); f1 = t;
+    bw6_double_step(r, l);
+    bw6_ell(f1, l, px, py);
+    if ((T761::LOOP1 >> i) & 1) {
+      bw6_add_step(r, qx, qy, l);
+      bw6_ell(f1, l, px, py);
+    }
+  }
+  // f_{x^3-x^2-x,Q}(P), signed digits
+  r = {qx, qy, Fw::one()};
+  const Fw nqy = BW::wred(BW::neg<4>(qy));
+  Fw6 f2 = quad_one<Base761>();
+  for (int i = T761::LOOP2_LEN - 1; i >= 1; i--) {
+    if (i != T761::LOOP2_LEN - 1) { quad_sqr(t, f2); f2 = t; }
+    bw6_double_step(r, l);
+    bw6_ell(f2, l, px, py);
+    int d = T761::LOOP2_NAF[i - 1];
+    if (d != 0) {
+      bw6_add_step(r, qx, d > 0 ? qy : nqy, l);
+      bw6_ell(f2, l, px, py);
+    }
+  }
+  fw6_frob1(t, f2);
+  quad_mul(out, f1, t);
+}
+template <int NLIMBS> TW_FN void bw6_pow(Fw6& r, const Fw6& f, const uint64_t* e, int bits, bool neg) {
+  Fw6 acc = f, t;  // top bit
+  for (int i = bits - 2; i >= 0; i--) {
+    quad_sqr(t, acc); acc = t;
+    if ((e[i >> 6] >> (i & 63)) & 1) { quad_mul(t, acc, f); acc = t; }
+  }
+  r = neg ? quad_conj(acc) : acc;  // inverse == conjugate in the cyclotomic subgroup
+}
+TW_FN void bw6_final_exponentiation(Fw6& out, const Fw6& f) {
+  Fw6 inv, a, m, t, p0, p1, mq;
+  quad_inv(inv, f);
+  quad_mul(a, quad_conj(f), inv);       // f^(q^3 - 1)
+  fw6_frob1(t, a);
+  quad_mul(m, t, a);                    // ^(q + 1)
+  uint64_t e0[sizeof(T761::R0_MAG) / 8], e1[sizeof(T761::R1_MAG) / 8];
+  for (unsigned i = 0; i < sizeof(T761::R0_MAG) / 8; i++) e0[i] = T761::R0_MAG[i];
+  for (unsigned i = 0; i < sizeof(T761::R1_MAG) / 8; i++) e1[i] = T761::R1_MAG[i];
+  bw6_pow<8>(p0, m, e0, T761::R0_BITS, T761::R0_NEG);
+  fw6_frob1(mq, m);
+  bw6_pow<9>(p1, mq, e1, T761::R1_BITS, T761::R1_NEG);
+  quad_mul(out, p0, p1);
+}
+
+// ================================================================== pairing policies (one per curve) for the kernels below
+struct PP377 {
+  typedef Base377 BP;
+  typedef Fq12 Gt;
+  static constexpr int G1_ARK64 = 12, G2_ARK64 = 24;
+  HD static void miller(Gt& f, const uint64_t* g1, const uint64_t* g2) {
+    Fq px = Fq::from_ark(g1), py = Fq::from_ark(g1 + 6);
+    Fq2 qx = Fq2::from_ark(g2), qy = Fq2::from_ark(g2 + 12);
+    miller_loop_single(f, px, py, qx, qy);
+  }
+  HD static void final_exp(Gt& r, const Gt& f) { final_exponentiation(r, f); }
+};
+struct PP761 {
+  typedef Base761 BP;
+  typedef Fw6 Gt;
+  static constexpr int G1_ARK64 = 24, G2_ARK64 = 24;
+  HD static void miller(Gt& f, const uint64_t* g1, const uint64_t* g2) {
+    Fw px = Fw::from_ark(g1), py = Fw::from_ark(g1 + 12);
+    Fw qx = Fw::from_ark(g2), qy = Fw::from_ark(g2 + 12);
+    bw6_miller_loop_single(f, px, py, qx, qy);
+  }
+  HD static void final_exp(Gt& r, const Gt& f) { bw6_final_exponentiation(r, f); }
+};
+
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------- kernels
-// pairs in arkworks layout: g1 = x||y (2*6 u64), g2 = x.c0||x.c1||y.c0||y.c1 (4*6 u64)
+template <class PP>
 __global__ void __launch_bounds__(64) k_miller(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1,
                                                const uint64_t* __restrict__ g2, const uint8_t* __restrict__ inf2,
                                                uint32_t* __restrict__ f_out, uint32_t n) {
+  typedef QuadIO<typename PP::BP> IO;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fq12 f;
-  if ((inf1 && inf1[i]) || (inf2 && inf2[i])) {
-    f = f12_one();
-  } else {
-    Fq px = Fq::from_ark(g1 + (size_t)i * 12), py = Fq::from_ark(g1 + (size_t)i * 12 + 6);
-    Fq2 qx = Fq2::from_ark(g2 + (size_t)i * 24), qy = Fq2::from_ark(g2 + (size_t)i * 24 + 12);
-    miller_loop_single(f, px, py, qx, qy);
-  }
-  f12_store(f_out + (size_t)i * FQ12_WORDS, f);
+  typename PP::Gt f;
+  if ((inf1 && inf1[i]) || (inf2 && inf2[i])) f = quad_one<typename PP::BP>();
+  else PP::miller(f, g1 + (size_t)i * PP::G1_ARK64, g2 + (size_t)i * PP::G2_ARK64);
+  IO::store(f_out + (size_t)i * IO::WORDS, f);
 }
 // product p covers pairs [offsets[p], offsets[p+1])
+template <class PP>
 __global__ void __launch_bounds__(64) k_gt_product(const uint32_t* __restrict__ f_in, const uint32_t* __restrict__ offsets,
                                                    uint32_t* __restrict__ prod, uint32_t m) {
+  typedef QuadIO<typename PP::BP> IO;
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= m) return;
   uint32_t lo = offsets[p], hi = offsets[p + 1];
-  Fq12 acc = f12_one();
+  typename PP::Gt acc = quad_one<typename PP::BP>();
   for (uint32_t k = lo; k < hi; k++) {
-    Fq12 v = f12_load(f_in + (size_t)k * FQ12_WORDS), t;
+    typename PP::Gt v = IO::load(f_in + (size_t)k * IO::WORDS), t;
     if (k == lo) acc = v;
-    else { f12_mul(t, acc, v); acc = t; }
+    else { quad_mul(t, acc, v); acc = t; }
   }
-  f12_store(prod + (size_t)p * FQ12_WORDS, acc);
+  IO::store(prod + (size_t)p * IO::WORDS, acc);
 }
 // pairwise tree level for ONE large product: out[t] = in[2t] * in[2t+1] (odd tail copied)
+template <class PP>
 __global__ void __launch_bounds__(64) k_gt_tree(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_in) {
+  typedef QuadIO<typename PP::BP> IO;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t n_out = (n_in + 1) / 2;
   if (t >= n_out) return;
-  Fq12 a = f12_load(in + (size_t)(2 * t) * FQ12_WORDS);
+  typename PP::Gt a = IO::load(in + (size_t)(2 * t) * IO::WORDS);
   if (2 * t + 1 < n_in) {
-    Fq12 b = f12_load(in + (size_t)(2 * t + 1) * FQ12_WORDS), r;
-    f12_mul(r, a, b);
+    typename PP::Gt b = IO::load(in + (size_t)(2 * t + 1) * IO::WORDS), r;
+    quad_mul(r, a, b);
     a = r;
   }
-  f12_store(out + (size_t)t * FQ12_WORDS, a);
+  IO::store(out + (size_t)t * IO::WORDS, a);
 }
+template <class PP>
 __global__ void __launch_bounds__(64) k_final_exp(const uint32_t* __restrict__ prod, uint8_t* __restrict__ is_one,
                                                   uint64_t* __restrict__ gt_ark, uint32_t m, int do_final_exp) {
+  typedef QuadIO<typename PP::BP> IO;
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= m) return;
-  Fq12 f = f12_load(prod + (size_t)p * FQ12_WORDS), r;
-  if (do_final_exp) final_exponentiation(r, f);
+  typename PP::Gt f = IO::load(prod + (size_t)p * IO::WORDS), r;
+  if (do_final_exp) PP::final_exp(r, f);
   else r = f;
-  if (is_one) is_one[p] = f12_is_one(r) ? 1 : 0;
-  if (gt_ark) f12_to_ark(r, gt_ark + (size_t)p * 72);
+  if (is_one) is_one[p] = quad_is_one(r) ? 1 : 0;
+  if (gt_ark) IO::to_ark(r, gt_ark + (size_t)p * 72);
 }
 
 #define PAIR_HIP_OK(x)                                                                                          \
@@ -219,8 +364,9 @@ __global__ void __launch_bounds__(64) k_final_exp(const uint32_t* __restrict__ p
 
 struct PairingTimings { float miller = 0, product = 0, final_exp = 0, total = 0; };
 
-class PairingEngine {
+template <class PP> class PairingEngine {
  public:
+  typedef QuadIO<typename PP::BP> IO;
   ~PairingEngine() { release(); }
   void release() {
     if (arena) { (void)hipFree(arena); arena = nullptr; arena_bytes = 0; }
@@ -234,11 +380,12 @@ class PairingEngine {
           uint8_t* out_is_one, uint64_t* out_gt, int mode, hipStream_t stream) {
     if (m == 0) return 0;
     const uint32_t k = offsets[m];
+    const size_t W = IO::WORDS;
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += (b + 255) & ~size_t(255); return o; };
-    const size_t o_g1 = take((size_t)k * 96 + 8), o_g2 = take((size_t)k * 192 + 8), o_i1 = take(k + 8), o_i2 = take(k + 8);
-    const size_t o_off = take((m + 1) * 4), o_f = take(((size_t)k + 1) * FQ12_WORDS * 4), o_f2 = take(((size_t)k / 2 + 2) * FQ12_WORDS * 4);
-    const size_t o_prod = take((size_t)m * FQ12_WORDS * 4), o_one = take(m + 8), o_gt = take((size_t)m * 72 * 8);
+    const size_t o_g1 = take((size_t)k * PP::G1_ARK64 * 8 + 8), o_g2 = take((size_t)k * PP::G2_ARK64 * 8 + 8), o_i1 = take(k + 8), o_i2 = take(k + 8);
+    const size_t o_off = take((m + 1) * 4), o_f = take(((size_t)k + 1) * W * 4), o_f2 = take(((size_t)k / 2 + 2) * W * 4);
+    const size_t o_prod = take((size_t)m * W * 4), o_one = take(m + 8), o_gt = take((size_t)m * 72 * 8);
     if (ensure(off)) return 1;
     char* A = arena;
     uint64_t* d_g1 = (uint64_t*)(A + o_g1); uint64_t* d_g2 = (uint64_t*)(A + o_g2);
@@ -246,30 +393,30 @@ class PairingEngine {
     uint32_t* d_off = (uint32_t*)(A + o_off); uint32_t* d_f = (uint32_t*)(A + o_f); uint32_t* d_f2 = (uint32_t*)(A + o_f2);
     uint32_t* d_prod = (uint32_t*)(A + o_prod); uint8_t* d_one = (uint8_t*)(A + o_one); uint64_t* d_gt = (uint64_t*)(A + o_gt);
     if (k) {
-      PAIR_HIP_OK(hipMemcpyAsync(d_g1, g1, (size_t)k * 96, hipMemcpyHostToDevice, stream));
-      PAIR_HIP_OK(hipMemcpyAsync(d_g2, g2, (size_t)k * 192, hipMemcpyHostToDevice, stream));
+      PAIR_HIP_OK(hipMemcpyAsync(d_g1, g1, (size_t)k * PP::G1_ARK64 * 8, hipMemcpyHostToDevice, stream));
+      PAIR_HIP_OK(hipMemcpyAsync(d_g2, g2, (size_t)k * PP::G2_ARK64 * 8, hipMemcpyHostToDevice, stream));
       if (inf1) PAIR_HIP_OK(hipMemcpyAsync(d_i1, inf1, k, hipMemcpyHostToDevice, stream));
       if (inf2) PAIR_HIP_OK(hipMemcpyAsync(d_i2, inf2, k, hipMemcpyHostToDevice, stream));
     }
     PAIR_HIP_OK(hipMemcpyAsync(d_off, offsets, (m + 1) * 4, hipMemcpyHostToDevice, stream));
     PAIR_HIP_OK(hipEventRecord(ev[0], stream));
-    if (k) hipLaunchKernelGGL(k_miller, dim3((k + 63) / 64), dim3(64), 0, stream, d_g1, inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_f, k);
+    if (k) hipLaunchKernelGGL((k_miller<PP>), dim3((k + 63) / 64), dim3(64), 0, stream, d_g1, inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_f, k);
     PAIR_HIP_OK(hipEventRecord(ev[1], stream));
     if (m == 1 && k > 8) {  // one large product: pairwise tree, log2(k) levels
       uint32_t n_in = k;
       uint32_t* src = d_f; uint32_t* dst = d_f2;
       while (n_in > 1) {
         uint32_t n_out = (n_in + 1) / 2;
-        hipLaunchKernelGGL(k_gt_tree, dim3((n_out + 63) / 64), dim3(64), 0, stream, src, dst, n_in);
+        hipLaunchKernelGGL((k_gt_tree<PP>), dim3((n_out + 63) / 64), dim3(64), 0, stream, src, dst, n_in);
         n_in = n_out;
         uint32_t* t = src; src = dst; dst = t;
       }
-      PAIR_HIP_OK(hipMemcpyAsync(d_prod, src, (size_t)FQ12_WORDS * 4, hipMemcpyDeviceToDevice, stream));
+      PAIR_HIP_OK(hipMemcpyAsync(d_prod, src, W * 4, hipMemcpyDeviceToDevice, stream));
     } else {
-      hipLaunchKernelGGL(k_gt_product, dim3(((uint32_t)m + 63) / 64), dim3(64), 0, stream, d_f, d_off, d_prod, (uint32_t)m);
+      hipLaunchKernelGGL((k_gt_product<PP>), dim3(((uint32_t)m + 63) / 64), dim3(64), 0, stream, d_f, d_off, d_prod, (uint32_t)m);
     }
     PAIR_HIP_OK(hipEventRecord(ev[2], stream));
-    hipLaunchKernelGGL(k_final_exp, dim3(((uint32_t)m + 63) / 64), dim3(64), 0, stream, d_prod, out_is_one ? d_one : nullptr,
+    hipLaunchKernelGGL((k_final_exp<PP>), dim3(((uint32_t)m + 63) / 64), dim3(64), 0, stream, d_prod, out_is_one ? d_one : nullptr,
                        out_gt ? d_gt : nullptr, (uint32_t)m, mode == 0 ? 1 : 0);
     PAIR_HIP_OK(hipEventRecord(ev[3], stream));
     if (out_is_one) PAIR_HIP_OK(hipMemcpyAsync(out_is_one, d_one, m, hipMemcpyDeviceToHost, stream));

@@ -5,7 +5,7 @@
 namespace celo {
 std::mutex& api_mutex();
 int api_ensure_init();
-static PairingEngine eng_pairing;
+static PairingEngine<PP377> eng_pairing;
 
 int pairing_run_377(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2, const uint32_t* offsets, size_t m,
                     uint8_t* is_one, uint64_t* gt, int mode) {

@@ -19,7 +19,7 @@ EXPORTS = [
     "msm_batch_bls12_377_g1", "msm_batch_bls12_377_g2", "msm_batch_bw6_761_g1", "msm_batch_bw6_761_g2",
     "msm_bls12_377_g1_dev", "msm_bls12_377_g2_dev", "msm_bw6_761_g1_dev", "msm_bw6_761_g2_dev",
     "pairing_product_is_one_bls12_377", "pairing_product_is_one_batch_bls12_377", "celo_amd_pairing_gt_bls12_377",
-    "celo_amd_pairing_last_timings",
+    "celo_amd_pairing_last_timings", "pairing_product_is_one_bw6_761", "celo_amd_pairing_gt_bw6_761",
     "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
     "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
@@ -167,4 +167,28 @@ def msm_batch(group, bases_xy, inf, scalars, offsets):
     rc = getattr(lib(), "msm_batch_" + group)(_p(bases_xy), _p(inf), _p(scalars), _p(offsets), C.c_size_t(m), _p(out))
     if rc != 0:
         raise RuntimeError(f"msm_batch_{group} failed rc={rc}")
+    return out
+
+
+def pairing_product_is_one_bw6(g1_xy, inf1, g2_xy, inf2):
+    g1_xy = np.ascontiguousarray(g1_xy, dtype=np.uint64)
+    g2_xy = np.ascontiguousarray(g2_xy, dtype=np.uint64)
+    k = g1_xy.size // 24
+    one = C.c_int(0)
+    rc = lib().pairing_product_is_one_bw6_761(_p(g1_xy), _p(inf1), _p(g2_xy), _p(inf2), C.c_size_t(k), C.byref(one))
+    if rc != 0:
+        raise RuntimeError(f"pairing_product_is_one_bw6_761 failed rc={rc}")
+    return bool(one.value)
+
+
+def pairing_gt_bw6(g1_xy, inf1, g2_xy, inf2, offsets, miller_only=False):
+    g1_xy = np.ascontiguousarray(g1_xy, dtype=np.uint64)
+    g2_xy = np.ascontiguousarray(g2_xy, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    m = offsets.size - 1
+    out = np.zeros((m, 72), dtype=np.uint64)
+    rc = lib().celo_amd_pairing_gt_bw6_761(_p(g1_xy), _p(inf1), _p(g2_xy), _p(inf2), _p(offsets), C.c_size_t(m),
+                                           C.c_int(1 if miller_only else 0), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"celo_amd_pairing_gt_bw6_761 failed rc={rc}")
     return out

@@ -73,6 +73,14 @@ int pairing_product_is_one_batch_bls12_377(const uint64_t* g1_xy, const uint8_t*
  * miller_only != 0 skips the final exponentiation (product of Miller-loop values). */
 int celo_amd_pairing_gt_bls12_377(const uint64_t* g1_xy, const uint8_t* inf1, const uint64_t* g2_xy, const uint8_t* inf2,
                                   const uint32_t* offsets, size_t m, int miller_only, uint64_t* gt72);
+/* BW6-761: the pairing product check underneath ark_groth16::verify_proof (crates/epoch-snark/src/api/verifier.rs:35, reached
+ * from the FFI `verify` at crates/bls-snark-sys/src/snark/mod.rs:23-45):
+ *   e(A,B) * e(acc,-gamma) * e(C,-delta) == e(alpha,beta)   <=>   product over {(A,B),(acc,-gamma),(C,-delta),(-alpha,beta)} == 1.
+ * g1_xy: k*24 u64, g2_xy: k*24 u64 (G2 coordinates are in Fq: M-type sextic twist). */
+int pairing_product_is_one_bw6_761(const uint64_t* g1_xy, const uint8_t* inf1, const uint64_t* g2_xy, const uint8_t* inf2, size_t k,
+                                   int* is_one);
+int celo_amd_pairing_gt_bw6_761(const uint64_t* g1_xy, const uint8_t* inf1, const uint64_t* g2_xy, const uint8_t* inf2,
+                                const uint32_t* offsets, size_t m, int miller_only, uint64_t* gt72);
 /* ms[4] = {miller loops, GT products, final exponentiations, total} of the last pairing call (HIP events). */
 int celo_amd_pairing_last_timings(float ms[4]);
 

@@ -94,3 +94,25 @@ def test_verify_shape_accept_reject(ht):
     assert hp(ht, 0, g1, g2, 2)[1]
     g2b, _ = co.pack_g2_377([ecc.E2_377.neg(ecc.G2_377), ecc.E2_377.mul(ecc.G2_377, sk + 1)])
     assert not hp(ht, 0, g1, g2b, 2)[1]
+
+
+def test_bw6_pairing_matches_oracle(ht, golden):
+    """BW6-761 tower + two-loop optimal ate + final exponentiation (host build, bounds tracked) == oracle, bit for bit."""
+    from oracle.py import epoch as ep
+    vk = ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))
+    g1, _ = co.pack_761([vk["alpha_g1"]])
+    g2, _ = co.pack_761([vk["beta_g2"]])
+
+    def hp761(mode, a, b, k):
+        out = np.zeros(72, dtype=np.uint64)
+        one = C.c_int(0)
+        ht.ht_pairing_761(mode, _p(a), _p(b), C.c_size_t(k), _p(out), C.byref(one))
+        return out, bool(one.value)
+
+    ml, _ = hp761(1, g1, g2, 1)
+    oml = np.zeros(72, dtype=np.uint64)
+    co.lib().orc_miller_loop_bw6_761(_p(g1), None, _p(g2), None, C.c_size_t(1), _p(oml))
+    assert np.array_equal(ml, oml)
+    gt, one = hp761(0, g1, g2, 1)
+    ogt, oone = co.pairing_product_761(g1, None, g2, None)
+    assert np.array_equal(gt, ogt) and one == oone == False

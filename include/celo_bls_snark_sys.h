@@ -1,0 +1,60 @@
+/* celo_bls_snark_sys.h — "Seam A" (SURVEY.md §8b): the C ABI of crates/bls-snark-sys, rebuilt over the gfx950 hot path.
+ *
+ * Same symbol names, argument order and ownership rules as the reference (file:line cited per entry) so that existing
+ * cgo / FFI callers link unchanged.  `bool` return = "no internal error" (reference: convert_result_to_bool,
+ * crates/bls-snark-sys/src/lib.rs:21-27); verdicts are separate out-params.
+ *
+ * Exported in this round: lifecycle, key handles, all (de)serialisation and compression symbols, the three aggregate_*
+ * symbols, and the GPU verification core `celo_amd_verify_hash` (verify_* after hashing).
+ * NOT yet exported (next rows f1/f4 of SURVEY.md §8f — they need the Blake2Xs / Bowe-Hopwood hashers and the epoch encoder):
+ * sign_message, sign_pop, hash_*, verify_signature, verify_pop, batch_verify_signature, batch_verify_strict, verify,
+ * encode_epoch_block_to_bytes[_cip22].  Their arithmetic cores already exist behind include/celo_bls_amd.h.
+ */
+#ifndef CELO_BLS_SNARK_SYS_H
+#define CELO_BLS_SNARK_SYS_H
+#include <stdbool.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PrivateKey PrivateKey; /* opaque: Fr                      (crates/bls-crypto/src/bls/secret.rs:12) */
+typedef struct PublicKey PublicKey;   /* opaque: G2 point, Jacobian      (crates/bls-crypto/src/bls/public.rs:16) */
+typedef struct Signature Signature;   /* opaque: G1 point, Jacobian      (crates/bls-crypto/src/bls/signature.rs:17) */
+
+bool init(void);                                                                       /* lib.rs:31 */
+bool generate_private_key(PrivateKey** out_private_key);                               /* signatures.rs:19 */
+bool private_key_to_public_key(const PrivateKey* in_private_key, PublicKey** out_public_key); /* signatures.rs:28 */
+
+bool deserialize_private_key(const uint8_t* in_bytes, int in_len, PrivateKey** out);   /* serialization.rs:13 */
+bool serialize_private_key(const PrivateKey* in, uint8_t** out_bytes, int* out_len);   /* serialization.rs:26 */
+bool deserialize_public_key(const uint8_t* in_bytes, int in_len, PublicKey** out);     /* serialization.rs:35  (96-byte compressed G2, subgroup-checked) */
+bool deserialize_public_key_cached(const uint8_t* in_bytes, int in_len, PublicKey** out); /* serialization.rs:44 */
+bool serialize_public_key(const PublicKey* in, uint8_t** out_bytes, int* out_len);     /* serialization.rs:63 */
+bool serialize_public_key_uncompressed(const PublicKey* in, uint8_t** out_bytes, int* out_len); /* serialization.rs:72 */
+bool deserialize_signature(const uint8_t* in_bytes, int in_len, Signature** out);      /* serialization.rs:81  (48-byte compressed G1) */
+bool serialize_signature(const Signature* in, uint8_t** out_bytes, int* out_len);      /* serialization.rs:90 */
+bool serialize_signature_uncompressed(const Signature* in, uint8_t** out_bytes, int* out_len); /* serialization.rs:99 */
+bool compress_signature(const uint8_t* in, int in_len, uint8_t** out, int* out_len);   /* serialization.rs:167 (96 -> 48 bytes) */
+bool compress_pubkey(const uint8_t* in, int in_len, uint8_t** out, int* out_len);      /* serialization.rs:192 (192 -> 96 bytes) */
+
+bool destroy_private_key(PrivateKey* p);                                               /* serialization.rs:224 */
+bool free_vec(uint8_t* bytes, int len);                                                /* serialization.rs:236 */
+bool destroy_public_key(PublicKey* p);                                                 /* serialization.rs:248 */
+bool destroy_signature(Signature* p);                                                  /* serialization.rs:260 */
+
+bool aggregate_public_keys(const PublicKey* const* in, int n, PublicKey** out);        /* signatures.rs:428 */
+bool aggregate_public_keys_subtract(const PublicKey* agg, const PublicKey* const* in, int n, PublicKey** out); /* signatures.rs:454 */
+bool aggregate_signatures(const Signature* const* in, int n, Signature** out);         /* signatures.rs:485 */
+
+/* GPU verification core: what verify_signature / verify_pop (signatures.rs:244,407) compute once the message has been
+ * hashed to G1 — e(sig, -g2) * e(H(m), pk) == 1 (crates/bls-crypto/src/bls/public.rs:94-120).  message_hash_xy: affine
+ * G1 point, 12 u64, arkworks Montgomery limbs. */
+bool celo_amd_verify_hash(const PublicKey* pk, const uint64_t* message_hash_xy, const Signature* sig, bool* out_verified);
+/* The BLS12-377 G2 generator (affine, 24 u64, arkworks Montgomery limbs). */
+bool celo_amd_g2_generator(uint64_t out_xy[24]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

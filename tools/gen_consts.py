@@ -97,6 +97,16 @@ def emit_tower377():
             pw = fq2_mul(pw, g, p)
             s += arr(f"FROB{i}_{k}_C0", dev(pw[0]))
             s += arr(f"FROB{i}_{k}_C1", dev(pw[1]))
+    G2 = ((233578398248691099356572568220835526895379068987715365179118596935057653620464273615301663571204657964920925606294,
+           140913150380207355837477652521042157274541796891053068589147167627541651775299824604154852141315666357241556069118),
+          (63160294768292073209381361943935198908131692476676907196754037919244929611450776219210369229519898517858833747423,
+           149157405641012693445398062341192467754805999074082136895788947234480009303640899064710353187729182149407503257491))
+    G1 = (81937999373150964239938255573465948239988671502647976594219695644855304257327692006745978603320413799295628339695,
+          241266749859715473739788878240585681733927191168601896383759122102112907357779751001206799952863815012735208165030)
+    # generators (G2 recovered from crates/epoch-snark/src/epoch_block.rs:246), device Montgomery form
+    s += arr("G1_GEN_X", dev(G1[0])); s += arr("G1_GEN_Y", dev(G1[1]))
+    s += arr("G2_GEN_X0", dev(G2[0][0])); s += arr("G2_GEN_X1", dev(G2[0][1]))
+    s += arr("G2_GEN_Y0", dev(G2[1][0])); s += arr("G2_GEN_Y1", dev(G2[1][1]))
     s += arr("TWO_INV", dev(pow(2, -1, p)))
     s += arr("TWIST_B_C1", dev((-pow(5, -1, p)) % p))
     s += "  static constexpr uint64_t X = 0x8508c00000000001ULL;  // BLS12-377 seed\n"

@@ -43,10 +43,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # CELO_BENCH_BACKEND=gloo + CELO_BENCH_DEVICE=0 lets the N>1 code path be smoke-tested on a 1-GPU box (both ranks on
+    # one device, host-staged exchange); the driver's multi-GPU runs use the defaults: RCCL, one GPU per rank.
+    backend = os.environ.get("CELO_BENCH_BACKEND", "nccl")
+    if "CELO_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["CELO_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
 
     from celo_bls_snark_rs_amd import ffi, codec
@@ -76,12 +81,13 @@ def main():
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream().cuda_stream
-    gather_buf = [torch.empty(18, dtype=torch.int64, device="cuda") for _ in range(world)] if world > 1 else None
+    xdev = "cuda" if backend == "nccl" else "cpu"
+    gather_buf = [torch.empty(18, dtype=torch.int64, device=xdev) for _ in range(world)] if world > 1 else None
 
     def step():
         out = ffi.msm_dev(group, bases.data_ptr(), 0, d_sc.data_ptr(), n, stream)
         if world > 1:
-            mine = torch.from_numpy(out.view(np.int64)).cuda()
+            mine = torch.from_numpy(out.view(np.int64).copy()).to(xdev)
             dist.all_gather(gather_buf, mine)
             parts = np.stack([g.cpu().numpy().view(np.uint64) for g in gather_buf])
             out = ffi.sum_jacobian(group, parts)
@@ -105,7 +111,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

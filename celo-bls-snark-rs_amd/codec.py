@@ -79,3 +79,25 @@ def jacobian_to_affine(arr, p, ext=1):
     zi = (Z[0] * ni % p, -Z[1] * ni % p)
     zi2 = mul(zi, zi)
     return (mul(X, zi2), mul(Y, mul(zi2, zi)))
+
+
+def decompress_bw6_761(data, g2=False):
+    """96-byte arkworks compressed BW6-761 point -> affine tuple.  G1: y^2 = x^3 - 1; G2 (M-twist, coordinates in Fq):
+    y^2 = x^3 + 4.  q = 3 (mod 4), so the square root is one exponentiation.  (VerifyingKey / Proof points of
+    crates/bls-snark-sys/src/snark/mod.rs:23-45 arrive in this form.)"""
+    p = Q761
+    b = bytearray(data)
+    flags = b[-1] & 0xC0
+    b[-1] &= 0x3F
+    if flags & 0x40:
+        return None
+    x = int.from_bytes(b, "little")
+    if x >= p:
+        raise ValueError("non-canonical x")
+    rhs = (x * x * x + (4 if g2 else p - 1)) % p
+    y = pow(rhs, (p + 1) // 4, p)
+    if y * y % p != rhs:
+        raise ValueError("x not on curve")
+    if (y > (p - 1) // 2) != bool(flags & 0x80):
+        y = p - y
+    return (x, y)

@@ -29,15 +29,7 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HD __host__ __device__ __forceinline__
-// The multiply bodies are ~600 instructions each; a mixed add inlines ten of them (~40 KB of straight-line code,
-// larger than the instruction cache).  CELO_MUL_NOINLINE keeps ONE copy of mul / sqr per kernel instead.
-#ifdef CELO_MUL_NOINLINE
-#define HD_MUL __host__ __device__ __attribute__((noinline))
 #else
-#define HD_MUL __host__ __device__ __forceinline__
-#endif
-#else
-#define HD_MUL inline
 #define HD inline
 struct uint4 { uint32_t x, y, z, w; };  // host-only builds (bounds-tracking unit tests)
 #endif
@@ -79,7 +71,7 @@ template <class P> struct Fp {
   // For L > 25 (BW6-761: 28 limbs) a column of 2L products only fits 64 bits when lb_a*lb_b <= 8, so the
   // un-normalised subtraction results (lb 3) the curve formulas feed in are normalised on entry there.
   static constexpr bool NORM_IN = (L * 10 > 255);
-  HD static Fp mul_body(const Fp& a_, const Fp& b) {
+  HD static Fp mul(const Fp& a_, const Fp& b) {
     const Fp a = NORM_IN ? norm(a_) : a_;
     TRK(assert(L * (a.lb * b.lb + 1) <= 255.5); assert(a.vb * b.vb <= 32768.0);)
     Fp r;
@@ -109,7 +101,7 @@ template <class P> struct Fp {
     TRK(r.lb = 1; r.vb = 2;)
     return r;
   }
-  HD static Fp sqr_body(const Fp& a_) {
+  HD static Fp sqr(const Fp& a_) {
     const Fp a = NORM_IN ? norm(a_) : a_;
     TRK(assert(L * (a.lb * a.lb + 1) <= 255.5); assert(a.vb * a.vb <= 32768.0);)
     Fp r;
@@ -144,39 +136,6 @@ template <class P> struct Fp {
     return r;
   }
 
-  // ---- out-of-line dispatch (device, L <= 16): operands travel in 16-wide register vectors so the call
-  // passes everything in VGPRs (struct arguments would go through scratch memory).
-#if defined(__HIP_DEVICE_COMPILE__) && defined(CELO_MUL_NOINLINE)
-  typedef uint32_t vec16 __attribute__((ext_vector_type(16)));
-  __device__ __forceinline__ static vec16 pack16(const Fp& a) {
-    vec16 v;
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = i < L ? a.l[i] : 0u;
-    return v;
-  }
-  __device__ __forceinline__ static Fp unpack16(vec16 v) {
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < L; i++) r.l[i] = v[i];
-    return r;
-  }
-  __device__ __attribute__((noinline)) static vec16 mul_outline(vec16 a, vec16 b) { return pack16(mul_body(unpack16(a), unpack16(b))); }
-  __device__ __attribute__((noinline)) static vec16 sqr_outline(vec16 a) { return pack16(sqr_body(unpack16(a))); }
-#endif
-  HD static Fp mul(const Fp& a, const Fp& b) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(CELO_MUL_NOINLINE)
-    if constexpr (L <= 16) return unpack16(mul_outline(pack16(a), pack16(b)));
-    else
-#endif
-    return mul_body(a, b);
-  }
-  HD static Fp sqr(const Fp& a) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(CELO_MUL_NOINLINE)
-    if constexpr (L <= 16) return unpack16(sqr_outline(pack16(a)));
-    else
-#endif
-    return sqr_body(a);
-  }
   HD static Fp add(const Fp& a, const Fp& b) {
     Fp r;
 #pragma unroll

@@ -252,6 +252,152 @@ bool on_curve_g2(const Affine<Fq2_>& p) {
   Fq2_ l = Fq2_::sqr(p.y), r = Fq2_::norm(Fq2_::add(Fq2_::mul(Fq2_::sqr(p.x), p.x), twist_b()));
   return fq_eq(l.c0, r.c0) && fq_eq(l.c1, r.c1);
 }
+
+// ---------------------------------------------------------------- DirectHasher (crates/bls-crypto/src/hashers/direct.rs:8-80)
+// Blake2s (RFC 7693) with an explicit parameter block: the XOF uses fanout = depth = 0, leaf/inner length 32 and the
+// BLAKE2X node-offset trick (xof length in bits 32..47 of the 48-bit node offset).  Host plumbing.
+const uint32_t B2S_IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+const uint8_t B2S_SIGMA[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+inline uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+void b2s_compress(uint32_t h[8], const uint8_t block[64], uint64_t t, bool last) {
+  uint32_t m[16], v[16];
+  for (int i = 0; i < 16; i++) memcpy(&m[i], block + 4 * i, 4);
+  for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = B2S_IV[i]; }
+  v[12] ^= (uint32_t)t;
+  v[13] ^= (uint32_t)(t >> 32);
+  if (last) v[14] ^= 0xFFFFFFFFu;
+#define B2S_G(a, b, c, d, x, y)                                   \
+  v[a] = v[a] + v[b] + (x); v[d] = rotr32(v[d] ^ v[a], 16);       \
+  v[c] = v[c] + v[d];       v[b] = rotr32(v[b] ^ v[c], 12);       \
+  v[a] = v[a] + v[b] + (y); v[d] = rotr32(v[d] ^ v[a], 8);        \
+  v[c] = v[c] + v[d];       v[b] = rotr32(v[b] ^ v[c], 7);
+  for (int r = 0; r < 10; r++) {
+    const uint8_t* s = B2S_SIGMA[r];
+    B2S_G(0, 4, 8, 12, m[s[0]], m[s[1]]) B2S_G(1, 5, 9, 13, m[s[2]], m[s[3]])
+    B2S_G(2, 6, 10, 14, m[s[4]], m[s[5]]) B2S_G(3, 7, 11, 15, m[s[6]], m[s[7]])
+    B2S_G(0, 5, 10, 15, m[s[8]], m[s[9]]) B2S_G(1, 6, 11, 12, m[s[10]], m[s[11]])
+    B2S_G(2, 7, 8, 13, m[s[12]], m[s[13]]) B2S_G(3, 4, 9, 14, m[s[14]], m[s[15]])
+  }
+#undef B2S_G
+  for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+}
+struct B2sParams { uint8_t digest_length = 32, fanout = 1, depth = 1, node_depth = 0, inner_length = 0; uint32_t leaf_length = 0; uint64_t node_offset = 0; };
+std::vector<uint8_t> blake2s(const uint8_t* data, size_t len, const B2sParams& p, const uint8_t* personal, size_t plen) {
+  uint8_t pb[32];
+  memset(pb, 0, 32);
+  pb[0] = p.digest_length; pb[1] = 0; pb[2] = p.fanout; pb[3] = p.depth;
+  memcpy(pb + 4, &p.leaf_length, 4);
+  for (int i = 0; i < 6; i++) pb[8 + i] = (uint8_t)(p.node_offset >> (8 * i));
+  pb[14] = p.node_depth; pb[15] = p.inner_length;
+  memcpy(pb + 24, personal, plen < 8 ? plen : 8);
+  uint32_t h[8];
+  for (int i = 0; i < 8; i++) { uint32_t w; memcpy(&w, pb + 4 * i, 4); h[i] = B2S_IV[i] ^ w; }
+  uint64_t t = 0;
+  size_t off = 0;
+  while (len - off > 64) { t += 64; b2s_compress(h, data + off, t, false); off += 64; }
+  uint8_t lastb[64];
+  memset(lastb, 0, 64);
+  if (len - off) memcpy(lastb, data + off, len - off);
+  t += len - off;
+  b2s_compress(h, lastb, t, true);
+  std::vector<uint8_t> out(p.digest_length);
+  uint8_t full[32];
+  memcpy(full, h, 32);
+  memcpy(out.data(), full, p.digest_length);
+  return out;
+}
+uint64_t xof_node_offset(uint64_t i, size_t xof_len) { return i | ((uint64_t)(xof_len & 0xFF) << 32) | ((uint64_t)((xof_len >> 8) & 0xFF) << 40); }
+std::vector<uint8_t> direct_crh(const uint8_t* dom, size_t dlen, const uint8_t* msg, size_t mlen, size_t xof_len) {
+  B2sParams p;
+  p.node_offset = xof_node_offset(0, xof_len);
+  return blake2s(msg, mlen, p, dom, dlen);
+}
+std::vector<uint8_t> direct_xof(const uint8_t* dom, size_t dlen, const uint8_t* hashed, size_t hlen, size_t xof_len) {
+  size_t n = (xof_len + 31) / 32;
+  std::vector<uint8_t> out;
+  for (size_t i = 0; i < n; i++) {
+    B2sParams p;
+    p.digest_length = (uint8_t)((i == n - 1 && (xof_len % 32)) ? xof_len % 32 : 32);
+    p.fanout = 0; p.depth = 0; p.leaf_length = 32; p.inner_length = 32;
+    p.node_offset = xof_node_offset(i, xof_len);
+    std::vector<uint8_t> h = blake2s(hashed, hlen, p, dom, dlen);
+    out.insert(out.end(), h.begin(), h.end());
+  }
+  return out;
+}
+std::vector<uint8_t> direct_hash(const uint8_t* dom, size_t dlen, const uint8_t* msg, size_t mlen, size_t n) {
+  std::vector<uint8_t> c = direct_crh(dom, dlen, msg, mlen, n);
+  return direct_xof(dom, dlen, c.data(), c.size(), n);
+}
+const uint8_t SIG_DOMAIN[8] = {'U', 'L', 'f', 'o', 'r', 'x', 'o', 'f'};  // crates/bls-crypto/src/lib.rs:75
+const uint8_t POP_DOMAIN[8] = {'U', 'L', 'f', 'o', 'r', 'p', 'o', 'p'};  // lib.rs:78
+const uint64_t G1_COFACTOR[2] = {0x0000000000000000ULL, 0x170b5d4430000000ULL};  // (x-1)^2/3
+
+// TryAndIncrement<DirectHasher, G1>::hash_with_attempt with the deployed `compat` bit logic
+// (crates/bls-crypto/src/hash_to_curve/try_and_increment.rs:87-139, mod.rs:146-158)
+bool hash_to_g1_direct(const uint8_t* dom, const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen, Affine<Fq_>& out, int& attempt) {
+  std::vector<uint8_t> buf(1 + elen + mlen);
+  if (elen) memcpy(buf.data() + 1, extra, elen);
+  if (mlen) memcpy(buf.data() + 1 + elen, msg, mlen);
+  for (int c = 0; c < 255; c++) {
+    buf[0] = (uint8_t)c;
+    std::vector<uint8_t> cand = direct_hash(dom, 8, buf.data(), buf.size(), 64);  // hash_length(48) = 64
+    cand.resize(48);
+    if (cand[47] & 2) cand[47] |= 0x80; else cand[47] &= 0x7F;
+    uint8_t flags = cand[47] & 0xC0;
+    cand[47] &= 0x01;  // bits below MODULUS_BITS = 377
+    Fq_ x;
+    if (!fq_from_bytes(cand.data(), x)) continue;
+    if (x.is_zero_mod_p() && (flags & 0x40)) continue;  // the zero point scales to zero
+    Fq_ rhs = Fq_::norm(Fq_::add(Fq_::mul(Fq_::sqr(x), x), Fq_::one())), y;
+    if (!fq_sqrt(rhs, y)) continue;
+    // get_point_from_x(x, greatest): greatest selects the lexicographically larger of {y, -y}
+    bool greatest = (flags & 0x80) != 0;
+    if (fq_lex_largest(y) != greatest) y = fq_neg(y);
+    Affine<Fq_> p = {Fq_::norm(x), Fq_::norm(y)};
+    Xyzz<Fq_> s = scalar_mul_host(p, G1_COFACTOR, 2);
+    if (s.is_identity() || s.ZZ.is_zero_mod_p()) continue;
+    Fq_ t = Fq_::inv(Fq_::mul(s.ZZ, s.ZZZ));
+    out.x = Fq_::norm(Fq_::mul(s.X, Fq_::mul(t, s.ZZZ)));
+    out.y = Fq_::norm(Fq_::mul(s.Y, Fq_::mul(t, s.ZZ)));
+    attempt = c;
+    return true;
+  }
+  return false;
+}
+// Montgomery's trick: Jacobian (ark limbs, stride 3*A u64) -> affine xy (ark limbs); inf[i] = 1 for the identity
+template <class F> void batch_to_affine(const uint64_t* jac, size_t n, uint64_t* xy, uint8_t* inf) {
+  constexpr int A = F::ARK64;
+  std::vector<F> z(n), pre(n);
+  F acc = F::one();
+  for (size_t i = 0; i < n; i++) {
+    z[i] = F::norm(F::from_ark(jac + i * 3 * A + 2 * A));
+    inf[i] = z[i].is_zero_mod_p() ? 1 : 0;
+    pre[i] = acc;
+    if (!inf[i]) acc = F::mul(acc, z[i]);
+  }
+  F ai = F::inv(acc);
+  for (size_t i = n; i-- > 0;) {
+    uint64_t* o = xy + i * 2 * A;
+    if (inf[i]) { memset(o, 0, 2 * A * 8); continue; }
+    F zi = F::mul(ai, pre[i]);
+    ai = F::mul(ai, z[i]);
+    F zi2 = F::sqr(zi);
+    F::mul(F::from_ark(jac + i * 3 * A), zi2).to_ark(o);
+    F::mul(F::from_ark(jac + i * 3 * A + A), F::mul(zi2, zi)).to_ark(o + A);
+  }
+}
+void neg_g2_generator(uint64_t out_xy[24]) {
+  Fq_::from_limbs(T377::G2_GEN_X0).to_ark(out_xy);
+  Fq_::from_limbs(T377::G2_GEN_X1).to_ark(out_xy + 6);
+  fq_neg(Fq_::from_limbs(T377::G2_GEN_Y0)).to_ark(out_xy + 12);
+  fq_neg(Fq_::from_limbs(T377::G2_GEN_Y1)).to_ark(out_xy + 18);
+}
 }  // namespace
 
 extern "C" {
@@ -466,5 +612,161 @@ bool celo_amd_verify_hash(const PublicKey* pk, const uint64_t* message_hash_xy, 
   if (pairing_product_is_one_bls12_377(g1, inf1, g2, inf2, 2, &one) != 0) return false;
   *out_verified = one != 0;
   return true;
+}
+
+// ---------------------------------------------------------------- hashing / signing with the DIRECT hasher
+// (composite = Bowe-Hopwood over Edwards-BW6-761 is not built yet: those flag combinations return false, logged)
+static bool hash_flags_supported(bool composite, bool cip22) {
+  if (!composite && cip22) { log_err("(composite=false, cip22=true) is rejected by the reference too (signatures.rs:61)"); return false; }
+  if (composite) { log_err("composite (Bowe-Hopwood) hasher not built yet — SURVEY.md §8f f1"); return false; }
+  return true;
+}
+static bool emit_affine_tobytes(const Affine<Fq_>& p, uint8_t** out, int* out_len) {  // ToBytes: x || y || infinity byte
+  std::vector<uint8_t> v(97, 0);
+  fq_to_bytes(p.x, v.data());
+  fq_to_bytes(p.y, v.data() + 48);
+  return emit(v, out, out_len);
+}
+bool hash_direct(const uint8_t* msg, int len, uint8_t** out_hash, int* out_len, bool use_pop) {                /* signatures.rs:93 */
+  if ((!msg && len) || !out_hash || !out_len || len < 0) return false;
+  Affine<Fq_> h; int c;
+  if (!hash_to_g1_direct(use_pop ? POP_DOMAIN : SIG_DOMAIN, msg, (size_t)len, nullptr, 0, h, c)) return false;
+  return emit_affine_tobytes(h, out_hash, out_len);
+}
+bool hash_direct_with_attempt(const uint8_t* msg, int len, uint8_t** out_hash, int* out_len, int* out_attempt, bool use_pop) { /* :117 */
+  if ((!msg && len) || !out_hash || !out_len || !out_attempt || len < 0) return false;
+  Affine<Fq_> h; int c;
+  if (!hash_to_g1_direct(use_pop ? POP_DOMAIN : SIG_DOMAIN, msg, (size_t)len, nullptr, 0, h, c)) return false;
+  *out_attempt = c;
+  return emit_affine_tobytes(h, out_hash, out_len);
+}
+bool hash_direct_first_step(const uint8_t* msg, int len, int hash_bytes, uint8_t** out_hash, int* out_len) {    /* signatures.rs:192 */
+  if ((!msg && len) || !out_hash || !out_len || len < 0 || hash_bytes < 0 || hash_bytes > 65535) return false;
+  return emit(direct_hash(SIG_DOMAIN, 8, msg, (size_t)len, (size_t)hash_bytes), out_hash, out_len);
+}
+static bool sign_with(const PrivateKey* sk, const uint8_t* dom, const uint8_t* msg, int mlen, const uint8_t* extra, int elen, Signature** out) {
+  if (!sk || !out || mlen < 0 || elen < 0) return false;
+  Affine<Fq_> h; int c;
+  if (!hash_to_g1_direct(dom, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
+  Xyzz<Fq_> r = scalar_mul_host(h, sk->k, 4);                 // PrivateKey::sign_raw (crates/bls-crypto/src/bls/secret.rs:65)
+  Signature* s = new Signature;
+  if (r.is_identity() || r.ZZ.is_zero_mod_p()) identity_jac<Fq_>(s->xyz);
+  else { Fq_::mul(r.X, r.ZZ).to_ark(s->xyz); Fq_::mul(r.Y, r.ZZZ).to_ark(s->xyz + 6); r.ZZ.to_ark(s->xyz + 12); }
+  *out = s;
+  return true;
+}
+bool sign_message(const PrivateKey* sk, const uint8_t* msg, int mlen, const uint8_t* extra, int elen, bool composite, bool cip22,
+                  Signature** out) {                                                                                  /* signatures.rs:44 */
+  if (!hash_flags_supported(composite, cip22)) return false;
+  return sign_with(sk, SIG_DOMAIN, msg, mlen, extra, elen, out);
+}
+bool sign_pop(const PrivateKey* sk, const uint8_t* msg, int mlen, Signature** out) {                                  /* signatures.rs:74 */
+  return sign_with(sk, POP_DOMAIN, msg, mlen, nullptr, 0, out);
+}
+
+// ---------------------------------------------------------------- verification (hash on the host, pairings / MSMs on the GPU)
+static bool verify_with(const PublicKey* pk, const uint8_t* dom, const uint8_t* msg, int mlen, const uint8_t* extra, int elen,
+                        const Signature* sig, bool* out_verified) {
+  if (!pk || !sig || !out_verified || mlen < 0 || elen < 0) return false;
+  Affine<Fq_> h; int c;
+  if (!hash_to_g1_direct(dom, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
+  uint64_t hxy[12];
+  h.x.to_ark(hxy); h.y.to_ark(hxy + 6);
+  return celo_amd_verify_hash(pk, hxy, sig, out_verified);
+}
+bool verify_signature(const PublicKey* pk, const uint8_t* msg, int mlen, const uint8_t* extra, int elen, const Signature* sig,
+                      bool composite, bool cip22, bool* out_verified) {                                               /* signatures.rs:244 */
+  if (!hash_flags_supported(composite, cip22)) return false;
+  return verify_with(pk, SIG_DOMAIN, msg, mlen, extra, elen, sig, out_verified);
+}
+bool verify_pop(const PublicKey* pk, const uint8_t* msg, int mlen, const Signature* sig, bool* out_verified) {        /* signatures.rs:407 */
+  return verify_with(pk, POP_DOMAIN, msg, mlen, nullptr, 0, sig, out_verified);
+}
+// Signature::batch_verify (crates/bls-crypto/src/bls/signature.rs:101-155): aggregate the signatures, hash every message,
+// ONE (n+1)-pair product on the GPU
+bool batch_verify_signature(const MessageFFI* messages, size_t n, bool composite, bool cip22, bool* verified) {       /* signatures.rs:290 */
+  if (!hash_flags_supported(composite, cip22) || (!messages && n) || !verified) return false;
+  std::vector<uint64_t> sigs(n * 18), pkj(n * 36);
+  for (size_t i = 0; i < n; i++) {
+    if (!messages[i].public_key || !messages[i].sig) return false;
+    memcpy(&sigs[i * 18], messages[i].sig->xyz, 144);
+    memcpy(&pkj[i * 36], messages[i].public_key->xyz, 288);
+  }
+  uint64_t asig[18];
+  if (celo_amd_sum_jacobian_bls12_377_g1(sigs.data(), n, asig) != 0) return false;
+  std::vector<uint64_t> g1((n + 1) * 12), g2((n + 1) * 24);
+  std::vector<uint8_t> i1(n + 1, 0), i2(n + 1, 0);
+  batch_to_affine<Fq_>(asig, 1, g1.data(), i1.data());
+  neg_g2_generator(g2.data());
+  batch_to_affine<Fq2_>(pkj.data(), n, g2.data() + 24, i2.data() + 1);
+  for (size_t i = 0; i < n; i++) {
+    Affine<Fq_> h; int c;
+    if (!hash_to_g1_direct(SIG_DOMAIN, messages[i].data.ptr, messages[i].data.len, messages[i].extra.ptr, messages[i].extra.len, h, c)) return false;
+    h.x.to_ark(&g1[(i + 1) * 12]); h.y.to_ark(&g1[(i + 1) * 12 + 6]);
+  }
+  int one = 0;
+  if (pairing_product_is_one_bls12_377(g1.data(), i1.data(), g2.data(), i2.data(), n + 1, &one) != 0) return false;
+  *verified = one != 0;
+  return true;
+}
+// Batch::verify per batch (crates/bls-crypto/src/bls/batch.rs:44-84), all batches at once: random exponents from the OS
+// RNG, all G2 MSMs in one call, all G1 MSMs in one call, all 2-pair checks in one call.  out_results is always filled;
+// the return value is false if any batch fails (signatures.rs:392-400).
+bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composite, bool cip22, bool* out_results) {   /* signatures.rs:343 */
+  if ((!batches && m) || !out_results) return false;
+  if (!composite && cip22) { for (size_t i = 0; i < m; i++) out_results[i] = false; return false; }  // per-batch false (signatures.rs:387)
+  if (composite) { log_err("composite (Bowe-Hopwood) hasher not built yet — SURVEY.md §8f f1"); for (size_t i = 0; i < m; i++) out_results[i] = false; return false; }
+  if (m == 0) return true;
+  std::vector<uint32_t> offs(m + 1, 0);
+  for (size_t b = 0; b < m; b++) {
+    if (batches[b].public_keys_len != batches[b].signatures_len) return false;  // the reference panics here (batch.rs:71,78)
+    offs[b + 1] = offs[b] + (uint32_t)batches[b].public_keys_len;
+  }
+  const size_t tot = offs[m];
+  std::vector<uint64_t> pkj(tot * 36), sgj(tot * 18), pk_xy(tot * 24), sg_xy(tot * 12), sc(tot * 4, 0);
+  std::vector<uint8_t> pk_inf(tot, 0), sg_inf(tot, 0);
+  std::random_device rd;
+  for (size_t b = 0; b < m; b++) {
+    const size_t n = batches[b].public_keys_len;
+    size_t lg = 0;
+    while (((size_t)1 << lg) < n) lg++;                               // ark_std::log2 = ceil(log2)
+    size_t nbytes = (128 + lg + 7) / 8;                               // byte_count_from_target_batch_size (batch.rs:23-28)
+    if (nbytes > 31) nbytes = 31;
+    for (size_t i = 0; i < n; i++) {
+      if (!batches[b].public_keys[i] || !batches[b].signatures[i]) return false;
+      memcpy(&pkj[(offs[b] + i) * 36], batches[b].public_keys[i]->xyz, 288);
+      memcpy(&sgj[(offs[b] + i) * 18], batches[b].signatures[i]->xyz, 144);
+      uint8_t rb[32];
+      memset(rb, 0, 32);
+      for (size_t k = 0; k < nbytes; k += 4) { uint32_t r = rd(); memcpy(rb + k, &r, (nbytes - k) < 4 ? (nbytes - k) : 4); }
+      memcpy(&sc[(offs[b] + i) * 4], rb, 32);
+    }
+  }
+  batch_to_affine<Fq2_>(pkj.data(), tot, pk_xy.data(), pk_inf.data());
+  batch_to_affine<Fq_>(sgj.data(), tot, sg_xy.data(), sg_inf.data());
+  std::vector<uint64_t> bpk(m * 36), bsg(m * 18);
+  if (msm_batch_bls12_377_g2(pk_xy.data(), pk_inf.data(), sc.data(), offs.data(), m, bpk.data()) != 0) return false;
+  if (msm_batch_bls12_377_g1(sg_xy.data(), sg_inf.data(), sc.data(), offs.data(), m, bsg.data()) != 0) return false;
+  std::vector<uint64_t> g1(2 * m * 12), g2(2 * m * 24), tmp1(m * 12), tmp2(m * 24);
+  std::vector<uint8_t> i1(2 * m, 0), i2(2 * m, 0), t1(m), t2(m);
+  batch_to_affine<Fq_>(bsg.data(), m, tmp1.data(), t1.data());
+  batch_to_affine<Fq2_>(bpk.data(), m, tmp2.data(), t2.data());
+  uint64_t ng2[24];
+  neg_g2_generator(ng2);
+  for (size_t b = 0; b < m; b++) {
+    memcpy(&g1[(2 * b) * 12], &tmp1[b * 12], 96); i1[2 * b] = t1[b];
+    memcpy(&g2[(2 * b) * 24], ng2, 192);
+    Affine<Fq_> h; int c;
+    if (!hash_to_g1_direct(SIG_DOMAIN, batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, h, c)) return false;
+    h.x.to_ark(&g1[(2 * b + 1) * 12]); h.y.to_ark(&g1[(2 * b + 1) * 12 + 6]);
+    memcpy(&g2[(2 * b + 1) * 24], &tmp2[b * 24], 192); i2[2 * b + 1] = t2[b];
+  }
+  std::vector<uint32_t> po(m + 1);
+  for (size_t b = 0; b <= m; b++) po[b] = (uint32_t)(2 * b);
+  std::vector<uint8_t> ok(m, 0);
+  if (pairing_product_is_one_batch_bls12_377(g1.data(), i1.data(), g2.data(), i2.data(), po.data(), m, ok.data()) != 0) return false;
+  bool all = true;
+  for (size_t b = 0; b < m; b++) { out_results[b] = ok[b] != 0; all = all && out_results[b]; }
+  return all;
 }
 }

@@ -4,15 +4,18 @@
  * cgo / FFI callers link unchanged.  `bool` return = "no internal error" (reference: convert_result_to_bool,
  * crates/bls-snark-sys/src/lib.rs:21-27); verdicts are separate out-params.
  *
- * Exported in this round: lifecycle, key handles, all (de)serialisation and compression symbols, the three aggregate_*
- * symbols, and the GPU verification core `celo_amd_verify_hash` (verify_* after hashing).
- * NOT yet exported (next rows f1/f4 of SURVEY.md §8f — they need the Blake2Xs / Bowe-Hopwood hashers and the epoch encoder):
- * sign_message, sign_pop, hash_*, verify_signature, verify_pop, batch_verify_signature, batch_verify_strict, verify,
- * encode_epoch_block_to_bytes[_cip22].  Their arithmetic cores already exist behind include/celo_bls_amd.h.
+ * Exported: lifecycle, key handles, all (de)serialisation and compression symbols, the three aggregate_* symbols,
+ * sign / hash / verify / batch-verify with the DIRECT hasher (Blake2s CRH + Blake2Xs XOF, try-and-increment with the deployed
+ * `compat` bit logic) — `should_use_composite = false`.  With `should_use_composite = true` these functions return false
+ * (logged under CELO_AMD_LOG=1): the Bowe-Hopwood composite hasher is not built yet.
+ * `(composite = false, cip22 = true)` is an error exactly as in the reference (signatures.rs:61,265,321,387).
+ * NOT yet exported: hash_composite, hash_crh, hash_composite_cip22, verify (Groth16 over the FFI
+ * structs), encode_epoch_block_to_bytes[_cip22].  The arithmetic core of `verify` is pairing_product_is_one_bw6_761.
  */
 #ifndef CELO_BLS_SNARK_SYS_H
 #define CELO_BLS_SNARK_SYS_H
 #include <stdbool.h>
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -21,6 +24,15 @@ extern "C" {
 typedef struct PrivateKey PrivateKey; /* opaque: Fr                      (crates/bls-crypto/src/bls/secret.rs:12) */
 typedef struct PublicKey PublicKey;   /* opaque: G2 point, Jacobian      (crates/bls-crypto/src/bls/public.rs:16) */
 typedef struct Signature Signature;   /* opaque: G1 point, Jacobian      (crates/bls-crypto/src/bls/signature.rs:17) */
+
+/* #[repr(C)] structs of crates/bls-snark-sys/src/utils.rs:20-82 */
+typedef struct Buffer { const uint8_t* ptr; size_t len; } Buffer;
+typedef struct MessageFFI { Buffer data; Buffer extra; const PublicKey* public_key; const Signature* sig; } MessageFFI;
+typedef struct BatchMessageFFI {
+  Buffer data; Buffer extra;
+  const PublicKey* const* public_keys; size_t public_keys_len;
+  const Signature* const* signatures; size_t signatures_len;
+} BatchMessageFFI;
 
 bool init(void);                                                                       /* lib.rs:31 */
 bool generate_private_key(PrivateKey** out_private_key);                               /* signatures.rs:19 */
@@ -46,6 +58,20 @@ bool destroy_signature(Signature* p);                                           
 bool aggregate_public_keys(const PublicKey* const* in, int n, PublicKey** out);        /* signatures.rs:428 */
 bool aggregate_public_keys_subtract(const PublicKey* agg, const PublicKey* const* in, int n, PublicKey** out); /* signatures.rs:454 */
 bool aggregate_signatures(const Signature* const* in, int n, Signature** out);         /* signatures.rs:485 */
+
+bool sign_message(const PrivateKey* sk, const uint8_t* msg, int msg_len, const uint8_t* extra, int extra_len,
+                  bool should_use_composite, bool should_use_cip22, Signature** out_signature);              /* signatures.rs:44 */
+bool sign_pop(const PrivateKey* sk, const uint8_t* msg, int msg_len, Signature** out_signature);           /* signatures.rs:74 */
+bool hash_direct(const uint8_t* msg, int msg_len, uint8_t** out_hash, int* out_len, bool use_pop);         /* signatures.rs:93  (97 bytes: x || y || inf) */
+bool hash_direct_with_attempt(const uint8_t* msg, int msg_len, uint8_t** out_hash, int* out_len, int* out_attempt, bool use_pop); /* :117 */
+bool hash_direct_first_step(const uint8_t* msg, int msg_len, int hash_bytes, uint8_t** out_hash, int* out_len); /* signatures.rs:192 */
+bool verify_signature(const PublicKey* pk, const uint8_t* msg, int msg_len, const uint8_t* extra, int extra_len, const Signature* sig,
+                      bool should_use_composite, bool should_use_cip22, bool* out_verified);               /* signatures.rs:244 */
+bool verify_pop(const PublicKey* pk, const uint8_t* msg, int msg_len, const Signature* sig, bool* out_verified); /* signatures.rs:407 */
+bool batch_verify_signature(const MessageFFI* messages, size_t messages_len, bool should_use_composite, bool should_use_cip22,
+                            bool* verified);                                                               /* signatures.rs:290 */
+bool batch_verify_strict(const BatchMessageFFI* batches, size_t batches_len, bool should_use_composite, bool should_use_cip22,
+                         bool* out_results);                                                               /* signatures.rs:343 */
 
 /* GPU verification core: what verify_signature / verify_pop (signatures.rs:244,407) compute once the message has been
  * hashed to G1 — e(sig, -g2) * e(H(m), pk) == 1 (crates/bls-crypto/src/bls/public.rs:94-120).  message_hash_xy: affine

@@ -51,7 +51,14 @@ def main():
         k += 1
     g = consts(f"{REF}/bls-snark-sys/src/snark/mod.rs")
     e = consts(f"{REF}/epoch-snark/src/epoch_block.rs")
+    # DirectHasher vectors with fully specified inputs (crates/bls-crypto/src/hashers/direct.rs:88-96, 149-172)
+    dtxt = open(f"{REF}/bls-crypto/src/hashers/direct.rs").read()
+    crh_empty = re.search(r'fn test_crh_empty.*?"([0-9a-f]{64})"', dtxt, re.S).group(1)
+    tv_block = dtxt[dtxt.index("fn test_blake2s_test_vectors"):]
+    strs = re.findall(r'"([0-9a-fA-F]+)"', tv_block)
+    tv = list(zip(strs[0::2], strs[1::2]))
     out = {
+        "direct_hasher": {"crh_empty_xof96": crh_empty, "blake2x_hash_vectors": [{"input": a, "output": b} for a, b in tv]},
         "_source": "celo-org/celo-bls-snark-rs test vectors (data literals only); see extract_reference_vectors.py",
         "hash_to_curve": vec,
         "groth16_bw6_761": {

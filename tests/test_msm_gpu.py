@@ -77,6 +77,27 @@ def test_g1_skewed_scalars(gpu):
     assert _affine(gpu.msm("bls12_377_g1", xy, inf, s), "g1_377") == exp
 
 
+def test_g1_heavy_skew_large(gpu):
+    """Skew at a size where runs are cut into many pieces (k_combine_mid / k_combine_big): 2^16 points, (a) every scalar
+    equal -> one bucket per window holds all points, (b) witness-like: 40% zero, 30% one, rest uniform."""
+    n = 1 << 16
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    bases = _gen_points_gpu(gpu, "bls12_377_g1", n, 0xABCD, gen.reshape(-1), 12)
+    h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 12)
+    k = 0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789AB % ecc.R377
+    sc = np.tile(co.ints_to_limbs([k], 4), (n, 1))
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", h_bases, None, sc, threads=8), "g1_377")
+    assert _affine(gpu.msm("bls12_377_g1", h_bases, None, sc), "g1_377") == exp
+    rng = np.random.default_rng(17)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)
+    kind = rng.integers(0, 10, size=n)
+    sc[kind < 4] = 0
+    sc[(kind >= 4) & (kind < 7)] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", h_bases, None, sc, threads=8), "g1_377")
+    assert _affine(gpu.msm("bls12_377_g1", h_bases, None, sc), "g1_377") == exp
+
+
 @pytest.mark.parametrize("c", [4, 7, 11, 13, 16])
 def test_g1_window_sizes(gpu, c):
     n = 700

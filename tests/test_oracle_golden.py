@@ -161,3 +161,18 @@ def test_cpp_pairing_product_accept_reject():
     g1c, i1c = co.pack_g1_377([sig, Hm, None])
     g2c, i2c = co.pack_g2_377([ecc.E2_377.neg(ecc.G2_377), pk, pk])
     assert co.pairing_product_377(g1c, i1c, g2c, i2c)[1]
+
+
+def test_reference_direct_hasher_vectors(golden):
+    """crates/bls-crypto/src/hashers/direct.rs:88-96 (CRH of the empty message) and :149-172 (three BLAKE2X vectors):
+    pins the hand-rolled Blake2s parameter block and the node-offset XOF construction."""
+    from oracle.py import hashing as hs
+    import hashlib
+    d = golden["direct_hasher"]
+    assert hs.direct_crh(b"", b"", 96).hex() == d["crh_empty_xof96"]
+    assert len(d["blake2x_hash_vectors"]) == 3
+    for v in d["blake2x_hash_vectors"]:
+        assert hs.direct_hash(b"", bytes.fromhex(v["input"]), len(v["output"]) // 2).hex() == v["output"]
+    for msg in (b"", b"abc", bytes(range(200))):
+        assert hs.blake2s(msg) == hashlib.blake2s(msg).digest()
+        assert hs.blake2s(msg, personal=b"ULforxof", digest_length=20) == hashlib.blake2s(msg, person=b"ULforxof", digest_size=20).digest()

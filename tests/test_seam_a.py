@@ -166,3 +166,144 @@ def test_verify_hash_core_on_gpu(sys_lib, gpu):
     assert sys_lib.celo_amd_verify_hash(pkh, hxy.ctypes.data_as(C.c_void_p), sgh, C.byref(ok)) and ok.value
     bad = _deser(sys_lib, "deserialize_signature", ecc.ser_point(ecc.E1_377, ecc.E1_377.mul(Hm, sk + 1)))
     assert sys_lib.celo_amd_verify_hash(pkh, hxy.ctypes.data_as(C.c_void_p), bad, C.byref(ok)) and not ok.value
+
+
+# ---------------------------------------------------------------- hashing / signing / verification with the DIRECT hasher
+def _hash_direct(lib, msg, use_pop=False):
+    out, n = C.c_void_p(), C.c_int()
+    lib.hash_direct.restype = C.c_bool
+    assert lib.hash_direct(msg, C.c_int(len(msg)), C.byref(out), C.byref(n), C.c_bool(use_pop))
+    b = _take(lib, out, n)
+    assert len(b) == 97 and b[96] == 0
+    return (int.from_bytes(b[:48], "little"), int.from_bytes(b[48:96], "little"))
+
+
+def test_hash_direct_matches_oracle_restatement(sys_lib):
+    """hash_direct / hash_direct_with_attempt / hash_direct_first_step (crates/bls-snark-sys/src/signatures.rs:93-215) vs the
+    oracle's Python restatement of DirectHasher + try-and-increment (itself pinned on the reference's Blake2 vectors)."""
+    from oracle.py import hashing as hs
+    msgs = [b"", b"hello", bytes(range(256)) * 3, b"\x00" * 64, b"celo epoch 1234"]
+    for i, m in enumerate(msgs):
+        for pop in (False, True):
+            exp, c = hs.hash_to_g1_direct(b"ULforpop" if pop else b"ULforxof", m, b"")
+            assert _hash_direct(sys_lib, m, pop) == exp
+            out, n, att = C.c_void_p(), C.c_int(), C.c_int(-1)
+            sys_lib.hash_direct_with_attempt.restype = C.c_bool
+            assert sys_lib.hash_direct_with_attempt(m, C.c_int(len(m)), C.byref(out), C.byref(n), C.byref(att), C.c_bool(pop))
+            _take(sys_lib, out, n)
+            assert att.value == c
+        out, n = C.c_void_p(), C.c_int()
+        sys_lib.hash_direct_first_step.restype = C.c_bool
+        assert sys_lib.hash_direct_first_step(m, C.c_int(len(m)), C.c_int(33 + 31 * i), C.byref(out), C.byref(n))
+        assert _take(sys_lib, out, n) == hs.direct_hash(b"ULforxof", m, 33 + 31 * i)
+
+
+def test_sign_message_is_sk_times_hash(sys_lib):
+    from oracle.py import hashing as hs
+    sk = 0x0123456789ABCDEF00112233445566778899AABBCCDDEEFF0011223344 % ecc.R377
+    skh = _deser(sys_lib, "deserialize_private_key", sk.to_bytes(32, "little"))
+    sys_lib.sign_message.restype = C.c_bool
+    sys_lib.sign_pop.restype = C.c_bool
+    sig = C.c_void_p()
+    msg, extra = b"message", b"extra-data"
+    assert sys_lib.sign_message(skh, msg, C.c_int(len(msg)), extra, C.c_int(len(extra)), C.c_bool(False), C.c_bool(False), C.byref(sig))
+    H, _ = hs.hash_to_g1_direct(b"ULforxof", msg, extra)
+    assert _ser(sys_lib, "serialize_signature", sig) == ecc.ser_point(ecc.E1_377, ecc.E1_377.mul(H, sk))
+    pop = C.c_void_p()
+    assert sys_lib.sign_pop(skh, msg, C.c_int(len(msg)), C.byref(pop))
+    Hp, _ = hs.hash_to_g1_direct(b"ULforpop", msg, b"")
+    assert _ser(sys_lib, "serialize_signature", pop) == ecc.ser_point(ecc.E1_377, ecc.E1_377.mul(Hp, sk))
+    # flag combinations: composite not built -> false; (composite=false, cip22=true) is an error in the reference as well
+    assert not sys_lib.sign_message(skh, msg, C.c_int(len(msg)), extra, C.c_int(len(extra)), C.c_bool(True), C.c_bool(False), C.byref(sig))
+    assert not sys_lib.sign_message(skh, msg, C.c_int(len(msg)), extra, C.c_int(len(extra)), C.c_bool(False), C.c_bool(True), C.byref(sig))
+
+
+class _Buffer(C.Structure):
+    _fields_ = [("ptr", C.c_char_p), ("len", C.c_size_t)]
+
+
+class _MessageFFI(C.Structure):
+    _fields_ = [("data", _Buffer), ("extra", _Buffer), ("public_key", C.c_void_p), ("sig", C.c_void_p)]
+
+
+class _BatchMessageFFI(C.Structure):
+    _fields_ = [("data", _Buffer), ("extra", _Buffer), ("public_keys", C.POINTER(C.c_void_p)), ("public_keys_len", C.c_size_t),
+                ("signatures", C.POINTER(C.c_void_p)), ("signatures_len", C.c_size_t)]
+
+
+@pytest.mark.gpu
+def test_sign_verify_flow_on_gpu(sys_lib, gpu):
+    """The reference's randomised self-consistency tests (crates/bls-crypto/src/bls/signature.rs:180-426) through the C ABI:
+    sign -> verify OK; wrong message / key -> not verified; PoP; batch_verify over epochs; strict batches accept then reject."""
+    for f in ("sign_message", "sign_pop", "verify_signature", "verify_pop", "batch_verify_signature", "batch_verify_strict"):
+        getattr(sys_lib, f).restype = C.c_bool
+    rng = ecc.SplitMix64(2024)
+
+    def keypair():
+        sk = ecc.random_scalar(rng, ecc.R377)
+        skh = _deser(sys_lib, "deserialize_private_key", sk.to_bytes(32, "little"))
+        pkh = C.c_void_p()
+        assert sys_lib.private_key_to_public_key(skh, C.byref(pkh))
+        return skh, pkh
+
+    def sign(skh, msg, extra=b""):
+        s = C.c_void_p()
+        assert sys_lib.sign_message(skh, msg, C.c_int(len(msg)), extra, C.c_int(len(extra)), C.c_bool(False), C.c_bool(False), C.byref(s))
+        return s
+
+    sk1, pk1 = keypair()
+    sk2, pk2 = keypair()
+    msg, extra = b"hello", b"extra"
+    s1 = sign(sk1, msg, extra)
+    ok = C.c_bool(False)
+    assert sys_lib.verify_signature(pk1, msg, C.c_int(5), extra, C.c_int(5), s1, C.c_bool(False), C.c_bool(False), C.byref(ok)) and ok.value
+    assert sys_lib.verify_signature(pk1, b"hellp", C.c_int(5), extra, C.c_int(5), s1, C.c_bool(False), C.c_bool(False), C.byref(ok)) and not ok.value
+    assert sys_lib.verify_signature(pk2, msg, C.c_int(5), extra, C.c_int(5), s1, C.c_bool(False), C.c_bool(False), C.byref(ok)) and not ok.value
+    assert not sys_lib.verify_signature(pk1, msg, C.c_int(5), extra, C.c_int(5), s1, C.c_bool(False), C.c_bool(True), C.byref(ok))
+    pop = C.c_void_p()
+    pkb = _ser(sys_lib, "serialize_public_key", pk1)
+    assert sys_lib.sign_pop(sk1, pkb, C.c_int(len(pkb)), C.byref(pop))
+    assert sys_lib.verify_pop(pk1, pkb, C.c_int(len(pkb)), pop, C.byref(ok)) and ok.value
+    assert sys_lib.verify_pop(pk2, pkb, C.c_int(len(pkb)), pop, C.byref(ok)) and not ok.value
+
+    # batch_verify_signature: 4 epochs, each with an aggregate key of 3 validators
+    msgs = []
+    keep = []
+    for e in range(4):
+        m = b"epoch-%d" % e
+        ks = [keypair() for _ in range(3)]
+        sigs = [sign(sk, m, b"x") for sk, _ in ks]
+        pk_arr = (C.c_void_p * 3)(*[pk.value for _, pk in ks])
+        apk = C.c_void_p()
+        assert sys_lib.aggregate_public_keys(pk_arr, C.c_int(3), C.byref(apk))
+        sg_arr = (C.c_void_p * 3)(*[s.value for s in sigs])
+        asig = C.c_void_p()
+        assert sys_lib.aggregate_signatures(sg_arr, C.c_int(3), C.byref(asig))
+        keep.append((m, apk, asig, ks, sigs))
+        msgs.append(_MessageFFI(_Buffer(m, len(m)), _Buffer(b"x", 1), apk.value, asig.value))
+    arr = (_MessageFFI * 4)(*msgs)
+    assert sys_lib.batch_verify_signature(arr, C.c_size_t(4), C.c_bool(False), C.c_bool(False), C.byref(ok)) and ok.value
+    msgs[2] = _MessageFFI(_Buffer(b"epoch-9", 7), _Buffer(b"x", 1), keep[2][1].value, keep[2][2].value)
+    arr = (_MessageFFI * 4)(*msgs)
+    assert sys_lib.batch_verify_signature(arr, C.c_size_t(4), C.c_bool(False), C.c_bool(False), C.byref(ok)) and not ok.value
+
+    # batch_verify_strict: 3 batches; the second contains one signature on the wrong message
+    batches, holders = [], []
+    for b in range(3):
+        m = b"strict-%d" % b
+        ks = [keypair() for _ in range(4)]
+        sigs = [sign(sk, m) for sk, _ in ks]
+        if b == 1:
+            sigs[2] = sign(ks[2][0], b"other")
+        pks = (C.c_void_p * 4)(*[pk.value for _, pk in ks])
+        sgs = (C.c_void_p * 4)(*[s.value for s in sigs])
+        holders.append((pks, sgs, m))
+        batches.append(_BatchMessageFFI(_Buffer(m, len(m)), _Buffer(b"", 0), pks, 4, sgs, 4))
+    barr = (_BatchMessageFFI * 3)(*batches)
+    res = (C.c_bool * 3)()
+    assert not sys_lib.batch_verify_strict(barr, C.c_size_t(3), C.c_bool(False), C.c_bool(False), res)
+    assert list(res) == [True, False, True]
+    good = (_BatchMessageFFI * 2)(batches[0], batches[2])
+    res2 = (C.c_bool * 2)()
+    assert sys_lib.batch_verify_strict(good, C.c_size_t(2), C.c_bool(False), C.c_bool(False), res2) and list(res2) == [True, True]
+    assert not sys_lib.batch_verify_strict(good, C.c_size_t(2), C.c_bool(False), C.c_bool(True), res2) and list(res2) == [False, False]

@@ -392,6 +392,127 @@ template <class F> void batch_to_affine(const uint64_t* jac, size_t n, uint64_t*
     F::mul(F::from_ark(jac + i * 3 * A + A), F::mul(zi2, zi)).to_ark(o + A);
   }
 }
+
+// ---------------------------------------------------------------- BW6-761 wire format (Groth16 VerifyingKey / Proof points)
+typedef Fp<P761> Fw_;
+bool fw_from_bytes(const uint8_t* in, Fw_& out) {
+  uint64_t w[12];
+  memcpy(w, in, 96);
+  if (cmp_n(w, P761::P64, 12) >= 0) return false;
+  out = Fw_::from_canonical(w);
+  return true;
+}
+bool fw_eq(const Fw_& a, const Fw_& b) { return Fw_::eq_mod_p(Fw_::norm(a), Fw_::norm(b)); }
+bool fw_lex_largest(const Fw_& a) {
+  uint64_t w[12];
+  a.to_canonical(w);
+  return cmp_n(w, P761::PM1_HALF64, 12) > 0;
+}
+Fw_ fw_neg(const Fw_& a) { return Fw_::wred(Fw_::norm(Fw_::neg<64, 1>(Fw_::norm(a)))); }
+bool fw_sqrt(const Fw_& a, Fw_& out) {  // q = 3 (mod 4): a^((q+1)/4)
+  uint64_t e[12];
+  memcpy(e, P761::P64, 96);
+  e[0] += 1;  // no carry: low limb of q is ...8b
+  for (int i = 0; i < 12; i++) e[i] = (e[i] >> 2) | (i + 1 < 12 ? e[i + 1] << 62 : 0);
+  Fw_ y = Fw_::pow64(Fw_::norm(a), e, 12);
+  if (!fw_eq(Fw_::sqr(y), a)) return false;
+  out = y;
+  return true;
+}
+// b = -1 for G1 (y^2 = x^3 - 1), +4 for G2 (M-twist, coordinates in Fq)
+bool bw6_decompress(const uint8_t* in, bool g2, Affine<Fw_>& p, bool& inf) {
+  uint8_t buf[96];
+  memcpy(buf, in, 96);
+  uint8_t flags = buf[95] & 0xC0;
+  buf[95] &= 0x3F;
+  inf = (flags & 0x40) != 0;
+  if (inf) return true;
+  Fw_ x;
+  if (!fw_from_bytes(buf, x)) return false;
+  Fw_ x3 = Fw_::mul(Fw_::sqr(x), x);
+  Fw_ rhs;
+  if (g2) { Fw_ one = Fw_::one(); rhs = Fw_::norm(Fw_::add(x3, Fw_::norm(Fw_::dbl(Fw_::dbl(one))))); }
+  else rhs = Fw_::norm(Fw_::sub<4, 1>(x3, Fw_::one()));
+  Fw_ y;
+  if (!fw_sqrt(rhs, y)) return false;
+  if (fw_lex_largest(y) != ((flags & 0x80) != 0)) y = fw_neg(y);
+  p = {Fw_::norm(x), Fw_::norm(y)};
+  // arkworks' GroupAffine::deserialize checks the prime-order subgroup (r_BW6 = q_BLS12-377)
+  Xyzz<Fw_> r = scalar_mul_host(p, P377::P64, 6);
+  return r.is_identity() || r.ZZ.is_zero_mod_p();
+}
+void bw6_store_xy(const Affine<Fw_>& p, uint64_t* out) { p.x.to_ark(out); p.y.to_ark(out + 12); }
+
+// ---------------------------------------------------------------- epoch encoding (crates/epoch-snark/src/{encoding,epoch_block}.rs,
+// crates/bls-gadgets/src/utils.rs:2-56, crates/epoch-snark/src/gadgets/mod.rs:75-83) — byte/bit plumbing
+typedef std::vector<uint8_t> Bits;
+void bits_append_le(Bits& b, const uint8_t* bytes, size_t nbytes, size_t take) {  // bytes_le_to_bits_le
+  for (size_t i = 0; i < take; i++) b.push_back(i / 8 < nbytes ? (bytes[i / 8] >> (i % 8)) & 1 : 0);
+}
+void bits_append_be(Bits& b, const uint8_t* bytes, size_t nbytes, size_t take) {  // bytes_le_to_bits_be: first `take` LE bits, reversed
+  for (size_t i = take; i-- > 0;) b.push_back(i / 8 < nbytes ? (bytes[i / 8] >> (i % 8)) & 1 : 0);
+}
+std::vector<uint8_t> bits_be_to_bytes_le(const Bits& bits) {
+  std::vector<uint8_t> out;
+  size_t n = bits.size();
+  for (size_t i = 0; i < n; i += 8) {
+    uint8_t byte = 0;
+    for (size_t k = 0; k < 8 && i + k < n; k++) byte |= (uint8_t)(bits[n - 1 - (i + k)] << k);
+    out.push_back(byte);
+  }
+  return out;
+}
+void encode_uint(Bits& b, uint64_t v, size_t nbytes) {
+  uint8_t le[8];
+  for (size_t i = 0; i < 8; i++) le[i] = (uint8_t)(v >> (8 * i));
+  bits_append_le(b, le, nbytes, 8 * nbytes);
+}
+void encode_public_key_bits(Bits& b, const Affine<Fq2_>& pk) {  // encoding.rs:23-47
+  uint8_t x0[48], x1[48];
+  fq_to_bytes(pk.x.c0, x0);
+  fq_to_bytes(pk.x.c1, x1);
+  bits_append_be(b, x0, 48, 377);
+  bits_append_be(b, x1, 48, 377);
+  bool over_half = fq_lex_largest(pk.y.c1) || (pk.y.c1.is_zero_mod_p() && fq_lex_largest(pk.y.c0));
+  b.push_back(over_half ? 1 : 0);
+}
+void encode_entropy_bits(Bits& b, const uint8_t* entropy) {  // epoch_block.rs:140-148 (None -> zero bits)
+  uint8_t zero[16];
+  memset(zero, 0, 16);
+  bits_append_le(b, entropy ? entropy : zero, 16, 128);
+}
+struct EpochBlockHost {
+  uint16_t index; uint8_t round; const uint8_t* epoch_entropy; const uint8_t* parent_entropy;
+  uint32_t maximum_non_signers; size_t maximum_validators; std::vector<Affine<Fq2_>> pubkeys; std::vector<uint64_t> pubkeys_jac;
+};
+Affine<Fq2_> g2_generator_affine() {
+  return {{Fq_::from_limbs(T377::G2_GEN_X0), Fq_::from_limbs(T377::G2_GEN_X1)}, {Fq_::from_limbs(T377::G2_GEN_Y0), Fq_::from_limbs(T377::G2_GEN_Y1)}};
+}
+void epoch_bits_cip22(const EpochBlockHost& e, bool first, Bits& b) {  // epoch_block.rs:118-138
+  encode_uint(b, e.index, 2);
+  encode_entropy_bits(b, first ? e.parent_entropy : e.epoch_entropy);
+  encode_uint(b, e.maximum_non_signers, 4);
+  for (const auto& pk : e.pubkeys) encode_public_key_bits(b, pk);
+  for (size_t i = e.pubkeys.size(); i < e.maximum_validators; i++) encode_public_key_bits(b, g2_generator_affine());
+}
+std::vector<uint8_t> blake2s_out_domain(const std::vector<uint8_t>& data) {  // epoch_block.rs:226-236, OUT_DOMAIN = "ULforout"
+  static const uint8_t OUT_DOMAIN[8] = {'U', 'L', 'f', 'o', 'r', 'o', 'u', 't'};
+  B2sParams p;
+  return blake2s(data.data(), data.size(), p, OUT_DOMAIN, 8);
+}
+bool epoch_from_ffi(const EpochBlockFFI& src, EpochBlockHost& e) {  // snark/epoch_block.rs:129-146
+  e.index = src.index; e.round = src.round; e.epoch_entropy = src.epoch_entropy; e.parent_entropy = src.parent_entropy;
+  e.maximum_non_signers = src.maximum_non_signers; e.maximum_validators = src.maximum_validators;
+  e.pubkeys.resize(src.pubkeys_num);
+  e.pubkeys_jac.resize(src.pubkeys_num * 36);
+  for (size_t i = 0; i < src.pubkeys_num; i++) {
+    bool inf;
+    if (!g2_decompress(src.pubkeys + 96 * i, e.pubkeys[i], inf) || inf) return false;
+    if (!in_subgroup(e.pubkeys[i])) return false;
+    affine_to_jac(e.pubkeys[i], &e.pubkeys_jac[i * 36]);
+  }
+  return true;
+}
 void neg_g2_generator(uint64_t out_xy[24]) {
   Fq_::from_limbs(T377::G2_GEN_X0).to_ark(out_xy);
   Fq_::from_limbs(T377::G2_GEN_X1).to_ark(out_xy + 6);
@@ -768,5 +889,96 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   bool all = true;
   for (size_t b = 0; b < m; b++) { out_results[b] = ok[b] != 0; all = all && out_results[b]; }
   return all;
+}
+
+// ---------------------------------------------------------------- Groth16 verification over BW6-761 through the FFI
+// crates/bls-snark-sys/src/snark/mod.rs:23-45 -> crates/epoch-snark/src/api/verifier.rs:23-40 -> ark_groth16::verify_proof.
+// Decoding, hashing and packing are host plumbing; the two input scalar-muls go through msm_bw6_761_g1 and the check
+//   e(A,B) * e(acc,-gamma) * e(C,-delta) * e(-alpha,beta) == 1   through pairing_product_is_one_bw6_761 (GPU).
+bool verify(const uint8_t* vk, uint32_t vk_len, const uint8_t* proof, uint32_t proof_len, EpochBlockFFI first_epoch, EpochBlockFFI last_epoch) {
+  if (!vk || !proof || proof_len < 288 || vk_len < 392) return false;
+  EpochBlockHost first, last;
+  if (!epoch_from_ffi(first_epoch, first) || !epoch_from_ffi(last_epoch, last)) { log_err("verify: bad epoch public keys"); return false; }
+  // ---- VerifyingKey = alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | u64 len | gamma_abc_g1[len];  Proof = A | B | C
+  Affine<Fw_> alpha, beta, gamma, delta, A, B, Cc;
+  bool inf;
+  if (!bw6_decompress(vk, false, alpha, inf) || inf || !bw6_decompress(vk + 96, true, beta, inf) || inf ||
+      !bw6_decompress(vk + 192, true, gamma, inf) || inf || !bw6_decompress(vk + 288, true, delta, inf) || inf) { log_err("verify: bad vk"); return false; }
+  uint64_t nabc;
+  memcpy(&nabc, vk + 384, 8);
+  if (nabc != 3 || vk_len < 392 + 96 * nabc) { log_err("verify: vk must carry 2 public inputs"); return false; }
+  Affine<Fw_> abc[3];
+  for (int i = 0; i < 3; i++) if (!bw6_decompress(vk + 392 + 96 * i, false, abc[i], inf) || inf) { log_err("verify: bad gamma_abc"); return false; }
+  if (!bw6_decompress(proof, false, A, inf) || inf || !bw6_decompress(proof + 96, true, B, inf) || inf ||
+      !bw6_decompress(proof + 192, false, Cc, inf) || inf) { log_err("verify: bad proof"); return false; }
+  // ---- public inputs: Blake2s("ULforout") of the first epoch and of the last epoch + aggregated key, 512 bits, packed 376|136
+  Bits fb, lb;
+  epoch_bits_cip22(first, true, fb);
+  epoch_bits_cip22(last, false, lb);
+  uint64_t agg[36];
+  if (celo_amd_sum_jacobian_bls12_377_g2(last.pubkeys_jac.data(), last.pubkeys.size(), agg) != 0) return false;
+  Affine<Fq2_> aggp;
+  if (!jac_to_affine<Fq2_>(agg, aggp)) return false;  // encode_public_key assumes a finite key
+  encode_public_key_bits(lb, aggp);
+  std::vector<uint8_t> h1 = blake2s_out_domain(bits_be_to_bytes_le(fb)), h2 = blake2s_out_domain(bits_be_to_bytes_le(lb));
+  Bits hb;
+  bits_append_le(hb, h1.data(), 32, 256);
+  bits_append_le(hb, h2.data(), 32, 256);
+  uint64_t scalars[3 * 6];
+  memset(scalars, 0, sizeof scalars);
+  scalars[0] = 1;  // gamma_abc[0] enters with scalar 1
+  for (int chunk = 0; chunk < 2; chunk++) {  // pack::<Fr, CAPACITY = 376>: big-endian bits
+    size_t lo = chunk * 376, hi = lo + 376 < hb.size() ? lo + 376 : hb.size();
+    uint64_t* sc = scalars + 6 * (chunk + 1);
+    size_t nb = hi - lo;
+    for (size_t i = 0; i < nb; i++)
+      if (hb[lo + i]) { size_t bit = nb - 1 - i; sc[bit >> 6] |= 1ULL << (bit & 63); }
+  }
+  uint64_t bases[3 * 24], accj[36], accxy[24];
+  for (int i = 0; i < 3; i++) bw6_store_xy(abc[i], bases + 24 * i);
+  if (msm_bw6_761_g1(bases, nullptr, scalars, 3, accj) != 0) return false;
+  uint8_t ainf;
+  batch_to_affine<Fw_>(accj, 1, accxy, &ainf);
+  // ---- the 4-pair product
+  uint64_t g1[4 * 24], g2[4 * 24];
+  uint8_t i1[4] = {0, ainf, 0, 0}, i2[4] = {0, 0, 0, 0};
+  bw6_store_xy(A, g1); bw6_store_xy(B, g2);
+  memcpy(g1 + 24, accxy, 192); bw6_store_xy({gamma.x, fw_neg(gamma.y)}, g2 + 24);
+  bw6_store_xy(Cc, g1 + 48); bw6_store_xy({delta.x, fw_neg(delta.y)}, g2 + 48);
+  bw6_store_xy({alpha.x, fw_neg(alpha.y)}, g1 + 72); bw6_store_xy(beta, g2 + 72);
+  int one = 0;
+  if (pairing_product_is_one_bw6_761(g1, i1, g2, i2, 4, &one) != 0) return false;
+  return one != 0;
+}
+
+static bool collect_pubkeys(const PublicKey* const* in, int n, std::vector<Affine<Fq2_>>& out) {
+  if (n < 0 || (n > 0 && !in)) return false;
+  out.resize((size_t)n);
+  for (int i = 0; i < n; i++) if (!in[i] || !jac_to_affine<Fq2_>(in[i]->xyz, out[(size_t)i])) return false;
+  return true;
+}
+bool encode_epoch_block_to_bytes_cip22(unsigned short index, unsigned char round, const uint8_t* epoch_entropy, const uint8_t* parent_entropy,
+                                       unsigned int maximum_non_signers, unsigned int maximum_validators, const PublicKey* const* added_public_keys,
+                                       int added_public_keys_len, uint8_t** out_bytes, int* out_len, uint8_t** out_extra, int* out_extra_len) {
+  if (!out_bytes || !out_len || !out_extra || !out_extra_len) return false;                                  /* snark/epoch_block.rs:17 */
+  std::vector<Affine<Fq2_>> pks;
+  if (!collect_pubkeys(added_public_keys, added_public_keys_len, pks)) return false;
+  Bits eb, xb;                                                                                                /* epoch_block.rs:150-169 */
+  encode_uint(xb, index, 2); encode_uint(xb, round, 1); encode_uint(xb, maximum_non_signers, 4);
+  encode_entropy_bits(eb, epoch_entropy);
+  encode_entropy_bits(eb, parent_entropy);
+  for (const auto& pk : pks) encode_public_key_bits(eb, pk);
+  for (size_t i = pks.size(); i < maximum_validators; i++) encode_public_key_bits(eb, g2_generator_affine());
+  return emit(bits_be_to_bytes_le(eb), out_bytes, out_len) && emit(bits_be_to_bytes_le(xb), out_extra, out_extra_len);
+}
+bool encode_epoch_block_to_bytes(unsigned short index, unsigned int maximum_non_signers, const PublicKey* const* added_public_keys,
+                                 int added_public_keys_len, uint8_t** out_bytes, int* out_len) {              /* snark/epoch_block.rs:69 */
+  if (!out_bytes || !out_len) return false;
+  std::vector<Affine<Fq2_>> pks;
+  if (!collect_pubkeys(added_public_keys, added_public_keys_len, pks)) return false;
+  Bits b;                                                                                                     /* epoch_block.rs:106-114 */
+  encode_uint(b, index, 2); encode_uint(b, maximum_non_signers, 4);
+  for (const auto& pk : pks) encode_public_key_bits(b, pk);
+  return emit(bits_be_to_bytes_le(b), out_bytes, out_len);
 }
 }

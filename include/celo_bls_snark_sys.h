@@ -9,8 +9,8 @@
  * `compat` bit logic) — `should_use_composite = false`.  With `should_use_composite = true` these functions return false
  * (logged under CELO_AMD_LOG=1): the Bowe-Hopwood composite hasher is not built yet.
  * `(composite = false, cip22 = true)` is an error exactly as in the reference (signatures.rs:61,265,321,387).
- * NOT yet exported: hash_composite, hash_crh, hash_composite_cip22, verify (Groth16 over the FFI
- * structs), encode_epoch_block_to_bytes[_cip22].  The arithmetic core of `verify` is pairing_product_is_one_bw6_761.
+ * `verify` (Groth16 over BW6-761) and the two epoch encoders are exported too.
+ * NOT yet exported: hash_composite, hash_crh, hash_composite_cip22 (composite hasher).
  */
 #ifndef CELO_BLS_SNARK_SYS_H
 #define CELO_BLS_SNARK_SYS_H
@@ -72,6 +72,23 @@ bool batch_verify_signature(const MessageFFI* messages, size_t messages_len, boo
                             bool* verified);                                                               /* signatures.rs:290 */
 bool batch_verify_strict(const BatchMessageFFI* batches, size_t batches_len, bool should_use_composite, bool should_use_cip22,
                          bool* out_results);                                                               /* signatures.rs:343 */
+
+/* snark (crates/bls-snark-sys/src/snark/) */
+typedef struct EpochBlockFFI {                 /* snark/epoch_block.rs:109-127, passed BY VALUE */
+  uint16_t index; uint8_t round;
+  const uint8_t* epoch_entropy;                /* 16 bytes or NULL */
+  const uint8_t* parent_entropy;               /* 16 bytes or NULL */
+  const uint8_t* pubkeys;                      /* pubkeys_num * 96 bytes, compressed G2 */
+  size_t pubkeys_num; uint32_t maximum_non_signers; size_t maximum_validators;
+} EpochBlockFFI;
+bool verify(const uint8_t* vk, uint32_t vk_len, const uint8_t* proof, uint32_t proof_len, EpochBlockFFI first_epoch,
+            EpochBlockFFI last_epoch);                                                                       /* snark/mod.rs:23 */
+bool encode_epoch_block_to_bytes_cip22(unsigned short index, unsigned char round, const uint8_t* epoch_entropy,
+                                       const uint8_t* parent_entropy, unsigned int maximum_non_signers, unsigned int maximum_validators,
+                                       const PublicKey* const* added_public_keys, int added_public_keys_len, uint8_t** out_bytes,
+                                       int* out_len, uint8_t** out_extra_data_bytes, int* out_extra_data_len);  /* snark/epoch_block.rs:17 */
+bool encode_epoch_block_to_bytes(unsigned short index, unsigned int maximum_non_signers, const PublicKey* const* added_public_keys,
+                                 int added_public_keys_len, uint8_t** out_bytes, int* out_len);              /* snark/epoch_block.rs:69 */
 
 /* GPU verification core: what verify_signature / verify_pop (signatures.rs:244,407) compute once the message has been
  * hashed to G1 — e(sig, -g2) * e(H(m), pk) == 1 (crates/bls-crypto/src/bls/public.rs:94-120).  message_hash_xy: affine

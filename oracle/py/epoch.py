@@ -143,3 +143,14 @@ def groth16_pairs(vk, proof, inputs):
         acc = E1_761.add(acc, E1_761.mul(P, s))
     return [(proof["a"], proof["b"]), (acc, E2_761.neg(vk["gamma_g2"])), (proof["c"], E2_761.neg(vk["delta_g2"])),
             (E1_761.neg(vk["alpha_g1"]), vk["beta_g2"])]
+
+
+def encode_inner_to_bytes_cip22(block):
+    """EpochBlock::encode_inner_to_bytes_cip22 (crates/epoch-snark/src/epoch_block.rs:150-169, 207-214): (inner, extra_data)."""
+    extra = encode_uint(block.index, 2) + encode_uint(block.round, 1) + encode_uint(block.maximum_non_signers, 4)
+    bits = encode_entropy(block.epoch_entropy) + encode_entropy(block.parent_entropy)
+    for pk in block.pubkeys:
+        bits += encode_public_key(pk)
+    for _ in range(max(0, block.maximum_validators - len(block.pubkeys))):
+        bits += encode_public_key(G2_377)
+    return bits_be_to_bytes_le(bits), bits_be_to_bytes_le(extra)

@@ -307,3 +307,55 @@ def test_sign_verify_flow_on_gpu(sys_lib, gpu):
     res2 = (C.c_bool * 2)()
     assert sys_lib.batch_verify_strict(good, C.c_size_t(2), C.c_bool(False), C.c_bool(False), res2) and list(res2) == [True, True]
     assert not sys_lib.batch_verify_strict(good, C.c_size_t(2), C.c_bool(False), C.c_bool(True), res2) and list(res2) == [False, False]
+
+
+# ---------------------------------------------------------------- snark half of the FFI
+class _EpochBlockFFI(C.Structure):
+    _fields_ = [("index", C.c_uint16), ("round", C.c_uint8), ("epoch_entropy", C.c_char_p), ("parent_entropy", C.c_char_p),
+                ("pubkeys", C.c_char_p), ("pubkeys_num", C.c_size_t), ("maximum_non_signers", C.c_uint32),
+                ("maximum_validators", C.c_size_t)]
+
+
+def test_encode_epoch_block_symbols(sys_lib, golden):
+    """encode_epoch_block_to_bytes reproduces the reference's pre-Donut golden encoding
+    (crates/epoch-snark/src/epoch_block.rs:246,287-299) byte for byte; the CIP22 inner encoding matches the oracle restatement."""
+    from oracle.py import epoch as ep
+    gen = _deser(sys_lib, "deserialize_public_key", ecc.ser_point(ecc.E2_377, ecc.G2_377))
+    arr = (C.c_void_p * 10)(*[gen.value] * 10)
+    out, n = C.c_void_p(), C.c_int()
+    sys_lib.encode_epoch_block_to_bytes.restype = C.c_bool
+    assert sys_lib.encode_epoch_block_to_bytes(C.c_ushort(120), C.c_uint(3), arr, C.c_int(10), C.byref(out), C.byref(n))
+    assert _take(sys_lib, out, n).hex() == golden["epoch_encoding"]["EXPECTED_ENCODING_BEFORE_DONUT"]
+    sys_lib.encode_epoch_block_to_bytes_cip22.restype = C.c_bool
+    o1, n1, o2, n2 = C.c_void_p(), C.c_int(), C.c_void_p(), C.c_int()
+    e_ent, p_ent = bytes([7] * 16), bytes([9] * 16)
+    assert sys_lib.encode_epoch_block_to_bytes_cip22(C.c_ushort(120), C.c_ubyte(5), e_ent, p_ent, C.c_uint(3), C.c_uint(12), arr, C.c_int(10),
+                                                     C.byref(o1), C.byref(n1), C.byref(o2), C.byref(n2))
+    inner, extra = ep.encode_inner_to_bytes_cip22(ep.EpochBlock(120, 5, e_ent, p_ent, 3, 12, [ecc.G2_377] * 10))
+    assert _take(sys_lib, o1, n1) == inner and _take(sys_lib, o2, n2) == extra
+
+
+@pytest.mark.gpu
+def test_reference_groth16_ffi_test_passes_on_gpu(sys_lib, gpu, golden):
+    """The reference's own FFI test `simple_verifier_groth16_with_entropy` (crates/bls-snark-sys/src/snark/mod.rs:52-119),
+    replayed against this library's `verify` symbol: must return true; flipping a byte of the proof or of an entropy value
+    must return false."""
+    g = golden["groth16_bw6_761"]
+    vk, proof = bytes.fromhex(g["vk"]), bytes.fromhex(g["proof"])
+    fp, lp = bytes.fromhex(g["first_pubkeys"]), bytes.fromhex(g["last_pubkeys"])
+
+    def blk(d, pk, ee, pe):
+        return _EpochBlockFFI(d["index"], d["round"], ee, pe, pk, d["pubkeys_num"], d["maximum_non_signers"], d["maximum_validators"])
+
+    fe, fpe = bytes.fromhex(g["first_epoch_entropy"]), bytes.fromhex(g["first_parent_entropy"])
+    le, lpe = bytes.fromhex(g["last_epoch_entropy"]), bytes.fromhex(g["last_parent_entropy"])
+    sys_lib.verify.restype = C.c_bool
+    sys_lib.verify.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, _EpochBlockFFI, _EpochBlockFFI]
+    first, last = blk(g["first"], fp, fe, fpe), blk(g["last"], lp, le, lpe)
+    assert sys_lib.verify(vk, len(vk), proof, len(proof), first, last) is True
+    bad_entropy = bytes([le[0] ^ 1]) + le[1:]
+    assert sys_lib.verify(vk, len(vk), proof, len(proof), first, blk(g["last"], lp, bad_entropy, lpe)) is False
+    assert sys_lib.verify(vk, len(vk), proof, len(proof), blk(g["first"], fp, fe, bytes([fpe[0] ^ 1]) + fpe[1:]), last) is False
+    # a different (valid) G1 point as the proof's C: swap A and C
+    swapped = proof[192:288] + proof[96:192] + proof[0:96]
+    assert sys_lib.verify(vk, len(vk), swapped, len(swapped), first, last) is False

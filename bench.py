@@ -190,7 +190,7 @@ def pairing_leg(ffi, codec):
     from oracle import cpu_oracle as co
     from oracle.py import ecc
     import time as _t
-    m = 2048
+    m = 32768                                 # large enough to fill the chip: one lane per pair, one wave per SIMD at 65536 pairs
     rng = ecc.SplitMix64(0x5EED0005)
     base = []
     ng2 = ecc.E2_377.neg(ecc.G2_377)

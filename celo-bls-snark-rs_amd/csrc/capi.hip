@@ -24,7 +24,8 @@ int api_ensure_init() {
   int msm_timings_##TAG(float*, int*);                                                                \
   int msm_set_c_##TAG(int);                                                                           \
   int gen_points_##TAG(void*, size_t, uint64_t, const uint64_t*, void*);                              \
-  int sum_jac_##TAG(const uint64_t*, size_t, uint64_t*);
+  int sum_jac_##TAG(const uint64_t*, size_t, uint64_t*);                                              \
+  void msm_note_big_call_##TAG();
 DECL(g1_377) DECL(g2_377) DECL(761)
 int pairing_run_377(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
 int pairing_timings_377(float*);
@@ -49,14 +50,14 @@ int celo_amd_device_name(char* buf, size_t buflen) {
   snprintf(buf, buflen, "%s", p.gcnArchName);
   return 0;
 }
-int msm_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { return msm_host_g1_377(b, inf, s, n, out); }
-int msm_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { return msm_host_g2_377(b, inf, s, n, out); }
-int msm_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { return msm_host_761(b, inf, s, n, out); }
-int msm_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { return msm_host_761(b, inf, s, n, out); }
-int msm_bls12_377_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_g1_377(b, inf, s, n, out, st); }
-int msm_bls12_377_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_g2_377(b, inf, s, n, out, st); }
-int msm_bw6_761_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_761(b, inf, s, n, out, st); }
-int msm_bw6_761_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { return msm_dev_761(b, inf, s, n, out, st); }
+int msm_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g1_377(); return msm_host_g1_377(b, inf, s, n, out); }
+int msm_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g2_377(); return msm_host_g2_377(b, inf, s, n, out); }
+int msm_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_761(); return msm_host_761(b, inf, s, n, out); }
+int msm_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_761(); return msm_host_761(b, inf, s, n, out); }
+int msm_bls12_377_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g1_377(); return msm_dev_g1_377(b, inf, s, n, out, st); }
+int msm_bls12_377_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g2_377(); return msm_dev_g2_377(b, inf, s, n, out, st); }
+int msm_bw6_761_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_761(); return msm_dev_761(b, inf, s, n, out, st); }
+int msm_bw6_761_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_761(); return msm_dev_761(b, inf, s, n, out, st); }
 int msm_batch_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g1_377(b, inf, s, off, m, out); }
 int msm_batch_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g2_377(b, inf, s, off, m, out); }
 int msm_batch_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_761(b, inf, s, off, m, out); }

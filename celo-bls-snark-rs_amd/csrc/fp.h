@@ -28,7 +28,14 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+// Device pass: everything is force-inlined (register-resident operands).  Host pass: plain `inline` — the host only runs
+// epilogues and plumbing, and force-inlining the ~600-instruction multiply bodies everywhere made the host pass the long
+// pole of the build (158 s of a 180 s unit).
+#if defined(__HIP_DEVICE_COMPILE__)
 #define HD __host__ __device__ __forceinline__
+#else
+#define HD __host__ __device__ inline
+#endif
 #else
 #define HD inline
 struct uint4 { uint32_t x, y, z, w; };  // host-only builds (bounds-tracking unit tests)
@@ -136,6 +143,14 @@ template <class P> struct Fp {
     return r;
   }
 
+  // one out-of-line copy per translation unit (see curve.h FieldOps)
+#if defined(__HIPCC__)
+  __host__ __device__ __attribute__((noinline)) static Fp mul_ol(const Fp& a, const Fp& b) { return mul(a, b); }
+  __host__ __device__ __attribute__((noinline)) static Fp sqr_ol(const Fp& a) { return sqr(a); }
+#else
+  static Fp mul_ol(const Fp& a, const Fp& b) { return mul(a, b); }
+  static Fp sqr_ol(const Fp& a) { return sqr(a); }
+#endif
   HD static Fp add(const Fp& a, const Fp& b) {
     Fp r;
 #pragma unroll

@@ -77,6 +77,8 @@ template <class F> int sum_jacobian_impl(const uint64_t* jac, size_t k, uint64_t
 }
 }  // namespace celo
 
+// The large-MSM engine and the auxiliary entry points (batched MSMs, generators, host sums) are separate macros so that
+// each group compiles as two translation units in parallel (the 28-limb instantiations are the long pole of the build).
 #define CELO_DEFINE_MSM_UNIT(G, TAG)                                                                                     \
   namespace celo {                                                                                                       \
   static MsmEngine<G> eng_##TAG;                                                                                         \
@@ -90,21 +92,40 @@ template <class F> int sum_jacobian_impl(const uint64_t* jac, size_t k, uint64_t
     if (int rc = api_ensure_init()) return rc;                                                                           \
     return eng_##TAG.run_device((const uint64_t*)b, (const uint8_t*)inf, (const uint32_t*)s, n, out, (hipStream_t)st);   \
   }                                                                                                                      \
-  int msm_batch_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { \
-    std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
-    if (int rc = api_ensure_init()) return rc;                                                                           \
-    return eng_##TAG.run_batch_host(b, inf, s, off, m, out, nullptr);                                                    \
-  }                                                                                                                      \
-  int msm_timings_##TAG(float ms[5], int cfg[3]) {                                                                       \
-    std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
+  void msm_big_timings_##TAG(float ms[5], int cfg[3]) {                                                                  \
     const MsmTimings& t = eng_##TAG.tm;                                                                                  \
     ms[0] = t.convert; ms[1] = t.sort; ms[2] = t.accumulate; ms[3] = t.reduce; ms[4] = t.total;                          \
     cfg[0] = eng_##TAG.last_c; cfg[1] = eng_##TAG.last_nw; cfg[2] = (int)eng_##TAG.last_buckets;                         \
+  }                                                                                                                      \
+  void msm_big_set_c_##TAG(int c) { eng_##TAG.force_c = c; }                                                             \
+  }
+
+#define CELO_DEFINE_MSM_AUX_UNIT(G, TAG)                                                                                 \
+  namespace celo {                                                                                                       \
+  static MsmEngine<G> eng_aux_##TAG;                                                                                     \
+  static int last_was_batch_##TAG = 0;                                                                                   \
+  void msm_big_timings_##TAG(float ms[5], int cfg[3]);                                                                   \
+  void msm_big_set_c_##TAG(int c);                                                                                       \
+  int msm_batch_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { \
+    std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
+    if (int rc = api_ensure_init()) return rc;                                                                           \
+    last_was_batch_##TAG = 1;                                                                                            \
+    return eng_aux_##TAG.run_batch_host(b, inf, s, off, m, out, nullptr);                                                \
+  }                                                                                                                      \
+  int msm_timings_##TAG(float ms[5], int cfg[3]) {                                                                       \
+    std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
+    if (last_was_batch_##TAG) {                                                                                          \
+      const MsmTimings& t = eng_aux_##TAG.tm;                                                                            \
+      ms[0] = t.convert; ms[1] = t.sort; ms[2] = t.accumulate; ms[3] = t.reduce; ms[4] = t.total;                        \
+      cfg[0] = eng_aux_##TAG.last_c; cfg[1] = eng_aux_##TAG.last_nw; cfg[2] = (int)eng_aux_##TAG.last_buckets;           \
+    } else msm_big_timings_##TAG(ms, cfg);                                                                               \
     return 0;                                                                                                            \
   }                                                                                                                      \
+  void msm_note_big_call_##TAG() { last_was_batch_##TAG = 0; }                                                           \
   int msm_set_c_##TAG(int c) {                                                                                           \
     std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
-    eng_##TAG.force_c = c;                                                                                               \
+    eng_aux_##TAG.force_c = c;                                                                                           \
+    msm_big_set_c_##TAG(c);                                                                                              \
     return 0;                                                                                                            \
   }                                                                                                                      \
   int gen_points_##TAG(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) {                                  \

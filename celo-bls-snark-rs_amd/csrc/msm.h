@@ -603,6 +603,7 @@ template <class G> class MsmEngine {
     const uint32_t n = (uint32_t)n_;
     const int c = force_c ? force_c : window_bits(n);
     const int nw = (G::SCALAR_BITS + c) / c;
+    if ((uint64_t)n * (uint64_t)nw >= (uint64_t(1) << 32)) return 2;  // run offsets are 32-bit (n*windows < 2^32: n <= 2^27 at c = 16)
     const uint32_t B = 1u << (c - 1);
     const uint32_t total = (uint32_t)nw * B;
     // blocks per window for the LDS counting sort: fill the chip, at least ~4096 digits per block

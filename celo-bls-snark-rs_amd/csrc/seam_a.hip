@@ -18,6 +18,8 @@
 #include <random>
 #include <mutex>
 #include <vector>
+#include <thread>
+#include <atomic>
 #include "curve.h"
 #include "fp2.h"
 #include "../../include/celo_bls_amd.h"
@@ -369,6 +371,34 @@ bool hash_to_g1_direct(const uint8_t* dom, const uint8_t* msg, size_t mlen, cons
     return true;
   }
   return false;
+}
+// hash many messages on all host cores (hash-to-curve is host plumbing for now; one attempt costs a
+// Blake2Xs call, a 377-bit square root and a 125-bit cofactor multiplication)
+struct HashJob { const uint8_t* msg; size_t mlen; const uint8_t* extra; size_t elen; uint64_t* out_xy; };
+bool hash_many_direct(const uint8_t* dom, std::vector<HashJob>& jobs) {
+  (void)sqrt_ctx();  // initialise shared constants before the threads start
+  std::atomic<size_t> next(0);
+  std::atomic<bool> ok(true);
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > 64) nt = 64;
+  if (nt > jobs.size()) nt = (unsigned)jobs.size();
+  auto work = [&]() {
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= jobs.size()) break;
+      Affine<Fq_> h; int c;
+      if (!hash_to_g1_direct(dom, jobs[i].msg, jobs[i].mlen, jobs[i].extra, jobs[i].elen, h, c)) { ok = false; continue; }
+      h.x.to_ark(jobs[i].out_xy); h.y.to_ark(jobs[i].out_xy + 6);
+    }
+  };
+  if (nt <= 1) work();
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work);
+    for (auto& t : th) t.join();
+  }
+  return ok;
 }
 // Montgomery's trick: Jacobian (ark limbs, stride 3*A u64) -> affine xy (ark limbs); inf[i] = 1 for the identity
 template <class F> void batch_to_affine(const uint64_t* jac, size_t n, uint64_t* xy, uint8_t* inf) {
@@ -820,11 +850,9 @@ bool batch_verify_signature(const MessageFFI* messages, size_t n, bool composite
   batch_to_affine<Fq_>(asig, 1, g1.data(), i1.data());
   neg_g2_generator(g2.data());
   batch_to_affine<Fq2_>(pkj.data(), n, g2.data() + 24, i2.data() + 1);
-  for (size_t i = 0; i < n; i++) {
-    Affine<Fq_> h; int c;
-    if (!hash_to_g1_direct(SIG_DOMAIN, messages[i].data.ptr, messages[i].data.len, messages[i].extra.ptr, messages[i].extra.len, h, c)) return false;
-    h.x.to_ark(&g1[(i + 1) * 12]); h.y.to_ark(&g1[(i + 1) * 12 + 6]);
-  }
+  std::vector<HashJob> jobs(n);
+  for (size_t i = 0; i < n; i++) jobs[i] = {messages[i].data.ptr, messages[i].data.len, messages[i].extra.ptr, messages[i].extra.len, &g1[(i + 1) * 12]};
+  if (n && !hash_many_direct(SIG_DOMAIN, jobs)) return false;
   int one = 0;
   if (pairing_product_is_one_bls12_377(g1.data(), i1.data(), g2.data(), i2.data(), n + 1, &one) != 0) return false;
   *verified = one != 0;
@@ -874,14 +902,14 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   batch_to_affine<Fq2_>(bpk.data(), m, tmp2.data(), t2.data());
   uint64_t ng2[24];
   neg_g2_generator(ng2);
+  std::vector<HashJob> jobs(m);
   for (size_t b = 0; b < m; b++) {
     memcpy(&g1[(2 * b) * 12], &tmp1[b * 12], 96); i1[2 * b] = t1[b];
     memcpy(&g2[(2 * b) * 24], ng2, 192);
-    Affine<Fq_> h; int c;
-    if (!hash_to_g1_direct(SIG_DOMAIN, batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, h, c)) return false;
-    h.x.to_ark(&g1[(2 * b + 1) * 12]); h.y.to_ark(&g1[(2 * b + 1) * 12 + 6]);
+    jobs[b] = {batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, &g1[(2 * b + 1) * 12]};
     memcpy(&g2[(2 * b + 1) * 24], &tmp2[b * 24], 192); i2[2 * b + 1] = t2[b];
   }
+  if (!hash_many_direct(SIG_DOMAIN, jobs)) return false;
   std::vector<uint32_t> po(m + 1);
   for (size_t b = 0; b <= m; b++) po[b] = (uint32_t)(2 * b);
   std::vector<uint8_t> ok(m, 0);

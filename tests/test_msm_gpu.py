@@ -152,6 +152,40 @@ def test_g1_large_device_resident(gpu, logn):
         assert b == ecc.E1_377.add(a, a)
 
 
+def test_g1_two_to_22_device_resident(gpu):
+    """Beyond the headline size (BASELINE config 5's G1 leg is 2^22): oracle comparison at 4M terms."""
+    n = 1 << 22
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    bases = _gen_points_gpu(gpu, "bls12_377_g1", n, 0x5EED0022, gen.reshape(-1), 12)
+    rng = np.random.default_rng(22)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    sc ^= rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = gpu.msm_dev("bls12_377_g1", bases.data_ptr(), 0, d_sc.data_ptr(), n)
+    h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 12)
+    exp = co.msm("bls12_377_g1", h_bases, None, sc, threads=max(1, min(32, co.lib().orc_hardware_threads())))
+    assert _affine(out, "g1_377") == co.jac_to_affine(exp, "g1_377")
+
+
+def test_bw6_761_two_to_17_device_resident(gpu, golden):
+    """BASELINE config 4 shape (Groth16 prover MSM over BW6-761 G1) at 2^17 terms per GPU, uniform 376-bit scalars."""
+    from oracle.py import epoch as ep
+    vk = ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))
+    n = 1 << 17
+    gen, _ = co.pack_761([vk["alpha_g1"]])
+    bases = _gen_points_gpu(gpu, "bw6_761_g1", n, 0x5EED0761, gen.reshape(-1), 24)
+    rng = np.random.default_rng(761)
+    sc = rng.integers(0, 1 << 63, size=(n, 6), dtype=np.int64).astype(np.uint64)
+    sc ^= rng.integers(0, 1 << 63, size=(n, 6), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    sc[:, 5] &= np.uint64((1 << 56) - 1)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = gpu.msm_dev("bw6_761_g1", bases.data_ptr(), 0, d_sc.data_ptr(), n)
+    h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 24)
+    exp = co.msm("bw6_761_g1", h_bases, None, sc, threads=max(1, min(32, co.lib().orc_hardware_threads())))
+    assert _affine(out, "761") == co.jac_to_affine(exp, "761")
+
+
 @pytest.mark.parametrize("n", [1, 33, 300])
 def test_g2_vs_oracle(gpu, n):
     pts = H.seeded_points(ecc.E2_377, ecc.G2_377, n, 300 + n)

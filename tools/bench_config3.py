@@ -8,8 +8,11 @@ import numpy as np, torch
 from celo_bls_snark_rs_amd import ffi, codec, bls
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+force_c = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 ffi.init(0)
+if force_c:
+    ffi.set_window_bits("bls12_377_g1", force_c); ffi.set_window_bits("bls12_377_g2", force_c)
 G1 = (81937999373150964239938255573465948239988671502647976594219695644855304257327692006745978603320413799295628339695,
       241266749859715473739788878240585681733927191168601896383759122102112907357779751001206799952863815012735208165030)
 tot = m * n

@@ -48,7 +48,7 @@ template <class F> HD Xyzz<F> xyzz_dbl_affine(const Affine<F>& p) {
   F M2 = F::sqr(M);                                   // 9 ok
   F X3 = F::norm(F::template sub<16, 3>(M2, F::dbl(S)));   // [1, 10]
   F t = F::template sub<32, 1>(S, X3);                // [3, 18]
-  F Y3 = F::norm(F::template sub<4, 1>(F::mul(M, t), F::mul(W, p.y)));  // [1, 6]
+  F Y3 = F::mul_sub(M, t, W, p.y);                    // [1, <=7]
   return {X3, Y3, V, W};
 }
 
@@ -65,7 +65,7 @@ template <class F, bool OL = false> HD Xyzz<F> xyzz_dbl(const Xyzz<F>& a) {
   F M2 = O::sqr(M);
   F X3 = F::norm(F::template sub<16, 3>(M2, F::dbl(S)));
   F t = F::template sub<32, 1>(S, X3);
-  F Y3 = F::norm(F::template sub<4, 1>(O::mul(M, t), O::mul(W, a.Y)));
+  F Y3 = OL ? F::norm(F::template sub<4, 1>(O::mul(M, t), O::mul(W, a.Y))) : F::mul_sub(M, t, W, a.Y);
   return {X3, Y3, O::mul(V, a.ZZ), O::mul(W, a.ZZZ)};
 }
 
@@ -88,7 +88,7 @@ template <class F> HD void xyzz_madd(Xyzz<F>& a, const Affine<F>& p) {
   F s = F::add(F::add(PPP, Q), Q);                    // [3, 6]
   F X3 = F::norm(F::template sub<16, 3>(R2, s));       // [1, 10]
   F t = F::template sub<32, 1>(Q, X3);                // [3, 18]
-  F Y3 = F::norm(F::template sub<4, 1>(F::mul(R, t), F::mul(a.Y, PPP)));  // [1, 6]
+  F Y3 = F::mul_sub(R, t, a.Y, PPP);                  // R*t - Y1*PPP, one reduction pass on 14-limb fields: [1, <=7]
   a.ZZ = F::mul(a.ZZ, PP);
   a.ZZZ = F::mul(a.ZZZ, PPP);
   a.X = X3;
@@ -118,7 +118,7 @@ template <class F, bool OL = false> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& 
   F s = F::add(F::add(PPP, Q), Q);
   F X3 = F::norm(F::template sub<16, 3>(R2, s));
   F t = F::template sub<32, 1>(Q, X3);
-  F Y3 = F::norm(F::template sub<4, 1>(O::mul(R, t), O::mul(S1, PPP)));
+  F Y3 = OL ? F::norm(F::template sub<4, 1>(O::mul(R, t), O::mul(S1, PPP))) : F::mul_sub(R, t, S1, PPP);
   a.ZZ = O::mul(O::mul(a.ZZ, b.ZZ), PP);
   a.ZZZ = O::mul(O::mul(a.ZZZ, b.ZZZ), PPP);
   a.X = X3;

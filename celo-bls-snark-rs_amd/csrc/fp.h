@@ -334,22 +334,25 @@ template <class P> struct Fp {
     }
   }
 
-  // ---- sum of two products in one reduction pass:  (a*b + c*d)/R   or, with SUB5,  (a*b - 5*c*d)/R + p
-  // Inputs must be normalised (lb <= 1).  Used by Fp2 (u^2 = -5): two passes per Fp2 product
-  // instead of three full multiplications' worth of carries/adds.
-  template <bool SUB5> HD static Fp mul2(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
-    TRK(assert(a.lb <= 1 && b.lb <= 1 && c.lb <= 1 && d.lb <= 1); assert(a.vb * b.vb + 5 * c.vb * d.vb <= 32768.0);)
+  // ---- sum of two products in one reduction pass:  (a*b + KC*c*d)/R  (+ p when KC < 0, which keeps the result positive)
+  // with KC in {+1, -1, -5}.  One Montgomery reduction for two limb-product sweeps.  Users: Fp2 (u^2 = -5: c0 = a0 b0 - 5 a1 b1,
+  // c1 = a0 b1 + a1 b0) and the curve formulas (Y3 = R*t - Y1*PPP).  Column bound: L*(lb_a*lb_b + |KC|*lb_c*lb_d + 1) <= 255.
+  template <int KC> HD static Fp mul2k(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+    static_assert(KC == 1 || KC == -1 || KC == -5, "unsupported multiplier");
+    constexpr uint32_t AK = KC < 0 ? (uint32_t)(-KC) : (uint32_t)KC;
+    constexpr bool NEG = KC < 0;
+    TRK(assert(L * (a.lb * b.lb + AK * c.lb * d.lb + 1) <= 255.5); assert(a.vb * b.vb + AK * c.vb * d.vb <= 32768.0);)
     Fp r;
     uint32_t m[L], cc[L];
 #pragma unroll
-    for (int i = 0; i < L; i++) cc[i] = SUB5 ? c.l[i] * 5u : c.l[i];
+    for (int i = 0; i < L; i++) cc[i] = AK == 1 ? c.l[i] : c.l[i] * AK;
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < L; k++) {
 #pragma unroll
       for (int i = 0; i <= k; i++) {
         acc += (uint64_t)a.l[i] * b.l[k - i];
-        if (SUB5) acc -= (uint64_t)cc[i] * d.l[k - i];
+        if (NEG) acc -= (uint64_t)cc[i] * d.l[k - i];
         else acc += (uint64_t)cc[i] * d.l[k - i];
       }
 #pragma unroll
@@ -364,19 +367,28 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = k - L + 1; i < L; i++) {
         acc += (uint64_t)a.l[i] * b.l[k - i];
-        if (SUB5) acc -= (uint64_t)cc[i] * d.l[k - i];
+        if (NEG) acc -= (uint64_t)cc[i] * d.l[k - i];
         else acc += (uint64_t)cc[i] * d.l[k - i];
       }
 #pragma unroll
       for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::P[k - i];
-      if (SUB5) acc += P::P[k - L];  // + p after the division by R keeps the result positive
+      if (NEG) acc += P::P[k - L];  // + p after the division by R keeps the result positive
       r.l[k - L] = (uint32_t)acc & MASK;
       acc = (uint64_t)((int64_t)acc >> W);
     }
-    if (SUB5) acc += P::P[L - 1];
+    if (NEG) acc += P::P[L - 1];
     r.l[L - 1] = (uint32_t)acc;
-    TRK(r.lb = 1; r.vb = SUB5 ? 3 : 2;)
+    TRK(r.lb = 1; r.vb = NEG ? 3 : 2;)
     return r;
+  }
+  template <bool SUB5> HD static Fp mul2(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {  // inputs normalised (Fp2)
+    TRK(assert(a.lb <= 1 && b.lb <= 1 && c.lb <= 1 && d.lb <= 1);)
+    return mul2k<SUB5 ? -5 : 1>(a, b, c, d);
+  }
+  // a*b - c*d in one pass where the column bound allows it (14-limb fields), two products and a subtraction otherwise
+  HD static Fp mul_sub(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+    if constexpr (L * 12 <= 255) return mul2k<-1>(a, b, c, d);   // lb_a*lb_b <= 9, lb_c*lb_d <= 1
+    else return norm(sub<4, 1>(mul(a, b), mul(c, d)));
   }
 
   // ---- arkworks Montgomery (R = 2^(64*N64), 64-bit limbs) <-> device form

@@ -35,6 +35,7 @@ template <class P> struct Fp2 {
   static Fp2 mul_ol(const Fp2& a, const Fp2& b) { return mul(a, b); }
   static Fp2 sqr_ol(const Fp2& a) { return sqr(a); }
 #endif
+  HD static Fp2 mul_sub(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { return norm(sub<4, 1>(mul(a, b), mul(c, d))); }
   HD static Fp2 mul_fp(const Fp2& a, const B& k) {  // k normalised or lb*lb within Fp::mul's bound
     return {B::mul(a.c0, k), B::mul(a.c1, k)};
   }

@@ -146,6 +146,18 @@ def main():
                                  "kernel ms from HIP events on the MSM stream: accumulate=%.3f of total=%.3f (convert=%.3f sort=%.3f reduce=%.3f)"
                                  % (acc_avg, float(np.mean(tot_ms)), tm["convert_ms"], tm["sort_ms"], tm["reduce_ms"])},
         }
+        # The honest roofline of this path is integer-VALU issue, not HBM (SURVEY.md §8d "Which roofline bounds it").
+        # Work: one XYZZ mixed add per (scalar, window) = 8 Fq multiplications + 2 squarings; peak = the chip-wide rate of
+        # the same multiply/square bodies in a register-resident loop (tools/ubench_fp.hip on this GPU: 78 G mul/s, 94 G sqr/s
+        # -> 80.8 G/s for the 8:2 mix).
+        madds = n * tm["windows"]
+        fq_ops = madds * 10
+        valu_achieved = fq_ops / (acc_avg * 1e-3) / 1e9
+        valu_peak = 10.0 / (8.0 / 78.0 + 2.0 / 94.0)
+        line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": "k_accumulate<G1_377>", "achieved": valu_achieved,
+                                 "peak": valu_peak, "unit": "G Fq-mul-or-sqr/s", "frac": valu_achieved / valu_peak,
+                                 "note": "peak measured with tools/ubench_fp.hip (register-resident multiply loops, 8 waves/SIMD); "
+                                         "achieved = n*windows mixed adds * (8M+2S) / accumulate kernel time"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(bases, sc, n, result if world == 1 else None)
             if world == 1:

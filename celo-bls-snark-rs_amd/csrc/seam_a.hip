@@ -372,11 +372,174 @@ bool hash_to_g1_direct(const uint8_t* dom, const uint8_t* msg, size_t mlen, cons
   }
   return false;
 }
+
+// ---------------------------------------------------------------- CompositeHasher (crates/bls-crypto/src/hashers/composite.rs)
+// Bowe-Hopwood-Pedersen CRH over the twisted Edwards curve ed-on-BW6-761 (-x^2 + y^2 = 1 + 79743 x^2 y^2 over Fq of
+// BLS12-377), WINDOW_SIZE = 93, NUM_WINDOWS = 560, generators drawn from ChaCha20 seeded with
+// Blake2s("ULTRALIGHT PRNG SEED", personal "UL_prngs") exactly as rand 0.7 / rand_chacha 0.2 / ark-ff 0.1 consume it, then
+// the Blake2Xs XOF.  Host plumbing; pinned on the reference's CRH vector and its 20 compat hash-to-G1
+// vectors through the oracle restatement (tests/test_oracle_golden.py, tests/test_seam_a.py).
+struct SF {  // "safe" host field element: every result weak-reduced and normalised (speed is irrelevant here)
+  Fq_ v;
+  static SF from(const Fq_& x) { return {Fq_::wred(Fq_::norm(x))}; }
+  SF operator+(const SF& o) const { return from(Fq_::add(v, o.v)); }
+  SF operator-(const SF& o) const { return from(Fq_::sub<4, 1>(v, o.v)); }
+  SF operator*(const SF& o) const { return from(Fq_::mul(v, o.v)); }
+  SF neg() const { return from(Fq_::neg<4, 1>(v)); }
+  SF dbl() const { return from(Fq_::add(v, v)); }
+};
+struct EdPoint { SF X, Y, Z, T; };  // extended twisted Edwards, a = -1
+SF sf_small(uint64_t k) { uint64_t w[6] = {k, 0, 0, 0, 0, 0}; return SF::from(Fq_::from_canonical(w)); }
+EdPoint ed_add(const EdPoint& p, const EdPoint& q) {  // add-2008-hwcd-3 (a = -1)
+  static const SF d2 = sf_small(2 * 79743);
+  SF A = (p.Y - p.X) * (q.Y - q.X), B = (p.Y + p.X) * (q.Y + q.X), C = p.T * d2 * q.T, D = (p.Z * q.Z).dbl();
+  SF E = B - A, F = D - C, G = D + C, H = B + A;
+  return {E * F, G * H, F * G, E * H};
+}
+EdPoint ed_dbl(const EdPoint& p) {  // dbl-2008-hwcd (a = -1)
+  SF A = p.X * p.X, B = p.Y * p.Y, C = (p.Z * p.Z).dbl(), D = A.neg();
+  SF E = (p.X + p.Y) * (p.X + p.Y) - A - B, G = D + B, F = G - C, H = D - B;
+  return {E * F, G * H, F * G, E * H};
+}
+EdPoint ed_neg(const EdPoint& p) { return {p.X.neg(), p.Y, p.Z, p.T.neg()}; }
+EdPoint ed_zero() { return {sf_small(0), sf_small(1), sf_small(1), sf_small(0)}; }
+
+struct ChaCha20Rng {  // rand_chacha 0.2 behind rand_core 0.5 BlockRng: 64-word buffer (4 blocks), 64-bit block counter
+  uint32_t key[8]; uint64_t counter = 0; uint32_t buf[64]; int idx = 64;
+  static uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+  void block(uint32_t* out) {
+    uint32_t s[16] = {0x61707865u, 0x3320646Eu, 0x79622D32u, 0x6B206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                      (uint32_t)counter, (uint32_t)(counter >> 32), 0, 0};
+    uint32_t w[16];
+    memcpy(w, s, sizeof w);
+#define CC_QR(a, b, c, d) w[a] += w[b]; w[d] = rotl(w[d] ^ w[a], 16); w[c] += w[d]; w[b] = rotl(w[b] ^ w[c], 12); \
+                          w[a] += w[b]; w[d] = rotl(w[d] ^ w[a], 8);  w[c] += w[d]; w[b] = rotl(w[b] ^ w[c], 7);
+    for (int r = 0; r < 10; r++) {
+      CC_QR(0, 4, 8, 12) CC_QR(1, 5, 9, 13) CC_QR(2, 6, 10, 14) CC_QR(3, 7, 11, 15)
+      CC_QR(0, 5, 10, 15) CC_QR(1, 6, 11, 12) CC_QR(2, 7, 8, 13) CC_QR(3, 4, 9, 14)
+    }
+#undef CC_QR
+    for (int i = 0; i < 16; i++) out[i] = w[i] + s[i];
+    counter++;
+  }
+  void generate() { for (int b = 0; b < 4; b++) block(buf + 16 * b); idx = 0; }
+  uint32_t next_u32() { if (idx >= 64) generate(); return buf[idx++]; }
+  uint64_t next_u64() {
+    if (idx < 63) { uint64_t v = ((uint64_t)buf[idx + 1] << 32) | buf[idx]; idx += 2; return v; }
+    if (idx >= 64) { generate(); uint64_t v = ((uint64_t)buf[1] << 32) | buf[0]; idx = 2; return v; }
+    uint64_t lo = buf[63]; generate(); uint64_t hi = buf[0]; idx = 1; return (hi << 32) | lo;
+  }
+};
+struct CompositeParams {
+  std::vector<EdPoint> gens;  // [NUM_WINDOWS * WINDOW_SIZE]: window-major, generator j = 16^j * base
+  static constexpr int WINDOW_SIZE = 93, NUM_WINDOWS = 560;
+  CompositeParams() {
+    static const uint8_t PERS[8] = {'U', 'L', '_', 'p', 'r', 'n', 'g', 's'};
+    static const char* SEED_MSG = "ULTRALIGHT PRNG SEED";
+    B2sParams p;
+    std::vector<uint8_t> seed = blake2s((const uint8_t*)SEED_MSG, strlen(SEED_MSG), p, PERS, 8);
+    ChaCha20Rng rng;
+    memcpy(rng.key, seed.data(), 32);
+    const SF one = sf_small(1), dcoef = sf_small(79743);
+    gens.reserve((size_t)WINDOW_SIZE * NUM_WINDOWS);
+    for (int w = 0; w < NUM_WINDOWS; w++) {
+      EdPoint base;
+      for (;;) {  // TEProjective::rand: x = Fq::rand (raw Montgomery limbs, top 7 bits masked, rejection), greatest = rng.gen::<bool>()
+        uint64_t raw[6];
+        for (;;) {
+          for (int i = 0; i < 6; i++) raw[i] = rng.next_u64();
+          raw[5] &= (1ULL << 57) - 1;
+          if (cmp_n(raw, P377::P64, 6) < 0) break;
+        }
+        bool greatest = (rng.next_u32() >> 31) != 0;
+        SF x = SF::from(Fq_::from_ark(raw));
+        SF x2 = x * x;
+        SF num = x2.neg() - one, den = dcoef * x2 - one;      // (a x^2 - 1) / (d x^2 - 1), a = -1
+        if (den.v.is_zero_mod_p()) continue;
+        SF y2 = num * SF::from(Fq_::inv(den.v));
+        Fq_ yv;
+        if (!fq_sqrt(y2.v, yv)) continue;
+        if (fq_lex_largest(yv) != greatest) yv = fq_neg(yv);   // (y < -y) ^ greatest ? y : -y
+        SF y = SF::from(yv);
+        base = {x, y, one, x * y};
+        for (int k = 0; k < 3; k++) base = ed_dbl(base);       // scale_by_cofactor (8)
+        break;
+      }
+      for (int j = 0; j < WINDOW_SIZE; j++) {
+        gens.push_back(base);
+        for (int k = 0; k < 4; k++) base = ed_dbl(base);
+      }
+    }
+  }
+};
+const CompositeParams& composite_params() { static CompositeParams p; return p; }
+bool composite_crh(const uint8_t* msg, size_t len, std::vector<uint8_t>& out) {  // bowe_hopwood::CRH::evaluate -> affine x, 48 bytes
+  const CompositeParams& cp = composite_params();
+  if (len * 8 > (size_t)CompositeParams::WINDOW_SIZE * CompositeParams::NUM_WINDOWS * 3) return false;  // the reference panics
+  size_t nbits = len * 8, nchunks = (nbits + 2) / 3;
+  auto bit = [&](size_t i) -> int { return i < nbits ? (msg[i >> 3] >> (i & 7)) & 1 : 0; };  // LSB-first, zero padded
+  EdPoint total = ed_zero();
+  for (size_t ch = 0; ch < nchunks; ch++) {
+    const EdPoint& g = cp.gens[ch];  // chunk ch of the message uses generator (ch / 93, ch % 93): window-major order
+    EdPoint enc = g;
+    if (bit(3 * ch)) enc = ed_add(enc, g);
+    if (bit(3 * ch + 1)) enc = ed_add(enc, ed_dbl(g));
+    if (bit(3 * ch + 2)) enc = ed_neg(enc);
+    total = ed_add(total, enc);
+  }
+  SF x = total.X * SF::from(Fq_::inv(total.Z.v));
+  out.assign(48, 0);
+  fq_to_bytes(x.v, out.data());
+  return true;
+}
+// generic try-and-increment over {direct, composite} x {plain, cip22} with the `compat` bit logic
+bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen,
+                Affine<Fq_>& out, int& attempt) {
+  auto crh = [&](const uint8_t* m, size_t l, std::vector<uint8_t>& o) -> bool {
+    if (composite) return composite_crh(m, l, o);
+    o = direct_crh(dom, 8, m, l, 64);
+    return true;
+  };
+  std::vector<uint8_t> inner, buf, pre;
+  if (cip22 && !crh(msg, mlen, inner)) return false;
+  const uint8_t* tail = cip22 ? inner.data() : msg;
+  const size_t tlen = cip22 ? inner.size() : mlen;
+  buf.resize(1 + elen + tlen);
+  if (elen) memcpy(buf.data() + 1, extra, elen);
+  if (tlen) memcpy(buf.data() + 1 + elen, tail, tlen);
+  for (int c = 0; c < 255; c++) {
+    buf[0] = (uint8_t)c;
+    std::vector<uint8_t> cand;
+    if (cip22) cand = direct_xof(dom, 8, buf.data(), buf.size(), 64);
+    else { if (!crh(buf.data(), buf.size(), pre)) return false; cand = direct_xof(dom, 8, pre.data(), pre.size(), 64); }
+    cand.resize(48);
+    if (cand[47] & 2) cand[47] |= 0x80; else cand[47] &= 0x7F;
+    uint8_t flags = cand[47] & 0xC0;
+    cand[47] &= 0x01;
+    Fq_ x;
+    if (!fq_from_bytes(cand.data(), x)) continue;
+    if (x.is_zero_mod_p() && (flags & 0x40)) continue;
+    Fq_ rhs = Fq_::norm(Fq_::add(Fq_::mul(Fq_::sqr(x), x), Fq_::one())), y;
+    if (!fq_sqrt(rhs, y)) continue;
+    if (fq_lex_largest(y) != ((flags & 0x80) != 0)) y = fq_neg(y);
+    Affine<Fq_> p = {Fq_::norm(x), Fq_::norm(y)};
+    Xyzz<Fq_> s = scalar_mul_host(p, G1_COFACTOR, 2);
+    if (s.is_identity() || s.ZZ.is_zero_mod_p()) continue;
+    Fq_ t = Fq_::inv(Fq_::mul(s.ZZ, s.ZZZ));
+    out.x = Fq_::norm(Fq_::mul(s.X, Fq_::mul(t, s.ZZZ)));
+    out.y = Fq_::norm(Fq_::mul(s.Y, Fq_::mul(t, s.ZZ)));
+    attempt = c;
+    return true;
+  }
+  return false;
+}
+
 // hash many messages on all host cores (hash-to-curve is host plumbing for now; one attempt costs a
 // Blake2Xs call, a 377-bit square root and a 125-bit cofactor multiplication)
 struct HashJob { const uint8_t* msg; size_t mlen; const uint8_t* extra; size_t elen; uint64_t* out_xy; };
-bool hash_many_direct(const uint8_t* dom, std::vector<HashJob>& jobs) {
-  (void)sqrt_ctx();  // initialise shared constants before the threads start
+bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJob>& jobs) {
+  (void)sqrt_ctx();
+  if (composite) (void)composite_params();  // initialise shared constants before the threads start
   std::atomic<size_t> next(0);
   std::atomic<bool> ok(true);
   unsigned nt = std::thread::hardware_concurrency();
@@ -388,7 +551,7 @@ bool hash_many_direct(const uint8_t* dom, std::vector<HashJob>& jobs) {
       size_t i = next.fetch_add(1);
       if (i >= jobs.size()) break;
       Affine<Fq_> h; int c;
-      if (!hash_to_g1_direct(dom, jobs[i].msg, jobs[i].mlen, jobs[i].extra, jobs[i].elen, h, c)) { ok = false; continue; }
+      if (!hash_to_g1(composite, cip22, dom, jobs[i].msg, jobs[i].mlen, jobs[i].extra, jobs[i].elen, h, c)) { ok = false; continue; }
       h.x.to_ark(jobs[i].out_xy); h.y.to_ark(jobs[i].out_xy + 6);
     }
   };
@@ -553,7 +716,11 @@ void neg_g2_generator(uint64_t out_xy[24]) {
 
 extern "C" {
 
-bool init(void) { return celo_amd_init(0) == 0; }
+bool init(void) {  // lib.rs:28-36: force both lazy hashers (the Bowe-Hopwood generator table) and bring the device up
+  (void)composite_params();
+  (void)sqrt_ctx();
+  return celo_amd_init(0) == 0;
+}
 
 // ---------------------------------------------------------------- keys (crates/bls-snark-sys/src/signatures.rs:19-42)
 bool generate_private_key(PrivateKey** out_private_key) {
@@ -769,7 +936,6 @@ bool celo_amd_verify_hash(const PublicKey* pk, const uint64_t* message_hash_xy, 
 // (composite = Bowe-Hopwood over Edwards-BW6-761 is not built yet: those flag combinations return false, logged)
 static bool hash_flags_supported(bool composite, bool cip22) {
   if (!composite && cip22) { log_err("(composite=false, cip22=true) is rejected by the reference too (signatures.rs:61)"); return false; }
-  if (composite) { log_err("composite (Bowe-Hopwood) hasher not built yet — SURVEY.md §8f f1"); return false; }
   return true;
 }
 static bool emit_affine_tobytes(const Affine<Fq_>& p, uint8_t** out, int* out_len) {  // ToBytes: x || y || infinity byte
@@ -795,10 +961,60 @@ bool hash_direct_first_step(const uint8_t* msg, int len, int hash_bytes, uint8_t
   if ((!msg && len) || !out_hash || !out_len || len < 0 || hash_bytes < 0 || hash_bytes > 65535) return false;
   return emit(direct_hash(SIG_DOMAIN, 8, msg, (size_t)len, (size_t)hash_bytes), out_hash, out_len);
 }
-static bool sign_with(const PrivateKey* sk, const uint8_t* dom, const uint8_t* msg, int mlen, const uint8_t* extra, int elen, Signature** out) {
+// hash_composite / hash_composite_cip22 return ToBytes of a G1Projective (x || y || z, 144 bytes).  arkworks' Jacobian bit pattern
+// depends on its scalar-multiplication schedule; this library returns the representative (x, y, 1) of the same point.
+static bool emit_projective_tobytes(const Affine<Fq_>& p, uint8_t** out, int* out_len) {
+  std::vector<uint8_t> v(144, 0);
+  fq_to_bytes(p.x, v.data());
+  fq_to_bytes(p.y, v.data() + 48);
+  v[96] = 1;
+  return emit(v, out, out_len);
+}
+bool hash_composite(const uint8_t* msg, int mlen, const uint8_t* extra, int elen, uint8_t** out_hash, int* out_len) {   /* signatures.rs:143 */
+  if ((!msg && mlen) || (!extra && elen) || !out_hash || !out_len || mlen < 0 || elen < 0) return false;
+  Affine<Fq_> h; int c;
+  if (!hash_to_g1(true, false, SIG_DOMAIN, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
+  return emit_projective_tobytes(h, out_hash, out_len);
+}
+bool hash_composite_cip22(const uint8_t* msg, int mlen, const uint8_t* extra, int elen, uint8_t** out_hash, int* out_len,
+                          uint8_t* attempt_counter) {                                                                   /* signatures.rs:215 */
+  if ((!msg && mlen) || (!extra && elen) || !out_hash || !out_len || !attempt_counter || mlen < 0 || elen < 0) return false;
+  Affine<Fq_> h; int c;
+  if (!hash_to_g1(true, true, SIG_DOMAIN, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
+  *attempt_counter = (uint8_t)c;
+  return emit_projective_tobytes(h, out_hash, out_len);
+}
+bool hash_crh(const uint8_t* msg, int mlen, int hash_bytes, uint8_t** out_hash, int* out_len) {                         /* signatures.rs:169 */
+  (void)hash_bytes;  // the Bowe-Hopwood CRH ignores the domain and the output length (composite.rs:79-86)
+  if ((!msg && mlen) || !out_hash || !out_len || mlen < 0) return false;
+  std::vector<uint8_t> o;
+  if (!composite_crh(msg, (size_t)mlen, o)) return false;
+  return emit(o, out_hash, out_len);
+}
+/* test hook: CompositeHasher::hash = xof(domain, crh(message), out_bytes) (hashers/mod.rs Hasher::hash) */
+bool celo_amd_composite_hash(const uint8_t* domain8, const uint8_t* msg, int mlen, int out_bytes, uint8_t* out) {
+  if (!domain8 || !out || mlen < 0 || out_bytes < 0) return false;
+  std::vector<uint8_t> c;
+  if (!composite_crh(msg, (size_t)mlen, c)) return false;
+  std::vector<uint8_t> x = direct_xof(domain8, 8, c.data(), c.size(), (size_t)out_bytes);
+  memcpy(out, x.data(), (size_t)out_bytes);
+  return true;
+}
+/* test hook: hash-to-G1 with an arbitrary 8-byte domain (the reference's golden vectors use random domains), compressed 48-byte output */
+bool celo_amd_hash_to_g1(bool composite, bool cip22, const uint8_t* domain8, const uint8_t* msg, int mlen, const uint8_t* extra, int elen,
+                         uint8_t* out48, int* out_attempt) {
+  if (!domain8 || !out48 || mlen < 0 || elen < 0 || (!composite && cip22)) return false;
+  Affine<Fq_> h; int c;
+  if (!hash_to_g1(composite, cip22, domain8, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
+  g1_compress(h, false, out48);
+  if (out_attempt) *out_attempt = c;
+  return true;
+}
+static bool sign_with(const PrivateKey* sk, bool composite, bool cip22, const uint8_t* dom, const uint8_t* msg, int mlen, const uint8_t* extra,
+                      int elen, Signature** out) {
   if (!sk || !out || mlen < 0 || elen < 0) return false;
   Affine<Fq_> h; int c;
-  if (!hash_to_g1_direct(dom, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
+  if (!hash_to_g1(composite, cip22, dom, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
   Xyzz<Fq_> r = scalar_mul_host(h, sk->k, 4);                 // PrivateKey::sign_raw (crates/bls-crypto/src/bls/secret.rs:65)
   Signature* s = new Signature;
   if (r.is_identity() || r.ZZ.is_zero_mod_p()) identity_jac<Fq_>(s->xyz);
@@ -809,18 +1025,18 @@ static bool sign_with(const PrivateKey* sk, const uint8_t* dom, const uint8_t* m
 bool sign_message(const PrivateKey* sk, const uint8_t* msg, int mlen, const uint8_t* extra, int elen, bool composite, bool cip22,
                   Signature** out) {                                                                                  /* signatures.rs:44 */
   if (!hash_flags_supported(composite, cip22)) return false;
-  return sign_with(sk, SIG_DOMAIN, msg, mlen, extra, elen, out);
+  return sign_with(sk, composite, cip22, SIG_DOMAIN, msg, mlen, extra, elen, out);
 }
 bool sign_pop(const PrivateKey* sk, const uint8_t* msg, int mlen, Signature** out) {                                  /* signatures.rs:74 */
-  return sign_with(sk, POP_DOMAIN, msg, mlen, nullptr, 0, out);
+  return sign_with(sk, false, false, POP_DOMAIN, msg, mlen, nullptr, 0, out);
 }
 
 // ---------------------------------------------------------------- verification (hash on the host, pairings / MSMs on the GPU)
-static bool verify_with(const PublicKey* pk, const uint8_t* dom, const uint8_t* msg, int mlen, const uint8_t* extra, int elen,
-                        const Signature* sig, bool* out_verified) {
+static bool verify_with(const PublicKey* pk, bool composite, bool cip22, const uint8_t* dom, const uint8_t* msg, int mlen, const uint8_t* extra,
+                        int elen, const Signature* sig, bool* out_verified) {
   if (!pk || !sig || !out_verified || mlen < 0 || elen < 0) return false;
   Affine<Fq_> h; int c;
-  if (!hash_to_g1_direct(dom, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
+  if (!hash_to_g1(composite, cip22, dom, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
   uint64_t hxy[12];
   h.x.to_ark(hxy); h.y.to_ark(hxy + 6);
   return celo_amd_verify_hash(pk, hxy, sig, out_verified);
@@ -828,10 +1044,10 @@ static bool verify_with(const PublicKey* pk, const uint8_t* dom, const uint8_t* 
 bool verify_signature(const PublicKey* pk, const uint8_t* msg, int mlen, const uint8_t* extra, int elen, const Signature* sig,
                       bool composite, bool cip22, bool* out_verified) {                                               /* signatures.rs:244 */
   if (!hash_flags_supported(composite, cip22)) return false;
-  return verify_with(pk, SIG_DOMAIN, msg, mlen, extra, elen, sig, out_verified);
+  return verify_with(pk, composite, cip22, SIG_DOMAIN, msg, mlen, extra, elen, sig, out_verified);
 }
 bool verify_pop(const PublicKey* pk, const uint8_t* msg, int mlen, const Signature* sig, bool* out_verified) {        /* signatures.rs:407 */
-  return verify_with(pk, POP_DOMAIN, msg, mlen, nullptr, 0, sig, out_verified);
+  return verify_with(pk, false, false, POP_DOMAIN, msg, mlen, nullptr, 0, sig, out_verified);
 }
 // Signature::batch_verify (crates/bls-crypto/src/bls/signature.rs:101-155): aggregate the signatures, hash every message,
 // ONE (n+1)-pair product on the GPU
@@ -852,7 +1068,7 @@ bool batch_verify_signature(const MessageFFI* messages, size_t n, bool composite
   batch_to_affine<Fq2_>(pkj.data(), n, g2.data() + 24, i2.data() + 1);
   std::vector<HashJob> jobs(n);
   for (size_t i = 0; i < n; i++) jobs[i] = {messages[i].data.ptr, messages[i].data.len, messages[i].extra.ptr, messages[i].extra.len, &g1[(i + 1) * 12]};
-  if (n && !hash_many_direct(SIG_DOMAIN, jobs)) return false;
+  if (n && !hash_many(composite, cip22, SIG_DOMAIN, jobs)) return false;
   int one = 0;
   if (pairing_product_is_one_bls12_377(g1.data(), i1.data(), g2.data(), i2.data(), n + 1, &one) != 0) return false;
   *verified = one != 0;
@@ -864,7 +1080,6 @@ bool batch_verify_signature(const MessageFFI* messages, size_t n, bool composite
 bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composite, bool cip22, bool* out_results) {   /* signatures.rs:343 */
   if ((!batches && m) || !out_results) return false;
   if (!composite && cip22) { for (size_t i = 0; i < m; i++) out_results[i] = false; return false; }  // per-batch false (signatures.rs:387)
-  if (composite) { log_err("composite (Bowe-Hopwood) hasher not built yet — SURVEY.md §8f f1"); for (size_t i = 0; i < m; i++) out_results[i] = false; return false; }
   if (m == 0) return true;
   std::vector<uint32_t> offs(m + 1, 0);
   for (size_t b = 0; b < m; b++) {
@@ -909,7 +1124,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     jobs[b] = {batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, &g1[(2 * b + 1) * 12]};
     memcpy(&g2[(2 * b + 1) * 24], &tmp2[b * 24], 192); i2[2 * b + 1] = t2[b];
   }
-  if (!hash_many_direct(SIG_DOMAIN, jobs)) return false;
+  if (!hash_many(composite, cip22, SIG_DOMAIN, jobs)) return false;
   std::vector<uint32_t> po(m + 1);
   for (size_t b = 0; b <= m; b++) po[b] = (uint32_t)(2 * b);
   std::vector<uint8_t> ok(m, 0);

@@ -4,13 +4,11 @@
  * cgo / FFI callers link unchanged.  `bool` return = "no internal error" (reference: convert_result_to_bool,
  * crates/bls-snark-sys/src/lib.rs:21-27); verdicts are separate out-params.
  *
- * Exported: lifecycle, key handles, all (de)serialisation and compression symbols, the three aggregate_* symbols,
- * sign / hash / verify / batch-verify with the DIRECT hasher (Blake2s CRH + Blake2Xs XOF, try-and-increment with the deployed
- * `compat` bit logic) — `should_use_composite = false`.  With `should_use_composite = true` these functions return false
- * (logged under CELO_AMD_LOG=1): the Bowe-Hopwood composite hasher is not built yet.
- * `(composite = false, cip22 = true)` is an error exactly as in the reference (signatures.rs:61,265,321,387).
- * `verify` (Groth16 over BW6-761) and the two epoch encoders are exported too.
- * NOT yet exported: hash_composite, hash_crh, hash_composite_cip22 (composite hasher).
+ * All 36 symbols of the reference are exported: lifecycle, key handles, (de)serialisation and compression, aggregate_*, sign / hash /
+ * verify / batch-verify with BOTH hashers (DIRECT: Blake2s CRH + Blake2Xs XOF; COMPOSITE: Bowe-Hopwood-Pedersen CRH over
+ * ed-on-BW6-761 + Blake2Xs XOF), plain and CIP22 try-and-increment with the deployed `compat` bit logic, Groth16 `verify`
+ * and the two epoch encoders.  `(composite = false, cip22 = true)` is an error exactly as in the reference
+ * (signatures.rs:61,265,321,387).  Hashing, decompression and bit-packing run on the host; every MSM and pairing on the GPU.
  */
 #ifndef CELO_BLS_SNARK_SYS_H
 #define CELO_BLS_SNARK_SYS_H
@@ -65,6 +63,15 @@ bool sign_pop(const PrivateKey* sk, const uint8_t* msg, int msg_len, Signature**
 bool hash_direct(const uint8_t* msg, int msg_len, uint8_t** out_hash, int* out_len, bool use_pop);         /* signatures.rs:93  (97 bytes: x || y || inf) */
 bool hash_direct_with_attempt(const uint8_t* msg, int msg_len, uint8_t** out_hash, int* out_len, int* out_attempt, bool use_pop); /* :117 */
 bool hash_direct_first_step(const uint8_t* msg, int msg_len, int hash_bytes, uint8_t** out_hash, int* out_len); /* signatures.rs:192 */
+bool hash_composite(const uint8_t* msg, int msg_len, const uint8_t* extra, int extra_len, uint8_t** out_hash, int* out_len); /* signatures.rs:143 (144 bytes: x || y || z) */
+bool hash_crh(const uint8_t* msg, int msg_len, int hash_bytes, uint8_t** out_hash, int* out_len);          /* signatures.rs:169 (48 bytes: Bowe-Hopwood CRH x-coordinate) */
+bool hash_composite_cip22(const uint8_t* msg, int msg_len, const uint8_t* extra, int extra_len, uint8_t** out_hash, int* out_len,
+                          uint8_t* attempt_counter);                                                       /* signatures.rs:215 */
+/* test hook: CompositeHasher::hash(domain, msg, out_bytes) = Blake2Xs XOF of the Bowe-Hopwood CRH (hashers/composite.rs:88-97) */
+bool celo_amd_composite_hash(const uint8_t* domain8, const uint8_t* msg, int msg_len, int out_bytes, uint8_t* out);
+/* test hook: try-and-increment with an explicit 8-byte domain; out48 = compressed G1 point */
+bool celo_amd_hash_to_g1(bool composite, bool cip22, const uint8_t* domain8, const uint8_t* msg, int msg_len, const uint8_t* extra,
+                         int extra_len, uint8_t* out48, int* out_attempt);
 bool verify_signature(const PublicKey* pk, const uint8_t* msg, int msg_len, const uint8_t* extra, int extra_len, const Signature* sig,
                       bool should_use_composite, bool should_use_cip22, bool* out_verified);               /* signatures.rs:244 */
 bool verify_pop(const PublicKey* pk, const uint8_t* msg, int msg_len, const Signature* sig, bool* out_verified); /* signatures.rs:407 */

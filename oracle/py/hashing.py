@@ -133,3 +133,42 @@ def hash_to_g1_direct(domain, message, extra_data):
             continue
         return S, c
     raise ValueError("HashToCurveError")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# generic try-and-increment over a (crh, xof) hasher: composite = Bowe-Hopwood CRH (ignores the domain) + Blake2Xs XOF
+def _hasher(composite):
+    if composite:
+        from .composite import composite_crh
+        return (lambda dom, msg, n: composite_crh(msg)), direct_xof
+    return direct_crh, direct_xof
+
+
+def _candidate_to_point(cand48):
+    cand = bytearray(cand48)
+    if cand[47] & 2:                 # `compat` bit logic: bit 1 of the last byte selects the y sign
+        cand[47] |= 0x80
+    else:
+        cand[47] &= 0x7F
+    return from_random_bytes_g1(bytes(cand))
+
+
+def hash_to_g1(domain, message, extra_data, composite=False, cip22=False):
+    """TryAndIncrement::hash_with_attempt (try_and_increment.rs:87-139) or TryAndIncrementCIP22::hash_with_attempt_cip22
+    (try_and_increment_cip22.rs:81-134), `compat` feature on.  Returns (affine point, attempt)."""
+    crh, xof = _hasher(composite)
+    hb = hash_length(48)
+    inner = crh(domain, message, hb) if cip22 else None
+    for c in range(255):
+        if cip22:
+            cand = xof(domain, bytes([c]) + extra_data + inner, hb)[:48]
+        else:
+            cand = xof(domain, crh(domain, bytes([c]) + extra_data + message, hb), hb)[:48]
+        P = _candidate_to_point(cand)
+        if P is None or P == "zero":
+            continue
+        S = E1_377.mul(P, H1_377)
+        if S is None:
+            continue
+        return S, c
+    raise ValueError("HashToCurveError")

@@ -8,6 +8,7 @@ holds them — never source text.  Sources (paths relative to /root/reference):
   crates/bls-crypto/src/hash_to_curve/mod.rs:412-513   hash-to-G1/G2 outputs (compressed points)
   crates/bls-snark-sys/src/snark/mod.rs:52-119         Groth16/BW6-761 accept vector
   crates/epoch-snark/src/epoch_block.rs:243-246        epoch encodings (embed the G2 generator)
+  crates/bls-crypto/src/hashers/composite.rs:105-190   CompositeHasher crh / xof / hash outputs (XorShift-seeded inputs)
 """
 import json, os, re, sys
 
@@ -57,7 +58,21 @@ def main():
     tv_block = dtxt[dtxt.index("fn test_blake2s_test_vectors"):]
     strs = re.findall(r'"([0-9a-fA-F]+)"', tv_block)
     tv = list(zip(strs[0::2], strs[1::2]))
+    # CompositeHasher vectors (crates/bls-crypto/src/hashers/composite.rs:105-190): per test fn, the first byte of the XorShift
+    # seed (the other 15 are shared with RNG_SEED), the message length, the output length and the expected hex
+    ctxt = open(f"{REF}/bls-crypto/src/hashers/composite.rs").read()
+    comp = {}
+    for m in re.finditer(r"fn (test_(?:crh|xof|hash)_\w+)\(\)", ctxt):
+        body = ctxt[m.end():]
+        body = body[:body.index("assert_eq!") + 4000]
+        exp = re.search(r'assert_eq!\(hex::encode\(\w+\),\s*"([0-9a-f]+)"', body).group(1)
+        seed = re.search(r"from_seed\(\[\s*0x([0-9a-f]{2})", body[:body.index("assert_eq!")])
+        mlen = re.search(r"vec!\[0; ([0-9 */]+)\]", body[:body.index("assert_eq!")])
+        nb = re.search(r"\.(?:xof|hash)\(b\"ULforxof\", &\w+, (\d+)\)", body[:body.index("assert_eq!")])
+        comp[m.group(1)] = {"seed0": int(seed.group(1), 16) if seed else None, "msg_len": eval(mlen.group(1).replace("/", "//")) if mlen else 0,
+                            "out_bytes": int(nb.group(1)) if nb else None, "expected": exp}
     out = {
+        "composite_hasher": comp,
         "direct_hasher": {"crh_empty_xof96": crh_empty, "blake2x_hash_vectors": [{"input": a, "output": b} for a, b in tv]},
         "_source": "celo-org/celo-bls-snark-rs test vectors (data literals only); see extract_reference_vectors.py",
         "hash_to_curve": vec,

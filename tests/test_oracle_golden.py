@@ -176,3 +176,48 @@ def test_reference_direct_hasher_vectors(golden):
     for msg in (b"", b"abc", bytes(range(200))):
         assert hs.blake2s(msg) == hashlib.blake2s(msg).digest()
         assert hs.blake2s(msg, personal=b"ULforxof", digest_length=20) == hashlib.blake2s(msg, person=b"ULforxof", digest_size=20).digest()
+
+
+def _xorshift_bytes(seed0, n):
+    from oracle.py import composite as comp
+    rng = comp.XorShiftRng(bytes([seed0]) + XORSHIFT_SEED_TAIL)
+    return bytes(rng.gen_u8() for _ in range(n))
+
+
+XORSHIFT_SEED_TAIL = bytes([0xbe, 0x62, 0x59, 0x8d, 0x31, 0x3d, 0x76, 0x32, 0x37, 0xdb, 0x17, 0xe5, 0xbc, 0x06, 0x54])
+
+
+def test_reference_composite_hasher_vectors(golden):
+    """crates/bls-crypto/src/hashers/composite.rs:105-190: Bowe-Hopwood CRH of the empty and of a XorShift-seeded message,
+    then the Blake2Xs XOF at 96 / 768 / 769 bytes (pins ChaCha20Rng, Fq::rand, the Edwards generators and the chunk encoding)."""
+    from oracle.py import composite as comp, hashing as hs
+    for name, v in golden["composite_hasher"].items():
+        msg = _xorshift_bytes(v["seed0"], v["msg_len"]) if v["seed0"] is not None else b""
+        if name == "test_hash_random":
+            continue  # 4910-byte message: covered through the C ABI (tests/test_seam_a.py); too slow for the Python oracle
+        c = comp.composite_crh(msg)
+        got = c if v["out_bytes"] is None else hs.direct_xof(b"ULforxof", c, v["out_bytes"])
+        assert got.hex() == v["expected"], name
+
+
+def reference_hash_test_inputs(n):
+    """hash_to_curve/mod.rs:215-234 generate_test_data under XorShiftRng::from_seed(RNG_SEED): (domain, msg, extra) triples."""
+    from oracle.py import composite as comp
+    rng = comp.XorShiftRng(bytes([0x5d]) + XORSHIFT_SEED_TAIL)
+    out = []
+    for _ in range(n):
+        msg = bytes(rng.gen_u8() for _ in range(rng.gen_u8()))
+        dom = bytes(rng.gen_u8() for _ in range(8))
+        extra = bytes(rng.gen_u8() for _ in range(rng.gen_u8()))
+        out.append((dom, msg, extra))
+    return out
+
+
+@pytest.mark.parametrize("key,cip22", [("g1_compat", False), ("g1_compat_cip22", True)])
+def test_reference_composite_hash_to_g1_vectors(golden, key, cip22):
+    """hash_to_curve/mod.rs:412-455: the deployed (compat) try-and-increment over the composite hasher, before and after Donut."""
+    from oracle.py import hashing as hs
+    pts = golden["hash_to_curve"][key]["points"]
+    for (dom, msg, extra), hx in zip(reference_hash_test_inputs(len(pts)), pts):
+        P, _ = hs.hash_to_g1(dom, msg, extra, composite=True, cip22=cip22)
+        assert ecc.ser_point(ecc.E1_377, P).hex() == hx

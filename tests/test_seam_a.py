@@ -213,8 +213,13 @@ def test_sign_message_is_sk_times_hash(sys_lib):
     assert sys_lib.sign_pop(skh, msg, C.c_int(len(msg)), C.byref(pop))
     Hp, _ = hs.hash_to_g1_direct(b"ULforpop", msg, b"")
     assert _ser(sys_lib, "serialize_signature", pop) == ecc.ser_point(ecc.E1_377, ecc.E1_377.mul(Hp, sk))
-    # flag combinations: composite not built -> false; (composite=false, cip22=true) is an error in the reference as well
-    assert not sys_lib.sign_message(skh, msg, C.c_int(len(msg)), extra, C.c_int(len(extra)), C.c_bool(True), C.c_bool(False), C.byref(sig))
+    # composite hasher (plain and cip22): sigma = sk * H_composite(message)
+    for cip22 in (False, True):
+        csig = C.c_void_p()
+        assert sys_lib.sign_message(skh, msg, C.c_int(len(msg)), extra, C.c_int(len(extra)), C.c_bool(True), C.c_bool(cip22), C.byref(csig))
+        Hc, _ = hs.hash_to_g1(b"ULforxof", msg, extra, composite=True, cip22=cip22)
+        assert _ser(sys_lib, "serialize_signature", csig) == ecc.ser_point(ecc.E1_377, ecc.E1_377.mul(Hc, sk))
+    # (composite=false, cip22=true) is an error in the reference as well (signatures.rs:61)
     assert not sys_lib.sign_message(skh, msg, C.c_int(len(msg)), extra, C.c_int(len(extra)), C.c_bool(False), C.c_bool(True), C.byref(sig))
 
 
@@ -232,9 +237,12 @@ class _BatchMessageFFI(C.Structure):
 
 
 @pytest.mark.gpu
-def test_sign_verify_flow_on_gpu(sys_lib, gpu):
+@pytest.mark.parametrize("composite,cip22", [(False, False), (True, False), (True, True)])
+def test_sign_verify_flow_on_gpu(sys_lib, gpu, composite, cip22):
     """The reference's randomised self-consistency tests (crates/bls-crypto/src/bls/signature.rs:180-426) through the C ABI:
-    sign -> verify OK; wrong message / key -> not verified; PoP; batch_verify over epochs; strict batches accept then reject."""
+    sign -> verify OK; wrong message / key -> not verified; PoP; batch_verify over epochs; strict batches accept then reject —
+    with the direct hasher and with the composite hasher before / after CIP22 (signatures.rs:45-400 flag combinations)."""
+    CF, C22 = C.c_bool(composite), C.c_bool(cip22)
     for f in ("sign_message", "sign_pop", "verify_signature", "verify_pop", "batch_verify_signature", "batch_verify_strict"):
         getattr(sys_lib, f).restype = C.c_bool
     rng = ecc.SplitMix64(2024)
@@ -248,7 +256,7 @@ def test_sign_verify_flow_on_gpu(sys_lib, gpu):
 
     def sign(skh, msg, extra=b""):
         s = C.c_void_p()
-        assert sys_lib.sign_message(skh, msg, C.c_int(len(msg)), extra, C.c_int(len(extra)), C.c_bool(False), C.c_bool(False), C.byref(s))
+        assert sys_lib.sign_message(skh, msg, C.c_int(len(msg)), extra, C.c_int(len(extra)), CF, C22, C.byref(s))
         return s
 
     sk1, pk1 = keypair()
@@ -256,9 +264,9 @@ def test_sign_verify_flow_on_gpu(sys_lib, gpu):
     msg, extra = b"hello", b"extra"
     s1 = sign(sk1, msg, extra)
     ok = C.c_bool(False)
-    assert sys_lib.verify_signature(pk1, msg, C.c_int(5), extra, C.c_int(5), s1, C.c_bool(False), C.c_bool(False), C.byref(ok)) and ok.value
-    assert sys_lib.verify_signature(pk1, b"hellp", C.c_int(5), extra, C.c_int(5), s1, C.c_bool(False), C.c_bool(False), C.byref(ok)) and not ok.value
-    assert sys_lib.verify_signature(pk2, msg, C.c_int(5), extra, C.c_int(5), s1, C.c_bool(False), C.c_bool(False), C.byref(ok)) and not ok.value
+    assert sys_lib.verify_signature(pk1, msg, C.c_int(5), extra, C.c_int(5), s1, CF, C22, C.byref(ok)) and ok.value
+    assert sys_lib.verify_signature(pk1, b"hellp", C.c_int(5), extra, C.c_int(5), s1, CF, C22, C.byref(ok)) and not ok.value
+    assert sys_lib.verify_signature(pk2, msg, C.c_int(5), extra, C.c_int(5), s1, CF, C22, C.byref(ok)) and not ok.value
     assert not sys_lib.verify_signature(pk1, msg, C.c_int(5), extra, C.c_int(5), s1, C.c_bool(False), C.c_bool(True), C.byref(ok))
     pop = C.c_void_p()
     pkb = _ser(sys_lib, "serialize_public_key", pk1)
@@ -282,10 +290,10 @@ def test_sign_verify_flow_on_gpu(sys_lib, gpu):
         keep.append((m, apk, asig, ks, sigs))
         msgs.append(_MessageFFI(_Buffer(m, len(m)), _Buffer(b"x", 1), apk.value, asig.value))
     arr = (_MessageFFI * 4)(*msgs)
-    assert sys_lib.batch_verify_signature(arr, C.c_size_t(4), C.c_bool(False), C.c_bool(False), C.byref(ok)) and ok.value
+    assert sys_lib.batch_verify_signature(arr, C.c_size_t(4), CF, C22, C.byref(ok)) and ok.value
     msgs[2] = _MessageFFI(_Buffer(b"epoch-9", 7), _Buffer(b"x", 1), keep[2][1].value, keep[2][2].value)
     arr = (_MessageFFI * 4)(*msgs)
-    assert sys_lib.batch_verify_signature(arr, C.c_size_t(4), C.c_bool(False), C.c_bool(False), C.byref(ok)) and not ok.value
+    assert sys_lib.batch_verify_signature(arr, C.c_size_t(4), CF, C22, C.byref(ok)) and not ok.value
 
     # batch_verify_strict: 3 batches; the second contains one signature on the wrong message
     batches, holders = [], []
@@ -301,11 +309,11 @@ def test_sign_verify_flow_on_gpu(sys_lib, gpu):
         batches.append(_BatchMessageFFI(_Buffer(m, len(m)), _Buffer(b"", 0), pks, 4, sgs, 4))
     barr = (_BatchMessageFFI * 3)(*batches)
     res = (C.c_bool * 3)()
-    assert not sys_lib.batch_verify_strict(barr, C.c_size_t(3), C.c_bool(False), C.c_bool(False), res)
+    assert not sys_lib.batch_verify_strict(barr, C.c_size_t(3), CF, C22, res)
     assert list(res) == [True, False, True]
     good = (_BatchMessageFFI * 2)(batches[0], batches[2])
     res2 = (C.c_bool * 2)()
-    assert sys_lib.batch_verify_strict(good, C.c_size_t(2), C.c_bool(False), C.c_bool(False), res2) and list(res2) == [True, True]
+    assert sys_lib.batch_verify_strict(good, C.c_size_t(2), CF, C22, res2) and list(res2) == [True, True]
     assert not sys_lib.batch_verify_strict(good, C.c_size_t(2), C.c_bool(False), C.c_bool(True), res2) and list(res2) == [False, False]
 
 
@@ -359,3 +367,73 @@ def test_reference_groth16_ffi_test_passes_on_gpu(sys_lib, gpu, golden):
     # a different (valid) G1 point as the proof's C: swap A and C
     swapped = proof[192:288] + proof[96:192] + proof[0:96]
     assert sys_lib.verify(vk, len(vk), swapped, len(swapped), first, last) is False
+
+
+# ---------------------------------------------------------------- composite (Bowe-Hopwood) hasher through the C ABI
+def _composite_inputs():
+    from tests.test_oracle_golden import reference_hash_test_inputs, _xorshift_bytes
+    return reference_hash_test_inputs, _xorshift_bytes
+
+
+def test_composite_hasher_reference_vectors(sys_lib, golden):
+    """crates/bls-crypto/src/hashers/composite.rs:105-190 through hash_crh (signatures.rs:169) and the XOF hook."""
+    _, xs = _composite_inputs()
+    lib = sys_lib
+    lib.hash_crh.restype = C.c_bool
+    lib.celo_amd_composite_hash.restype = C.c_bool
+    for name, v in golden["composite_hasher"].items():
+        msg = xs(v["seed0"], v["msg_len"]) if v["seed0"] is not None else b""
+        if v["out_bytes"] is None:
+            out, n = C.c_void_p(), C.c_int()
+            assert lib.hash_crh(msg, len(msg), 96, C.byref(out), C.byref(n))
+            assert n.value == 48
+            got = _take(lib, out, n)
+        else:
+            buf = (C.c_ubyte * v["out_bytes"])()
+            assert lib.celo_amd_composite_hash(b"ULforxof", msg, len(msg), v["out_bytes"], buf)
+            got = bytes(buf)
+        assert got.hex() == v["expected"], name
+    # test_invalid_message (composite.rs:193): a 1 MB message exceeds 93 * 560 * 3 bits -> error, not a crash
+    big = bytes(1_000_000)
+    out, n = C.c_void_p(), C.c_int()
+    assert not lib.hash_crh(big, len(big), 96, C.byref(out), C.byref(n))
+
+
+@pytest.mark.parametrize("key,cip22", [("g1_compat", False), ("g1_compat_cip22", True)])
+def test_composite_hash_to_g1_reference_vectors(sys_lib, golden, key, cip22):
+    """hash_to_curve/mod.rs:412-455 through the product's try-and-increment (both variants, compat bit logic)."""
+    gen, _ = _composite_inputs()
+    lib = sys_lib
+    lib.celo_amd_hash_to_g1.restype = C.c_bool
+    pts = golden["hash_to_curve"][key]["points"]
+    for (dom, msg, extra), hx in zip(gen(len(pts)), pts):
+        out = (C.c_ubyte * 48)()
+        att = C.c_int(-1)
+        assert lib.celo_amd_hash_to_g1(True, cip22, dom, msg, len(msg), extra, len(extra), out, C.byref(att))
+        assert bytes(out).hex() == hx
+        assert 0 <= att.value < 255
+
+
+def test_hash_composite_symbols(sys_lib):
+    """hash_composite / hash_composite_cip22 (signatures.rs:143,215): 144-byte projective ToBytes of the SIG_DOMAIN hash; the point
+    equals the oracle's hash and the attempt counter is reported."""
+    from oracle.py import hashing as hs
+    lib = sys_lib
+    lib.hash_composite.restype = C.c_bool
+    lib.hash_composite_cip22.restype = C.c_bool
+    msg, extra = b"composite message", b"\x01\x02"
+    for cip22 in (False, True):
+        out, n = C.c_void_p(), C.c_int()
+        att = C.c_ubyte(255)
+        if cip22:
+            assert lib.hash_composite_cip22(msg, len(msg), extra, len(extra), C.byref(out), C.byref(n), C.byref(att))
+        else:
+            assert lib.hash_composite(msg, len(msg), extra, len(extra), C.byref(out), C.byref(n))
+        assert n.value == 144
+        b = _take(lib, out, n)
+        x, y, z = (int.from_bytes(b[i:i + 48], "little") for i in (0, 48, 96))
+        zi = pow(z, -1, ecc.Q377)
+        P, c = hs.hash_to_g1(b"ULforxof", msg, extra, composite=True, cip22=cip22)
+        assert (x * zi * zi % ecc.Q377, y * zi * zi * zi % ecc.Q377) == tuple(P)
+        if cip22:
+            assert att.value == c

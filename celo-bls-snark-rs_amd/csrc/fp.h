@@ -219,6 +219,28 @@ template <class P> struct Fp {
     return r;
   }
 
+  // ---- exact halving mod p: (a + (a odd ? p : 0)) >> 1.  lb = 1, vb -> (vb + 1) / 2.  Used by the lane-parallel pairing
+  // (pairing_quad.h) in place of the multiplications by 1/2 of ark-ec's doubling step: same field element, ~50 VALU ops.
+  HD static Fp half(const Fp& a_) {
+    const Fp a = norm(a_);
+    const uint32_t odd = 0u - (a.l[0] & 1u);
+    Fp t;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) {
+      uint32_t s = a.l[i] + (P::P[i] & odd) + c;
+      t.l[i] = s & MASK;
+      c = s >> W;
+    }
+    t.l[L - 1] = a.l[L - 1] + (P::P[L - 1] & odd) + c;
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) r.l[i] = (t.l[i] >> 1) | ((t.l[i + 1] & 1u) << (W - 1));
+    r.l[L - 1] = t.l[L - 1] >> 1;
+    TRK(r.lb = 1; r.vb = (a.vb + 1) / 2;)
+    return r;
+  }
+
   // ---- weak reduction: value < ~300p (normalised limbs)  ->  value < ~2.1p.  Quotient estimate from the top limb(s),
   // one multiply-subtract sweep, ~60-110 VALU ops: used by the pairing towers
   // to stop the value growth of lazy additions without paying a full Montgomery multiplication.

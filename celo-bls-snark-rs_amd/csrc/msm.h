@@ -18,8 +18,8 @@
 //     k_size_*          schedule, lanes of a wave get equal-length pieces
 //   4 k_accumulate      one lane per piece: gathers its points (128 B each), XYZZ mixed adds      <- dominant kernel
 //   5 k_combine_big     (skewed inputs only) folds buckets that were cut into many pieces
-//     k_reduce_chunks   running-sum over CH consecutive buckets per lane -> (sum, weighted sum)
-//     k_fixup / k_tree  weighted fix-up by small scalar, then 8-ary tree sums down to <=4 points/window
+//     k_bitsum          bit-sliced bucket reduction: binary tree over the bucket index + the odd-node sums of every level
+//                       (depth log2(buckets) point additions, no scalar multiplication; see the kernel)
 //   6 host              <=4*NW XYZZ points: Horner over windows (c doublings each) -> Jacobian, ark form
 #pragma once
 #include <hip/hip_runtime.h>
@@ -382,54 +382,50 @@ template <class G> HD Xyzz<typename G::F> load_bucket(const uint32_t* partials, 
   return IO::load_xyzz(partials + (size_t)pfirst[t] * IO::XYZZ_WORDS);
 }
 
-// running sums over CH consecutive buckets (descending): out[2*t] = sum_{j} (j - lo + 1) * B_j, out[2*t+1] = sum_j B_j
+// ---- bucket reduction: window sum S = sum_b (b + 1) B_b with no scalar multiplication and depth log2(B).
+// Binary tree over the bucket index: node(l, p) = sum of the buckets whose top l index bits are p (leaves at level LB).
+// Bit k = LB - l of b is set exactly for the leaves under the odd-indexed nodes of level l, so
+//   S = node(0, 0) + sum_{l=1..LB} 2^(LB - l) O_l,   O_l = sum_{p odd} node(l, p).
+// Launch t builds level LB - t from level LB - t + 1 and halves every pending odd list once; a list is born strided
+// (its first halving reads nodes 4i+1 and 4i+3 of its level).  LB launches, 2 point additions of work per bucket (the same
+// as a running sum), every addition independent of the others of its launch: the depth of the whole reduction is LB
+// additions instead of 16 (running sum) + ~18 (fix-up scalar) + log2 (tree).  The 2^(LB-l) weights are applied by the host
+// inside the Horner recombination it runs anyway (one addition per doubling).
+struct BitsumJobs {
+  static constexpr int MAXJ = 20;
+  uint32_t njobs;
+  uint32_t end[MAXJ];    // cumulative number of outputs
+  uint32_t src[MAXJ];    // point index into the work area (modes 0, 1, 4); unused for the leaf modes
+  uint32_t dst[MAXJ];    // point index into the work area
+  uint32_t mode[MAXJ];   // 0: in[2i] + in[2i+1]   1: in[4i+1] + in[4i+3]   2, 3: the same on the buckets themselves   4: in[2i+1]
+};
 template <class G>
-__global__ void __launch_bounds__(128) k_reduce_chunks(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
-                                                       const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ pieces_of,
-                                                       uint32_t SEG, uint32_t* __restrict__ out, uint32_t CH, uint32_t nchunks) {
+__global__ void __launch_bounds__(128) k_bitsum(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
+                                                const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ pieces_of, uint32_t SEG,
+                                                uint32_t* __restrict__ work, BitsumJobs jobs) {
   typedef typename G::F F;
   typedef PointIO<F> IO;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nchunks) return;
-  Xyzz<F> running = Xyzz<F>::identity(), acc = Xyzz<F>::identity();
-  for (int j = (int)CH - 1; j >= 0; j--) {
-    Xyzz<F> v = load_bucket<G>(partials, counts, pfirst, pieces_of, t * CH + (uint32_t)j, SEG);
-    xyzz_add_fn(running, v);
-    xyzz_add_fn(acc, running);
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= jobs.end[jobs.njobs - 1]) return;
+  uint32_t j = 0;
+  while (t >= jobs.end[j]) j++;
+  const uint32_t i = t - (j ? jobs.end[j - 1] : 0u);
+  const uint32_t mode = jobs.mode[j];
+  Xyzz<F> a, b;
+  if (mode == 2) {
+    a = load_bucket<G>(partials, counts, pfirst, pieces_of, 2 * i, SEG);
+    b = load_bucket<G>(partials, counts, pfirst, pieces_of, 2 * i + 1, SEG);
+  } else if (mode == 3) {
+    a = load_bucket<G>(partials, counts, pfirst, pieces_of, 4 * i + 1, SEG);
+    b = load_bucket<G>(partials, counts, pfirst, pieces_of, 4 * i + 3, SEG);
+  } else {
+    const uint32_t* in = work + (size_t)jobs.src[j] * IO::XYZZ_WORDS;
+    const size_t ia = mode == 0 ? 2 * (size_t)i : mode == 1 ? 4 * (size_t)i + 1 : 2 * (size_t)i + 1;
+    a = IO::load_xyzz(in + ia * IO::XYZZ_WORDS);
+    if (mode != 4) b = IO::load_xyzz(in + (ia + (mode == 0 ? 1 : 2)) * IO::XYZZ_WORDS);
   }
-  IO::store_xyzz(out + (size_t)(2 * t) * IO::XYZZ_WORDS, acc);
-  IO::store_xyzz(out + (size_t)(2 * t + 1) * IO::XYZZ_WORDS, running);
-}
-
-// weighted part of chunk t (within its window): t_in_window * running_t.  The window sum is
-//   sum_t acc_t + CH * sum_t (t * running_t);  the factor CH (log2 CH doublings) is applied once per window on the host.
-template <class G>
-__global__ void __launch_bounds__(128) k_fixup(const uint32_t* __restrict__ in, uint32_t* __restrict__ out_acc,
-                                               uint32_t* __restrict__ out_w, uint32_t chunks_per_window, uint32_t nchunks) {
-  typedef typename G::F F;
-  typedef PointIO<F> IO;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nchunks) return;
-  Xyzz<F> acc = IO::load_xyzz(in + (size_t)(2 * t) * IO::XYZZ_WORDS);
-  Xyzz<F> run = IO::load_xyzz(in + (size_t)(2 * t + 1) * IO::XYZZ_WORDS);
-  IO::store_xyzz(out_acc + (size_t)t * IO::XYZZ_WORDS, acc);
-  Xyzz<F> m = xyzz_mul_small(run, t % chunks_per_window);
-  IO::store_xyzz(out_w + (size_t)t * IO::XYZZ_WORDS, m);
-}
-
-// out[t] = sum of in[t*grp .. t*grp+grp-1]
-template <class G>
-__global__ void __launch_bounds__(128) k_tree(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t grp, uint32_t nout) {
-  typedef typename G::F F;
-  typedef PointIO<F> IO;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nout) return;
-  Xyzz<F> acc = IO::load_xyzz(in + (size_t)t * grp * IO::XYZZ_WORDS);
-  for (uint32_t j = 1; j < grp; j++) {
-    Xyzz<F> v = IO::load_xyzz(in + ((size_t)t * grp + j) * IO::XYZZ_WORDS);
-    xyzz_add_fn(acc, v);
-  }
-  IO::store_xyzz(out + (size_t)t * IO::XYZZ_WORDS, acc);
+  if (mode != 4) xyzz_add_fn(a, b);
+  IO::store_xyzz(work + ((size_t)jobs.dst[j] + i) * IO::XYZZ_WORDS, a);
 }
 
 // =====================================================================================================================
@@ -618,8 +614,9 @@ template <class G> class MsmEngine {
     if (SEG > SIZE_BINS - 1) SEG = SIZE_BINS - 1;
     const uint32_t PW = B + n / SEG + 1;       // static piece region per window
     const uint32_t slots = (uint32_t)nw * PW;
-    const uint32_t CH = B >= 8 ? 8 : B;
-    const uint32_t cpw = B / CH, nchunks = cpw * nw;
+    const int LB = c - 1;                                          // bucket-index bits (c >= 4)
+    const uint32_t res_pts = (uint32_t)(LB + 1) * (uint32_t)nw;    // results: [0] = node(0,0), [l] = O_l, nw points each
+    const uint32_t half_pts = (uint32_t)nw * (B / 2 + B / 4);      // most outputs of one launch (the first)
 
     // ---- workspace arena
     size_t off = 0;
@@ -639,8 +636,7 @@ template <class G> class MsmEngine {
     const size_t o_order = take((size_t)slots * 4);
     const size_t o_bins = take((size_t)SIZE_BINS * 4 + 256);  // + nwork, nbig
     const size_t o_partials = take((size_t)slots * IO::XYZZ_WORDS * 4);
-    const size_t o_tmpA = take(((size_t)2 * nchunks + 64) * IO::XYZZ_WORDS * 4);
-    const size_t o_tmpB = take(((size_t)2 * nchunks + 64) * IO::XYZZ_WORDS * 4);
+    const size_t o_work = take(((size_t)res_pts + 2 * (size_t)half_pts + 64) * IO::XYZZ_WORDS * 4);
     if (ensure(off)) return 1;
     char* A = arena;
     uint32_t* d_bases = (uint32_t*)(A + o_bases);
@@ -661,8 +657,7 @@ template <class G> class MsmEngine {
     uint32_t* d_nbig = d_bins + SIZE_BINS + 1;
     uint32_t* d_nmid = d_bins + SIZE_BINS + 2;
     uint32_t* d_partials = (uint32_t*)(A + o_partials);
-    uint32_t* d_tmpA = (uint32_t*)(A + o_tmpA);
-    uint32_t* d_tmpB = (uint32_t*)(A + o_tmpB);
+    uint32_t* d_work = (uint32_t*)(A + o_work);
 
     HIP_OK(hipEventRecord(ev[0], stream));
     hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_ark_bases, d_bases, (size_t)n);
@@ -690,25 +685,52 @@ template <class G> class MsmEngine {
     // ---- bucket reduction
     hipLaunchKernelGGL((k_combine_mid<G>), dim3(256), dim3(128), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
     hipLaunchKernelGGL((k_combine_big<G>), dim3(256), dim3(256), 0, stream, d_big, d_nbig, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
-    hipLaunchKernelGGL((k_reduce_chunks<G>), dim3((nchunks + 127) / 128), dim3(128), 0, stream, d_partials, d_counts, d_pfirst,
-                       d_piecesof, SEG, d_tmpA, CH, nchunks);
-    // d_tmpB: [0, nchunks) = acc_t, [nchunks, 2 nchunks) = t * running_t; binary trees (depth log2) down to <= 2 per window
-    uint32_t* accs = d_tmpB;
-    uint32_t* wts = d_tmpB + (size_t)nchunks * IO::XYZZ_WORDS;
-    hipLaunchKernelGGL((k_fixup<G>), dim3((nchunks + 127) / 128), dim3(128), 0, stream, d_tmpA, accs, wts, cpw, nchunks);
-    // both arrays have the same shape, so one launch per level handles them as 2*nw "windows" of per_window items
-    uint32_t per_window = cpw;
-    uint32_t* src = d_tmpB;
-    uint32_t* dst = d_tmpA;
-    while (per_window > 2) {
-      uint32_t nout = per_window / 2 * 2 * nw;
-      hipLaunchKernelGGL((k_tree<G>), dim3((nout + 127) / 128), dim3(128), 0, stream, src, dst, 2u, nout);
-      per_window /= 2;
-      uint32_t* t = src; src = dst; dst = t;
+    {
+      // work area (in points): [0, res_pts) results, then two launch-alternating halves of half_pts
+      struct Arr { uint32_t at, per_window; bool born; int level; };  // `born`: odd list not yet halved (read strided from its level)
+      uint32_t half_at[2] = {res_pts, res_pts + half_pts};
+      Arr tree = {0, B, true, LB};            // current tree level (level LB = the buckets themselves)
+      std::vector<Arr> lists;                 // pending odd lists
+      for (int t = 1; t <= LB; t++) {
+        BitsumJobs jobs;
+        jobs.njobs = 0;
+        uint32_t cursor = half_at[t & 1], total_out = 0;
+        auto push = [&](uint32_t src, uint32_t outs_per_window, uint32_t mode, int result_slot) -> uint32_t {
+          const uint32_t outs = outs_per_window * (uint32_t)nw;
+          uint32_t dst;
+          if (result_slot >= 0) dst = (uint32_t)result_slot * (uint32_t)nw;
+          else { dst = cursor; cursor += outs; }
+          const int j = (int)jobs.njobs++;
+          total_out += outs;
+          jobs.end[j] = total_out; jobs.src[j] = src; jobs.dst[j] = dst; jobs.mode[j] = mode;
+          return dst;
+        };
+        std::vector<Arr> next_lists;
+        // the odd list of the current tree level is born now (level >= 2: at least two odd nodes per window)
+        if (tree.level >= 2) {
+          const uint32_t outs = tree.per_window / 4;
+          const uint32_t dst = push(tree.at, outs, tree.level == LB ? 3u : 1u, outs == 1 ? tree.level : -1);
+          if (outs > 1) next_lists.push_back({dst, outs, false, tree.level});
+        } else {  // level 1: O_1 = node(1, 1)
+          push(tree.at, 1, 4u, 1);
+        }
+        for (const Arr& L : lists) {
+          const uint32_t outs = L.per_window / 2;
+          const uint32_t dst = push(L.at, outs, 0u, outs == 1 ? L.level : -1);
+          if (outs > 1) next_lists.push_back({dst, outs, false, L.level});
+        }
+        {  // next tree level
+          const uint32_t outs = tree.per_window / 2;
+          const uint32_t dst = push(tree.at, outs, tree.level == LB ? 2u : 0u, outs == 1 ? 0 : -1);
+          tree = {dst, outs, true, tree.level - 1};
+        }
+        lists.swap(next_lists);
+        hipLaunchKernelGGL((k_bitsum<G>), dim3((total_out + 127) / 128), dim3(128), 0, stream, d_partials, d_counts, d_pfirst, d_piecesof, SEG,
+                           d_work, jobs);
+      }
     }
     HIP_OK(hipEventRecord(ev[4], stream));
-    size_t out_words = (size_t)per_window * 2 * nw * IO::XYZZ_WORDS;
-    HIP_OK(hipMemcpyAsync(h_out, src, out_words * 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(h_out, d_work, (size_t)res_pts * IO::XYZZ_WORDS * 4, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ev[5], stream));
     HIP_OK(hipStreamSynchronize(stream));
     HIP_OK(hipGetLastError());
@@ -718,23 +740,17 @@ template <class G> class MsmEngine {
     (void)hipEventElapsedTime(&tm.reduce, ev[3], ev[4]);
     (void)hipEventElapsedTime(&tm.total, ev[0], ev[5]);
     last_c = c; last_nw = nw; last_buckets = total;
-    // ---- host epilogue: window sum = A_w + CH * T_w, then Horner over windows (c doublings each)
-    int log_ch = 0;
-    while ((1u << log_ch) < CH) log_ch++;
+    // ---- host epilogue: total = sum_w 2^(c w) (node_w + sum_l 2^(LB-l) O_{w,l}): one Horner pass, c doublings and c additions per window
     Xyzz<F> total_pt = Xyzz<F>::identity();
     for (int w = nw - 1; w >= 0; w--) {
-      for (int k = 0; k < c; k++) total_pt = xyzz_dbl(total_pt);
-      Xyzz<F> tw = Xyzz<F>::identity();
-      for (uint32_t j = 0; j < per_window; j++) {
-        Xyzz<F> v = IO::load_xyzz(h_out + ((size_t)(nw + w) * per_window + j) * IO::XYZZ_WORDS);
-        xyzz_add(tw, v);
-      }
-      for (int k = 0; k < log_ch; k++) tw = xyzz_dbl(tw);
-      xyzz_add(total_pt, tw);
-      for (uint32_t j = 0; j < per_window; j++) {
-        Xyzz<F> v = IO::load_xyzz(h_out + ((size_t)w * per_window + j) * IO::XYZZ_WORDS);
+      total_pt = xyzz_dbl(total_pt);
+      for (int l = 1; l <= LB; l++) {
+        Xyzz<F> v = IO::load_xyzz(h_out + ((size_t)l * nw + w) * IO::XYZZ_WORDS);
+        total_pt = xyzz_dbl(total_pt);
         xyzz_add(total_pt, v);
       }
+      Xyzz<F> v = IO::load_xyzz(h_out + (size_t)w * IO::XYZZ_WORDS);
+      xyzz_add(total_pt, v);
     }
     write_jacobian(total_pt, out_jac);
     return 0;
@@ -876,7 +892,7 @@ template <class G> class MsmEngine {
     if (!ev[0])
       for (int i = 0; i < 6; i++) HIP_OK(hipEventCreate(&ev[i]));
     if (!h_out) {
-      HIP_OK(hipHostMalloc(&h_out, (size_t)4 * 128 * IO::XYZZ_WORDS * 4));
+      HIP_OK(hipHostMalloc(&h_out, (size_t)17 * 64 * IO::XYZZ_WORDS * 4));
       // the LDS histograms use up to 128 KB of dynamic LDS (2^15 counters)
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_count<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

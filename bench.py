@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of bases per GPU (default 2^20 = BASELINE config)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pairing", action="store_true", help="skip the secondary pairings/s leg")
     ap.add_argument("--balanced", action="store_true", help="diagnostic: scalars whose digits fill every bucket equally (not the headline workload)")
     args = ap.parse_args()
 
@@ -160,8 +161,8 @@ def main():
                                          "achieved = n*windows mixed adds * (8M+2S) / accumulate kernel time"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(bases, sc, n, result if world == 1 else None)
-            if world == 1:
-                line["pairing"] = pairing_leg(ffi, codec)
+        if world == 1 and not args.no_pairing:
+            line["pairing"] = pairing_leg(ffi, codec, check_oracle=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -194,7 +195,7 @@ def cpu_baseline(bases, sc, n, gpu_result):
             "seconds": secs, "parity_with_gpu": ok}
 
 
-def pairing_leg(ffi, codec):
+def pairing_leg(ffi, codec, check_oracle=True):
     """Secondary metric of BASELINE.json ("+ pairings/sec"): m independent 2-pair checks e(sig,-g2)*e(H,pk) == 1
     (the shape of PublicKey::verify / Batch::verify's final check) in one launch; Miller loops/s with one final
     exponentiation per 2 loops.  The oracle runs a sample of the same products on one host core and the accept
@@ -202,7 +203,7 @@ def pairing_leg(ffi, codec):
     from oracle import cpu_oracle as co
     from oracle.py import ecc
     import time as _t
-    m = 32768                                 # large enough to fill the chip: one lane per pair, one wave per SIMD at 65536 pairs
+    m = 32768                                 # 65536 pairs = 65536 quads of lanes = 4096 waves: two resident rounds at 2 waves/SIMD
     rng = ecc.SplitMix64(0x5EED0005)
     base = []
     ng2 = ecc.E2_377.neg(ecc.G2_377)
@@ -224,15 +225,20 @@ def pairing_leg(ffi, codec):
     dt = _t.perf_counter() - t0
     tm = ffi.pairing_timings()
     ok = got.tolist() == expect
-    t0 = _t.perf_counter()
-    cpu_ok = [co.pairing_product_377(g1[2 * i:2 * i + 2], None, g2[2 * i:2 * i + 2], None)[1] for i in range(16)]
-    cdt = (_t.perf_counter() - t0) / 16
-    ok = ok and [int(x) for x in cpu_ok] == expect[:16]
+    cpu_rate = None
+    if check_oracle:
+        t0 = _t.perf_counter()
+        cpu_ok = [co.pairing_product_377(g1[2 * i:2 * i + 2], None, g2[2 * i:2 * i + 2], None)[1] for i in range(16)]
+        cdt = (_t.perf_counter() - t0) / 16
+        cpu_rate = 2 / cdt
+        ok = ok and [int(x) for x in cpu_ok] == expect[:16]
     if not ok:
-        raise SystemExit("PARITY FAILURE: GPU pairing accept vector != oracle")
-    return {"metric": "BLS12-377 Miller loops/s (2-pair products, 1 final exponentiation per product)", "value": 2 * m / dt,
-            "products": m, "wall_ms": dt * 1e3, "miller_ms": tm["miller_ms"], "final_exp_ms": tm["final_exp_ms"],
-            "bytes_per_miller_loop": 288, "cpu_port_miller_loops_per_s_1core": 2 / cdt, "accept_vector_matches_oracle": ok}
+        raise SystemExit("PARITY FAILURE: GPU pairing accept vector != expected / oracle")
+    # value: device time of the three kernels (inputs resident, HIP events on the library's stream); wall_ms includes the PCIe copies
+    return {"metric": "BLS12-377 Miller loops/s (2-pair products, 1 final exponentiation per product)", "value": 2 * m / (tm["total_ms"] * 1e-3),
+            "products": m, "device_ms": tm["total_ms"], "wall_ms_incl_pcie": dt * 1e3, "miller_ms": tm["miller_ms"],
+            "final_exp_ms": tm["final_exp_ms"], "bytes_per_miller_loop": 288, "cpu_port_miller_loops_per_s_1core": cpu_rate,
+            "accept_vector_matches_oracle": ok if check_oracle else None, "accept_vector_as_constructed": got.tolist() == expect}
 
 
 if __name__ == "__main__":

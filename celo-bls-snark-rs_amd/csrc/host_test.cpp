@@ -82,31 +82,40 @@ static void pairing_op(int mode, const uint64_t* g1, const uint64_t* g2, size_t 
   if (is_one) *is_one = f12_is_one(r) ? 1 : 0;
 }
 
-// the lane-parallel pairing (pairing_quad.h) on its four-explicit-lanes host backend; same modes as pairing_op
+// the lane-parallel pairing (pairing_lanes.h) on its three-explicit-lanes host backend; same modes as pairing_op
 typedef QTower<QHost377> HQT;
 typedef QPairing377<QHost377> HQP;
-static HQT::E12 quad_from_f12(const Fq12& x) {
+static HQT::E12 lanes_from_f12(const Fq12& x) {
   HQT::E12 e;
   const Fq2* c[6] = {&x.c0.c0, &x.c0.c1, &x.c0.c2, &x.c1.c0, &x.c1.c1, &x.c1.c2};
   for (int j = 0; j < 3; j++) { e.a.v[j] = *c[j]; e.b.v[j] = *c[3 + j]; }
-  e.a.v[3] = Fq2::zero(); e.b.v[3] = Fq2::zero();
   return e;
 }
-static Fq12 quad_to_f12(const HQT::E12& e) {
+static Fq12 lanes_to_f12(const HQT::E12& e) {
   Fq12 x;
   Fq2* c[6] = {&x.c0.c0, &x.c0.c1, &x.c0.c2, &x.c1.c0, &x.c1.c1, &x.c1.c2};
   for (int j = 0; j < 3; j++) { *c[j] = e.a.v[j]; *c[3 + j] = e.b.v[j]; }
   return x;
 }
-static void pairing_op_quad(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
+static void pairing_op_lanes(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
                             uint64_t* out72, int* is_one) {
   HQT::E12 r;
-  if (mode <= 1) {
+  if (mode == 10 || mode == 11) {  // whole product in one group with a shared accumulator (k <= 4); 10: GT value, 11: Miller value
+    QHost377::F px[4], py[4];
+    QHost377::V Qc[4];
+    for (size_t i = 0; i < k && i < 4; i++)
+      for (int l = 0; l < 3; l++) {
+        px[i].v[l] = Fq::from_ark(g1 + i * 12); py[i].v[l] = Fq::from_ark(g1 + i * 12 + 6);
+        Qc[i].v[l] = Fq2::from_ark(g2 + i * 24 + (l & 1) * 12);
+      }
+    HQT::E12 acc = HQP::miller_multi<4>((int)k, px, py, Qc);
+    r = mode == 10 ? HQP::final_exponentiation(acc) : acc;
+  } else if (mode <= 1) {
     HQT::E12 acc = HQT::one12();
     for (size_t i = 0; i < k; i++) {
       QHost377::F px, py;
       QHost377::V Qc;
-      for (int l = 0; l < 4; l++) {
+      for (int l = 0; l < 3; l++) {
         px.v[l] = Fq::from_ark(g1 + i * 12); py.v[l] = Fq::from_ark(g1 + i * 12 + 6);
         Qc.v[l] = Fq2::from_ark(g2 + i * 24 + (l & 1) * 12);
       }
@@ -114,10 +123,10 @@ static void pairing_op_quad(int mode, const uint64_t* g1, const uint64_t* g2, si
     }
     r = mode == 0 ? HQP::final_exponentiation(acc) : acc;
   } else {
-    HQT::E12 a = quad_from_f12(f12_from_ark(in72));
+    HQT::E12 a = lanes_from_f12(f12_from_ark(in72));
     switch (mode) {
       case 2: r = HQP::final_exponentiation(a); break;
-      case 3: r = HQT::mul12(a, quad_from_f12(f12_from_ark(in72b))); break;
+      case 3: r = HQT::mul12(a, lanes_from_f12(f12_from_ark(in72b))); break;
       case 4: r = HQT::inv12(a); break;
       case 5: r = HQT::cyclotomic_sqr(a); break;
       case 6: r = HQT::frob12<1>(a); break;
@@ -126,7 +135,7 @@ static void pairing_op_quad(int mode, const uint64_t* g1, const uint64_t* g2, si
       default: r = HQT::sqr12(a); break;
     }
   }
-  f12_to_ark(quad_to_f12(r), out72);
+  f12_to_ark(lanes_to_f12(r), out72);
   if (is_one) *is_one = HQT::is_one12(r) ? 1 : 0;
 }
 
@@ -149,8 +158,8 @@ extern "C" {
 void ht_pairing_761(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out72, int* is_one) { pairing_op_761(mode, g1, g2, k, out72, is_one); }
 void ht_pairing_377(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
                     uint64_t* out72, int* is_one) { pairing_op(mode, g1, g2, k, in72, in72b, out72, is_one); }
-void ht_pairing_377_quad(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
-                         uint64_t* out72, int* is_one) { pairing_op_quad(mode, g1, g2, k, in72, in72b, out72, is_one); }
+void ht_pairing_377_lanes(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
+                         uint64_t* out72, int* is_one) { pairing_op_lanes(mode, g1, g2, k, in72, in72b, out72, is_one); }
 void ht_fq377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp<P377>>(op, a, b, out); }
 void ht_fq761(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp<P761>>(op, a, b, out); }
 void ht_fq2_377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp2<P377>>(op, a, b, out); }

@@ -272,7 +272,7 @@ TW_FN void bw6_final_exponentiation(Fw6& out, const Fw6& f) {
 }
 
 }  // namespace celo
-#include "pairing_quad.h"
+#include "pairing_lanes.h"
 namespace celo {
 
 // ================================================================== pairing policies (one per curve) for the kernels below
@@ -280,7 +280,7 @@ struct PP377 {
   typedef Base377 BP;
   typedef Fq12 Gt;
   static constexpr int G1_ARK64 = 12, G2_ARK64 = 24;
-  static constexpr bool QUAD = true;   // lane-parallel kernels (pairing_quad.h); the one-lane functions stay as the host-checked twin
+  static constexpr bool LANES = true;   // lane-parallel kernels (pairing_lanes.h); the one-lane functions stay as the host-checked twin
   HD static void miller(Gt& f, const uint64_t* g1, const uint64_t* g2) {
     Fq px = Fq::from_ark(g1), py = Fq::from_ark(g1 + 6);
     Fq2 qx = Fq2::from_ark(g2), qy = Fq2::from_ark(g2 + 12);
@@ -292,7 +292,7 @@ struct PP761 {
   typedef Base761 BP;
   typedef Fw6 Gt;
   static constexpr int G1_ARK64 = 24, G2_ARK64 = 24;
-  static constexpr bool QUAD = false;
+  static constexpr bool LANES = false;
   HD static void miller(Gt& f, const uint64_t* g1, const uint64_t* g2) {
     Fw px = Fw::from_ark(g1), py = Fw::from_ark(g1 + 12);
     Fw qx = Fw::from_ark(g2), qy = Fw::from_ark(g2 + 12);
@@ -359,14 +359,17 @@ __global__ void __launch_bounds__(64) k_final_exp(const uint32_t* __restrict__ p
   if (gt_ark) IO::to_ark(r, gt_ark + (size_t)p * 72);
 }
 
-// ---------------------------------------------------------------- lane-parallel kernels (BLS12-377): 4 lanes per pairing / product.
-// Defined in pairing_quad_kernels.h, compiled in their own translation units (unit_pairing_qm.hip, unit_pairing_qf.hip).
-__global__ void k_miller_quad(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1, const uint64_t* __restrict__ g2,
-                              const uint8_t* __restrict__ inf2, uint32_t* __restrict__ f_out, uint32_t n);
-__global__ void k_gt_product_quad(const uint32_t* __restrict__ f_in, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ prod, uint32_t m);
-__global__ void k_gt_tree_quad(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_in);
-__global__ void k_final_exp_quad(const uint32_t* __restrict__ prod, uint8_t* __restrict__ is_one, uint64_t* __restrict__ gt_ark, uint32_t m,
-                                 int do_final_exp);
+// ---------------------------------------------------------------- lane-parallel kernels (BLS12-377): 3 lanes per pairing / product.
+// Defined in pairing_lanes_kernels.h, compiled in their own translation units (unit_pairing_lm.hip, unit_pairing_lf.hip).
+__global__ void k_miller_lanes(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1, const uint64_t* __restrict__ g2,
+                               const uint8_t* __restrict__ inf2, uint32_t* __restrict__ f_out, uint32_t n);
+__global__ void k_miller_product_lanes(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1, const uint64_t* __restrict__ g2,
+                                       const uint8_t* __restrict__ inf2, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ prod, uint32_t m);
+__global__ void k_gt_product_lanes(const uint32_t* __restrict__ f_in, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ prod, uint32_t m);
+__global__ void k_gt_tree_lanes(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_in);
+__global__ void k_final_exp_lanes(const uint32_t* __restrict__ prod, uint8_t* __restrict__ is_one, uint64_t* __restrict__ gt_ark, uint32_t m,
+                                  int do_final_exp);
+constexpr uint32_t LANES_PER_BLOCK = 21;   // groups of three lanes per 64-thread block
 
 #define PAIR_HIP_OK(x)                                                                                          \
   do {                                                                                                          \
@@ -415,30 +418,44 @@ template <class PP> class PairingEngine {
     }
     PAIR_HIP_OK(hipMemcpyAsync(d_off, offsets, (m + 1) * 4, hipMemcpyHostToDevice, stream));
     PAIR_HIP_OK(hipEventRecord(ev[0], stream));
-    if constexpr (PP::QUAD) {
-      if (k) hipLaunchKernelGGL(k_miller_quad, dim3((k + 15) / 16), dim3(64), 0, stream, d_g1, inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_f, k);
+    // shared-accumulator mode: one lane group per product (<= 4 pairs each) when the products alone fill the chip
+    bool shared = false;
+    if constexpr (PP::LANES) {
+      if (m >= 16384) {
+        shared = true;
+        for (size_t p = 0; p < m && shared; p++) shared = offsets[p + 1] - offsets[p] <= 4;
+      }
+      if (shared) {
+        hipLaunchKernelGGL(k_miller_product_lanes, dim3(((uint32_t)m + LANES_PER_BLOCK - 1) / LANES_PER_BLOCK), dim3(64), 0, stream, d_g1,
+                           inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m);
+      } else if (k) {
+        hipLaunchKernelGGL(k_miller_lanes, dim3((k + LANES_PER_BLOCK - 1) / LANES_PER_BLOCK), dim3(64), 0, stream, d_g1, inf1 ? d_i1 : nullptr, d_g2,
+                           inf2 ? d_i2 : nullptr, d_f, k);
+      }
     } else {
       if (k) hipLaunchKernelGGL((k_miller<PP>), dim3((k + 63) / 64), dim3(64), 0, stream, d_g1, inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_f, k);
     }
     PAIR_HIP_OK(hipEventRecord(ev[1], stream));
-    if (m == 1 && k > 8) {  // one large product: pairwise tree, log2(k) levels
+    if (shared) {
+      // products already formed by k_miller_product_lanes
+    } else if (m == 1 && k > 8) {  // one large product: pairwise tree, log2(k) levels
       uint32_t n_in = k;
       uint32_t* src = d_f; uint32_t* dst = d_f2;
       while (n_in > 1) {
         uint32_t n_out = (n_in + 1) / 2;
-        if constexpr (PP::QUAD) hipLaunchKernelGGL(k_gt_tree_quad, dim3((n_out + 15) / 16), dim3(64), 0, stream, src, dst, n_in);
+        if constexpr (PP::LANES) hipLaunchKernelGGL(k_gt_tree_lanes, dim3((n_out + LANES_PER_BLOCK - 1) / LANES_PER_BLOCK), dim3(64), 0, stream, src, dst, n_in);
         else hipLaunchKernelGGL((k_gt_tree<PP>), dim3((n_out + 63) / 64), dim3(64), 0, stream, src, dst, n_in);
         n_in = n_out;
         uint32_t* t = src; src = dst; dst = t;
       }
       PAIR_HIP_OK(hipMemcpyAsync(d_prod, src, W * 4, hipMemcpyDeviceToDevice, stream));
     } else {
-      if constexpr (PP::QUAD) hipLaunchKernelGGL(k_gt_product_quad, dim3(((uint32_t)m + 15) / 16), dim3(64), 0, stream, d_f, d_off, d_prod, (uint32_t)m);
+      if constexpr (PP::LANES) hipLaunchKernelGGL(k_gt_product_lanes, dim3(((uint32_t)m + LANES_PER_BLOCK - 1) / LANES_PER_BLOCK), dim3(64), 0, stream, d_f, d_off, d_prod, (uint32_t)m);
       else hipLaunchKernelGGL((k_gt_product<PP>), dim3(((uint32_t)m + 63) / 64), dim3(64), 0, stream, d_f, d_off, d_prod, (uint32_t)m);
     }
     PAIR_HIP_OK(hipEventRecord(ev[2], stream));
-    if constexpr (PP::QUAD)
-      hipLaunchKernelGGL(k_final_exp_quad, dim3(((uint32_t)m + 15) / 16), dim3(64), 0, stream, d_prod, out_is_one ? d_one : nullptr,
+    if constexpr (PP::LANES)
+      hipLaunchKernelGGL(k_final_exp_lanes, dim3(((uint32_t)m + LANES_PER_BLOCK - 1) / LANES_PER_BLOCK), dim3(64), 0, stream, d_prod, out_is_one ? d_one : nullptr,
                          out_gt ? d_gt : nullptr, (uint32_t)m, mode == 0 ? 1 : 0);
     else
       hipLaunchKernelGGL((k_final_exp<PP>), dim3(((uint32_t)m + 63) / 64), dim3(64), 0, stream, d_prod, out_is_one ? d_one : nullptr,

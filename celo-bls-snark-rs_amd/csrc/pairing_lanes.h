@@ -1,23 +1,29 @@
-// Lane-parallel BLS12-377 pairing: ONE PAIRING PER QUAD (4 adjacent lanes of a wave64), state in registers.
+// Lane-parallel BLS12-377 pairing: ONE PAIRING PER GROUP OF THREE ADJACENT LANES (21 groups per wave64), state in registers.
 //
 // Why: the one-lane-per-pairing kernels of pairing.h keep an Fq12 accumulator (168 words) plus the G2 point, the line and
 // the tower temporaries per lane; that does not fit 256 VGPRs, so every Fq2 product round-trips its operands through
 // scratch and the kernels run at the scratch (L2 / Infinity Cache) bandwidth, not at the integer-VALU rate: two waves per
 // SIMD take 2.3x the time of one (measured), i.e. no latency is being hidden, the memory pipe is simply full.
 //
-// Shape: an Fq12 element f = (a0 + a1 v + a2 v^2) + (b0 + b1 v + b2 v^2) w is spread over lanes 0..2 of the quad, lane j
+// Shape: an Fq12 element f = (a0 + a1 v + a2 v^2) + (b0 + b1 v + b2 v^2) w is spread over the three lanes of a group, lane j
 // holding the Fq2 pair (a_j, b_j) = 56 words.  Every Fq6 product is Karatsuba ACROSS lanes: lane j forms its own product
-// x_j*y_j and one cross product, operands and results travel by DPP quad_perm moves (full rate, no LDS), so an Fq12
-// product is 6 dependent Fq2 products per lane instead of 18, a squaring 4 instead of 12, a sparse line product 5 instead
-// of 13, a cyclotomic squaring 2 instead of 6.  The G2 point R = (X, Y, Z) lives one coordinate per lane; a doubling
-// step is 3 four-lane product rounds (all four lanes busy in two of them), an addition step 4.  Lane 3 carries no part
-// of f; it is a fourth multiplier for the point arithmetic.
+// x_j*y_j and one cross product; operands and results travel by ds_bpermute_b32 (the LDS crossbar, no LDS storage; ~3 % of
+// the instructions), so an Fq12 product is 6 dependent Fq2 products per lane instead of 18, a squaring 4 instead of 12,
+// a sparse line product 5 instead of 13, a cyclotomic squaring 2 instead of 6.  The G2 point R = (X, Y, Z) lives one
+// coordinate per lane; a doubling step is 3 three-lane product rounds (+ the twist-constant product as two Fq products),
+// an addition step 5.  All three lanes work in every round.  (The first version used quads and DPP quad_perm with the
+// fourth lane as an extra multiplier for the point arithmetic: 16 pairings per wave instead of 21, and ROCm 7.2's
+// DPP-combine pass miscompiled the inlined addition step - see DESIGN.md section 5.)
+//
+// A product of k <= 4 pairs can run in ONE group with a shared accumulator (one squaring of f per iteration for all its
+// pairs, as ark-ec's multi-Miller loop does): miller_multi.  The engine picks it when there are enough products to fill
+// the chip and falls back to one group per pair + a GT product otherwise.
 //
 // Same field elements as ark-ec's bls12 engine at every step that is observable (Miller-loop value, GT value), so the
 // outputs stay bit-identical with pairing.h and with the oracle.  Two local formula changes keep lanes uniform:
 // h = 2YZ instead of (Y+Z)^2 - Y^2 - Z^2, and x/2 by an exact halving instead of a multiplication by 1/2.
 //
-// The algorithms are templates over a backend QB: QDev377 (device, DPP) and QHost377 (host, four explicit lanes) so the
+// The algorithms are templates over a backend QB: QTri377 (device) and QHost377 (host, three explicit lanes) so the
 // same code runs under the bounds-tracking host build (-DCELO_FP_TRACK, host_test.cpp) and against the oracle on the CPU.
 // Replaces the arithmetic behind crates/bls-crypto/src/bls/public.rs:102 and signature.rs:149 (product_of_pairings).
 #pragma once
@@ -25,15 +31,26 @@
 
 namespace celo {
 
-#define QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+// lane j of a group reads lane QP(..)[j] of the same group
+#define QP(a, b, c) ((a) | ((b) << 2) | ((c) << 4))
 
-// ================================================================== host backend: four explicit lanes
+// B' * x for the D-twist constant B' = (0, b1): (0 + b1 u)(x0 + x1 u) = -5 b1 x1 + b1 x0 u  (two Fq products)
+HD Fq2 twist_b_times(const Fq2& x) {
+  const Fq b1 = Fq::from_limbs(T377::TWIST_B_C1);
+  const Fq2 n = Fq2::norm(x);
+  const Fq p0 = Fq::mul(n.c0, b1), p1 = Fq::mul(n.c1, b1);
+  const Fq p5 = Fq::norm(Fq::add(Fq::dbl(Fq::dbl(p1)), p1));          // 5 b1 x1, vb 10
+  return {Fq::wred(Fq::norm(Fq::template neg<16, 1>(p5))), p0};
+}
+
+// ================================================================== host backend: three explicit lanes
 struct QHost377 {
-  struct V { Fq2 v[4]; };
-  struct F { Fq v[4]; };
-  template <class Fn> static V map2(const V& a, const V& b, Fn fn) { V r; for (int i = 0; i < 4; i++) r.v[i] = fn(a.v[i], b.v[i]); return r; }
-  template <class Fn> static V map1(const V& a, Fn fn) { V r; for (int i = 0; i < 4; i++) r.v[i] = fn(a.v[i]); return r; }
-  static V uni(const Fq2& x) { V r; for (int i = 0; i < 4; i++) r.v[i] = x; return r; }
+  static constexpr int NL = 3;
+  struct V { Fq2 v[NL]; };
+  struct F { Fq v[NL]; };
+  template <class Fn> static V map2(const V& a, const V& b, Fn fn) { V r; for (int i = 0; i < NL; i++) r.v[i] = fn(a.v[i], b.v[i]); return r; }
+  template <class Fn> static V map1(const V& a, Fn fn) { V r; for (int i = 0; i < NL; i++) r.v[i] = fn(a.v[i]); return r; }
+  static V uni(const Fq2& x) { V r; for (int i = 0; i < NL; i++) r.v[i] = x; return r; }
   static V mul(const V& a, const V& b) { return map2(a, b, [](const Fq2& x, const Fq2& y) { return Fq2::mul(x, y); }); }
   static V add(const V& a, const V& b) { return map2(a, b, [](const Fq2& x, const Fq2& y) { return Base377::add(x, y); }); }
   static V dbl(const V& a) { return map1(a, [](const Fq2& x) { return Base377::dbl(x); }); }
@@ -45,16 +62,17 @@ struct QHost377 {
   static V half(const V& a) { return map1(a, [](const Fq2& x) { return Fq2{Fq::half(x.c0), Fq::half(x.c1)}; }); }
   static V conj(const V& a) { return map1(a, [](const Fq2& x) { return Fq2{x.c0, Fq::wred(Fq::norm(Fq::neg<4, 1>(x.c1)))}; }); }
   static V inv(const V& a) { return map1(a, [](const Fq2& x) { return Fq2::inv(x); }); }
-  static V mul_fp(const V& a, const F& k) { V r; for (int i = 0; i < 4; i++) r.v[i] = Fq2::mul_fp(Fq2::norm(a.v[i]), k.v[i]); return r; }
-  template <int CTRL> static V perm(const V& x) { V r; for (int i = 0; i < 4; i++) r.v[i] = x.v[(CTRL >> (2 * i)) & 3]; return r; }
-  template <int K> static V bcast(const V& x) { return perm<QP(K, K, K, K)>(x); }
-  template <int K> static V sel(const V& onk, const V& other) { V r; for (int i = 0; i < 4; i++) r.v[i] = (i == K) ? onk.v[i] : other.v[i]; return r; }
-  static V pick(const V& a0, const V& a1, const V& a2, const V& a3) { V r; r.v[0] = a0.v[0]; r.v[1] = a1.v[1]; r.v[2] = a2.v[2]; r.v[3] = a3.v[3]; return r; }
+  static V mul_fp(const V& a, const F& k) { V r; for (int i = 0; i < NL; i++) r.v[i] = Fq2::mul_fp(Fq2::norm(a.v[i]), k.v[i]); return r; }
+  static V twist_mul(const V& a) { return map1(a, [](const Fq2& x) { return twist_b_times(x); }); }
+  template <int CTRL> static V perm(const V& x) { V r; for (int i = 0; i < NL; i++) r.v[i] = x.v[(CTRL >> (2 * i)) & 3]; return r; }
+  template <int K> static V bcast(const V& x) { return perm<QP(K, K, K)>(x); }
+  template <int K> static V sel(const V& onk, const V& other) { V r; for (int i = 0; i < NL; i++) r.v[i] = (i == K) ? onk.v[i] : other.v[i]; return r; }
+  static V pick(const V& a0, const V& a1, const V& a2) { V r; r.v[0] = a0.v[0]; r.v[1] = a1.v[1]; r.v[2] = a2.v[2]; return r; }
+  static F pickf(const F& a0, const F& a1, const F& a2) { F r; r.v[0] = a0.v[0]; r.v[1] = a1.v[1]; r.v[2] = a2.v[2]; return r; }
   static V zero() { return uni(Fq2::zero()); }
   static V one() { return uni(Fq2::one()); }
   static V constant(const uint32_t* c0, const uint32_t* c1) { return uni(f2_from(c0, c1)); }
-  static V twist_b() { return uni(Fq2{Fq::zero(), Fq::from_limbs(T377::TWIST_B_C1)}); }
-  // lanes 0..2 must all hold: a == (lane 0 ? 1 : 0) and b == 0
+  // all three lanes must hold: a == (lane 0 ? 1 : 0) and b == 0
   static bool is_one3(const V& a, const V& b) {
     bool ok = Base377::is_one(a.v[0]) && Base377::is_zero(b.v[0]);
     for (int i = 1; i < 3; i++) ok = ok && Base377::is_zero(a.v[i]) && Base377::is_zero(b.v[i]);
@@ -63,13 +81,15 @@ struct QHost377 {
 };
 
 #if defined(__HIPCC__)
-// ================================================================== device backend: DPP quad permutes
+// ================================================================== device backend: groups of three lanes, ds_bpermute
 #define QDEV __device__ __forceinline__
-struct QDev377 {
+struct QTri377 {
   typedef Fq2 V;
   typedef Fq F;
-  static constexpr int NW = 28;
-  QDEV static int lane() { return threadIdx.x & 3; }
+  static constexpr int NL = 3, GROUPS_PER_WAVE = 21;
+  QDEV static int wave_lane() { return (int)__lane_id(); }
+  QDEV static int group() { return (wave_lane() * 86) >> 8; }            // lane / 3 for lane < 64
+  QDEV static int lane() { return wave_lane() - 3 * group(); }          // lane % 3
   QDEV static V mul(const V& a, const V& b) { return Fq2::mul(a, b); }
   QDEV static V add(const V& a, const V& b) { return Base377::add(a, b); }
   QDEV static V dbl(const V& a) { return Base377::dbl(a); }
@@ -82,27 +102,22 @@ struct QDev377 {
   QDEV static V conj(const V& a) { return {a.c0, Fq::wred(Fq::norm(Fq::neg<4, 1>(a.c1)))}; }
   QDEV static V inv(const V& a) { return Fq2::inv(a); }
   QDEV static V mul_fp(const V& a, const F& k) { return Fq2::mul_fp(Fq2::norm(a), k); }
-  template <int CTRL> QDEV static uint32_t perm_word(uint32_t w) {
-#if defined(CELO_QUAD_BPERMUTE)
-    const int lane_id = (int)__lane_id();
-    const int src = (lane_id & ~3) | ((CTRL >> (2 * (lane_id & 3))) & 3);
-    return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)w);
-#elif defined(CELO_QUAD_UPDATE_DPP)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, CTRL, 0xF, 0xF, false);
-#else
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)w, CTRL, 0xF, 0xF, true);
-#endif
+  QDEV static V twist_mul(const V& a) { return twist_b_times(a); }
+  template <int CTRL> QDEV static int src_addr() {
+    const int j = lane();
+    return (wave_lane() - j + ((CTRL >> (2 * j)) & 3)) << 2;
   }
   template <int CTRL> QDEV static V perm(const V& x) {
+    const int addr = src_addr<CTRL>();
     V r;
 #pragma unroll
     for (int i = 0; i < 14; i++) {
-      r.c0.l[i] = perm_word<CTRL>(x.c0.l[i]);
-      r.c1.l[i] = perm_word<CTRL>(x.c1.l[i]);
+      r.c0.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)x.c0.l[i]);
+      r.c1.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)x.c1.l[i]);
     }
     return r;
   }
-  template <int K> QDEV static V bcast(const V& x) { return perm<QP(K, K, K, K)>(x); }
+  template <int K> QDEV static V bcast(const V& x) { return perm<QP(K, K, K)>(x); }
   template <int K> QDEV static V sel(const V& onk, const V& other) {
     const bool c = lane() == K;
     V r;
@@ -113,27 +128,31 @@ struct QDev377 {
     }
     return r;
   }
-  QDEV static V pick(const V& a0, const V& a1, const V& a2, const V& a3) {
+  QDEV static V pick(const V& a0, const V& a1, const V& a2) {
     const int q = lane();
     V r;
 #pragma unroll
     for (int i = 0; i < 14; i++) {
-      r.c0.l[i] = q == 0 ? a0.c0.l[i] : q == 1 ? a1.c0.l[i] : q == 2 ? a2.c0.l[i] : a3.c0.l[i];
-      r.c1.l[i] = q == 0 ? a0.c1.l[i] : q == 1 ? a1.c1.l[i] : q == 2 ? a2.c1.l[i] : a3.c1.l[i];
+      r.c0.l[i] = q == 0 ? a0.c0.l[i] : q == 1 ? a1.c0.l[i] : a2.c0.l[i];
+      r.c1.l[i] = q == 0 ? a0.c1.l[i] : q == 1 ? a1.c1.l[i] : a2.c1.l[i];
     }
+    return r;
+  }
+  QDEV static F pickf(const F& a0, const F& a1, const F& a2) {
+    const int q = lane();
+    F r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = q == 0 ? a0.l[i] : q == 1 ? a1.l[i] : a2.l[i];
     return r;
   }
   QDEV static V zero() { return Fq2::zero(); }
   QDEV static V one() { return Fq2::one(); }
   QDEV static V constant(const uint32_t* c0, const uint32_t* c1) { return f2_from(c0, c1); }
-  QDEV static V twist_b() { return {Fq::zero(), Fq::from_limbs(T377::TWIST_B_C1)}; }
   QDEV static bool is_one3(const V& a, const V& b) {
     const int q = lane();
-    bool ok = (q == 0 ? Base377::is_one(a) : Base377::is_zero(a)) && Base377::is_zero(b);
-    int v = (ok || q == 3) ? 1 : 0;
-    v &= __builtin_amdgcn_mov_dpp(v, QP(1, 0, 3, 2), 0xF, 0xF, true);
-    v &= __builtin_amdgcn_mov_dpp(v, QP(2, 3, 0, 1), 0xF, 0xF, true);
-    return v != 0;
+    const int ok = ((q == 0 ? Base377::is_one(a) : Base377::is_zero(a)) && Base377::is_zero(b)) ? 1 : 0;
+    const int base = (wave_lane() - q) << 2;
+    return (__builtin_amdgcn_ds_bpermute(base, ok) & __builtin_amdgcn_ds_bpermute(base + 4, ok) & __builtin_amdgcn_ds_bpermute(base + 8, ok)) != 0;
   }
 };
 #define QFN __host__ __device__ __forceinline__
@@ -143,7 +162,7 @@ struct QDev377 {
 #define QNI inline
 #endif
 
-// ================================================================== tower arithmetic, one Fq12 per quad
+// ================================================================== tower arithmetic, one Fq12 per lane group
 template <class QB> struct QTower {
   typedef typename QB::V V;
   struct E12 { V a, b; };  // lane j < 3: a = c0.c_j, b = c1.c_j (tower order of QuadIO: coefficient j and 3 + j)
@@ -151,7 +170,7 @@ template <class QB> struct QTower {
   QFN static E12 one12() { return {QB::template sel<0>(QB::one(), QB::zero()), QB::zero()}; }
   // multiplication of an Fq6 element (one coefficient per lane) by v: (xi*x2, x0, x1); needs vb <= 12, result vb <= 64
   QFN static V mul_by_gen(const V& x) {
-    V r = QB::template perm<QP(2, 0, 1, 3)>(x);
+    V r = QB::template perm<QP(2, 0, 1)>(x);
     return QB::template sel<0>(QB::mul_nr(r), r);
   }
   // Fq6 product, Karatsuba across lanes: lane j computes v_j = x_j y_j and the cross product it needs.  Inputs vb <= 40,
@@ -159,11 +178,11 @@ template <class QB> struct QTower {
   QFN static V mul6(const V& x, const V& y) {
     V v = QB::mul(x, y);
     // cross operands: lane 0 -> (1, 2), lane 1 -> (0, 1), lane 2 -> (0, 2)
-    V xs = QB::add(QB::template perm<QP(1, 0, 0, 3)>(x), QB::template perm<QP(2, 1, 2, 3)>(x));
-    V ys = QB::add(QB::template perm<QP(1, 0, 0, 3)>(y), QB::template perm<QP(2, 1, 2, 3)>(y));
+    V xs = QB::add(QB::template perm<QP(1, 0, 0)>(x), QB::template perm<QP(2, 1, 2)>(x));
+    V ys = QB::add(QB::template perm<QP(1, 0, 0)>(y), QB::template perm<QP(2, 1, 2)>(y));
     V c = QB::mul(xs, ys);
-    V t = QB::template sub<4>(QB::template sub<4>(c, QB::template perm<QP(1, 0, 0, 3)>(v)), QB::template perm<QP(2, 1, 2, 3)>(v));  // vb <= 11
-    V vr = QB::template perm<QP(0, 2, 1, 3)>(v);   // lane 0: v0, lane 1: v2, lane 2: v1
+    V t = QB::template sub<4>(QB::template sub<4>(c, QB::template perm<QP(1, 0, 0)>(v)), QB::template perm<QP(2, 1, 2)>(v));  // vb <= 11
+    V vr = QB::template perm<QP(0, 2, 1)>(v);   // lane 0: v0, lane 1: v2, lane 2: v1
     V w = QB::template sel<0>(t, vr);              // what xi multiplies on lanes 0 and 1
     V xw = QB::mul_nr(w);
     // z0 = v0 + xi (c12 - v1 - v2);  z1 = (c01 - v0 - v1) + xi v2;  z2 = (c02 - v0 - v2) + v1
@@ -188,13 +207,13 @@ template <class QB> struct QTower {
     return {QB::wred(c0), QB::wred(QB::dbl(ab))};
   }
   QFN static E12 conj12(const E12& x) { return {x.a, QB::wred(QB::template neg<4>(x.b))}; }
-  // x * (d0 + d1 v) for quad-uniform d0, d1: lane j: x_j d0 + x_{j-1} d1 (xi on the wrapped term of lane 0)
+  // x * (d0 + d1 v) for group-uniform d0, d1: lane j: x_j d0 + x_{j-1} d1 (xi on the wrapped term of lane 0)
   QFN static V mul6_by_01(const V& x, const V& d0, const V& d1) {
     V p = QB::mul(x, d0);
-    V qv = QB::mul(QB::template perm<QP(2, 0, 1, 3)>(x), d1);
+    V qv = QB::mul(QB::template perm<QP(2, 0, 1)>(x), d1);
     return QB::wred(QB::add(p, QB::template sel<0>(QB::mul_nr(qv), qv)));
   }
-  // f *= s0 + (s3 + s4 v) w   (ark-ff Fp12::mul_by_034), s* quad-uniform
+  // f *= s0 + (s3 + s4 v) w   (ark-ff Fp12::mul_by_034), s* group-uniform
   QFN static void mul_by_034(E12& f, const V& s0, const V& s3, const V& s4) {
     V A = QB::mul(f.a, s0);
     V b = mul6_by_01(f.b, s3, s4);
@@ -204,14 +223,14 @@ template <class QB> struct QTower {
   }
   // Granger-Scott cyclotomic squaring: lane k squares the Fq4 pair k: (a0, b1), (b0, a2), (a1, b2)
   QNI static E12 cyclotomic_sqr(const E12& f) {
-    V x = QB::template sel<1>(QB::template perm<QP(0, 0, 1, 3)>(f.b), QB::template perm<QP(0, 0, 1, 3)>(f.a));
-    V y = QB::template sel<1>(QB::template perm<QP(1, 2, 2, 3)>(f.a), QB::template perm<QP(1, 1, 2, 3)>(f.b));
+    V x = QB::template sel<1>(QB::template perm<QP(0, 0, 1)>(f.b), QB::template perm<QP(0, 0, 1)>(f.a));
+    V y = QB::template sel<1>(QB::template perm<QP(1, 2, 2)>(f.a), QB::template perm<QP(1, 1, 2)>(f.b));
     V tmp = QB::mul(x, y);
     V m = QB::mul(QB::add(x, y), QB::add(QB::mul_nr(y), x));
     V o0 = QB::wred(QB::template sub<64>(QB::template sub<4>(m, tmp), QB::mul_nr(tmp)));
     V o1 = QB::dbl(tmp);
     // a_j' = 3 o0 - 2 a_j on every lane;  b_j' = 3 u + 2 b_j with u = o1 of the previous lane (xi on the wrap to lane 0)
-    V u = QB::template perm<QP(2, 0, 1, 3)>(o1);
+    V u = QB::template perm<QP(2, 0, 1)>(o1);
     u = QB::template sel<0>(QB::wred(QB::mul_nr(u)), u);
     E12 z;
     z.a = QB::wred(QB::add(QB::dbl(QB::template sub<4>(o0, f.a)), o0));
@@ -221,9 +240,9 @@ template <class QB> struct QTower {
   // Fq6 inverse, coefficients one per lane (ark-ff Fp6::inverse)
   QFN static V inv6(const V& x) {
     V x0 = QB::template bcast<0>(x), x1 = QB::template bcast<1>(x), x2 = QB::template bcast<2>(x);
-    V sA = QB::pick(x0, x2, x1, x0);
+    V sA = QB::pick(x0, x2, x1);
     V s = QB::mul(sA, sA);                                     // x0^2, x2^2, x1^2
-    V m = QB::mul(QB::pick(x1, x0, x0, x0), QB::pick(x2, x1, x2, x2));  // x1 x2, x0 x1, x0 x2
+    V m = QB::mul(QB::pick(x1, x0, x0), QB::pick(x2, x1, x2));  // x1 x2, x0 x1, x0 x2
     // t0 = x0^2 - xi x1 x2;  t1 = xi x2^2 - x0 x1;  t2 = x1^2 - x0 x2
     V u1 = QB::template sel<1>(QB::mul_nr(s), s);
     V u2 = QB::template sel<0>(QB::mul_nr(m), m);
@@ -246,9 +265,9 @@ template <class QB> struct QTower {
   template <int I> QNI static E12 frob12(const E12& x) {
 #define QFC(k) QB::constant(T377::FROB##k##_C0, T377::FROB##k##_C1)
     V ca, cb;
-    if constexpr (I == 1) { ca = QB::pick(QB::one(), QFC(1_2), QFC(1_4), QB::one()); cb = QB::pick(QFC(1_1), QFC(1_3), QFC(1_5), QB::one()); }
-    else if constexpr (I == 2) { ca = QB::pick(QB::one(), QFC(2_2), QFC(2_4), QB::one()); cb = QB::pick(QFC(2_1), QFC(2_3), QFC(2_5), QB::one()); }
-    else { ca = QB::pick(QB::one(), QFC(3_2), QFC(3_4), QB::one()); cb = QB::pick(QFC(3_1), QFC(3_3), QFC(3_5), QB::one()); }
+    if constexpr (I == 1) { ca = QB::pick(QB::one(), QFC(1_2), QFC(1_4)); cb = QB::pick(QFC(1_1), QFC(1_3), QFC(1_5)); }
+    else if constexpr (I == 2) { ca = QB::pick(QB::one(), QFC(2_2), QFC(2_4)); cb = QB::pick(QFC(2_1), QFC(2_3), QFC(2_5)); }
+    else { ca = QB::pick(QB::one(), QFC(3_2), QFC(3_4)); cb = QB::pick(QFC(3_1), QFC(3_3), QFC(3_5)); }
 #undef QFC
     V a = (I & 1) ? QB::conj(x.a) : x.a, b = (I & 1) ? QB::conj(x.b) : x.b;
     return {QB::mul(a, ca), QB::mul(b, cb)};
@@ -262,24 +281,23 @@ template <class QB> struct QPairing377 {
   typedef typename QB::F F;
   typedef QTower<QB> TW;
   typedef typename TW::E12 E12;
-  struct Line { V c0, c1, c2; };  // quad-uniform
+  struct Line { V c0, c1, c2; };  // group-uniform
 
-  // ark-ec bls12/g2.rs doubling_step on R = (X, Y, Z), one coordinate per lane (lanes 0, 1, 2)
+  // ark-ec bls12/g2.rs doubling_step on R = (X, Y, Z), one coordinate per lane
   QFN static void double_step(V& Rc, Line& l) {
-    V r1 = QB::mul(QB::template perm<QP(0, 1, 2, 0)>(Rc), QB::template perm<QP(0, 1, 2, 1)>(Rc));  // X^2, Y^2, Z^2, XY
+    V r1 = QB::mul(Rc, Rc);                                           // X^2, Y^2, Z^2
     V b = QB::template bcast<1>(r1), c = QB::template bcast<2>(r1);
-    // round 2: lane 0: Y Z, lane 1: e = B' * 3c (lanes 2, 3 repeat lane 0)
-    V tb = QB::twist_b();
-    V r2 = QB::mul(QB::template sel<1>(tb, QB::template bcast<1>(Rc)), QB::template sel<1>(QB::tpl(c), QB::template bcast<2>(Rc)));
-    V e = QB::template bcast<1>(r2);
+    V e = QB::twist_mul(QB::tpl(c));                                  // B' * 3c: two Fq products, every lane
+    // round 2: lane 0: Y Z, lane 1: X Y, lane 2: e^2
+    V r2 = QB::mul(QB::pick(QB::template bcast<1>(Rc), QB::template bcast<0>(Rc), e), QB::pick(QB::template bcast<2>(Rc), QB::template bcast<1>(Rc), e));
     V h = QB::dbl(QB::template bcast<0>(r2));          // 2YZ = (Y+Z)^2 - (b + c); vb 6
     V f3 = QB::tpl(e);                                 // vb 9
     V g = QB::half(QB::add(b, f3));                    // vb 6.5
-    V a = QB::half(QB::template bcast<3>(r1));         // XY / 2
+    V a = QB::half(QB::template bcast<1>(r2));         // XY / 2
     V i = QB::template sub<4>(e, b);
-    // round 3: lane 0: a (b - f3) = X', lane 1: g^2, lane 2: b h = Z', lane 3: e^2
-    V r3 = QB::mul(QB::pick(a, g, b, e), QB::pick(QB::template sub<16>(b, f3), g, h, e));
-    V e2 = QB::template perm<QP(0, 3, 2, 3)>(r3);
+    V e2 = QB::template bcast<2>(r2);
+    // round 3: lane 0: a (b - f3) = X', lane 1: g^2, lane 2: b h = Z'
+    V r3 = QB::mul(QB::pick(a, g, b), QB::pick(QB::template sub<16>(b, f3), g, h));
     V y3 = QB::wred(QB::template sub<16>(r3, QB::tpl(e2)));   // lane 1: g^2 - 3 e^2
     Rc = QB::template sel<1>(y3, r3);
     l.c0 = QB::wred(QB::template neg<16>(h));
@@ -292,37 +310,62 @@ template <class QB> struct QPairing377 {
     V qx = QB::template bcast<0>(Qc), qy = QB::template bcast<1>(Qc);
     V r1 = QB::mul(QB::template sel<0>(qy, qx), Z);                       // lane 0: qy Z, others: qx Z
     V theta = QB::template sub<4>(Y, QB::template bcast<0>(r1)), lambda = QB::template sub<4>(X, QB::template bcast<1>(r1));
-    V r2 = QB::mul(QB::pick(theta, lambda, theta, lambda), QB::pick(theta, lambda, qx, qy));  // c, d, theta qx, lambda qy
+    V r2 = QB::mul(QB::pick(theta, lambda, theta), QB::pick(theta, lambda, qx));  // c = theta^2, d = lambda^2, theta qx
     V c = QB::template bcast<0>(r2), d = QB::template bcast<1>(r2);
-    l.c2 = QB::wred(QB::template sub<4>(QB::template bcast<2>(r2), QB::template bcast<3>(r2)));
-    V r3 = QB::mul(QB::pick(lambda, Z, X, X), QB::pick(d, c, d, d));      // e, f, g
+    V r3 = QB::mul(QB::pick(lambda, Z, X), QB::pick(d, c, d));            // e, f, g
     V e = QB::template bcast<0>(r3), g = QB::template bcast<2>(r3);
     V h = QB::template sub<8>(QB::add(e, QB::template bcast<1>(r3)), QB::dbl(g));  // vb 14
-    // lane 0: lambda h = X', lane 1: theta (g - h), lane 2: Z e = Z', lane 3: e Y
-    V r4 = QB::mul(QB::pick(lambda, theta, Z, e), QB::pick(h, QB::template sub<16>(g, h), e, Y));
-    V y3 = QB::wred(QB::template sub<4>(r4, QB::template perm<QP(0, 3, 2, 3)>(r4)));
-    Rc = QB::template sel<1>(y3, r4);
+    // round 4: lane 0: lambda qy, lane 1: e Y, lane 2: Z e = Z'
+    V r4 = QB::mul(QB::pick(lambda, e, Z), QB::pick(qy, Y, e));
+    l.c2 = QB::wred(QB::template sub<4>(QB::template bcast<2>(r2), QB::template bcast<0>(r4)));
+    // round 5: lane 0: lambda h = X', lane 1: theta (g - h)
+    V r5 = QB::mul(QB::template sel<0>(lambda, theta), QB::template sel<0>(h, QB::template sub<16>(g, h)));
+    V y3 = QB::wred(QB::template sub<4>(r5, r4));                         // lane 1: theta (g - h) - e Y
+    Rc = QB::pick(r5, y3, r4);
     l.c0 = QB::wred(lambda);
     l.c1 = QB::wred(QB::template neg<8>(theta));
   }
-  QNI static void ell(E12& f, const Line& l, const F& px, const F& py) {
-    TW::mul_by_034(f, QB::mul_fp(l.c0, py), QB::mul_fp(l.c1, px), l.c2);
+  // f *= line evaluated at P (D-twist: c0 *= P.y, c1 *= P.x): lane 0 scales c0, lane 1 scales c1, then both are broadcast
+  QFN static void ell(E12& f, const Line& l, const F& px, const F& py) {
+    V t = QB::mul_fp(QB::template sel<0>(l.c0, l.c1), QB::pickf(py, px, px));
+    TW::mul_by_034(f, QB::template bcast<0>(t), QB::template bcast<1>(t), l.c2);
   }
-  // f_{x,Q}(P): Qc lane 0 = Q.x, lane 1 = Q.y (clean values); px, py quad-uniform
+  QNI static void step_double(V& Rc, E12& f, const F& px, const F& py) { Line l; double_step(Rc, l); ell(f, l, px, py); }
+  QNI static void step_add(V& Rc, const V& Qc, E12& f, const F& px, const F& py) { Line l; add_step(Rc, Qc, l); ell(f, l, px, py); }
+  // f_{x,Q}(P): Qc lane 0 = Q.x, lane 1 = Q.y (clean values); px, py group-uniform
   QFN static E12 miller(const F& px, const F& py, const V& Qc) {
     V Rc = QB::template sel<2>(QB::one(), Qc);
     E12 f = TW::one12();
-    Line l;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
     for (int i = 62; i >= 0; i--) {
       f = TW::sqr12(f);
-      double_step(Rc, l);
-      ell(f, l, px, py);
+      step_double(Rc, f, px, py);
+      if ((T377::X >> i) & 1) step_add(Rc, Qc, f, px, py);
+    }
+    return f;
+  }
+  // Miller value of a whole product of k <= MAXK pairs with ONE accumulator (ark-ec's multi-Miller loop: f is squared once per
+  // iteration for all pairs).  px/py/Qc as in miller(), one entry per pair.
+  template <int MAXK> QFN static E12 miller_multi(int k, const F* px, const F* py, const V* Qc) {
+    V Rc[MAXK];
+    for (int p = 0; p < k; p++) Rc[p] = QB::template sel<2>(QB::one(), Qc[p]);
+    E12 f = TW::one12();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = 62; i >= 0; i--) {
+      f = TW::sqr12(f);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+      for (int p = 0; p < k; p++) step_double(Rc[p], f, px[p], py[p]);
       if ((T377::X >> i) & 1) {
-        add_step(Rc, Qc, l);
-        ell(f, l, px, py);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int p = 0; p < k; p++) step_add(Rc[p], Qc[p], f, px[p], py[p]);
       }
     }
     return f;

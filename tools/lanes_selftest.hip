@@ -1,13 +1,13 @@
 // Device self-test of the lane-parallel pairing pieces against the one-lane twins (both on the GPU).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Icelo-bls-snark-rs_amd/csrc -o tools/quad_selftest tools/quad_selftest.hip
-#include "pairing_quad_kernels.h"
+// build: make -C celo-bls-snark-rs_amd/csrc ../build/lanes_selftest
+#include "pairing_lanes_kernels.h"
 #include <vector>
 #include <cstring>
 using namespace celo;
 
 // op 0: mul12, 1: sqr12, 2: cyclotomic, 3: mul_by_034 (s from y's first three coefficients), 4: inv12, 5: frob1, 6: conj, 7: identity (load/store)
 __global__ void k_quad_op(int op, const uint32_t* x, const uint32_t* y, uint32_t* out) {
-  QTow::E12 a = quad_load(x), b = quad_load(y), r;
+  QTow::E12 a = lanes_load(x), b = lanes_load(y), r;
   switch (op) {
     case 0: r = QTow::mul12(a, b); break;
     case 1: r = QTow::sqr12(a); break;
@@ -18,7 +18,7 @@ __global__ void k_quad_op(int op, const uint32_t* x, const uint32_t* y, uint32_t
     case 6: r = QTow::conj12(a); break;
     default: r = a; break;
   }
-  quad_store(out, r);
+  lanes_store(out, r);
 }
 __global__ void k_lane_op(int op, const uint32_t* x, const uint32_t* y, uint32_t* out) {
   Fq12 a = f12_load(x), b = f12_load(y), r;
@@ -38,18 +38,18 @@ __global__ void k_lane_op(int op, const uint32_t* x, const uint32_t* y, uint32_t
   for (int i = 0; i < 72; i++) ((uint64_t*)out)[i] = tmp[i];
 }
 __global__ void k_quad_canon(const uint32_t* in, uint64_t* out) {
-  QTow::E12 r = quad_load(in);
-  int q = threadIdx.x & 3;
-  if (q < 3) { r.a.to_ark(out + 12 * q); r.b.to_ark(out + 12 * (3 + q)); }
+  QTow::E12 r = lanes_load(in);
+  int q = QTri377::lane();
+  r.a.to_ark(out + 12 * q); r.b.to_ark(out + 12 * (3 + q));
 }
 // point steps: in: R (3 Fq2 at x, x+32, x+64), Q (y, y+32); out: R' (3 Fq2) then line (3 Fq2) as ark u64 (6*12)
 __global__ void k_quad_step(int add, const uint32_t* x, const uint32_t* y, uint64_t* out) {
-  int q = threadIdx.x & 3;
-  Fq2 Rc = Fq2::load(x + 32 * (q < 3 ? q : 0));
+  int q = QTri377::lane();
+  Fq2 Rc = Fq2::load(x + 32 * q);
   Fq2 Qc = Fq2::load(y + 32 * (q & 1));
   QPair::Line l;
   if (add) QPair::add_step(Rc, Qc, l); else QPair::double_step(Rc, l);
-  if (q < 3) Rc.to_ark(out + 12 * q);
+  Rc.to_ark(out + 12 * q);
   if (q == 0) { l.c0.to_ark(out + 36); l.c1.to_ark(out + 48); l.c2.to_ark(out + 60); }
 }
 __global__ void k_lane_step(int add, const uint32_t* x, const uint32_t* y, uint64_t* out) {
@@ -74,20 +74,19 @@ __global__ void k_fill(uint32_t* x, uint64_t seed) {  // six pseudo-random Fq2 (
 }
 // truncated Miller loops: `iters` top iterations of the loop, quad vs one-lane
 __global__ void k_quad_miller(int iters, const uint32_t* x, const uint32_t* y, uint32_t* out) {
-  int q = threadIdx.x & 3;
+  int q = QTri377::lane();
   Fq px = Fq::load(x), py = Fq::load(x + 16);
   Fq2 Qc = Fq2::load(y + 32 * (q & 1));
-  Fq2 Rc = QDev377::sel<2>(QDev377::one(), Qc);
+  Fq2 Rc = QTri377::sel<2>(QTri377::one(), Qc);
   QTow::E12 f = QTow::one12();
   QPair::Line l;
 #pragma unroll 1
   for (int i = 62; i > 62 - iters; i--) {
     f = QTow::sqr12(f);
-    QPair::double_step(Rc, l);
-    QPair::ell(f, l, px, py);
-    if ((T377::X >> i) & 1) { QPair::add_step(Rc, Qc, l); QPair::ell(f, l, px, py); }
+    QPair::step_double(Rc, f, px, py);
+    if ((T377::X >> i) & 1) QPair::step_add(Rc, Qc, f, px, py);
   }
-  quad_store(out, f);
+  lanes_store(out, f);
 }
 __global__ void k_lane_miller(int iters, const uint32_t* x, const uint32_t* y, uint64_t* out) {
   Fq px = Fq::load(x), py = Fq::load(x + 16);
@@ -111,8 +110,8 @@ int main() {
   int bad = 0;
   const char* names[] = {"mul12", "sqr12", "cyclotomic", "mul_by_034", "inv12", "frob1", "conj", "identity"};
   for (int op = 0; op < 8; op++) {
-    k_quad_op<<<1, 4>>>(op, x, y, oq);
-    k_quad_canon<<<1, 4>>>(oq, c1);
+    k_quad_op<<<1, 3>>>(op, x, y, oq);
+    k_quad_canon<<<1, 3>>>(oq, c1);
     k_lane_op<<<1, 1>>>(op, x, y, (uint32_t*)c2);
     std::vector<uint64_t> a(72), b(72);
     hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost); hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost);
@@ -121,7 +120,7 @@ int main() {
     if (!ok) { bad++; for (int c = 0; c < 6; c++) printf("   coeff %d: %s\n", c, memcmp(a.data() + 12 * c, b.data() + 12 * c, 96) ? "diff" : "same"); }
   }
   for (int add = 0; add < 2; add++) {
-    k_quad_step<<<1, 4>>>(add, x, y, c1);
+    k_quad_step<<<1, 3>>>(add, x, y, c1);
     k_lane_step<<<1, 1>>>(add, x, y, c2);
     std::vector<uint64_t> a(72), b(72);
     hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost); hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost);
@@ -130,8 +129,8 @@ int main() {
     if (!ok) { bad++; const char* nm[] = {"X", "Y", "Z", "l.c0", "l.c1", "l.c2"}; for (int c = 0; c < 6; c++) printf("   %s: %s\n", nm[c], memcmp(a.data() + 12 * c, b.data() + 12 * c, 96) ? "diff" : "same"); }
   }
   for (int iters : {1, 2, 3, 5, 8, 63}) {
-    k_quad_miller<<<1, 4>>>(iters, x, y, oq);
-    k_quad_canon<<<1, 4>>>(oq, c1);
+    k_quad_miller<<<1, 3>>>(iters, x, y, oq);
+    k_quad_canon<<<1, 3>>>(oq, c1);
     k_lane_miller<<<1, 1>>>(iters, x, y, c2);
     std::vector<uint64_t> a(72), b(72);
     hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost); hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost);

@@ -163,6 +163,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(bases, sc, n, result if world == 1 else None)
         if world == 1 and not args.no_pairing:
             line["pairing"] = pairing_leg(ffi, codec, check_oracle=not args.no_cpu_baseline)
+            line["ntt"] = ntt_leg(ffi, check_oracle=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -239,6 +240,41 @@ def pairing_leg(ffi, codec, check_oracle=True):
             "products": m, "device_ms": tm["total_ms"], "wall_ms_incl_pcie": dt * 1e3, "miller_ms": tm["miller_ms"],
             "final_exp_ms": tm["final_exp_ms"], "bytes_per_miller_loop": 288, "cpu_port_miller_loops_per_s_1core": cpu_rate,
             "accept_vector_matches_oracle": ok if check_oracle else None, "accept_vector_as_constructed": got.tolist() == expect}
+
+
+def ntt_leg(ffi, check_oracle=True):
+    """Third leg (the prover's witness-map FFTs): one 2^20-point NTT over Fr(BW6-761), data resident
+    in HBM.  Algorithmic bytes: one 48-B read + one 48-B write per element; algorithmic work: (n/2) log2 n field products."""
+    from oracle import cpu_oracle as co
+    from oracle.py import ntt as ontt, ecc
+    log_n = 20
+    n = 1 << log_n
+    w_int = ontt.root_of_unity(log_n)
+    w = co.to_mont([w_int], ecc.Q377)[0]
+    x = np.random.default_rng(0x5EED0006).integers(0, 1 << 62, size=(n, 6), dtype=np.int64)
+    x[:, 5] &= (1 << 56) - 1
+    d = torch.from_numpy(x).cuda()
+    ffi.ntt_dev(d.data_ptr(), log_n, w)               # warm-up: builds the twiddle table
+    best = None
+    for _ in range(5):
+        ffi.ntt_dev(d.data_ptr(), log_n, w)
+        tm = ffi.ntt_timings()
+        if best is None or tm["total_ms"] < best["total_ms"]:
+            best = tm
+    secs = best["total_ms"] * 1e-3
+    res = {"metric": "Fr(BW6-761) NTT elements/s (2^20 points, forward, in place)", "value": n / secs, "device_ms": best["total_ms"],
+           "butterfly_passes": best["passes"], "alg_GBps": n * 96 / secs / 1e9, "hbm_frac": n * 96 / secs / 1e9 / 8000.0,
+           "field_products_per_s": (n // 2) * log_n / secs, "valu_frac": (n // 2) * log_n / secs / 78e9}
+    if check_oracle:
+        m = 1 << 16                                   # parity + CPU rate on a 2^16 sample of the same data
+        wm = ontt.root_of_unity(16)
+        xs = np.ascontiguousarray(x[:m]).view(np.uint64)
+        cpu_secs = co.time_ntt_fq377(xs, 16, wm)
+        ok = np.array_equal(ffi.ntt(xs, 16, co.to_mont([wm], ecc.Q377)[0]), co.ntt_fq377(xs, 16, wm))
+        if not ok:
+            raise SystemExit("PARITY FAILURE: GPU NTT != oracle NTT")
+        res.update({"cpu_port_elements_per_s_1core": m / cpu_secs, "parity_2p16_vs_oracle": ok})
+    return res
 
 
 if __name__ == "__main__":

@@ -29,6 +29,8 @@ int api_ensure_init() {
 DECL(g1_377) DECL(g2_377) DECL(761)
 int pairing_run_377(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
 int pairing_timings_377(float*);
+int ntt_run(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const uint64_t*, int, void*);
+int ntt_timings(float*, int*);
 int pairing_run_761(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
 }  // namespace celo
 using namespace celo;
@@ -89,6 +91,14 @@ int celo_amd_pairing_gt_bw6_761(const uint64_t* g1, const uint8_t* inf1, const u
   return pairing_run_761(g1, inf1, g2, inf2, offsets, m, nullptr, gt72, miller_only ? 1 : 0);
 }
 int celo_amd_pairing_last_timings(float ms[4]) { return pairing_timings_377(ms); }
+int ntt_bw6_761_fr(uint64_t* data, unsigned log_n, const uint64_t omega[6], const uint64_t* coset, int coset_after, const uint64_t* scale) {
+  return ntt_run(data, log_n, omega, coset, coset_after, scale, 0, nullptr);
+}
+int ntt_bw6_761_fr_dev(uint64_t* d_data, unsigned log_n, const uint64_t omega[6], const uint64_t* coset, int coset_after, const uint64_t* scale,
+                       void* hip_stream) {
+  return ntt_run(d_data, log_n, omega, coset, coset_after, scale, 1, hip_stream);
+}
+int celo_amd_ntt_last_timings(float ms[4], int* passes) { return ntt_timings(ms, passes); }
 int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]) {
   switch (group) {
     case 0: return msm_timings_g1_377(ms, cfg);

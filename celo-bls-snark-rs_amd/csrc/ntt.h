@@ -1,0 +1,257 @@
+// Radix-2 number-theoretic transform over Fr(BW6-761) = Fq(BLS12-377) (377 bits, 2-adicity 46) for gfx950.
+//
+// Replaces ark-poly 0.1's Radix2EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place (un-vendored dependency,
+// Cargo.lock:213-215) as used by ark-groth16's witness map inside create_proof_no_zk, which the reference calls at
+// crates/epoch-snark/src/api/prover.rs:78,112 - SURVEY.md section 8f row f3, the step before the prover's MSMs.
+// The caller hands over the domain generator (and coset generator / n^-1 when it wants them applied), so no arkworks
+// constant is restated here.
+//
+// Shape (HBM-bound work: 64-B elements, one multiplication per butterfly):
+//   k_ntt_load   arkworks Montgomery (48 B) -> 28-bit-limb device form (64 B), optional coset pre-scaling x_i *= g^i
+//   k_ntt_pass   decimation-in-frequency, in place, THREE butterfly levels per launch: a lane loads 8 elements spaced by
+//                the lowest level's distance, runs 12 butterflies in registers, stores them back; log2(n)/3 passes over the
+//                array instead of log2(n).  Loads and stores are 64-B vectors, consecutive lanes touch consecutive elements.
+//   k_ntt_store  bit-reversal gather, optional coset post-scaling x_i *= g^i and final scale, -> arkworks Montgomery
+// Twiddles: one table W[k] = omega^k, k < n/2, in device form, built once per (omega, n) from two 1024-entry power
+// tables and kept by the engine (32 MB at 2^20: stays in the Infinity Cache across passes).
+#pragma once
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#endif
+#include <cstdio>
+#include <cstring>
+#include "fp.h"
+#include "fp_consts.h"
+
+namespace celo {
+
+typedef Fp<P377> Fr761;   // the scalar field of BW6-761 is the base field of BLS12-377
+constexpr int NTT_WORDS = 16;   // 14 limbs padded to 16 words: 64-B elements, uint4 loads/stores
+
+#if defined(__HIPCC__)
+// pw[i] = base^(i * stride) for i < 1024 (one lane each: square-and-multiply over the 10 bits of i)
+__global__ void __launch_bounds__(256) k_ntt_powers(const uint32_t* __restrict__ base_dev, uint32_t* __restrict__ pw) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 1024) return;
+  const Fr761 b = Fr761::load(base_dev);
+  Fr761 acc = Fr761::one();
+  for (int bit = 9; bit >= 0; bit--) {
+    acc = Fr761::sqr(acc);
+    if ((i >> bit) & 1) acc = Fr761::mul(acc, b);
+  }
+  Fr761::wred(acc).store(pw + (size_t)i * NTT_WORDS);
+}
+// out[k] = lo[k & 1023] * hi[k >> 10]   (lo = base^i, hi = base^(1024 i)); used for the twiddle table and coset powers
+__global__ void __launch_bounds__(256) k_ntt_table(const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi,
+                                                   uint32_t* __restrict__ out, uint32_t count) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  Fr761 v = Fr761::load(lo + (size_t)(k & 1023) * NTT_WORDS);
+  if (count > 1024) v = Fr761::mul(v, Fr761::load(hi + (size_t)(k >> 10) * NTT_WORDS));
+  Fr761::wred(v).store(out + (size_t)k * NTT_WORDS);
+}
+__global__ void __launch_bounds__(256) k_ntt_load(const uint64_t* __restrict__ ark, uint32_t* __restrict__ work, uint32_t n,
+                                                  const uint32_t* __restrict__ glo, const uint32_t* __restrict__ ghi) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr761 v = Fr761::from_ark(ark + (size_t)i * 6);
+  if (glo) {
+    v = Fr761::mul(v, Fr761::load(glo + (size_t)(i & 1023) * NTT_WORDS));
+    if (n > 1024) v = Fr761::mul(v, Fr761::load(ghi + (size_t)(i >> 10) * NTT_WORDS));
+  }
+  Fr761::wred(v).store(work + (size_t)i * NTT_WORDS);
+}
+// one decimation-in-frequency butterfly: (x, y) <- (x + y, (x - y) * omega^k)
+__device__ __forceinline__ void ntt_bf(Fr761& x, Fr761& y, uint32_t k, const uint32_t* __restrict__ tw) {
+  const Fr761 u = x, v = y;
+  x = Fr761::wred(Fr761::add(u, v));
+  const Fr761 d = Fr761::template sub<4, 1>(u, v);
+  y = Fr761::mul(d, Fr761::load(tw + (size_t)k * NTT_WORDS));     // tw[0] = 1
+}
+// R butterfly levels s_hi, s_hi-1, .., s_hi-R+1 (level s pairs i and i + 2^s) on 2^R elements per lane.  The elements are
+// named scalars (not an array) so that they stay in VGPRs; local bit b of the element number <-> global level s_lo + b, and the
+// twiddle exponent of a butterfly whose upper element has global index i is (i mod 2^s) * n / 2^(s+1).
+template <int R>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_ntt_pass(uint32_t* __restrict__ work, const uint32_t* __restrict__ tw, uint32_t log_n, int s_hi) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = 1u << log_n;
+  if (t >= (n >> R)) return;
+  const int s_lo = s_hi - R + 1;
+  const uint32_t m = 1u << s_lo;
+  const uint32_t low = t & (m - 1);
+  uint32_t* const p0 = work + ((size_t)(t >> s_lo) * ((size_t)m << R) + low) * NTT_WORDS;
+  const size_t st = (size_t)m * NTT_WORDS;
+#define NTT_K(j, lvl) ((low + ((uint32_t)((j) & ((1 << (lvl)) - 1)) << s_lo)) << (log_n - 1 - (uint32_t)(s_lo + (lvl))))
+  if constexpr (R == 3) {
+    Fr761 a0 = Fr761::load(p0), a1 = Fr761::load(p0 + st), a2 = Fr761::load(p0 + 2 * st), a3 = Fr761::load(p0 + 3 * st);
+    Fr761 a4 = Fr761::load(p0 + 4 * st), a5 = Fr761::load(p0 + 5 * st), a6 = Fr761::load(p0 + 6 * st), a7 = Fr761::load(p0 + 7 * st);
+    ntt_bf(a0, a4, NTT_K(0, 2), tw); ntt_bf(a1, a5, NTT_K(1, 2), tw); ntt_bf(a2, a6, NTT_K(2, 2), tw); ntt_bf(a3, a7, NTT_K(3, 2), tw);
+    ntt_bf(a0, a2, NTT_K(0, 1), tw); ntt_bf(a1, a3, NTT_K(1, 1), tw); ntt_bf(a4, a6, NTT_K(4, 1), tw); ntt_bf(a5, a7, NTT_K(5, 1), tw);
+    ntt_bf(a0, a1, NTT_K(0, 0), tw); ntt_bf(a2, a3, NTT_K(2, 0), tw); ntt_bf(a4, a5, NTT_K(4, 0), tw); ntt_bf(a6, a7, NTT_K(6, 0), tw);
+    a0.store(p0); a1.store(p0 + st); a2.store(p0 + 2 * st); a3.store(p0 + 3 * st);
+    a4.store(p0 + 4 * st); a5.store(p0 + 5 * st); a6.store(p0 + 6 * st); a7.store(p0 + 7 * st);
+  } else if constexpr (R == 2) {
+    Fr761 a0 = Fr761::load(p0), a1 = Fr761::load(p0 + st), a2 = Fr761::load(p0 + 2 * st), a3 = Fr761::load(p0 + 3 * st);
+    ntt_bf(a0, a2, NTT_K(0, 1), tw); ntt_bf(a1, a3, NTT_K(1, 1), tw);
+    ntt_bf(a0, a1, NTT_K(0, 0), tw); ntt_bf(a2, a3, NTT_K(2, 0), tw);
+    a0.store(p0); a1.store(p0 + st); a2.store(p0 + 2 * st); a3.store(p0 + 3 * st);
+  } else {
+    Fr761 a0 = Fr761::load(p0), a1 = Fr761::load(p0 + st);
+    ntt_bf(a0, a1, NTT_K(0, 0), tw);
+    a0.store(p0); a1.store(p0 + st);
+  }
+#undef NTT_K
+}
+__global__ void __launch_bounds__(256) k_ntt_store(const uint32_t* __restrict__ work, uint64_t* __restrict__ ark, uint32_t log_n,
+                                                   const uint32_t* __restrict__ glo, const uint32_t* __restrict__ ghi,
+                                                   const uint32_t* __restrict__ scale_dev) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = 1u << log_n;
+  if (i >= n) return;
+  const uint32_t r = log_n ? (__brev(i) >> (32 - log_n)) : 0;
+  Fr761 v = Fr761::load(work + (size_t)r * NTT_WORDS);
+  if (glo) {
+    v = Fr761::mul(v, Fr761::load(glo + (size_t)(i & 1023) * NTT_WORDS));
+    if (n > 1024) v = Fr761::mul(v, Fr761::load(ghi + (size_t)(i >> 10) * NTT_WORDS));
+  }
+  if (scale_dev) v = Fr761::mul(v, Fr761::load(scale_dev));
+  v.to_ark(ark + (size_t)i * 6);
+}
+
+#define NTT_HIP_OK(x)                                                                                           \
+  do {                                                                                                          \
+    hipError_t e_ = (x);                                                                                        \
+    if (e_ != hipSuccess) {                                                                                     \
+      fprintf(stderr, "[celo-amd] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);         \
+      return 1;                                                                                                 \
+    }                                                                                                           \
+  } while (0)
+
+struct NttTimings { float load = 0, passes = 0, store = 0, total = 0; int npasses = 0; };
+
+class NttEngine {
+ public:
+  ~NttEngine() { release(); }
+  void release() {
+    for (void** p : {(void**)&d_work, (void**)&d_tw, (void**)&d_small, (void**)&d_io}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    cap_work = cap_tw = cap_io = 0; tw_log_n = 0;
+    for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
+  }
+  NttTimings tm;
+  int max_radix_log2 = 3;   // butterfly levels per pass (tuning hook: 1..3)
+  // data_dev: n = 2^log_n elements, arkworks Montgomery, DEVICE memory, transformed in place.
+  // omega: domain generator of order n (its inverse for an inverse transform).  coset: nullptr or g: x_i *= g^i before
+  // (coset_after = 0) or after (1) the transform.  scale: nullptr or a factor applied to every output (n^-1).
+  int run_device(uint64_t* data_dev, unsigned log_n, const uint64_t* omega6, const uint64_t* coset6, int coset_after, const uint64_t* scale6,
+                 hipStream_t stream) {
+    if (log_n > 28) return 2;
+    const uint32_t n = 1u << log_n;
+    if (prepare(log_n, omega6, coset6, scale6, stream)) return 1;
+    uint32_t* glo = coset6 ? small(2) : nullptr;
+    uint32_t* ghi = coset6 ? small(3) : nullptr;
+    NTT_HIP_OK(hipEventRecord(ev[0], stream));
+    hipLaunchKernelGGL(k_ntt_load, dim3((n + 255) / 256), dim3(256), 0, stream, data_dev, d_work, n, (coset6 && !coset_after) ? glo : nullptr, ghi);
+    NTT_HIP_OK(hipEventRecord(ev[1], stream));
+    int s = (int)log_n - 1, np = 0;
+    while (s >= 0) {
+      const int r = s + 1 >= max_radix_log2 ? max_radix_log2 : s + 1;
+      const uint32_t threads = n >> r;
+      if (r == 3) hipLaunchKernelGGL((k_ntt_pass<3>), dim3((threads + 255) / 256), dim3(256), 0, stream, d_work, d_tw, log_n, s);
+      else if (r == 2) hipLaunchKernelGGL((k_ntt_pass<2>), dim3((threads + 255) / 256), dim3(256), 0, stream, d_work, d_tw, log_n, s);
+      else hipLaunchKernelGGL((k_ntt_pass<1>), dim3((threads + 255) / 256), dim3(256), 0, stream, d_work, d_tw, log_n, s);
+      s -= r; np++;
+    }
+    NTT_HIP_OK(hipEventRecord(ev[2], stream));
+    hipLaunchKernelGGL(k_ntt_store, dim3((n + 255) / 256), dim3(256), 0, stream, d_work, data_dev, log_n, (coset6 && coset_after) ? glo : nullptr, ghi,
+                       scale6 ? small(4) : nullptr);
+    NTT_HIP_OK(hipEventRecord(ev[3], stream));
+    NTT_HIP_OK(hipStreamSynchronize(stream));
+    NTT_HIP_OK(hipGetLastError());
+    (void)hipEventElapsedTime(&tm.load, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&tm.passes, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&tm.store, ev[2], ev[3]);
+    (void)hipEventElapsedTime(&tm.total, ev[0], ev[3]);
+    tm.npasses = np;
+    return 0;
+  }
+  int run_host(uint64_t* data, unsigned log_n, const uint64_t* omega6, const uint64_t* coset6, int coset_after, const uint64_t* scale6,
+               hipStream_t stream) {
+    if (log_n > 28) return 2;
+    const size_t bytes = ((size_t)48) << log_n;
+    if (bytes > cap_io) {
+      if (d_io) (void)hipFree(d_io);
+      d_io = nullptr; cap_io = 0;
+      NTT_HIP_OK(hipMalloc(&d_io, bytes));
+      cap_io = bytes;
+    }
+    NTT_HIP_OK(hipMemcpyAsync(d_io, data, bytes, hipMemcpyHostToDevice, stream));
+    if (int rc = run_device(d_io, log_n, omega6, coset6, coset_after, scale6, stream)) return rc;
+    NTT_HIP_OK(hipMemcpy(data, d_io, bytes, hipMemcpyDeviceToHost));
+    return 0;
+  }
+
+ private:
+  uint32_t* d_work = nullptr; size_t cap_work = 0;
+  uint32_t* d_tw = nullptr; size_t cap_tw = 0;
+  uint32_t* d_small = nullptr;       // 5 x 1024 elements: twiddle lo/hi power tables, coset lo/hi power tables, [4][0] = scale
+  uint64_t* d_io = nullptr; size_t cap_io = 0;
+  unsigned tw_log_n = 0; uint64_t tw_omega[6] = {0, 0, 0, 0, 0, 0};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* small(int i) { return d_small + (size_t)i * 1024 * NTT_WORDS; }
+
+  // device-form copy of an arkworks-Montgomery element: done on the host with the same templates
+  static void to_dev_words(const uint64_t* ark6, uint32_t* w16) {
+    Fr761 v = Fr761::wred(Fr761::from_ark(ark6));
+    memset(w16, 0, NTT_WORDS * 4);
+    v.store(w16);
+  }
+  static Fr761 host_pow1024(Fr761 b) { for (int i = 0; i < 10; i++) b = Fr761::sqr(b); return Fr761::wred(b); }
+  int upload_pair(const uint64_t* ark6, int slot_lo, int slot_hi, hipStream_t stream) {  // small(slot_lo)[i] = b^i, small(slot_hi)[i] = b^(1024 i)
+    uint32_t h[2][NTT_WORDS];
+    to_dev_words(ark6, h[0]);
+    Fr761 b = Fr761::load(h[0]);
+    memset(h[1], 0, sizeof h[1]);
+    host_pow1024(b).store(h[1]);
+    uint32_t* stage = small(4) + 4 * NTT_WORDS;   // scratch slots behind the scale element
+    NTT_HIP_OK(hipMemcpyAsync(stage, h, sizeof h, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_ntt_powers, dim3(4), dim3(256), 0, stream, stage, small(slot_lo));
+    hipLaunchKernelGGL(k_ntt_powers, dim3(4), dim3(256), 0, stream, stage + NTT_WORDS, small(slot_hi));
+    NTT_HIP_OK(hipStreamSynchronize(stream));     // h lives on this stack frame
+    return 0;
+  }
+  int prepare(unsigned log_n, const uint64_t* omega6, const uint64_t* coset6, const uint64_t* scale6, hipStream_t stream) {
+    if (!ev[0]) for (int i = 0; i < 4; i++) NTT_HIP_OK(hipEventCreate(&ev[i]));
+    const size_t n = size_t(1) << log_n;
+    if (!d_small) NTT_HIP_OK(hipMalloc(&d_small, (size_t)5 * 1024 * NTT_WORDS * 4));
+    if (n * NTT_WORDS * 4 > cap_work) {
+      if (d_work) (void)hipFree(d_work);
+      d_work = nullptr; cap_work = 0;
+      NTT_HIP_OK(hipMalloc(&d_work, n * NTT_WORDS * 4));
+      cap_work = n * NTT_WORDS * 4;
+    }
+    const size_t tw_count = n > 1 ? n / 2 : 1;
+    if (tw_count * NTT_WORDS * 4 > cap_tw) {
+      if (d_tw) (void)hipFree(d_tw);
+      d_tw = nullptr; cap_tw = 0; tw_log_n = 0;
+      NTT_HIP_OK(hipMalloc(&d_tw, tw_count * NTT_WORDS * 4));
+      cap_tw = tw_count * NTT_WORDS * 4;
+    }
+    if (tw_log_n != log_n || memcmp(tw_omega, omega6, 48) != 0) {
+      if (upload_pair(omega6, 0, 1, stream)) return 1;
+      hipLaunchKernelGGL(k_ntt_table, dim3(((uint32_t)tw_count + 255) / 256), dim3(256), 0, stream, small(0), small(1), d_tw, (uint32_t)tw_count);
+      tw_log_n = log_n;
+      memcpy(tw_omega, omega6, 48);
+    }
+    if (coset6 && upload_pair(coset6, 2, 3, stream)) return 1;
+    if (scale6) {
+      uint32_t h[NTT_WORDS];
+      to_dev_words(scale6, h);
+      NTT_HIP_OK(hipMemcpyAsync(small(4), h, sizeof h, hipMemcpyHostToDevice, stream));
+      NTT_HIP_OK(hipStreamSynchronize(stream));
+    }
+    return 0;
+  }
+};
+#endif  // __HIPCC__
+
+}  // namespace celo

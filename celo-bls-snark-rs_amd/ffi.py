@@ -149,6 +149,36 @@ def pairing_gt(g1_xy, inf1, g2_xy, inf2, offsets, miller_only=False):
     return out
 
 
+def ntt(data, log_n, omega6, coset6=None, coset_after=False, scale6=None):
+    """In-place NTT over Fr(BW6-761) on HOST data: (n, 6) uint64 arkworks Montgomery limbs; omega6 / coset6 / scale6: (6,) uint64
+    Montgomery limbs.  Returns the transformed array (a copy)."""
+    out = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    assert out.shape == (1 << log_n, 6)
+    w = np.ascontiguousarray(omega6, dtype=np.uint64)
+    g = None if coset6 is None else np.ascontiguousarray(coset6, dtype=np.uint64)
+    sc = None if scale6 is None else np.ascontiguousarray(scale6, dtype=np.uint64)
+    rc = lib().ntt_bw6_761_fr(_p(out), C.c_uint(log_n), _p(w), _p(g), C.c_int(1 if coset_after else 0), _p(sc))
+    if rc != 0:
+        raise RuntimeError("ntt_bw6_761_fr failed with code %d" % rc)
+    return out
+
+
+def ntt_dev(d_ptr, log_n, omega6, coset6=None, coset_after=False, scale6=None, stream=0):
+    w = np.ascontiguousarray(omega6, dtype=np.uint64)
+    g = None if coset6 is None else np.ascontiguousarray(coset6, dtype=np.uint64)
+    sc = None if scale6 is None else np.ascontiguousarray(scale6, dtype=np.uint64)
+    rc = lib().ntt_bw6_761_fr_dev(C.c_void_p(d_ptr), C.c_uint(log_n), _p(w), _p(g), C.c_int(1 if coset_after else 0), _p(sc), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError("ntt_bw6_761_fr_dev failed with code %d" % rc)
+
+
+def ntt_timings():
+    ms = (C.c_float * 4)()
+    n = C.c_int(0)
+    assert lib().celo_amd_ntt_last_timings(ms, C.byref(n)) == 0
+    return {"load_ms": ms[0], "passes_ms": ms[1], "store_ms": ms[2], "total_ms": ms[3], "passes": n.value}
+
+
 def pairing_timings():
     ms = (C.c_float * 4)()
     assert lib().celo_amd_pairing_last_timings(ms) == 0

@@ -84,6 +84,19 @@ int celo_amd_pairing_gt_bw6_761(const uint64_t* g1_xy, const uint8_t* inf1, cons
 /* ms[4] = {miller loops, GT products, final exponentiations, total} of the last pairing call (HIP events). */
 int celo_amd_pairing_last_timings(float ms[4]);
 
+/* ---- radix-2 NTT over Fr(BW6-761) (= Fq of BLS12-377, 377 bits), in place, natural order in and out: the witness-map
+ * FFTs of the Groth16 prover.  Replaces ark-poly 0.1 Radix2EvaluationDomain::{fft, ifft,
+ * coset_fft, coset_ifft}_in_place as called by ark_groth16::create_proof_no_zk (crates/epoch-snark/src/api/prover.rs:78,112).
+ * data: n = 2^log_n elements, arkworks Montgomery limbs (6 u64 each).  omega: the domain's group_gen (its inverse for an
+ * inverse transform).  coset: NULL, or a generator g: every x_i is multiplied by g^i BEFORE the transform (coset_after =
+ * 0: coset_fft with g = the coset offset) or AFTER it (coset_after = 1: coset_ifft with g = offset^-1).  scale: NULL, or a
+ * factor applied to every output (size_inv for the inverse transforms).  log_n <= 28. */
+int ntt_bw6_761_fr(uint64_t* data, unsigned log_n, const uint64_t omega[6], const uint64_t* coset, int coset_after, const uint64_t* scale);
+int ntt_bw6_761_fr_dev(uint64_t* d_data, unsigned log_n, const uint64_t omega[6], const uint64_t* coset, int coset_after,
+                       const uint64_t* scale, void* hip_stream);
+/* ms[4] = {load/convert, butterfly passes, bit-reversal store, total}, passes = number of butterfly launches (last NTT call). */
+int celo_amd_ntt_last_timings(float ms[4], int* passes);
+
 /* ---- plain sums of k Jacobian points (host pointers, arkworks layout; host-side, for small k): the fold of per-GPU
  * partial MSM results and small aggregates — Signature::aggregate / PublicKey::aggregate
  * (crates/bls-crypto/src/bls/signature.rs:61-67, public.rs:38-44). */

@@ -118,6 +118,52 @@ int orc_from_mont_761(const u64* in, u64* out, size_t count) {
   return 0;
 }
 
+// ---- radix-2 NTT over Fr(BW6-761) = Fq(BLS12-377): restatement of ark-poly 0.1 Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}
+// _in_place (ark-poly is an un-vendored dependency, Cargo.lock:213-215; it is used inside ark_groth16::create_proof_no_zk called at
+// crates/epoch-snark/src/api/prover.rs:78).  Textbook decimation-in-time: bit-reversal permutation, then log n butterfly
+// levels.  The caller supplies the domain generator (omega for a forward transform, omega^-1 for an inverse one), the
+// optional coset generator (forward: x_i *= g^i first; inverse: pass g^-1 and set coset_after: x_i *= g^-i last) and the
+// optional final scale (n^-1).  data: n = 2^log_n elements, arkworks Montgomery limbs.  PARITY UNPINNED against the
+// reference (it holds no NTT vector); pinned against the O(n^2) definition in oracle/py and by round-trip properties.
+int orc_ntt_fq377(u64* data, unsigned log_n, const u64* omega6, const u64* coset6, int coset_after, const u64* scale6) {
+  const size_t n = size_t(1) << log_n;
+  std::vector<Fq377> a(n);
+  for (size_t i = 0; i < n; i++) memcpy(a[i].v, data + 6 * i, 48);
+  Fq377 w, g, sc;
+  memcpy(w.v, omega6, 48);
+  if (coset6) memcpy(g.v, coset6, 48);
+  if (scale6) memcpy(sc.v, scale6, 48);
+  if (coset6 && !coset_after) { Fq377 p = Fq377::one(); for (size_t i = 0; i < n; i++) { a[i] = a[i] * p; p = p * g; } }
+  for (size_t i = 0; i < n; i++) {  // bit reversal
+    size_t r = 0;
+    for (unsigned b = 0; b < log_n; b++) r |= ((i >> b) & 1) << (log_n - 1 - b);
+    if (r > i) std::swap(a[i], a[r]);
+  }
+  for (unsigned s = 1; s <= log_n; s++) {
+    const size_t m = size_t(1) << s;
+    Fq377 wm = w;                                   // omega^(n/m)
+    for (unsigned k = s; k < log_n; k++) wm = wm * wm;
+    for (size_t k = 0; k < n; k += m) {
+      Fq377 t = Fq377::one();
+      for (size_t j = 0; j < m / 2; j++) {
+        Fq377 u = a[k + j], v = a[k + j + m / 2] * t;
+        a[k + j] = u + v;
+        a[k + j + m / 2] = u - v;
+        t = t * wm;
+      }
+    }
+  }
+  if (coset6 && coset_after) { Fq377 p = Fq377::one(); for (size_t i = 0; i < n; i++) { a[i] = a[i] * p; p = p * g; } }
+  if (scale6) for (size_t i = 0; i < n; i++) a[i] = a[i] * sc;
+  for (size_t i = 0; i < n; i++) memcpy(data + 6 * i, a[i].v, 48);
+  return 0;
+}
+double orc_time_ntt_fq377(u64* data, unsigned log_n, const u64* omega6) {
+  auto t0 = std::chrono::steady_clock::now();
+  orc_ntt_fq377(data, log_n, omega6, nullptr, 0, nullptr);
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 // ---- MSM: naive != 0 selects the sum-of-scalar-muls definition instead of Pippenger
 int orc_msm_bls12_377_g1(const u64* xy, const uint8_t* inf, const u64* sc, size_t n, int threads, int naive, u64* out18) {
   return msm_impl<Fq377, 4>(xy, inf, sc, n, 253, threads, naive, out18);

@@ -198,3 +198,20 @@ def gt761_to_flat(gt):
             out[2 * a + b] = v[idx]
             idx += 1
     return out
+
+
+def ntt_fq377(data, log_n, omega, coset=None, coset_after=False, scale=None):
+    """Radix-2 NTT over Fr(BW6-761) = Fq(BLS12-377) (orc_ntt_fq377).  data: (n, 6) uint64 arkworks Montgomery limbs
+    (copied); omega / coset / scale: ints (canonical values).  Returns a new (n, 6) array."""
+    out = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    w = to_mont([omega], Q377)
+    g = None if coset is None else to_mont([coset], Q377)
+    s = None if scale is None else to_mont([scale], Q377)
+    assert lib().orc_ntt_fq377(_p(out), C.c_uint(log_n), _p(w), _p(g), C.c_int(1 if coset_after else 0), _p(s)) == 0
+    return out
+
+
+def time_ntt_fq377(data, log_n, omega):
+    out = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    lib().orc_time_ntt_fq377.restype = C.c_double
+    return lib().orc_time_ntt_fq377(_p(out), C.c_uint(log_n), _p(to_mont([omega], Q377)))

@@ -221,3 +221,25 @@ def test_reference_composite_hash_to_g1_vectors(golden, key, cip22):
     for (dom, msg, extra), hx in zip(reference_hash_test_inputs(len(pts)), pts):
         P, _ = hs.hash_to_g1(dom, msg, extra, composite=True, cip22=cip22)
         assert ecc.ser_point(ecc.E1_377, P).hex() == hx
+
+
+@pytest.mark.parametrize("log_n", [1, 3, 6])
+def test_oracle_ntt_restatement_matches_definition(log_n):
+    """oracle/cpu orc_ntt_fq377 (decimation in time, the checker of tests/test_ntt_gpu.py) against the O(n^2) definition of the
+    transform (oracle/py/ntt.py), forward / inverse / coset variants.  The reference holds no NTT vector (parity unpinned there)."""
+    from oracle.py import ntt as ontt
+    from oracle import cpu_oracle as co
+    Q = ecc.Q377
+    rng = ecc.SplitMix64(5 + log_n)
+    n, w = 1 << log_n, ontt.root_of_unity(log_n)
+    assert pow(w, n, Q) == 1 and pow(w, n // 2, Q) == Q - 1
+    x = [ecc.random_scalar(rng, Q) for _ in range(n)]
+    X = co.from_mont(co.ntt_fq377(co.to_mont(x, Q), log_n, w), Q)
+    assert X == ontt.dft(x, w)
+    back = co.from_mont(co.ntt_fq377(co.to_mont(X, Q), log_n, pow(w, -1, Q), scale=pow(n, -1, Q)), Q)
+    assert back == x
+    g = 7
+    Xc = co.from_mont(co.ntt_fq377(co.to_mont(x, Q), log_n, w, coset=g), Q)
+    assert Xc == ontt.dft([xi * pow(g, i, Q) % Q for i, xi in enumerate(x)], w)
+    xb = co.from_mont(co.ntt_fq377(co.to_mont(Xc, Q), log_n, pow(w, -1, Q), coset=pow(g, -1, Q), coset_after=True, scale=pow(n, -1, Q)), Q)
+    assert xb == x

@@ -129,9 +129,9 @@ static void pairing_op_lanes(int mode, const uint64_t* g1, const uint64_t* g2, s
       case 3: r = HQT::mul12(a, lanes_from_f12(f12_from_ark(in72b))); break;
       case 4: r = HQT::inv12(a); break;
       case 5: r = HQT::cyclotomic_sqr(a); break;
-      case 6: r = HQT::frob12<1>(a); break;
-      case 7: r = HQT::frob12<2>(a); break;
-      case 8: r = HQT::frob12<3>(a); break;
+      case 6: r = HQP::frob12<1>(a); break;
+      case 7: r = HQP::frob12<2>(a); break;
+      case 8: r = HQP::frob12<3>(a); break;
       default: r = HQT::sqr12(a); break;
     }
   }
@@ -139,11 +139,32 @@ static void pairing_op_lanes(int mode, const uint64_t* g1, const uint64_t* g2, s
   if (is_one) *is_one = HQT::is_one12(r) ? 1 : 0;
 }
 
+static void pairing_op_761_lanes(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out72, int* is_one) {
+  typedef QTower<QHost761> T6;
+  typedef QPairing761<QHost761> P6;
+  T6::E12 acc = T6::one12();
+  for (size_t i = 0; i < k; i++) {
+    QHost761::V px, py, Qc;
+    for (int l = 0; l < 3; l++) {
+      px.v[l] = Fw::from_ark(g1 + i * 24); py.v[l] = Fw::from_ark(g1 + i * 24 + 12);
+      Qc.v[l] = Fw::from_ark(g2 + i * 24 + (l & 1) * 12);
+    }
+    acc = T6::mul12(acc, P6::miller(px, py, Qc));
+  }
+  T6::E12 r = mode == 0 ? P6::final_exponentiation(acc) : acc;
+  Fw6 x;
+  Fw* c[6] = {&x.c0.c0, &x.c0.c1, &x.c0.c2, &x.c1.c0, &x.c1.c1, &x.c1.c2};
+  for (int j = 0; j < 3; j++) { *c[j] = r.a.v[j]; *c[3 + j] = r.b.v[j]; }
+  QuadIO<Base761>::to_ark(x, out72);
+  if (is_one) *is_one = T6::is_one12(r) ? 1 : 0;
+}
+
 static void pairing_op_761(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out72, int* is_one) {
   Fw6 acc = quad_one<Base761>();
   for (size_t i = 0; i < k; i++) {
     Fw6 f, t;
-    PP761::miller(f, g1 + i * 24, g2 + i * 24);
+    { Fw px = Fw::from_ark(g1 + i * 24), py = Fw::from_ark(g1 + i * 24 + 12), qx = Fw::from_ark(g2 + i * 24), qy = Fw::from_ark(g2 + i * 24 + 12);
+      bw6_miller_loop_single(f, px, py, qx, qy); }
     quad_mul(t, acc, f);
     acc = t;
   }
@@ -155,6 +176,7 @@ static void pairing_op_761(int mode, const uint64_t* g1, const uint64_t* g2, siz
 }
 
 extern "C" {
+void ht_pairing_761_lanes(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out72, int* is_one) { pairing_op_761_lanes(mode, g1, g2, k, out72, is_one); }
 void ht_pairing_761(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out72, int* is_one) { pairing_op_761(mode, g1, g2, k, out72, is_one); }
 void ht_pairing_377(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
                     uint64_t* out72, int* is_one) { pairing_op(mode, g1, g2, k, in72, in72b, out72, is_one); }

@@ -10,12 +10,12 @@
 // compared bit-for-bit with the oracle: homogeneous-projective doubling/addition steps with the D-twist line
 // (-h, 3j, i) / (lambda, -theta, j), sparse mul_by_034, and arkworks' final-exponentiation chain (which yields the
 // cube of the reduced pairing).  What differs is the shape: arkworks precomputes 69 line triples per G2 point
-// (G2Prepared) and walks all pairs of a product inside one serial loop with a shared squaring; here
-//   k_miller     : ONE LANE PER PAIR runs a fused Miller loop (line coefficients are consumed as they are produced,
-//                  nothing is materialised in HBM) with its own accumulator f_i            — embarrassingly parallel
-//   k_gt_product : per product, the f_i are multiplied (the product of the per-pair Miller values equals the
-//                  shared-squaring multi-Miller value, since squaring distributes over the product)
-//   k_final_exp  : ONE LANE PER PRODUCT runs the final exponentiation and writes the accept bit
+// (G2Prepared) and walks all pairs of a product inside one serial loop with a shared squaring; here the Miller loop is
+// fused (line coefficients are consumed as they are produced, nothing is materialised in HBM) and runs either per pair
+// (the product of the per-pair Miller values equals the shared-squaring multi-Miller value) or per product with a shared
+// accumulator, then one final exponentiation per product writes the accept bit.
+// This header holds the ONE-LANE formulation (a whole pairing's state in one lane: the host-checked and self-tested twin)
+// and the engine; the kernels that run are the lane-parallel ones of pairing_lanes.h (three lanes per pairing).
 // Pairs with a point at infinity contribute 1 (ark-ec bls12 miller_loop skips them).
 #pragma once
 #if defined(__HIPCC__)
@@ -278,98 +278,29 @@ namespace celo {
 // ================================================================== pairing policies (one per curve) for the kernels below
 struct PP377 {
   typedef Base377 BP;
-  typedef Fq12 Gt;
   static constexpr int G1_ARK64 = 12, G2_ARK64 = 24;
-  static constexpr bool LANES = true;   // lane-parallel kernels (pairing_lanes.h); the one-lane functions stay as the host-checked twin
-  HD static void miller(Gt& f, const uint64_t* g1, const uint64_t* g2) {
-    Fq px = Fq::from_ark(g1), py = Fq::from_ark(g1 + 6);
-    Fq2 qx = Fq2::from_ark(g2), qy = Fq2::from_ark(g2 + 12);
-    miller_loop_single(f, px, py, qx, qy);
-  }
-  HD static void final_exp(Gt& r, const Gt& f) { final_exponentiation(r, f); }
+  typedef struct LaneLaunch377 LL;     // kernels: pairing_lanes_kernels.h (the one-lane functions above stay as the host- and self-tested twin)
 };
 struct PP761 {
   typedef Base761 BP;
-  typedef Fw6 Gt;
   static constexpr int G1_ARK64 = 24, G2_ARK64 = 24;
-  static constexpr bool LANES = false;
-  HD static void miller(Gt& f, const uint64_t* g1, const uint64_t* g2) {
-    Fw px = Fw::from_ark(g1), py = Fw::from_ark(g1 + 12);
-    Fw qx = Fw::from_ark(g2), qy = Fw::from_ark(g2 + 12);
-    bw6_miller_loop_single(f, px, py, qx, qy);
-  }
-  HD static void final_exp(Gt& r, const Gt& f) { bw6_final_exponentiation(r, f); }
+  typedef struct LaneLaunch761 LL;
 };
 
 #if defined(__HIPCC__)
-// ---------------------------------------------------------------- kernels
-template <class PP>
-__global__ void __launch_bounds__(64) k_miller(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1,
-                                               const uint64_t* __restrict__ g2, const uint8_t* __restrict__ inf2,
-                                               uint32_t* __restrict__ f_out, uint32_t n) {
-  typedef QuadIO<typename PP::BP> IO;
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  typename PP::Gt f;
-  if ((inf1 && inf1[i]) || (inf2 && inf2[i])) f = quad_one<typename PP::BP>();
-  else PP::miller(f, g1 + (size_t)i * PP::G1_ARK64, g2 + (size_t)i * PP::G2_ARK64);
-  IO::store(f_out + (size_t)i * IO::WORDS, f);
-}
-// product p covers pairs [offsets[p], offsets[p+1])
-template <class PP>
-__global__ void __launch_bounds__(64) k_gt_product(const uint32_t* __restrict__ f_in, const uint32_t* __restrict__ offsets,
-                                                   uint32_t* __restrict__ prod, uint32_t m) {
-  typedef QuadIO<typename PP::BP> IO;
-  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= m) return;
-  uint32_t lo = offsets[p], hi = offsets[p + 1];
-  typename PP::Gt acc = quad_one<typename PP::BP>();
-  for (uint32_t k = lo; k < hi; k++) {
-    typename PP::Gt v = IO::load(f_in + (size_t)k * IO::WORDS), t;
-    if (k == lo) acc = v;
-    else { quad_mul(t, acc, v); acc = t; }
-  }
-  IO::store(prod + (size_t)p * IO::WORDS, acc);
-}
-// pairwise tree level for ONE large product: out[t] = in[2t] * in[2t+1] (odd tail copied)
-template <class PP>
-__global__ void __launch_bounds__(64) k_gt_tree(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_in) {
-  typedef QuadIO<typename PP::BP> IO;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t n_out = (n_in + 1) / 2;
-  if (t >= n_out) return;
-  typename PP::Gt a = IO::load(in + (size_t)(2 * t) * IO::WORDS);
-  if (2 * t + 1 < n_in) {
-    typename PP::Gt b = IO::load(in + (size_t)(2 * t + 1) * IO::WORDS), r;
-    quad_mul(r, a, b);
-    a = r;
-  }
-  IO::store(out + (size_t)t * IO::WORDS, a);
-}
-template <class PP>
-__global__ void __launch_bounds__(64) k_final_exp(const uint32_t* __restrict__ prod, uint8_t* __restrict__ is_one,
-                                                  uint64_t* __restrict__ gt_ark, uint32_t m, int do_final_exp) {
-  typedef QuadIO<typename PP::BP> IO;
-  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= m) return;
-  typename PP::Gt f = IO::load(prod + (size_t)p * IO::WORDS), r;
-  if (do_final_exp) PP::final_exp(r, f);
-  else r = f;
-  if (is_one) is_one[p] = quad_is_one(r) ? 1 : 0;
-  if (gt_ark) IO::to_ark(r, gt_ark + (size_t)p * 72);
-}
-
-// ---------------------------------------------------------------- lane-parallel kernels (BLS12-377): 3 lanes per pairing / product.
-// Defined in pairing_lanes_kernels.h, compiled in their own translation units (unit_pairing_lm.hip, unit_pairing_lf.hip).
-__global__ void k_miller_lanes(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1, const uint64_t* __restrict__ g2,
-                               const uint8_t* __restrict__ inf2, uint32_t* __restrict__ f_out, uint32_t n);
-__global__ void k_miller_product_lanes(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1, const uint64_t* __restrict__ g2,
-                                       const uint8_t* __restrict__ inf2, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ prod, uint32_t m);
-__global__ void k_gt_product_lanes(const uint32_t* __restrict__ f_in, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ prod, uint32_t m);
-__global__ void k_gt_tree_lanes(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_in);
-__global__ void k_final_exp_lanes(const uint32_t* __restrict__ prod, uint8_t* __restrict__ is_one, uint64_t* __restrict__ gt_ark, uint32_t m,
-                                  int do_final_exp);
-constexpr uint32_t LANES_PER_BLOCK = 21;   // groups of three lanes per 64-thread block
+// ---------------------------------------------------------------- lane-parallel kernels: 3 lanes per pairing / product.
+// The kernels (pairing_lanes_kernels.h) are instantiated in their own translation units, which also define these launchers.
+#define CELO_DECLARE_LANE_LAUNCH(NAME)                                                                                              \
+  struct NAME {                                                                                                                     \
+    static void miller(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, uint32_t* f, uint32_t n, hipStream_t s); \
+    static void miller_product(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off,  \
+                               uint32_t* prod, uint32_t m, hipStream_t s);                                                         \
+    static void gt_product(const uint32_t* f, const uint32_t* off, uint32_t* prod, uint32_t m, hipStream_t s);                     \
+    static void gt_tree(const uint32_t* in, uint32_t* out, uint32_t n_in, hipStream_t s);                                          \
+    static void final_exp(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint32_t m, int do_fe, hipStream_t s);              \
+  };
+CELO_DECLARE_LANE_LAUNCH(LaneLaunch377)
+CELO_DECLARE_LANE_LAUNCH(LaneLaunch761)
 
 #define PAIR_HIP_OK(x)                                                                                          \
   do {                                                                                                          \
@@ -419,47 +350,28 @@ template <class PP> class PairingEngine {
     PAIR_HIP_OK(hipMemcpyAsync(d_off, offsets, (m + 1) * 4, hipMemcpyHostToDevice, stream));
     PAIR_HIP_OK(hipEventRecord(ev[0], stream));
     // shared-accumulator mode: one lane group per product (<= 4 pairs each) when the products alone fill the chip
-    bool shared = false;
-    if constexpr (PP::LANES) {
-      if (m >= 16384) {
-        shared = true;
-        for (size_t p = 0; p < m && shared; p++) shared = offsets[p + 1] - offsets[p] <= 4;
-      }
-      if (shared) {
-        hipLaunchKernelGGL(k_miller_product_lanes, dim3(((uint32_t)m + LANES_PER_BLOCK - 1) / LANES_PER_BLOCK), dim3(64), 0, stream, d_g1,
-                           inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m);
-      } else if (k) {
-        hipLaunchKernelGGL(k_miller_lanes, dim3((k + LANES_PER_BLOCK - 1) / LANES_PER_BLOCK), dim3(64), 0, stream, d_g1, inf1 ? d_i1 : nullptr, d_g2,
-                           inf2 ? d_i2 : nullptr, d_f, k);
-      }
-    } else {
-      if (k) hipLaunchKernelGGL((k_miller<PP>), dim3((k + 63) / 64), dim3(64), 0, stream, d_g1, inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_f, k);
-    }
+    bool shared = m >= 16384;
+    for (size_t p = 0; p < m && shared; p++) shared = offsets[p + 1] - offsets[p] <= 4;
+    typedef typename PP::LL LL;
+    if (shared) LL::miller_product(d_g1, inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
+    else if (k) LL::miller(d_g1, inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_f, k, stream);
     PAIR_HIP_OK(hipEventRecord(ev[1], stream));
     if (shared) {
-      // products already formed by k_miller_product_lanes
+      // products already formed by the Miller kernel
     } else if (m == 1 && k > 8) {  // one large product: pairwise tree, log2(k) levels
       uint32_t n_in = k;
       uint32_t* src = d_f; uint32_t* dst = d_f2;
       while (n_in > 1) {
-        uint32_t n_out = (n_in + 1) / 2;
-        if constexpr (PP::LANES) hipLaunchKernelGGL(k_gt_tree_lanes, dim3((n_out + LANES_PER_BLOCK - 1) / LANES_PER_BLOCK), dim3(64), 0, stream, src, dst, n_in);
-        else hipLaunchKernelGGL((k_gt_tree<PP>), dim3((n_out + 63) / 64), dim3(64), 0, stream, src, dst, n_in);
-        n_in = n_out;
+        LL::gt_tree(src, dst, n_in, stream);
+        n_in = (n_in + 1) / 2;
         uint32_t* t = src; src = dst; dst = t;
       }
       PAIR_HIP_OK(hipMemcpyAsync(d_prod, src, W * 4, hipMemcpyDeviceToDevice, stream));
     } else {
-      if constexpr (PP::LANES) hipLaunchKernelGGL(k_gt_product_lanes, dim3(((uint32_t)m + LANES_PER_BLOCK - 1) / LANES_PER_BLOCK), dim3(64), 0, stream, d_f, d_off, d_prod, (uint32_t)m);
-      else hipLaunchKernelGGL((k_gt_product<PP>), dim3(((uint32_t)m + 63) / 64), dim3(64), 0, stream, d_f, d_off, d_prod, (uint32_t)m);
+      LL::gt_product(d_f, d_off, d_prod, (uint32_t)m, stream);
     }
     PAIR_HIP_OK(hipEventRecord(ev[2], stream));
-    if constexpr (PP::LANES)
-      hipLaunchKernelGGL(k_final_exp_lanes, dim3(((uint32_t)m + LANES_PER_BLOCK - 1) / LANES_PER_BLOCK), dim3(64), 0, stream, d_prod, out_is_one ? d_one : nullptr,
-                         out_gt ? d_gt : nullptr, (uint32_t)m, mode == 0 ? 1 : 0);
-    else
-      hipLaunchKernelGGL((k_final_exp<PP>), dim3(((uint32_t)m + 63) / 64), dim3(64), 0, stream, d_prod, out_is_one ? d_one : nullptr,
-                         out_gt ? d_gt : nullptr, (uint32_t)m, mode == 0 ? 1 : 0);
+    LL::final_exp(d_prod, out_is_one ? d_one : nullptr, out_gt ? d_gt : nullptr, (uint32_t)m, mode == 0 ? 1 : 0, stream);
     PAIR_HIP_OK(hipEventRecord(ev[3], stream));
     if (out_is_one) PAIR_HIP_OK(hipMemcpyAsync(out_is_one, d_one, m, hipMemcpyDeviceToHost, stream));
     if (out_gt) PAIR_HIP_OK(hipMemcpyAsync(out_gt, d_gt, (size_t)m * 72 * 8, hipMemcpyDeviceToHost, stream));

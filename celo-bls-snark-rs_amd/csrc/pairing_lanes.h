@@ -43,78 +43,83 @@ HD Fq2 twist_b_times(const Fq2& x) {
   return {Fq::wred(Fq::norm(Fq::template neg<16, 1>(p5))), p0};
 }
 
-// ================================================================== host backend: three explicit lanes
-struct QHost377 {
+// ================================================================== host backend: three explicit lanes, any base policy
+template <class BP> struct QHostT {
+  typedef typename BP::T T;
   static constexpr int NL = 3;
-  struct V { Fq2 v[NL]; };
-  struct F { Fq v[NL]; };
+  struct V { T v[NL]; };
   template <class Fn> static V map2(const V& a, const V& b, Fn fn) { V r; for (int i = 0; i < NL; i++) r.v[i] = fn(a.v[i], b.v[i]); return r; }
   template <class Fn> static V map1(const V& a, Fn fn) { V r; for (int i = 0; i < NL; i++) r.v[i] = fn(a.v[i]); return r; }
-  static V uni(const Fq2& x) { V r; for (int i = 0; i < NL; i++) r.v[i] = x; return r; }
-  static V mul(const V& a, const V& b) { return map2(a, b, [](const Fq2& x, const Fq2& y) { return Fq2::mul(x, y); }); }
-  static V add(const V& a, const V& b) { return map2(a, b, [](const Fq2& x, const Fq2& y) { return Base377::add(x, y); }); }
-  static V dbl(const V& a) { return map1(a, [](const Fq2& x) { return Base377::dbl(x); }); }
-  static V tpl(const V& a) { return map1(a, [](const Fq2& x) { return Base377::tpl(x); }); }
-  template <int K> static V sub(const V& a, const V& b) { return map2(a, b, [](const Fq2& x, const Fq2& y) { return Base377::sub<K>(x, y); }); }
-  template <int K> static V neg(const V& a) { return map1(a, [](const Fq2& x) { return Base377::neg<K>(x); }); }
-  static V wred(const V& a) { return map1(a, [](const Fq2& x) { return Base377::wred(x); }); }
-  static V mul_nr(const V& a) { return map1(a, [](const Fq2& x) { return Base377::mul_nr(x); }); }
-  static V half(const V& a) { return map1(a, [](const Fq2& x) { return Fq2{Fq::half(x.c0), Fq::half(x.c1)}; }); }
-  static V conj(const V& a) { return map1(a, [](const Fq2& x) { return Fq2{x.c0, Fq::wred(Fq::norm(Fq::neg<4, 1>(x.c1)))}; }); }
-  static V inv(const V& a) { return map1(a, [](const Fq2& x) { return Fq2::inv(x); }); }
-  static V mul_fp(const V& a, const F& k) { V r; for (int i = 0; i < NL; i++) r.v[i] = Fq2::mul_fp(Fq2::norm(a.v[i]), k.v[i]); return r; }
-  static V twist_mul(const V& a) { return map1(a, [](const Fq2& x) { return twist_b_times(x); }); }
+  static V uni(const T& x) { V r; for (int i = 0; i < NL; i++) r.v[i] = x; return r; }
+  static V mul(const V& a, const V& b) { return map2(a, b, [](const T& x, const T& y) { return BP::mul_inl(x, y); }); }
+  static V add(const V& a, const V& b) { return map2(a, b, [](const T& x, const T& y) { return BP::add(x, y); }); }
+  static V dbl(const V& a) { return map1(a, [](const T& x) { return BP::dbl(x); }); }
+  static V tpl(const V& a) { return map1(a, [](const T& x) { return BP::tpl(x); }); }
+  template <int K> static V sub(const V& a, const V& b) { return map2(a, b, [](const T& x, const T& y) { return BP::template sub<K>(x, y); }); }
+  template <int K> static V neg(const V& a) { return map1(a, [](const T& x) { return BP::template neg<K>(x); }); }
+  static V wred(const V& a) { return map1(a, [](const T& x) { return BP::wred(x); }); }
+  static V mul_nr(const V& a) { return map1(a, [](const T& x) { return BP::mul_nr(x); }); }
+  static V half(const V& a) { return map1(a, [](const T& x) { return BP::half(x); }); }
+  static V inv(const V& a) { return map1(a, [](const T& x) { return BP::inv_inl(x); }); }
   template <int CTRL> static V perm(const V& x) { V r; for (int i = 0; i < NL; i++) r.v[i] = x.v[(CTRL >> (2 * i)) & 3]; return r; }
   template <int K> static V bcast(const V& x) { return perm<QP(K, K, K)>(x); }
   template <int K> static V sel(const V& onk, const V& other) { V r; for (int i = 0; i < NL; i++) r.v[i] = (i == K) ? onk.v[i] : other.v[i]; return r; }
   static V pick(const V& a0, const V& a1, const V& a2) { V r; r.v[0] = a0.v[0]; r.v[1] = a1.v[1]; r.v[2] = a2.v[2]; return r; }
-  static F pickf(const F& a0, const F& a1, const F& a2) { F r; r.v[0] = a0.v[0]; r.v[1] = a1.v[1]; r.v[2] = a2.v[2]; return r; }
-  static V zero() { return uni(Fq2::zero()); }
-  static V one() { return uni(Fq2::one()); }
-  static V constant(const uint32_t* c0, const uint32_t* c1) { return uni(f2_from(c0, c1)); }
+  static V zero() { return uni(BP::zero()); }
+  static V one() { return uni(BP::one()); }
   // all three lanes must hold: a == (lane 0 ? 1 : 0) and b == 0
   static bool is_one3(const V& a, const V& b) {
-    bool ok = Base377::is_one(a.v[0]) && Base377::is_zero(b.v[0]);
-    for (int i = 1; i < 3; i++) ok = ok && Base377::is_zero(a.v[i]) && Base377::is_zero(b.v[i]);
+    bool ok = BP::is_one(a.v[0]) && BP::is_zero(b.v[0]);
+    for (int i = 1; i < 3; i++) ok = ok && BP::is_zero(a.v[i]) && BP::is_zero(b.v[i]);
     return ok;
   }
+};
+struct QHost377 : QHostT<Base377> {       // BLS12-377 extras: Fq scalars (P's coordinates), conjugation, the twist constant
+  struct F { Fq v[NL]; };
+  static V conj(const V& a) { return map1(a, [](const Fq2& x) { return Fq2{x.c0, Fq::wred(Fq::norm(Fq::neg<4, 1>(x.c1)))}; }); }
+  static V mul_fp(const V& a, const F& k) { V r; for (int i = 0; i < NL; i++) r.v[i] = Fq2::mul_fp(Fq2::norm(a.v[i]), k.v[i]); return r; }
+  static V twist_mul(const V& a) { return map1(a, [](const Fq2& x) { return twist_b_times(x); }); }
+  static F pickf(const F& a0, const F& a1, const F& a2) { F r; r.v[0] = a0.v[0]; r.v[1] = a1.v[1]; r.v[2] = a2.v[2]; return r; }
+  static V constant(const uint32_t* c0, const uint32_t* c1) { return uni(f2_from(c0, c1)); }
+};
+struct QHost761 : QHostT<Base761> {
+  static V constant(const uint32_t* c) { return uni(Fw::from_limbs(c)); }
 };
 
 #if defined(__HIPCC__)
 // ================================================================== device backend: groups of three lanes, ds_bpermute
 #define QDEV __device__ __forceinline__
-struct QTri377 {
-  typedef Fq2 V;
-  typedef Fq F;
-  static constexpr int NL = 3, GROUPS_PER_WAVE = 21;
+template <class BP> struct QTriT {
+  typedef typename BP::T T;
+  typedef T V;
+  static constexpr int NL = 3, GROUPS_PER_WAVE = 21, NWORDS = 28;   // Fq2 of BLS12-377 and Fq of BW6-761 are both 28 limbs
   QDEV static int wave_lane() { return (int)__lane_id(); }
   QDEV static int group() { return (wave_lane() * 86) >> 8; }            // lane / 3 for lane < 64
   QDEV static int lane() { return wave_lane() - 3 * group(); }          // lane % 3
-  QDEV static V mul(const V& a, const V& b) { return Fq2::mul(a, b); }
-  QDEV static V add(const V& a, const V& b) { return Base377::add(a, b); }
-  QDEV static V dbl(const V& a) { return Base377::dbl(a); }
-  QDEV static V tpl(const V& a) { return Base377::tpl(a); }
-  template <int K> QDEV static V sub(const V& a, const V& b) { return Base377::sub<K>(a, b); }
-  template <int K> QDEV static V neg(const V& a) { return Base377::neg<K>(a); }
-  QDEV static V wred(const V& a) { return Base377::wred(a); }
-  QDEV static V mul_nr(const V& a) { return Base377::mul_nr(a); }
-  QDEV static V half(const V& a) { return {Fq::half(a.c0), Fq::half(a.c1)}; }
-  QDEV static V conj(const V& a) { return {a.c0, Fq::wred(Fq::norm(Fq::neg<4, 1>(a.c1)))}; }
-  QDEV static V inv(const V& a) { return Fq2::inv(a); }
-  QDEV static V mul_fp(const V& a, const F& k) { return Fq2::mul_fp(Fq2::norm(a), k); }
-  QDEV static V twist_mul(const V& a) { return twist_b_times(a); }
+  QDEV static V mul(const V& a, const V& b) { return BP::mul_inl(a, b); }
+  QDEV static V add(const V& a, const V& b) { return BP::add(a, b); }
+  QDEV static V dbl(const V& a) { return BP::dbl(a); }
+  QDEV static V tpl(const V& a) { return BP::tpl(a); }
+  template <int K> QDEV static V sub(const V& a, const V& b) { return BP::template sub<K>(a, b); }
+  template <int K> QDEV static V neg(const V& a) { return BP::template neg<K>(a); }
+  QDEV static V wred(const V& a) { return BP::wred(a); }
+  QDEV static V mul_nr(const V& a) { return BP::mul_nr(a); }
+  QDEV static V half(const V& a) { return BP::half(a); }
+  QDEV static V inv(const V& a) { return BP::inv_inl(a); }
   template <int CTRL> QDEV static int src_addr() {
     const int j = lane();
     return (wave_lane() - j + ((CTRL >> (2 * j)) & 3)) << 2;
   }
+  // word i of a base element: Fq2 = (c0.l[0..13], c1.l[0..13]), Fq761 = l[0..27] (member access keeps the values in VGPRs)
+  QDEV static uint32_t& word(Fq2& x, int i) { return i < 14 ? x.c0.l[i] : x.c1.l[i - 14]; }
+  QDEV static const uint32_t& word(const Fq2& x, int i) { return i < 14 ? x.c0.l[i] : x.c1.l[i - 14]; }
+  QDEV static uint32_t& word(Fw& x, int i) { return x.l[i]; }
+  QDEV static const uint32_t& word(const Fw& x, int i) { return x.l[i]; }
   template <int CTRL> QDEV static V perm(const V& x) {
     const int addr = src_addr<CTRL>();
     V r;
 #pragma unroll
-    for (int i = 0; i < 14; i++) {
-      r.c0.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)x.c0.l[i]);
-      r.c1.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)x.c1.l[i]);
-    }
+    for (int i = 0; i < NWORDS; i++) word(r, i) = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)word(x, i));
     return r;
   }
   template <int K> QDEV static V bcast(const V& x) { return perm<QP(K, K, K)>(x); }
@@ -122,22 +127,30 @@ struct QTri377 {
     const bool c = lane() == K;
     V r;
 #pragma unroll
-    for (int i = 0; i < 14; i++) {
-      r.c0.l[i] = c ? onk.c0.l[i] : other.c0.l[i];
-      r.c1.l[i] = c ? onk.c1.l[i] : other.c1.l[i];
-    }
+    for (int i = 0; i < NWORDS; i++) word(r, i) = c ? word(onk, i) : word(other, i);
     return r;
   }
   QDEV static V pick(const V& a0, const V& a1, const V& a2) {
     const int q = lane();
     V r;
 #pragma unroll
-    for (int i = 0; i < 14; i++) {
-      r.c0.l[i] = q == 0 ? a0.c0.l[i] : q == 1 ? a1.c0.l[i] : a2.c0.l[i];
-      r.c1.l[i] = q == 0 ? a0.c1.l[i] : q == 1 ? a1.c1.l[i] : a2.c1.l[i];
-    }
+    for (int i = 0; i < NWORDS; i++) word(r, i) = q == 0 ? word(a0, i) : q == 1 ? word(a1, i) : word(a2, i);
     return r;
   }
+  QDEV static V zero() { return BP::zero(); }
+  QDEV static V one() { return BP::one(); }
+  QDEV static bool is_one3(const V& a, const V& b) {
+    const int q = lane();
+    const int ok = ((q == 0 ? BP::is_one(a) : BP::is_zero(a)) && BP::is_zero(b)) ? 1 : 0;
+    const int base = (wave_lane() - q) << 2;
+    return (__builtin_amdgcn_ds_bpermute(base, ok) & __builtin_amdgcn_ds_bpermute(base + 4, ok) & __builtin_amdgcn_ds_bpermute(base + 8, ok)) != 0;
+  }
+};
+struct QTri377 : QTriT<Base377> {
+  typedef Fq F;
+  QDEV static V conj(const V& a) { return {a.c0, Fq::wred(Fq::norm(Fq::neg<4, 1>(a.c1)))}; }
+  QDEV static V mul_fp(const V& a, const F& k) { return Fq2::mul_fp(Fq2::norm(a), k); }
+  QDEV static V twist_mul(const V& a) { return twist_b_times(a); }
   QDEV static F pickf(const F& a0, const F& a1, const F& a2) {
     const int q = lane();
     F r;
@@ -145,15 +158,10 @@ struct QTri377 {
     for (int i = 0; i < 14; i++) r.l[i] = q == 0 ? a0.l[i] : q == 1 ? a1.l[i] : a2.l[i];
     return r;
   }
-  QDEV static V zero() { return Fq2::zero(); }
-  QDEV static V one() { return Fq2::one(); }
   QDEV static V constant(const uint32_t* c0, const uint32_t* c1) { return f2_from(c0, c1); }
-  QDEV static bool is_one3(const V& a, const V& b) {
-    const int q = lane();
-    const int ok = ((q == 0 ? Base377::is_one(a) : Base377::is_zero(a)) && Base377::is_zero(b)) ? 1 : 0;
-    const int base = (wave_lane() - q) << 2;
-    return (__builtin_amdgcn_ds_bpermute(base, ok) & __builtin_amdgcn_ds_bpermute(base + 4, ok) & __builtin_amdgcn_ds_bpermute(base + 8, ok)) != 0;
-  }
+};
+struct QTri761 : QTriT<Base761> {
+  QDEV static V constant(const uint32_t* c) { return Fw::from_limbs(c); }
 };
 #define QFN __host__ __device__ __forceinline__
 #define QNI __host__ __device__ __attribute__((noinline))   // out of line: one copy of the 6-product Fq12 routines per kernel
@@ -261,6 +269,17 @@ template <class QB> struct QTower {
     r.b = QB::wred(QB::template neg<4>(mul6(x.b, di)));
     return r;
   }
+  QFN static bool is_one12(const E12& x) { return QB::is_one3(x.a, x.b); }
+};
+
+// ================================================================== the pairing
+template <class QB> struct QPairing377 {
+  typedef typename QB::V V;
+  typedef typename QB::F F;
+  typedef QTower<QB> TW;
+  typedef typename TW::E12 E12;
+  struct Line { V c0, c1, c2; };  // group-uniform
+
   // x^(q^I): coefficient k (of w^k) is conjugated I times and scaled by xi^(k (q^I - 1) / 6); lane j: a -> k = 2j, b -> 2j + 1
   template <int I> QNI static E12 frob12(const E12& x) {
 #define QFC(k) QB::constant(T377::FROB##k##_C0, T377::FROB##k##_C1)
@@ -272,16 +291,6 @@ template <class QB> struct QTower {
     V a = (I & 1) ? QB::conj(x.a) : x.a, b = (I & 1) ? QB::conj(x.b) : x.b;
     return {QB::mul(a, ca), QB::mul(b, cb)};
   }
-  QFN static bool is_one12(const E12& x) { return QB::is_one3(x.a, x.b); }
-};
-
-// ================================================================== the pairing
-template <class QB> struct QPairing377 {
-  typedef typename QB::V V;
-  typedef typename QB::F F;
-  typedef QTower<QB> TW;
-  typedef typename TW::E12 E12;
-  struct Line { V c0, c1, c2; };  // group-uniform
 
   // ark-ec bls12/g2.rs doubling_step on R = (X, Y, Z), one coordinate per lane
   QFN static void double_step(V& Rc, Line& l) {
@@ -386,7 +395,7 @@ template <class QB> struct QPairing377 {
     E12 f2 = TW::inv12(f);
     E12 r = TW::mul12(TW::conj12(f), f2);
     f2 = r;
-    r = TW::mul12(TW::template frob12<2>(r), f2);
+    r = TW::mul12(frob12<2>(r), f2);
     E12 y0 = TW::conj12(TW::cyclotomic_sqr(r));
     E12 y5 = exp_by_x(r);
     E12 y1 = TW::cyclotomic_sqr(y5);
@@ -398,11 +407,139 @@ template <class QB> struct QPairing377 {
     y3 = TW::conj12(y3);
     y1 = TW::mul12(TW::mul12(y1, y3), r);
     y3 = TW::conj12(r);
-    y0 = TW::template frob12<3>(TW::mul12(y0, r));
-    y4 = TW::template frob12<1>(TW::mul12(y4, y3));
-    y5 = TW::template frob12<2>(TW::mul12(y5, y2));
+    y0 = frob12<3>(TW::mul12(y0, r));
+    y4 = frob12<1>(TW::mul12(y4, y3));
+    y5 = frob12<2>(TW::mul12(y5, y2));
     y5 = TW::mul12(TW::mul12(y5, y0), y4);
     return TW::mul12(y5, y1);
+  }
+};
+
+// ================================================================== BW6-761 (Groth16 verify, crates/epoch-snark/src/api/verifier.rs:35)
+// Same lane-parallel tower (QTower is generic over the base policy: here one Fq coefficient per lane and per half), ark-ec
+// models/bw6 formulas as in pairing.h: two Miller loops (x+1, and the signed digits of x^3-x^2-x), f1 * frob(f2), then
+// (q^3-1)(q+1) and the hard part m^R0(x) * (m^q)^R1(x).  G2 coordinates are in Fq (M-type twist, B' = 4).
+template <class QB> struct QPairing761 {
+  typedef typename QB::V V;
+  typedef V F;                       // P's coordinates live in the same field as the tower base
+  typedef QTower<QB> TW;
+  typedef typename TW::E12 E12;      // an Fq6 element of BW6-761 (the name is the tower template's)
+  struct Line { V c0, c1, c2; };
+
+  // x * (d1 v) for a group-uniform d1: lane j: x_{j-1} d1 (nonresidue on the wrap to lane 0)
+  QFN static V mul6_by_1(const V& x, const V& d1) {
+    V qv = QB::mul(QB::template perm<QP(2, 0, 1)>(x), d1);
+    return QB::wred(QB::template sel<0>(QB::mul_nr(qv), qv));
+  }
+  // f *= (s0 + s1 u) + (s4 u) v   (ark-ff Fp6_2over3::mul_by_014)
+  QFN static void mul_by_014(E12& f, const V& s0, const V& s1, const V& s4) {
+    V v0 = TW::mul6_by_01(f.a, s0, s1);
+    V v1 = mul6_by_1(f.b, s4);
+    V t = TW::mul6_by_01(QB::add(f.a, f.b), s0, QB::add(s1, s4));
+    f.b = QB::wred(QB::template sub<4>(QB::template sub<4>(t, v0), v1));
+    f.a = QB::wred(QB::add(v0, TW::mul_by_gen(v1)));
+  }
+  QFN static void double_step(V& Rc, Line& l) {
+    V r1 = QB::mul(Rc, Rc);                                           // X^2, Y^2, Z^2
+    V b = QB::template bcast<1>(r1), c = QB::template bcast<2>(r1);
+    V c3 = QB::tpl(c);
+    V e = QB::wred(QB::dbl(QB::dbl(c3)));                             // B' * 3c = 12 c
+    V e_2 = QB::dbl(e);
+    // round 2: lane 0: Y Z, lane 1: X Y, lane 2: (2e)^2
+    V r2 = QB::mul(QB::pick(QB::template bcast<1>(Rc), QB::template bcast<0>(Rc), e_2), QB::pick(QB::template bcast<2>(Rc), QB::template bcast<1>(Rc), e_2));
+    V h = QB::dbl(QB::template bcast<0>(r2));                         // 2YZ = (Y+Z)^2 - (b + c)
+    V f3 = QB::tpl(e);                                                // vb 9
+    V g = QB::add(b, f3);
+    V a2 = QB::dbl(QB::template bcast<1>(r2));                        // 2XY
+    V i = QB::template sub<4>(e, b);
+    V e2s = QB::template bcast<2>(r2);
+    // round 3: lane 0: 2a (b - f3) = X', lane 1: g^2, lane 2: 4b h = Z'
+    V r3 = QB::mul(QB::pick(a2, g, QB::dbl(QB::dbl(b))), QB::pick(QB::template sub<16>(b, f3), g, h));
+    V y3 = QB::wred(QB::template sub<8>(r3, QB::tpl(e2s)));           // lane 1: g^2 - 3 (2e)^2
+    Rc = QB::template sel<1>(y3, r3);
+    l.c0 = QB::wred(i);
+    l.c1 = QB::wred(QB::tpl(QB::template bcast<0>(r1)));
+    l.c2 = QB::wred(QB::template neg<16>(h));
+  }
+  QFN static void add_step(V& Rc, const V& Qc, Line& l) {            // Qc: lane 0 = Q.x, lane 1 = +-Q.y
+    V X = QB::template bcast<0>(Rc), Y = QB::template bcast<1>(Rc), Z = QB::template bcast<2>(Rc);
+    V qx = QB::template bcast<0>(Qc), qy = QB::template bcast<1>(Qc);
+    V r1 = QB::mul(QB::template sel<0>(qy, qx), Z);
+    V theta = QB::template sub<4>(Y, QB::template bcast<0>(r1)), lambda = QB::template sub<4>(X, QB::template bcast<1>(r1));
+    V r2 = QB::mul(QB::pick(theta, lambda, theta), QB::pick(theta, lambda, qx));
+    V c = QB::template bcast<0>(r2), d = QB::template bcast<1>(r2);
+    V r3 = QB::mul(QB::pick(lambda, Z, X), QB::pick(d, c, d));
+    V e = QB::template bcast<0>(r3), g = QB::template bcast<2>(r3);
+    V h = QB::template sub<8>(QB::add(e, QB::template bcast<1>(r3)), QB::dbl(g));
+    V r4 = QB::mul(QB::pick(lambda, e, Z), QB::pick(qy, Y, e));
+    l.c0 = QB::wred(QB::template sub<4>(QB::template bcast<2>(r2), QB::template bcast<0>(r4)));
+    V r5 = QB::mul(QB::template sel<0>(lambda, theta), QB::template sel<0>(h, QB::template sub<16>(g, h)));
+    V y3 = QB::wred(QB::template sub<4>(r5, r4));
+    Rc = QB::pick(r5, y3, r4);
+    l.c1 = QB::wred(QB::template neg<8>(theta));
+    l.c2 = QB::wred(lambda);
+  }
+  // f *= c0 + (c1 P.x) u + (c2 P.y) u v: lane 0 scales c1, lane 1 scales c2, both broadcast
+  QFN static void ell(E12& f, const Line& l, const F& px, const F& py) {
+    V t = QB::mul(QB::template sel<0>(l.c1, l.c2), QB::pick(px, py, py));
+    mul_by_014(f, l.c0, QB::template bcast<0>(t), QB::template bcast<1>(t));
+  }
+  QNI static void step_double(V& Rc, E12& f, const F& px, const F& py) { Line l; double_step(Rc, l); ell(f, l, px, py); }
+  QNI static void step_add(V& Rc, const V& Qc, E12& f, const F& px, const F& py) { Line l; add_step(Rc, Qc, l); ell(f, l, px, py); }
+  QNI static E12 frob1(const E12& x) {
+    V ca = QB::pick(QB::one(), QB::constant(T761::FROB1_2), QB::constant(T761::FROB1_4));
+    V cb = QB::pick(QB::constant(T761::FROB1_1), QB::constant(T761::FROB1_3), QB::constant(T761::FROB1_5));
+    return {QB::mul(x.a, ca), QB::mul(x.b, cb)};
+  }
+  QFN static E12 miller(const F& px, const F& py, const V& Qc) {
+    V Rc = QB::template sel<2>(QB::one(), Qc);
+    E12 f1 = TW::one12();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = 62; i >= 0; i--) {
+      f1 = TW::sqr12(f1);
+      step_double(Rc, f1, px, py);
+      if ((T761::LOOP1 >> i) & 1) step_add(Rc, Qc, f1, px, py);
+    }
+    Rc = QB::template sel<2>(QB::one(), Qc);
+    const V Qn = QB::template sel<1>(QB::wred(QB::template neg<4>(Qc)), Qc);   // (Q.x, -Q.y)
+    E12 f2 = TW::one12();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = T761::LOOP2_LEN - 1; i >= 1; i--) {
+      if (i != T761::LOOP2_LEN - 1) f2 = TW::sqr12(f2);
+      step_double(Rc, f2, px, py);
+      const int d = T761::LOOP2_NAF[i - 1];
+      if (d > 0) step_add(Rc, Qc, f2, px, py);
+      else if (d < 0) step_add(Rc, Qn, f2, px, py);
+    }
+    return TW::mul12(f1, frob1(f2));
+  }
+  // whole product in one group (k <= MAXK pairs, one accumulator per loop): same value as the product of the per-pair loops
+  template <int MAXK> QFN static E12 miller_multi(int k, const F* px, const F* py, const V* Qc) {
+    E12 acc = TW::one12();
+    for (int p = 0; p < k; p++) acc = (p == 0) ? miller(px[p], py[p], Qc[p]) : TW::mul12(acc, miller(px[p], py[p], Qc[p]));
+    return acc;
+  }
+  QNI static E12 pow(const E12& f, const uint64_t* e, int bits, bool neg) {
+    E12 acc = f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = bits - 2; i >= 0; i--) {
+      acc = TW::sqr12(acc);
+      if ((e[i >> 6] >> (i & 63)) & 1) acc = TW::mul12(acc, f);
+    }
+    return neg ? TW::conj12(acc) : acc;
+  }
+  QFN static E12 final_exponentiation(const E12& f) {
+    E12 a = TW::mul12(TW::conj12(f), TW::inv12(f));        // f^(q^3 - 1)
+    E12 m = TW::mul12(frob1(a), a);                        // ^(q + 1)
+    E12 p0 = pow(m, T761::R0_MAG, T761::R0_BITS, T761::R0_NEG);
+    E12 p1 = pow(frob1(m), T761::R1_MAG, T761::R1_BITS, T761::R1_NEG);
+    return TW::mul12(p0, p1);
   }
 };
 

@@ -34,6 +34,9 @@ struct Base377 {  // base = Fq2, cubic non-residue xi = u
   TW_FN static void mul(T& r, const T& a, const T& b) { r = Fq2::mul(a, b); }
   TW_FN static void sqr(T& r, const T& a) { r = Fq2::sqr(a); }
   TW_FN static void inv(T& r, const T& a) { r = Fq2::inv(a); }
+  HD static T mul_inl(const T& a, const T& b) { return Fq2::mul(a, b); }   // inlined variants for the lane-parallel kernels
+  HD static T inv_inl(const T& a) { return Fq2::inv(a); }
+  HD static T half(const T& a) { return {Fq::half(a.c0), Fq::half(a.c1)}; }
   HD static T add(const T& a, const T& b) { return Fq2::norm(Fq2::add(a, b)); }
   HD static T dbl(const T& a) { return Fq2::norm(Fq2::add(a, a)); }
   HD static T tpl(const T& a) { return Fq2::norm(Fq2::add(Fq2::add(a, a), a)); }
@@ -59,6 +62,9 @@ struct Base761 {  // base = Fq (761 bits), cubic non-residue -4
   TW_FN static void mul(T& r, const T& a, const T& b) { r = Fw::mul(a, b); }
   TW_FN static void sqr(T& r, const T& a) { r = Fw::sqr(a); }
   TW_FN static void inv(T& r, const T& a) { r = Fw::inv(a); }
+  HD static T mul_inl(const T& a, const T& b) { return Fw::mul(a, b); }
+  HD static T inv_inl(const T& a) { return Fw::inv(a); }
+  HD static T half(const T& a) { return Fw::half(a); }
   HD static T add(const T& a, const T& b) { return Fw::norm(Fw::add(a, b)); }
   HD static T dbl(const T& a) { return Fw::norm(Fw::add(a, a)); }
   HD static T tpl(const T& a) { return Fw::norm(Fw::add(Fw::add(a, a), a)); }

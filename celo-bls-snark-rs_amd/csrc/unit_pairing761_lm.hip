@@ -1,0 +1,3 @@
+// Translation unit: lane-parallel BW6-761 Miller loop and GT product kernels (pairing_lanes.h).
+#include "pairing_lanes_kernels.h"
+namespace celo { CELO_DEFINE_LANE_MILLER_LAUNCHERS(LaneLaunch761, LP761) }

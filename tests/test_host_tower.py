@@ -22,7 +22,7 @@ def ht():
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB, srcs[0]])
     lib = C.CDLL(LIB)
-    if not hasattr(lib, "ht_pairing_377_lanes"):
+    if not hasattr(lib, "ht_pairing_761_lanes"):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB, srcs[0]])
         lib = C.CDLL(LIB)
     return lib
@@ -119,19 +119,20 @@ def test_bw6_pairing_matches_oracle(ht, golden):
     g1, _ = co.pack_761([vk["alpha_g1"]])
     g2, _ = co.pack_761([vk["beta_g2"]])
 
-    def hp761(mode, a, b, k):
-        out = np.zeros(72, dtype=np.uint64)
-        one = C.c_int(0)
-        ht.ht_pairing_761(mode, _p(a), _p(b), C.c_size_t(k), _p(out), C.byref(one))
-        return out, bool(one.value)
-
-    ml, _ = hp761(1, g1, g2, 1)
     oml = np.zeros(72, dtype=np.uint64)
     co.lib().orc_miller_loop_bw6_761(_p(g1), None, _p(g2), None, C.c_size_t(1), _p(oml))
-    assert np.array_equal(ml, oml)
-    gt, one = hp761(0, g1, g2, 1)
     ogt, oone = co.pairing_product_761(g1, None, g2, None)
-    assert np.array_equal(gt, ogt) and one == oone == False
+    for fn in ("ht_pairing_761", "ht_pairing_761_lanes"):      # one-lane functions, then the lane-parallel algorithms (three host lanes)
+        def hp761(mode, a, b, k):
+            out = np.zeros(72, dtype=np.uint64)
+            one = C.c_int(0)
+            getattr(ht, fn)(mode, _p(a), _p(b), C.c_size_t(k), _p(out), C.byref(one))
+            return out, bool(one.value)
+
+        ml, _ = hp761(1, g1, g2, 1)
+        assert np.array_equal(ml, oml), fn
+        gt, one = hp761(0, g1, g2, 1)
+        assert np.array_equal(gt, ogt) and one == oone == False, fn
 
 
 def test_shared_accumulator_product_matches_oracle(ht):

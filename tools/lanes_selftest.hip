@@ -4,6 +4,10 @@
 #include <vector>
 #include <cstring>
 using namespace celo;
+typedef QPairing377<QTri377> QPair;
+typedef QTower<QTri377> QTow;
+#define lanes_load lanes_load<LP377>
+#define lanes_store lanes_store<LP377>
 
 // op 0: mul12, 1: sqr12, 2: cyclotomic, 3: mul_by_034 (s from y's first three coefficients), 4: inv12, 5: frob1, 6: conj, 7: identity (load/store)
 __global__ void k_quad_op(int op, const uint32_t* x, const uint32_t* y, uint32_t* out) {
@@ -14,7 +18,7 @@ __global__ void k_quad_op(int op, const uint32_t* x, const uint32_t* y, uint32_t
     case 2: r = QTow::cyclotomic_sqr(a); break;
     case 3: { Fq2 s0 = Fq2::load(y), s3 = Fq2::load(y + 32), s4 = Fq2::load(y + 64); r = a; QTow::mul_by_034(r, s0, s3, s4); } break;
     case 4: r = QTow::inv12(a); break;
-    case 5: r = QTow::frob12<1>(a); break;
+    case 5: r = QPair::frob12<1>(a); break;
     case 6: r = QTow::conj12(a); break;
     default: r = a; break;
   }

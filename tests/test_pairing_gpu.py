@@ -127,3 +127,45 @@ def test_lane_parallel_pieces_match_one_lane_twins(gpu):
     assert os.path.exists(exe), "run `make -C celo-bls-snark-rs_amd/csrc` (or __graft_entry__.build()) first"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "MISMATCH" not in r.stdout and r.stdout.count(" ok") >= 16, r.stdout + r.stderr
+
+
+def test_shared_accumulator_mode_at_scale(gpu):
+    """>= 16384 products of <= 4 pairs in one call take the one-group-per-product path (pairing_lanes.h miller_multi: one
+    accumulator per product).  20000 products tiled from 8 distinct ones: 2-pair verify shapes (one corrupted), a 3-pair
+    product, and 3-pair products whose third pair has a point at infinity (skipped, as ark-ec's miller_loop does).  The accept
+    vector must equal the oracle's on the distinct products and the GT value of a 3-pair product must be bit-exact."""
+    rng = ecc.SplitMix64(4242)
+    ng2 = ecc.E2_377.neg(ecc.G2_377)
+    prods = []   # (list of G1, list of G2, expect)
+    for i in range(8):
+        sk = ecc.random_scalar(rng, ecc.R377)
+        Hm = ecc.E1_377.mul(ecc.G1_377, rng.next() | 1)
+        sig = ecc.E1_377.mul(Hm, sk)
+        pk = ecc.E2_377.mul(ecc.G2_377, sk + (1 if i == 2 else 0))
+        if i < 4:
+            prods.append(([sig, Hm], [ng2, pk]))
+        elif i < 6:                      # a third pair that contributes 1: G1 or G2 at infinity
+            prods.append(([sig, Hm, None if i == 4 else Hm], [ng2, pk, pk if i == 4 else None]))
+        else:                            # e(aP, bQ) e(-abP, Q) e(P, Q) != 1 and a 3-pair product that is 1: e(P,Q) e(P,Q) e(-2P,Q)
+            P, Qp = ecc.G1_377, ecc.G2_377
+            if i == 6:
+                prods.append(([P, P, ecc.E1_377.neg(ecc.E1_377.mul(P, 2))], [Qp, Qp, Qp]))
+            else:
+                prods.append(([P, Hm, sig], [Qp, pk, ng2]))
+    g1l, g2l, offs = [], [], [0]
+    for a, b in prods:
+        g1l += a; g2l += b; offs.append(offs[-1] + len(a))
+    g1u, i1u = co.pack_g1_377(g1l)
+    g2u, i2u = co.pack_g2_377(g2l)
+    want = [bool(co.pairing_product_377(g1u[offs[i]:offs[i + 1]], i1u[offs[i]:offs[i + 1]], g2u[offs[i]:offs[i + 1]], i2u[offs[i]:offs[i + 1]])[1])
+            for i in range(8)]
+    assert want == [True, True, False, True, True, True, True, False]
+    reps = 2500                                                     # 20000 products
+    g1 = np.tile(g1u, (reps, 1)); g2 = np.tile(g2u, (reps, 1)); i1 = np.tile(i1u, reps); i2 = np.tile(i2u, reps)
+    per = offs[-1]
+    off_all = np.concatenate([np.array(offs[:-1], dtype=np.uint32) + np.uint32(per * r) for r in range(reps)] + [np.array([per * reps], dtype=np.uint32)])
+    got = gpu.pairing_product_is_one_batch(g1, i1, g2, i2, off_all)
+    assert got.reshape(reps, 8).astype(bool).tolist() == [want] * reps
+    gt = gpu.pairing_gt(g1, i1, g2, i2, off_all)
+    assert np.array_equal(gt[6], co.pairing_product_377(g1u[offs[6]:offs[7]], None, g2u[offs[6]:offs[7]], None)[0])
+    assert np.array_equal(gt[8 * 1234 + 7], co.pairing_product_377(g1u[offs[7]:offs[8]], None, g2u[offs[7]:offs[8]], None)[0])

@@ -19,15 +19,6 @@ template <class F> struct Affine {
   F x, y;  // normalised limbs (lb<=1), vb<=2
 };
 
-// multiply dispatch: OL = true routes through ONE out-of-line copy of the field multiply / square per translation unit
-// (operands by reference through private memory).  Measured: it costs the G2 reduction kernels 1.8x (3.1 -> 5.5 ms at
-// 2^20) for a device-compile saving that does not matter once the HOST pass stopped force-inlining (fp.h), so the
-// point-level outline wrappers below keep OL = false; the switch stays for experiments.
-template <class F, bool OL> struct FieldOps {
-  HD static F mul(const F& a, const F& b) { if constexpr (OL) return F::mul_ol(a, b); else return F::mul(a, b); }
-  HD static F sqr(const F& a) { if constexpr (OL) return F::sqr_ol(a); else return F::sqr(a); }
-};
-
 template <class F> struct Xyzz {
   F X, Y, ZZ, ZZZ;  // stored normalised: lb 1; vb(X) <= 19, vb(Y) <= 7, vb(ZZ), vb(ZZZ) <= 3 (Fp2 products are < 3p)
   HD static Xyzz identity() { return {F::zero(), F::zero(), F::zero(), F::zero()}; }
@@ -52,21 +43,20 @@ template <class F> HD Xyzz<F> xyzz_dbl_affine(const Affine<F>& p) {
   return {X3, Y3, V, W};
 }
 
-template <class F, bool OL = false> HD Xyzz<F> xyzz_dbl(const Xyzz<F>& a) {
-  typedef FieldOps<F, OL> O;
+template <class F> HD Xyzz<F> xyzz_dbl(const Xyzz<F>& a) {
   if (a.is_identity()) return a;
   if (a.Y.is_zero_mod_p()) return Xyzz<F>::identity();
   F U = F::dbl(a.Y);                                  // [2, 12]
-  F V = O::sqr(U);
-  F W = O::mul(U, V);
-  F S = O::mul(a.X, V);
-  F xx = O::sqr(a.X);
+  F V = F::sqr(U);
+  F W = F::mul(U, V);
+  F S = F::mul(a.X, V);
+  F xx = F::sqr(a.X);
   F M = F::add(F::add(xx, xx), xx);                   // [3, 6]
-  F M2 = O::sqr(M);
+  F M2 = F::sqr(M);
   F X3 = F::norm(F::template sub<16, 3>(M2, F::dbl(S)));
   F t = F::template sub<32, 1>(S, X3);
-  F Y3 = OL ? F::norm(F::template sub<4, 1>(O::mul(M, t), O::mul(W, a.Y))) : F::mul_sub(M, t, W, a.Y);
-  return {X3, Y3, O::mul(V, a.ZZ), O::mul(W, a.ZZZ)};
+  F Y3 = F::mul_sub(M, t, W, a.Y);
+  return {X3, Y3, F::mul(V, a.ZZ), F::mul(W, a.ZZZ)};
 }
 
 // acc += (x2, y2) affine (madd-2008-s).  acc may be the identity.
@@ -96,31 +86,30 @@ template <class F> HD void xyzz_madd(Xyzz<F>& a, const Affine<F>& p) {
 }
 
 // a += b (add-2008-s), both XYZZ, either may be the identity
-template <class F, bool OL = false> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& b) {
-  typedef FieldOps<F, OL> O;
+template <class F> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& b) {
   if (b.is_identity()) return;
   if (a.is_identity()) { a = b; return; }
-  F U1 = O::mul(a.X, b.ZZ);
-  F U2 = O::mul(b.X, a.ZZ);
-  F S1 = O::mul(a.Y, b.ZZZ);
-  F S2 = O::mul(b.Y, a.ZZZ);
+  F U1 = F::mul(a.X, b.ZZ);
+  F U2 = F::mul(b.X, a.ZZ);
+  F S1 = F::mul(a.Y, b.ZZZ);
+  F S2 = F::mul(b.Y, a.ZZZ);
   F Pd = F::template sub<4, 1>(U2, U1);               // [3, 6]
   F R = F::template sub<4, 1>(S2, S1);
   if (Pd.is_zero_mod_p()) {
-    if (R.is_zero_mod_p()) a = xyzz_dbl<F, OL>(a);
+    if (R.is_zero_mod_p()) a = xyzz_dbl<F>(a);
     else a = Xyzz<F>::identity();
     return;
   }
-  F PP = O::sqr(Pd);
-  F PPP = O::mul(Pd, PP);
-  F Q = O::mul(U1, PP);
-  F R2 = O::sqr(R);
+  F PP = F::sqr(Pd);
+  F PPP = F::mul(Pd, PP);
+  F Q = F::mul(U1, PP);
+  F R2 = F::sqr(R);
   F s = F::add(F::add(PPP, Q), Q);
   F X3 = F::norm(F::template sub<16, 3>(R2, s));
   F t = F::template sub<32, 1>(Q, X3);
-  F Y3 = OL ? F::norm(F::template sub<4, 1>(O::mul(R, t), O::mul(S1, PPP))) : F::mul_sub(R, t, S1, PPP);
-  a.ZZ = O::mul(O::mul(a.ZZ, b.ZZ), PP);
-  a.ZZZ = O::mul(O::mul(a.ZZZ, b.ZZZ), PPP);
+  F Y3 = F::mul_sub(R, t, S1, PPP);
+  a.ZZ = F::mul(F::mul(a.ZZ, b.ZZ), PP);
+  a.ZZZ = F::mul(F::mul(a.ZZZ, b.ZZZ), PPP);
   a.X = X3;
   a.Y = Y3;
 }
@@ -132,8 +121,8 @@ template <class F, bool OL = false> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& 
 #else
 #define CURVE_FN inline
 #endif
-template <class F> CURVE_FN void xyzz_add_outline(Xyzz<F>& a, const Xyzz<F>& b) { xyzz_add<F, false>(a, b); }
-template <class F> CURVE_FN void xyzz_dbl_outline(Xyzz<F>& a) { a = xyzz_dbl<F, false>(a); }
+template <class F> CURVE_FN void xyzz_add_outline(Xyzz<F>& a, const Xyzz<F>& b) { xyzz_add<F>(a, b); }
+template <class F> CURVE_FN void xyzz_dbl_outline(Xyzz<F>& a) { a = xyzz_dbl<F>(a); }
 // 14-limb fields (BLS12-377 G1, the headline path) keep the inlined bodies: out-of-line calls pass the points through
 // private memory and doubled the per-addition latency of the (latency-bound) reduction kernels.
 template <class F> HD void xyzz_add_fn(Xyzz<F>& a, const Xyzz<F>& b) {

@@ -143,14 +143,6 @@ template <class P> struct Fp {
     return r;
   }
 
-  // one out-of-line copy per translation unit (see curve.h FieldOps)
-#if defined(__HIPCC__)
-  __host__ __device__ __attribute__((noinline)) static Fp mul_ol(const Fp& a, const Fp& b) { return mul(a, b); }
-  __host__ __device__ __attribute__((noinline)) static Fp sqr_ol(const Fp& a) { return sqr(a); }
-#else
-  static Fp mul_ol(const Fp& a, const Fp& b) { return mul(a, b); }
-  static Fp sqr_ol(const Fp& a) { return sqr(a); }
-#endif
   HD static Fp add(const Fp& a, const Fp& b) {
     Fp r;
 #pragma unroll

@@ -28,13 +28,6 @@ template <class P> struct Fp2 {
     B a0 = B::norm(a.c0), a1 = B::norm(a.c1);
     return {B::template mul2<true>(a0, a0, a1, a1), B::mul(B::dbl(a0), a1)};
   }
-#if defined(__HIPCC__)
-  __host__ __device__ __attribute__((noinline)) static Fp2 mul_ol(const Fp2& a, const Fp2& b) { return mul(a, b); }
-  __host__ __device__ __attribute__((noinline)) static Fp2 sqr_ol(const Fp2& a) { return sqr(a); }
-#else
-  static Fp2 mul_ol(const Fp2& a, const Fp2& b) { return mul(a, b); }
-  static Fp2 sqr_ol(const Fp2& a) { return sqr(a); }
-#endif
   HD static Fp2 mul_sub(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { return norm(sub<4, 1>(mul(a, b), mul(c, d))); }
   HD static Fp2 mul_fp(const Fp2& a, const B& k) {  // k normalised or lb*lb within Fp::mul's bound
     return {B::mul(a.c0, k), B::mul(a.c1, k)};

@@ -15,11 +15,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
-#include <random>
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include <thread>
 #include <atomic>
+#include <memory>
+#include <algorithm>
+#include <sys/random.h>
 #include "curve.h"
 #include "fp2.h"
 #include "../../include/celo_bls_amd.h"
@@ -430,6 +433,19 @@ struct ChaCha20Rng {  // rand_chacha 0.2 behind rand_core 0.5 BlockRng: 64-word 
     uint64_t lo = buf[63]; generate(); uint64_t hi = buf[0]; idx = 1; return (hi << 32) | lo;
   }
 };
+// A ChaCha20 stream seeded with 32 bytes from the operating system (getrandom): what rand::thread_rng() is in the reference
+// (batch.rs:51 draws the batching exponents from it).  One system call per FFI call instead of one per exponent word.
+bool os_seeded_rng(ChaCha20Rng& rng) {
+  uint8_t seed[32];
+  size_t got = 0;
+  while (got < sizeof seed) {
+    ssize_t r = getrandom(seed + got, sizeof seed - got, 0);
+    if (r <= 0) return false;
+    got += (size_t)r;
+  }
+  memcpy(rng.key, seed, 32);
+  return true;
+}
 struct CompositeParams {
   std::vector<EdPoint> gens;  // [NUM_WINDOWS * WINDOW_SIZE]: window-major, generator j = 16^j * base
   static constexpr int WINDOW_SIZE = 93, NUM_WINDOWS = 560;
@@ -563,27 +579,57 @@ bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJ
   }
   return ok;
 }
-// Montgomery's trick: Jacobian (ark limbs, stride 3*A u64) -> affine xy (ark limbs); inf[i] = 1 for the identity
-template <class F> void batch_to_affine(const uint64_t* jac, size_t n, uint64_t* xy, uint8_t* inf) {
+// Jacobian (ark limbs, stride 3*A u64) -> affine xy (ark limbs); inf[i] = 1 for the identity.  Handles that came from the wire
+// (deserialize_*) carry Z = 1 and are copied without arithmetic; the rest share one inversion per chunk (Montgomery's
+// trick); large inputs are cut into chunks across the host cores (at BASELINE config 3's scale - 10^6 keys and signatures
+// per call - a serial pass here would cost 30x the GPU work it feeds).
+template <class F> void batch_to_affine_range(const uint64_t* jac, size_t n, uint64_t* xy, uint8_t* inf) {
   constexpr int A = F::ARK64;
-  std::vector<F> z(n), pre(n);
-  F acc = F::one();
+  uint64_t one_ark[A];
+  F::one().to_ark(one_ark);
+  std::vector<uint32_t> todo;
   for (size_t i = 0; i < n; i++) {
-    z[i] = F::norm(F::from_ark(jac + i * 3 * A + 2 * A));
-    inf[i] = z[i].is_zero_mod_p() ? 1 : 0;
-    pre[i] = acc;
-    if (!inf[i]) acc = F::mul(acc, z[i]);
+    const uint64_t* zp = jac + i * 3 * A + 2 * A;
+    if (memcmp(zp, one_ark, A * 8) == 0) { memcpy(xy + i * 2 * A, jac + i * 3 * A, 2 * A * 8); inf[i] = 0; continue; }
+    bool zero = true;
+    for (int k = 0; k < A; k++) zero = zero && zp[k] == 0;
+    if (zero) { memset(xy + i * 2 * A, 0, 2 * A * 8); inf[i] = 1; continue; }
+    todo.push_back((uint32_t)i);
+  }
+  if (todo.empty()) return;
+  std::vector<F> z(todo.size()), pre(todo.size());
+  F acc = F::one();
+  for (size_t t = 0; t < todo.size(); t++) {
+    z[t] = F::norm(F::from_ark(jac + (size_t)todo[t] * 3 * A + 2 * A));
+    inf[todo[t]] = z[t].is_zero_mod_p() ? 1 : 0;     // a non-canonical zero cannot come from this library; handled anyway
+    pre[t] = acc;
+    if (!inf[todo[t]]) acc = F::mul(acc, z[t]);
   }
   F ai = F::inv(acc);
-  for (size_t i = n; i-- > 0;) {
+  for (size_t t = todo.size(); t-- > 0;) {
+    const size_t i = todo[t];
     uint64_t* o = xy + i * 2 * A;
     if (inf[i]) { memset(o, 0, 2 * A * 8); continue; }
-    F zi = F::mul(ai, pre[i]);
-    ai = F::mul(ai, z[i]);
+    F zi = F::mul(ai, pre[t]);
+    ai = F::mul(ai, z[t]);
     F zi2 = F::sqr(zi);
     F::mul(F::from_ark(jac + i * 3 * A), zi2).to_ark(o);
     F::mul(F::from_ark(jac + i * 3 * A + A), F::mul(zi2, zi)).to_ark(o + A);
   }
+}
+template <class F> void batch_to_affine(const uint64_t* jac, size_t n, uint64_t* xy, uint8_t* inf) {
+  constexpr int A = F::ARK64;
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 64) nt = 64;
+  if (n < 4096 || nt < 2) { batch_to_affine_range<F>(jac, n, xy, inf); return; }
+  const size_t chunk = (n + nt - 1) / nt;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++) {
+    const size_t lo = (size_t)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    if (lo >= hi) break;
+    th.emplace_back([=]() { batch_to_affine_range<F>(jac + lo * 3 * A, hi - lo, xy + lo * 2 * A, inf + lo); });
+  }
+  for (auto& x : th) x.join();
 }
 
 // ---------------------------------------------------------------- BW6-761 wire format (Groth16 VerifyingKey / Proof points)
@@ -725,10 +771,11 @@ bool init(void) {  // lib.rs:28-36: force both lazy hashers (the Bowe-Hopwood ge
 // ---------------------------------------------------------------- keys (crates/bls-snark-sys/src/signatures.rs:19-42)
 bool generate_private_key(PrivateKey** out_private_key) {
   if (!out_private_key) return false;
-  std::random_device rd;
+  ChaCha20Rng rng;
+  if (!os_seeded_rng(rng)) return false;
   PrivateKey* sk = new PrivateKey;
   for (;;) {
-    for (int i = 0; i < 4; i++) sk->k[i] = ((uint64_t)rd() << 32) | rd();
+    for (int i = 0; i < 4; i++) sk->k[i] = rng.next_u64();
     sk->k[3] &= (1ULL << 61) - 1;  // 253 bits
     if (cmp_n(sk->k, R_ORDER, 4) < 0) break;
   }
@@ -1077,8 +1124,19 @@ bool batch_verify_signature(const MessageFFI* messages, size_t n, bool composite
 // Batch::verify per batch (crates/bls-crypto/src/bls/batch.rs:44-84), all batches at once: random exponents from the OS
 // RNG, all G2 MSMs in one call, all G1 MSMs in one call, all 2-pair checks in one call.  out_results is always filled;
 // the return value is false if any batch fails (signatures.rs:392-400).
+struct PhaseLog {  // CELO_AMD_LOG=1: wall time of the host / device phases of one FFI call
+  const char* fn; bool on; std::chrono::steady_clock::time_point t;
+  explicit PhaseLog(const char* f) : fn(f), on(getenv("CELO_AMD_LOG") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[celo-amd] %s: %-28s %9.3f ms\n", fn, what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
 bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composite, bool cip22, bool* out_results) {   /* signatures.rs:343 */
   if ((!batches && m) || !out_results) return false;
+  PhaseLog ph("batch_verify_strict");
   if (!composite && cip22) { for (size_t i = 0; i < m; i++) out_results[i] = false; return false; }  // per-batch false (signatures.rs:387)
   if (m == 0) return true;
   std::vector<uint32_t> offs(m + 1, 0);
@@ -1087,30 +1145,81 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     offs[b + 1] = offs[b] + (uint32_t)batches[b].public_keys_len;
   }
   const size_t tot = offs[m];
-  std::vector<uint64_t> pkj(tot * 36), sgj(tot * 18), pk_xy(tot * 24), sg_xy(tot * 12), sc(tot * 4, 0);
-  std::vector<uint8_t> pk_inf(tot, 0), sg_inf(tot, 0);
-  std::random_device rd;
-  for (size_t b = 0; b < m; b++) {
-    const size_t n = batches[b].public_keys_len;
-    size_t lg = 0;
-    while (((size_t)1 << lg) < n) lg++;                               // ark_std::log2 = ceil(log2)
-    size_t nbytes = (128 + lg + 7) / 8;                               // byte_count_from_target_batch_size (batch.rs:23-28)
-    if (nbytes > 31) nbytes = 31;
-    for (size_t i = 0; i < n; i++) {
+  // staging buffers are written in full below: plain new[] (a value-initialising vector would zero ~0.5 GB at config-3 scale)
+  std::unique_ptr<uint64_t[]> pk_xy_(new uint64_t[tot * 24 + 1]), sg_xy_(new uint64_t[tot * 12 + 1]), sc_(new uint64_t[tot * 4 + 1]);
+  std::unique_ptr<uint8_t[]> pk_inf_(new uint8_t[tot + 1]), sg_inf_(new uint8_t[tot + 1]);
+  uint64_t *pk_xy = pk_xy_.get(), *sg_xy = sg_xy_.get(), *sc = sc_.get();
+  uint8_t *pk_inf = pk_inf_.get(), *sg_inf = sg_inf_.get();
+  ChaCha20Rng master;
+  if (!os_seeded_rng(master)) { log_err("batch_verify_strict: no OS randomness"); return false; }
+  for (size_t b = 0; b < m; b++)
+    for (size_t i = 0; i < batches[b].public_keys_len; i++)
       if (!batches[b].public_keys[i] || !batches[b].signatures[i]) return false;
-      memcpy(&pkj[(offs[b] + i) * 36], batches[b].public_keys[i]->xyz, 288);
-      memcpy(&sgj[(offs[b] + i) * 18], batches[b].signatures[i]->xyz, 144);
-      uint8_t rb[32];
-      memset(rb, 0, 32);
-      for (size_t k = 0; k < nbytes; k += 4) { uint32_t r = rd(); memcpy(rb + k, &r, (nbytes - k) < 4 ? (nbytes - k) : 4); }
-      memcpy(&sc[(offs[b] + i) * 4], rb, 32);
+  // gather: ranges of batches across host threads; every thread draws its exponents from its own ChaCha20 stream (keys taken
+  // from the OS-seeded master stream).  Handles with Z = 1 (everything that came from the wire) are copied straight into the
+  // affine arrays; the others are normalised with one shared inversion per thread.
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 64) nt = 64;
+  if (nt < 1 || tot < 8192) nt = 1;
+  std::vector<ChaCha20Rng> rngs(nt);
+  for (unsigned t = 0; t < nt; t++) for (int k = 0; k < 8; k++) rngs[t].key[k] = master.next_u32();
+  uint64_t one2[12], one1[6];
+  Fq2_::one().to_ark(one2);
+  Fq_::one().to_ark(one1);
+  auto work = [&](unsigned t) {
+    const size_t b_lo = m * t / nt, b_hi = m * (t + 1) / nt;
+    ChaCha20Rng& rng = rngs[t];
+    std::vector<uint32_t> pk_todo, sg_todo;
+    for (size_t b = b_lo; b < b_hi; b++) {
+      const size_t n = batches[b].public_keys_len;
+      size_t lg = 0;
+      while (((size_t)1 << lg) < n) lg++;                               // ark_std::log2 = ceil(log2)
+      size_t nbytes = (128 + lg + 7) / 8;                               // byte_count_from_target_batch_size (batch.rs:23-28)
+      if (nbytes > 31) nbytes = 31;
+      for (size_t i = 0; i < n; i++) {
+        const size_t at = offs[b] + i;
+        const uint64_t* pk = batches[b].public_keys[i]->xyz;
+        const uint64_t* sg = batches[b].signatures[i]->xyz;
+        if (memcmp(pk + 24, one2, 96) == 0) { memcpy(pk_xy + at * 24, pk, 192); pk_inf[at] = 0; } else pk_todo.push_back((uint32_t)at);
+        if (memcmp(sg + 12, one1, 48) == 0) { memcpy(sg_xy + at * 12, sg, 96); sg_inf[at] = 0; } else sg_todo.push_back((uint32_t)at);
+        uint8_t rb[32];
+        memset(rb, 0, 32);
+        for (size_t k = 0; k < nbytes; k += 4) { uint32_t r = rng.next_u32(); memcpy(rb + k, &r, (nbytes - k) < 4 ? (nbytes - k) : 4); }
+        memcpy(sc + at * 4, rb, 32);
+      }
     }
+    // the handles that are not affine yet (aggregates, fresh signatures): gather, normalise, scatter
+    auto fix = [&](const std::vector<uint32_t>& todo, bool is_pk) {
+      if (todo.empty()) return;
+      const int A3 = is_pk ? 36 : 18, A2 = is_pk ? 24 : 12;
+      std::vector<uint64_t> jac(todo.size() * A3), xy(todo.size() * A2);
+      std::vector<uint8_t> inf(todo.size());
+      for (size_t k = 0; k < todo.size(); k++) {
+        size_t at = todo[k], b = std::upper_bound(offs.begin(), offs.end(), (uint32_t)at) - offs.begin() - 1, i = at - offs[b];
+        memcpy(&jac[k * A3], is_pk ? batches[b].public_keys[i]->xyz : batches[b].signatures[i]->xyz, A3 * 8);
+      }
+      if (is_pk) batch_to_affine_range<Fq2_>(jac.data(), todo.size(), xy.data(), inf.data());
+      else batch_to_affine_range<Fq_>(jac.data(), todo.size(), xy.data(), inf.data());
+      for (size_t k = 0; k < todo.size(); k++) {
+        memcpy((is_pk ? pk_xy : sg_xy) + (size_t)todo[k] * A2, &xy[k * A2], A2 * 8);
+        (is_pk ? pk_inf : sg_inf)[todo[k]] = inf[k];
+      }
+    };
+    fix(pk_todo, true);
+    fix(sg_todo, false);
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
   }
-  batch_to_affine<Fq2_>(pkj.data(), tot, pk_xy.data(), pk_inf.data());
-  batch_to_affine<Fq_>(sgj.data(), tot, sg_xy.data(), sg_inf.data());
+  ph.mark("gather handles -> affine, exponents");
   std::vector<uint64_t> bpk(m * 36), bsg(m * 18);
-  if (msm_batch_bls12_377_g2(pk_xy.data(), pk_inf.data(), sc.data(), offs.data(), m, bpk.data()) != 0) return false;
-  if (msm_batch_bls12_377_g1(sg_xy.data(), sg_inf.data(), sc.data(), offs.data(), m, bsg.data()) != 0) return false;
+  if (msm_batch_bls12_377_g2(pk_xy, pk_inf, sc, offs.data(), m, bpk.data()) != 0) return false;
+  ph.mark("G2 batch MSM (GPU)");
+  if (msm_batch_bls12_377_g1(sg_xy, sg_inf, sc, offs.data(), m, bsg.data()) != 0) return false;
+  ph.mark("G1 batch MSM (GPU)");
   std::vector<uint64_t> g1(2 * m * 12), g2(2 * m * 24), tmp1(m * 12), tmp2(m * 24);
   std::vector<uint8_t> i1(2 * m, 0), i2(2 * m, 0), t1(m), t2(m);
   batch_to_affine<Fq_>(bsg.data(), m, tmp1.data(), t1.data());
@@ -1124,11 +1233,14 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     jobs[b] = {batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, &g1[(2 * b + 1) * 12]};
     memcpy(&g2[(2 * b + 1) * 24], &tmp2[b * 24], 192); i2[2 * b + 1] = t2[b];
   }
+  ph.mark("pack pairs");
   if (!hash_many(composite, cip22, SIG_DOMAIN, jobs)) return false;
+  ph.mark("hash to G1");
   std::vector<uint32_t> po(m + 1);
   for (size_t b = 0; b <= m; b++) po[b] = (uint32_t)(2 * b);
   std::vector<uint8_t> ok(m, 0);
   if (pairing_product_is_one_batch_bls12_377(g1.data(), i1.data(), g2.data(), i2.data(), po.data(), m, ok.data()) != 0) return false;
+  ph.mark("pairing checks (GPU)");
   bool all = true;
   for (size_t b = 0; b < m; b++) { out_results[b] = ok[b] != 0; all = all && out_results[b]; }
   return all;

@@ -560,8 +560,8 @@ bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJ
   std::atomic<bool> ok(true);
   unsigned nt = std::thread::hardware_concurrency();
   if (nt == 0) nt = 1;
-  if (nt > 64) nt = 64;
-  if (nt > jobs.size()) nt = (unsigned)jobs.size();
+  if (nt > 128) nt = 128;
+  if (nt > jobs.size() / 4 + 1) nt = (unsigned)(jobs.size() / 4 + 1);    // at least ~4 hashes (~1 ms) per thread
   auto work = [&]() {
     for (;;) {
       size_t i = next.fetch_add(1);

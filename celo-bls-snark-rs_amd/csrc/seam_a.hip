@@ -1171,6 +1171,13 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     for (size_t i = 0; i < batches[b].public_keys_len; i++)
       if (!batches[b].public_keys[i] || !batches[b].signatures[i]) return false;
   ph.mark("validate + allocate");
+  // the message hashes depend on nothing computed here: they run on the host cores while the GPU does the two MSMs
+  std::vector<uint64_t> g1(2 * m * 12), g2(2 * m * 24);
+  std::vector<HashJob> jobs(m);
+  for (size_t b = 0; b < m; b++) jobs[b] = {batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, &g1[(2 * b + 1) * 12]};
+  bool hash_ok = false;
+  std::thread hasher([&]() { hash_ok = hash_many(composite, cip22, SIG_DOMAIN, jobs); });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } hasher_guard{hasher};   // early returns must not leave it running
   // gather: ranges of batches across host threads; every thread draws its exponents from its own ChaCha20 stream (keys taken
   // from the OS-seeded master stream).  Handles with Z = 1 (everything that came from the wire) are copied straight into the
   // affine arrays; the others are normalised with one shared inversion per thread.
@@ -1236,22 +1243,21 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   ph.mark("G2 batch MSM (GPU)");
   if (msm_batch_bls12_377_g1(sg_xy, sg_inf, sc, offs.data(), m, bsg.data()) != 0) return false;
   ph.mark("G1 batch MSM (GPU)");
-  std::vector<uint64_t> g1(2 * m * 12), g2(2 * m * 24), tmp1(m * 12), tmp2(m * 24);
+  std::vector<uint64_t> tmp1(m * 12), tmp2(m * 24);
   std::vector<uint8_t> i1(2 * m, 0), i2(2 * m, 0), t1(m), t2(m);
   batch_to_affine<Fq_>(bsg.data(), m, tmp1.data(), t1.data());
   batch_to_affine<Fq2_>(bpk.data(), m, tmp2.data(), t2.data());
   uint64_t ng2[24];
   neg_g2_generator(ng2);
-  std::vector<HashJob> jobs(m);
   for (size_t b = 0; b < m; b++) {
     memcpy(&g1[(2 * b) * 12], &tmp1[b * 12], 96); i1[2 * b] = t1[b];
     memcpy(&g2[(2 * b) * 24], ng2, 192);
-    jobs[b] = {batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, &g1[(2 * b + 1) * 12]};
     memcpy(&g2[(2 * b + 1) * 24], &tmp2[b * 24], 192); i2[2 * b + 1] = t2[b];
   }
   ph.mark("pack pairs");
-  if (!hash_many(composite, cip22, SIG_DOMAIN, jobs)) return false;
-  ph.mark("hash to G1");
+  hasher.join();
+  if (!hash_ok) return false;
+  ph.mark("wait for the hashes");
   std::vector<uint32_t> po(m + 1);
   for (size_t b = 0; b <= m; b++) po[b] = (uint32_t)(2 * b);
   std::vector<uint8_t> ok(m, 0);

@@ -547,9 +547,9 @@ __global__ void __launch_bounds__(128) k_batch_horner(const uint32_t* __restrict
   if (inst >= m) return;
   Xyzz<F> acc = Xyzz<F>::identity();
   for (int w = (int)nw - 1; w >= 0; w--) {
-    for (uint32_t k = 0; k < c; k++) xyzz_dbl_fn(acc);
+    for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl(acc);      // inlined: this chain is pure latency (c * nw dependent doublings)
     Xyzz<F> v = IO::load_xyzz(wsum + ((size_t)inst * nw + w) * IO::XYZZ_WORDS);
-    xyzz_add_fn(acc, v);
+    xyzz_add(acc, v);
   }
   uint64_t* o = out + (size_t)inst * 3 * IO::ARK64;
   if (acc.is_identity() || acc.ZZ.is_zero_mod_p()) {

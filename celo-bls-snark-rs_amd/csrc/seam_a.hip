@@ -1039,6 +1039,16 @@ bool hash_crh(const uint8_t* msg, int mlen, int hash_bytes, uint8_t** out_hash, 
   if (!composite_crh(msg, (size_t)mlen, o)) return false;
   return emit(o, out_hash, out_len);
 }
+/* test hook: DirectHasher with an arbitrary domain (<= 8 bytes, may be empty).  what: 0 = crh (32 bytes), 1 = xof of `msg`,
+   2 = hash = xof(domain, crh(domain, msg))  (hashers/direct.rs:20-78) */
+bool celo_amd_direct_hasher(int what, const uint8_t* domain, int dlen, const uint8_t* msg, int mlen, int out_bytes, uint8_t* out) {
+  if (!out || dlen < 0 || dlen > 8 || mlen < 0 || out_bytes < 0 || (!domain && dlen) || (!msg && mlen)) return false;
+  std::vector<uint8_t> r = what == 0 ? direct_crh(domain, (size_t)dlen, msg, (size_t)mlen, (size_t)out_bytes)
+                         : what == 1 ? direct_xof(domain, (size_t)dlen, msg, (size_t)mlen, (size_t)out_bytes)
+                                     : direct_hash(domain, (size_t)dlen, msg, (size_t)mlen, (size_t)out_bytes);
+  memcpy(out, r.data(), r.size());
+  return true;
+}
 /* test hook: CompositeHasher::hash = xof(domain, crh(message), out_bytes) (hashers/mod.rs Hasher::hash) */
 bool celo_amd_composite_hash(const uint8_t* domain8, const uint8_t* msg, int mlen, int out_bytes, uint8_t* out) {
   if (!domain8 || !out || mlen < 0 || out_bytes < 0) return false;

@@ -67,6 +67,9 @@ bool hash_composite(const uint8_t* msg, int msg_len, const uint8_t* extra, int e
 bool hash_crh(const uint8_t* msg, int msg_len, int hash_bytes, uint8_t** out_hash, int* out_len);          /* signatures.rs:169 (48 bytes: Bowe-Hopwood CRH x-coordinate) */
 bool hash_composite_cip22(const uint8_t* msg, int msg_len, const uint8_t* extra, int extra_len, uint8_t** out_hash, int* out_len,
                           uint8_t* attempt_counter);                                                       /* signatures.rs:215 */
+/* test hook: DirectHasher (hashers/direct.rs:20-78) with an explicit domain of 0..8 bytes.  what: 0 = crh (writes 32 bytes; out_bytes is
+ * the XOF length it is keyed on), 1 = xof(domain, msg, out_bytes), 2 = hash = xof(domain, crh(domain, msg, out_bytes), out_bytes). */
+bool celo_amd_direct_hasher(int what, const uint8_t* domain, int domain_len, const uint8_t* msg, int msg_len, int out_bytes, uint8_t* out);
 /* test hook: CompositeHasher::hash(domain, msg, out_bytes) = Blake2Xs XOF of the Bowe-Hopwood CRH (hashers/composite.rs:88-97) */
 bool celo_amd_composite_hash(const uint8_t* domain8, const uint8_t* msg, int msg_len, int out_bytes, uint8_t* out);
 /* test hook: try-and-increment with an explicit 8-byte domain; out48 = compressed G1 point */

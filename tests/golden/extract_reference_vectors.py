@@ -71,7 +71,19 @@ def main():
         nb = re.search(r"\.(?:xof|hash)\(b\"ULforxof\", &\w+, (\d+)\)", body[:body.index("assert_eq!")])
         comp[m.group(1)] = {"seed0": int(seed.group(1), 16) if seed else None, "msg_len": eval(mlen.group(1).replace("/", "//")) if mlen else 0,
                             "out_bytes": int(nb.group(1)) if nb else None, "expected": exp}
+    # DirectHasher vectors with XorShift-seeded inputs (crates/bls-crypto/src/hashers/direct.rs:99-147), same shape as the composite ones
+    direct_x = {}
+    for m in re.finditer(r"fn (test_(?:crh_random|xof_random_96|hash_random))\(\)", dtxt):
+        body = dtxt[m.end():]
+        head = body[:body.index("assert_eq!")]
+        exp = re.search(r'"([0-9a-f]{64,})"', body[body.index("assert_eq!"):]).group(1)
+        seed = re.search(r"from_seed\(\[\s*0x([0-9a-f]{2})", head)
+        mlen = re.search(r"vec!\[0; ([0-9 */]+)\]", head)
+        nb = re.search(r"\.(?:xof|hash)\(b\"ULforxof\", &\w+, (\d+)\)", head)
+        direct_x[m.group(1)] = {"seed0": int(seed.group(1), 16), "msg_len": eval(mlen.group(1).replace("/", "//")),
+                                "out_bytes": int(nb.group(1)) if nb else None, "expected": exp}
     out = {
+        "direct_hasher_random": direct_x,
         "composite_hasher": comp,
         "direct_hasher": {"crh_empty_xof96": crh_empty, "blake2x_hash_vectors": [{"input": a, "output": b} for a, b in tv]},
         "_source": "celo-org/celo-bls-snark-rs test vectors (data literals only); see extract_reference_vectors.py",

@@ -243,3 +243,18 @@ def test_oracle_ntt_restatement_matches_definition(log_n):
     assert Xc == ontt.dft([xi * pow(g, i, Q) % Q for i, xi in enumerate(x)], w)
     xb = co.from_mont(co.ntt_fq377(co.to_mont(Xc, Q), log_n, pow(w, -1, Q), coset=pow(g, -1, Q), coset_after=True, scale=pow(n, -1, Q)), Q)
     assert xb == x
+
+
+def test_reference_direct_hasher_random_vectors(golden):
+    """crates/bls-crypto/src/hashers/direct.rs:99-147: crh / xof / hash of XorShift-seeded messages (the remaining DirectHasher vectors)."""
+    from oracle.py import hashing as hs
+    for name, v in golden["direct_hasher_random"].items():
+        msg = _xorshift_bytes(v["seed0"], v["msg_len"])
+        if name == "test_crh_random":
+            got = hs.direct_crh(b"", msg, 96)
+        elif name == "test_xof_random_96":
+            got = hs.direct_xof(b"ULforxof", hs.direct_crh(b"", msg, 96), 96)
+        else:
+            got = hs.direct_hash(b"ULforxof", msg, 96)
+        assert got.hex() == v["expected"], name
+    assert hs.hash_length(48) == 64 and hs.hash_length(96) == 96      # hash_to_curve/mod.rs:176 test_hash_length

@@ -437,3 +437,25 @@ def test_hash_composite_symbols(sys_lib):
         assert (x * zi * zi % ecc.Q377, y * zi * zi * zi % ecc.Q377) == tuple(P)
         if cip22:
             assert att.value == c
+
+
+def test_direct_hasher_random_vectors(sys_lib, golden):
+    """crates/bls-crypto/src/hashers/direct.rs:99-147 through the product's DirectHasher (crh, xof, hash), explicit domains."""
+    from tests.test_oracle_golden import _xorshift_bytes
+    lib = sys_lib
+    lib.celo_amd_direct_hasher.restype = C.c_bool
+
+    def run(what, dom, msg, n, outlen):
+        buf = (C.c_ubyte * outlen)()
+        assert lib.celo_amd_direct_hasher(what, dom, len(dom), msg, len(msg), n, buf)
+        return bytes(buf)
+
+    for name, v in golden["direct_hasher_random"].items():
+        msg = _xorshift_bytes(v["seed0"], v["msg_len"])
+        if name == "test_crh_random":
+            got = run(0, b"", msg, 96, 32)
+        elif name == "test_xof_random_96":
+            got = run(1, b"ULforxof", run(0, b"", msg, 96, 32), 96, 96)
+        else:
+            got = run(2, b"ULforxof", msg, 96, 96)
+        assert got.hex() == v["expected"], name

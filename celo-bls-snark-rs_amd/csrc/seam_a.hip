@@ -21,6 +21,9 @@
 #include <thread>
 #include <atomic>
 #include <memory>
+#include <list>
+#include <string>
+#include <unordered_map>
 #include <algorithm>
 #include <sys/random.h>
 #include <hip/hip_runtime.h>
@@ -830,10 +833,32 @@ bool deserialize_public_key(const uint8_t* in_bytes, int in_len, PublicKey** out
   *out = pk;
   return true;
 }
+// The reference memoises decompression in a 512-entry LRU keyed by the serialized bytes (serialization.rs:44-61,
+// crates/bls-crypto/src/bls/cache.rs:36,49-65): validator keys recur epoch after epoch, and a hit replaces a square root and a
+// subgroup check (~1 ms) by a 288-byte copy.  Decoding is a pure function, so the cache is not observable through the ABI.
 bool deserialize_public_key_cached(const uint8_t* in_bytes, int in_len, PublicKey** out) {
-  // the reference memoises decompression in an LRU (serialization.rs:44-61); decoding is a pure function, so no cache is
-  // observable through the ABI
-  return deserialize_public_key(in_bytes, in_len, out);
+  if (!in_bytes || in_len != 96 || !out) return deserialize_public_key(in_bytes, in_len, out);
+  static std::mutex mu;
+  static std::list<std::pair<std::string, PublicKey>> lru;                                   // front = most recent
+  static std::unordered_map<std::string, std::list<std::pair<std::string, PublicKey>>::iterator> index;
+  const std::string key((const char*)in_bytes, 96);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = index.find(key);
+    if (it != index.end()) {
+      lru.splice(lru.begin(), lru, it->second);
+      *out = new PublicKey(it->second->second);
+      return true;
+    }
+  }
+  if (!deserialize_public_key(in_bytes, in_len, out)) return false;
+  std::lock_guard<std::mutex> lk(mu);
+  if (index.find(key) == index.end()) {
+    lru.emplace_front(key, **out);
+    index[key] = lru.begin();
+    if (lru.size() > 512) { index.erase(lru.back().first); lru.pop_back(); }
+  }
+  return true;
 }
 bool serialize_public_key(const PublicKey* in, uint8_t** out_bytes, int* out_len) {
   if (!in || !out_bytes || !out_len) return false;

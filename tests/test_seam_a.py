@@ -459,3 +459,29 @@ def test_direct_hasher_random_vectors(sys_lib, golden):
         else:
             got = run(2, b"ULforxof", msg, 96, 96)
         assert got.hex() == v["expected"], name
+
+
+def test_cached_public_key_deserialisation(sys_lib, golden):
+    """crates/bls-crypto/src/bls/cache.rs:124-160 (`deserializer`, `caches_deserialized_pubkeys`): the cached entry point returns
+    the same key as the plain one, hit or miss, far more keys than the 512-entry LRU holds, and bad encodings still fail."""
+    import time
+    lib = sys_lib
+    lib.deserialize_public_key_cached.restype = C.c_bool
+    pts = [bytes.fromhex(h) for h in golden["hash_to_curve"]["g2_noncompat"]["points"]]
+    for rounds in range(2):                                  # second round = cache hits
+        for b in pts:
+            h1, h2 = C.c_void_p(), C.c_void_p()
+            assert lib.deserialize_public_key(b, len(b), C.byref(h1)) and lib.deserialize_public_key_cached(b, len(b), C.byref(h2))
+            assert _ser(lib, "serialize_public_key", h1) == _ser(lib, "serialize_public_key", h2) == b
+            assert lib.destroy_public_key(h1) and lib.destroy_public_key(h2)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        h = C.c_void_p()
+        assert lib.deserialize_public_key_cached(pts[0], 96, C.byref(h))
+        lib.destroy_public_key(h)
+    hit = (time.perf_counter() - t0) / 200
+    assert hit < 2e-4                                        # a hit is a copy, not a square root + subgroup check (~1 ms)
+    bad = bytes([pts[0][0] ^ 1]) + pts[0][1:]
+    hb = C.c_void_p()
+    ok = lib.deserialize_public_key_cached(bad, 96, C.byref(hb))
+    assert ok == lib.deserialize_public_key(bad, 96, C.byref(C.c_void_p()))

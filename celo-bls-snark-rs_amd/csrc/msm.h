@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(128) k_bitsum(const uint32_t* __restrict__ par
     a = IO::load_xyzz(in + ia * IO::XYZZ_WORDS);
     if (mode != 4) b = IO::load_xyzz(in + (ia + (mode == 0 ? 1 : 2)) * IO::XYZZ_WORDS);
   }
-  if (mode != 4) xyzz_add_fn(a, b);
+  if (mode != 4) xyzz_add(a, b);     // inlined for every field: each launch is one addition deep, its latency is the cost
   IO::store_xyzz(work + ((size_t)jobs.dst[j] + i) * IO::XYZZ_WORDS, a);
 }
 

@@ -8,9 +8,10 @@
 //
 // Shape (HBM-bound work: 64-B elements, one multiplication per butterfly):
 //   k_ntt_load   arkworks Montgomery (48 B) -> 28-bit-limb device form (64 B), optional coset pre-scaling x_i *= g^i
-//   k_ntt_tile   decimation-in-frequency, in place, NINE butterfly levels per launch: a workgroup stages four 512-row tiles
-//                in LDS (128 KB of the 160 KB) and runs three radix-8 rounds on them; two launches cover 18 levels
-//   k_ntt_pass   the remaining (< 9) levels, THREE per launch: a lane loads 8 elements spaced by the lowest level's distance,
+//   k_ntt_tile4  decimation-in-frequency, in place, EIGHT (then six or four) butterfly levels per launch: a workgroup stages
+//                1024 elements in LDS (word-planar, 56 KB: two workgroups per CU = two waves per SIMD) and runs radix-4
+//                rounds on them, the first reading HBM, the last writing it; 2^20 points = three launches (8 + 8 + 4)
+//   k_ntt_pass   the remaining (< 4) levels, up to THREE per launch: a lane loads 8 elements spaced by the lowest level's distance,
 //                runs 12 butterflies in registers, stores them back.  Loads and stores are 64-B vectors, consecutive lanes
 //                touch consecutive elements.
 //   k_ntt_store  bit-reversal gather, optional coset post-scaling x_i *= g^i and final scale, -> arkworks Montgomery
@@ -104,79 +105,69 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
   }
 #undef NTT_K
 }
-// ---- LDS-tiled pass: NINE butterfly levels (s_top .. s_top-8) per launch.  A workgroup of 256 lanes owns four 512-row tiles
-// (2048 elements = 128 KB of the 160 KB LDS); a tile is the index set {hi * 2^(s_top+1) + row * 2^(s_lo) + lo : row < 512}.  Three
-// radix-8 rounds on local row bits (8,7,6), (5,4,3), (2,1,0): the first reads HBM, the last writes HBM, the two regroupings in
-// between go through LDS.  LDS is word-planar (plane k = word k of every element) with an XOR swizzle of the element number
-// chosen so that all three access patterns hit 64 distinct banks per wave.
-constexpr int NTT_TILE_LOG = 9, NTT_TILE_ELEMS = 2048;
-__device__ __forceinline__ uint32_t ntt_swz(uint32_t e) { return e ^ (((e >> 6) & 7u) << 2) ^ (((e >> 8) & 1u) << 5); }
-__device__ __forceinline__ void ntt_lds_put(uint32_t* lds, uint32_t e, const Fr761& v) {
-  const uint32_t p = ntt_swz(e);
-#pragma unroll
-  for (int k = 0; k < 14; k++) lds[k * NTT_TILE_ELEMS + p] = v.l[k];
+// twiddle exponent of the butterfly at sub-level b inside a radix-2^k group whose elements sit at rows r0 + j * 2^L0 (r0 has those
+// k row bits clear): (global index of the upper element mod 2^s) * n / 2^(s+1) with s = s_lo + L0 + b
+#define NTT_TK(j, b) ((((r0 & ((1u << L0) - 1)) + ((uint32_t)((j) & ((1 << (b)) - 1)) << L0)) << s_lo) + lo) << (log_n - 1 - (uint32_t)(s_lo + L0 + (b)))
+// ---- 2*NR levels per launch with 1024-element tiles (56 KB of LDS): two workgroups per CU = two waves per SIMD, which is what
+// the multiplier needs to run at its pipe rate (one wave issues a v_mad_u64_u32 every 9.6 cycles, two reach ~5).  NR radix-4
+// rounds on local row bits (2NR-1, 2NR-2), .., (1, 0); four elements per lane; a workgroup owns C = 1024 / 4^NR adjacent tiles
+// of 4^NR rows (NR = 4: four 256-row tiles, eight levels; NR = 3: sixteen 64-row tiles; NR = 2: sixty-four 16-row tiles).
+constexpr int NTT_TILE4_ELEMS = 1024;
+template <int NR> __device__ __forceinline__ uint32_t ntt_swz4(uint32_t e) {
+  if constexpr (NR == 4) { const uint32_t h = (e >> 6) & 3u; return e ^ (h << 2) ^ (h << 4); }   // 4 columns: rows reach the bank bits
+  else return e;                                                                                  // >= 16 columns: lanes are column-contiguous
 }
-__device__ __forceinline__ Fr761 ntt_lds_get(const uint32_t* lds, uint32_t e) {
-  const uint32_t p = ntt_swz(e);
+template <int NR> __device__ __forceinline__ void ntt_lds_put4(uint32_t* lds, uint32_t e, const Fr761& v) {
+  const uint32_t p = ntt_swz4<NR>(e);
+#pragma unroll
+  for (int k = 0; k < 14; k++) lds[k * NTT_TILE4_ELEMS + p] = v.l[k];
+}
+template <int NR> __device__ __forceinline__ Fr761 ntt_lds_get4(const uint32_t* lds, uint32_t e) {
+  const uint32_t p = ntt_swz4<NR>(e);
   Fr761 v;
 #pragma unroll
-  for (int k = 0; k < 14; k++) v.l[k] = lds[k * NTT_TILE_ELEMS + p];
+  for (int k = 0; k < 14; k++) v.l[k] = lds[k * NTT_TILE4_ELEMS + p];
   return v;
 }
-// the twelve butterflies of a radix-8 group whose elements sit at rows r0 + j * 2^L0 (j = 0..7; r0 has those three bits clear)
-#define NTT_TK(j, b) ((((r0 & ((1u << L0) - 1)) + ((uint32_t)((j) & ((1 << (b)) - 1)) << L0)) << s_lo) + lo) << (log_n - 1 - (uint32_t)(s_lo + L0 + (b)))
-#define NTT_RADIX8(a0, a1, a2, a3, a4, a5, a6, a7)                                                                                        \
-  ntt_bf(a0, a4, NTT_TK(0, 2), tw); ntt_bf(a1, a5, NTT_TK(1, 2), tw); ntt_bf(a2, a6, NTT_TK(2, 2), tw); ntt_bf(a3, a7, NTT_TK(3, 2), tw); \
-  ntt_bf(a0, a2, NTT_TK(0, 1), tw); ntt_bf(a1, a3, NTT_TK(1, 1), tw); ntt_bf(a4, a6, NTT_TK(4, 1), tw); ntt_bf(a5, a7, NTT_TK(5, 1), tw); \
-  ntt_bf(a0, a1, NTT_TK(0, 0), tw); ntt_bf(a2, a3, NTT_TK(2, 0), tw); ntt_bf(a4, a5, NTT_TK(4, 0), tw); ntt_bf(a6, a7, NTT_TK(6, 0), tw);
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_ntt_tile(uint32_t* __restrict__ work, const uint32_t* __restrict__ tw,
-                                                                                             uint32_t log_n, int s_top) {
+#define NTT_RADIX4(a0, a1, a2, a3)                                        \
+  ntt_bf(a0, a2, NTT_TK(0, 1), tw); ntt_bf(a1, a3, NTT_TK(1, 1), tw);     \
+  ntt_bf(a0, a1, NTT_TK(0, 0), tw); ntt_bf(a2, a3, NTT_TK(2, 0), tw);
+template <int NR>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_ntt_tile4(uint32_t* __restrict__ work, const uint32_t* __restrict__ tw,
+                                                                                              uint32_t log_n, int s_top) {
   extern __shared__ uint32_t lds[];
-  const int s_lo = s_top - (NTT_TILE_LOG - 1);
-  const uint32_t c = threadIdx.x & 3, u = threadIdx.x >> 2;
-  const uint32_t inst = blockIdx.x * 4 + c;
+  constexpr int LT = 2 * NR;                       // levels per launch = log2(rows per tile)
+  constexpr uint32_t C = 1024u >> LT;              // tiles per workgroup
+  const int s_lo = s_top - (LT - 1);
+  const uint32_t c = threadIdx.x & (C - 1), u = threadIdx.x / C;       // u in [0, rows / 4)
+  const uint32_t inst = blockIdx.x * C + c;
   const uint32_t lo = inst & ((1u << s_lo) - 1), hi = inst >> s_lo;
-  uint32_t* const g0 = work + (((size_t)hi << (s_top + 1)) + lo) * NTT_WORDS;      // row 0 of this lane's tile
+  uint32_t* const g0 = work + (((size_t)hi << (s_top + 1)) + lo) * NTT_WORDS;
   const size_t row_stride = ((size_t)1 << s_lo) * NTT_WORDS;
-  Fr761 a0, a1, a2, a3, a4, a5, a6, a7;
-  {  // round A: local bits 8,7,6; rows u + 64 j
-    constexpr int L0 = 6;
-    const uint32_t r0 = u;
-    a0 = Fr761::load(g0 + (size_t)(r0) * row_stride);       a1 = Fr761::load(g0 + (size_t)(r0 + 64) * row_stride);
-    a2 = Fr761::load(g0 + (size_t)(r0 + 128) * row_stride); a3 = Fr761::load(g0 + (size_t)(r0 + 192) * row_stride);
-    a4 = Fr761::load(g0 + (size_t)(r0 + 256) * row_stride); a5 = Fr761::load(g0 + (size_t)(r0 + 320) * row_stride);
-    a6 = Fr761::load(g0 + (size_t)(r0 + 384) * row_stride); a7 = Fr761::load(g0 + (size_t)(r0 + 448) * row_stride);
-    NTT_RADIX8(a0, a1, a2, a3, a4, a5, a6, a7)
-    ntt_lds_put(lds, (r0) * 4 + c, a0);       ntt_lds_put(lds, (r0 + 64) * 4 + c, a1);  ntt_lds_put(lds, (r0 + 128) * 4 + c, a2);
-    ntt_lds_put(lds, (r0 + 192) * 4 + c, a3); ntt_lds_put(lds, (r0 + 256) * 4 + c, a4); ntt_lds_put(lds, (r0 + 320) * 4 + c, a5);
-    ntt_lds_put(lds, (r0 + 384) * 4 + c, a6); ntt_lds_put(lds, (r0 + 448) * 4 + c, a7);
-  }
-  __syncthreads();
-  {  // round B: local bits 5,4,3; rows (u >> 3) * 64 + (u & 7) + 8 j
-    constexpr int L0 = 3;
-    const uint32_t r0 = ((u >> 3) << 6) + (u & 7);
-    a0 = ntt_lds_get(lds, (r0) * 4 + c);      a1 = ntt_lds_get(lds, (r0 + 8) * 4 + c);  a2 = ntt_lds_get(lds, (r0 + 16) * 4 + c);
-    a3 = ntt_lds_get(lds, (r0 + 24) * 4 + c); a4 = ntt_lds_get(lds, (r0 + 32) * 4 + c); a5 = ntt_lds_get(lds, (r0 + 40) * 4 + c);
-    a6 = ntt_lds_get(lds, (r0 + 48) * 4 + c); a7 = ntt_lds_get(lds, (r0 + 56) * 4 + c);
-    NTT_RADIX8(a0, a1, a2, a3, a4, a5, a6, a7)
-    ntt_lds_put(lds, (r0) * 4 + c, a0);      ntt_lds_put(lds, (r0 + 8) * 4 + c, a1);  ntt_lds_put(lds, (r0 + 16) * 4 + c, a2);
-    ntt_lds_put(lds, (r0 + 24) * 4 + c, a3); ntt_lds_put(lds, (r0 + 32) * 4 + c, a4); ntt_lds_put(lds, (r0 + 40) * 4 + c, a5);
-    ntt_lds_put(lds, (r0 + 48) * 4 + c, a6); ntt_lds_put(lds, (r0 + 56) * 4 + c, a7);
-  }
-  __syncthreads();
-  {  // round C: local bits 2,1,0; rows 8 u + j
-    constexpr int L0 = 0;
-    const uint32_t r0 = u << 3;
-    a0 = ntt_lds_get(lds, (r0) * 4 + c);     a1 = ntt_lds_get(lds, (r0 + 1) * 4 + c); a2 = ntt_lds_get(lds, (r0 + 2) * 4 + c);
-    a3 = ntt_lds_get(lds, (r0 + 3) * 4 + c); a4 = ntt_lds_get(lds, (r0 + 4) * 4 + c); a5 = ntt_lds_get(lds, (r0 + 5) * 4 + c);
-    a6 = ntt_lds_get(lds, (r0 + 6) * 4 + c); a7 = ntt_lds_get(lds, (r0 + 7) * 4 + c);
-    NTT_RADIX8(a0, a1, a2, a3, a4, a5, a6, a7)
-    a0.store(g0 + (size_t)(r0) * row_stride);     a1.store(g0 + (size_t)(r0 + 1) * row_stride); a2.store(g0 + (size_t)(r0 + 2) * row_stride);
-    a3.store(g0 + (size_t)(r0 + 3) * row_stride); a4.store(g0 + (size_t)(r0 + 4) * row_stride); a5.store(g0 + (size_t)(r0 + 5) * row_stride);
-    a6.store(g0 + (size_t)(r0 + 6) * row_stride); a7.store(g0 + (size_t)(r0 + 7) * row_stride);
+  Fr761 a0, a1, a2, a3;
+#pragma unroll
+  for (int q = NR - 1; q >= 0; q--) {              // round q works on local bits 2q+1, 2q: rows r0 + j * 4^q
+    const int L0 = 2 * q;
+    const uint32_t r0 = ((u >> L0) << (L0 + 2)) | (u & ((1u << L0) - 1)), d = 1u << L0;
+    if (q == NR - 1) {
+      a0 = Fr761::load(g0 + (size_t)r0 * row_stride);           a1 = Fr761::load(g0 + (size_t)(r0 + d) * row_stride);
+      a2 = Fr761::load(g0 + (size_t)(r0 + 2 * d) * row_stride); a3 = Fr761::load(g0 + (size_t)(r0 + 3 * d) * row_stride);
+    } else {
+      __syncthreads();
+      a0 = ntt_lds_get4<NR>(lds, r0 * C + c);           a1 = ntt_lds_get4<NR>(lds, (r0 + d) * C + c);
+      a2 = ntt_lds_get4<NR>(lds, (r0 + 2 * d) * C + c); a3 = ntt_lds_get4<NR>(lds, (r0 + 3 * d) * C + c);
+    }
+    NTT_RADIX4(a0, a1, a2, a3)
+    if (q == 0) {
+      a0.store(g0 + (size_t)r0 * row_stride);           a1.store(g0 + (size_t)(r0 + d) * row_stride);
+      a2.store(g0 + (size_t)(r0 + 2 * d) * row_stride); a3.store(g0 + (size_t)(r0 + 3 * d) * row_stride);
+    } else {
+      ntt_lds_put4<NR>(lds, r0 * C + c, a0);           ntt_lds_put4<NR>(lds, (r0 + d) * C + c, a1);
+      ntt_lds_put4<NR>(lds, (r0 + 2 * d) * C + c, a2); ntt_lds_put4<NR>(lds, (r0 + 3 * d) * C + c, a3);
+    }
   }
 }
-#undef NTT_RADIX8
+#undef NTT_RADIX4
 #undef NTT_TK
 
 __global__ void __launch_bounds__(256) k_ntt_store(const uint32_t* __restrict__ work, uint64_t* __restrict__ ark, uint32_t log_n,
@@ -216,7 +207,7 @@ class NttEngine {
   }
   NttTimings tm;
   int max_radix_log2 = 3;   // butterfly levels per register-only pass (tuning hook: 1..3)
-  bool use_tiles = true;    // LDS-tiled nine-level passes (tuning hook)
+  bool use_tiles = true;    // LDS-tiled passes (tuning hook)
   // data_dev: n = 2^log_n elements, arkworks Montgomery, DEVICE memory, transformed in place.
   // omega: domain generator of order n (its inverse for an inverse transform).  coset: nullptr or g: x_i *= g^i before
   // (coset_after = 0) or after (1) the transform.  scale: nullptr or a factor applied to every output (n^-1).
@@ -231,9 +222,12 @@ class NttEngine {
     hipLaunchKernelGGL(k_ntt_load, dim3((n + 255) / 256), dim3(256), 0, stream, data_dev, d_work, n, (coset6 && !coset_after) ? glo : nullptr, ghi);
     NTT_HIP_OK(hipEventRecord(ev[1], stream));
     int s = (int)log_n - 1, np = 0;
-    while (use_tiles && s + 1 >= NTT_TILE_LOG && n >= (uint32_t)NTT_TILE_ELEMS) {   // nine levels per launch while at least nine remain
-      hipLaunchKernelGGL(k_ntt_tile, dim3(n / NTT_TILE_ELEMS), dim3(256), 14 * NTT_TILE_ELEMS * 4, stream, d_work, d_tw, log_n, s);
-      s -= NTT_TILE_LOG; np++;
+    if (use_tiles && n >= (uint32_t)NTT_TILE4_ELEMS) {     // 1024-element tiles, two workgroups per CU: 8 levels per launch, then 6 or 4
+      const uint32_t blocks = n / NTT_TILE4_ELEMS;
+      const size_t lds_bytes = 14 * NTT_TILE4_ELEMS * 4;
+      while (s + 1 >= 8) { hipLaunchKernelGGL((k_ntt_tile4<4>), dim3(blocks), dim3(256), lds_bytes, stream, d_work, d_tw, log_n, s); s -= 8; np++; }
+      if (s + 1 >= 6) { hipLaunchKernelGGL((k_ntt_tile4<3>), dim3(blocks), dim3(256), lds_bytes, stream, d_work, d_tw, log_n, s); s -= 6; np++; }
+      else if (s + 1 >= 4) { hipLaunchKernelGGL((k_ntt_tile4<2>), dim3(blocks), dim3(256), lds_bytes, stream, d_work, d_tw, log_n, s); s -= 4; np++; }
     }
     while (s >= 0) {
       const int r = s + 1 >= max_radix_log2 ? max_radix_log2 : s + 1;

@@ -33,7 +33,7 @@ def test_matches_definition(gpu, log_n):
     assert X == ontt.dft(x, w)
 
 
-@pytest.mark.parametrize("log_n", [6, 10, 11, 13, 16])
+@pytest.mark.parametrize("log_n", [6, 10, 11, 12, 13, 14, 15, 16])   # 10: 8+2, 12: 8+4, 14: 8+6, 15: 8+6+1, 16: 8+8 levels per launch
 def test_all_four_transforms_match_oracle(gpu, log_n):
     """fft, ifft (omega^-1, scale n^-1), coset_fft (x_i *= g^i first), coset_ifft (x_i *= g^-i last, scale n^-1): bit-exact."""
     rng = ecc.SplitMix64(7 * log_n)

@@ -64,6 +64,35 @@ __global__ void __launch_bounds__(256) k_ntt_load(const uint64_t* __restrict__ a
   }
   Fr761::wred(v).store(work + (size_t)i * NTT_WORDS);
 }
+// Format conversion fused into the first and last butterfly launches: the first reads the caller's arkworks elements (and
+// applies the coset pre-scaling), the last writes arkworks elements at the bit-reversed index (coset post-scaling, final scale).
+// Null pointers = plain device-form loads / stores on the work array.
+struct NttIo {
+  const uint64_t* ark_in;    // first launch only
+  uint64_t* ark_out;         // last launch only
+  const uint32_t* glo;       // coset power tables g^i, g^(1024 i) (pre-scaling with ark_in, post-scaling with ark_out), or null
+  const uint32_t* ghi;
+  const uint32_t* scale;     // with ark_out, or null
+};
+__device__ __forceinline__ Fr761 ntt_coset(const Fr761& v, const NttIo& io, uint32_t i, uint32_t log_n) {
+  Fr761 r = Fr761::mul(v, Fr761::load(io.glo + (size_t)(i & 1023) * NTT_WORDS));
+  if (log_n > 10) r = Fr761::mul(r, Fr761::load(io.ghi + (size_t)(i >> 10) * NTT_WORDS));
+  return r;
+}
+__device__ __forceinline__ Fr761 ntt_ld(const uint32_t* __restrict__ work, const NttIo& io, size_t idx, uint32_t log_n) {
+  if (!io.ark_in) return Fr761::load(work + idx * NTT_WORDS);
+  Fr761 v = Fr761::from_ark(io.ark_in + idx * 6);
+  if (io.glo) v = ntt_coset(v, io, (uint32_t)idx, log_n);
+  return Fr761::wred(v);
+}
+__device__ __forceinline__ void ntt_st(uint32_t* __restrict__ work, const NttIo& io, size_t idx, uint32_t log_n, const Fr761& v) {
+  if (!io.ark_out) { v.store(work + idx * NTT_WORDS); return; }
+  const uint32_t r = __brev((uint32_t)idx) >> (32 - log_n);      // position idx holds output number bitrev(idx)
+  Fr761 w = v;
+  if (io.glo) w = ntt_coset(w, io, r, log_n);
+  if (io.scale) w = Fr761::mul(w, Fr761::load(io.scale));
+  w.to_ark(io.ark_out + (size_t)r * 6);
+}
 // one decimation-in-frequency butterfly: (x, y) <- (x + y, (x - y) * omega^k)
 __device__ __forceinline__ void ntt_bf(Fr761& x, Fr761& y, uint32_t k, const uint32_t* __restrict__ tw) {
   const Fr761 u = x, v = y;
@@ -75,34 +104,36 @@ __device__ __forceinline__ void ntt_bf(Fr761& x, Fr761& y, uint32_t k, const uin
 // named scalars (not an array) so that they stay in VGPRs; local bit b of the element number <-> global level s_lo + b, and the
 // twiddle exponent of a butterfly whose upper element has global index i is (i mod 2^s) * n / 2^(s+1).
 template <int R>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_ntt_pass(uint32_t* __restrict__ work, const uint32_t* __restrict__ tw, uint32_t log_n, int s_hi) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_ntt_pass(uint32_t* __restrict__ work, const uint32_t* __restrict__ tw,
+                                                                                         uint32_t log_n, int s_hi, NttIo io) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = 1u << log_n;
   if (t >= (n >> R)) return;
   const int s_lo = s_hi - R + 1;
   const uint32_t m = 1u << s_lo;
   const uint32_t low = t & (m - 1);
-  uint32_t* const p0 = work + ((size_t)(t >> s_lo) * ((size_t)m << R) + low) * NTT_WORDS;
-  const size_t st = (size_t)m * NTT_WORDS;
+  const size_t i0 = (size_t)(t >> s_lo) * ((size_t)m << R) + low;       // element j of this lane: i0 + j * m
 #define NTT_K(j, lvl) ((low + ((uint32_t)((j) & ((1 << (lvl)) - 1)) << s_lo)) << (log_n - 1 - (uint32_t)(s_lo + (lvl))))
+#define NTT_LD(j) ntt_ld(work, io, i0 + (size_t)(j) * m, log_n)
+#define NTT_ST(j, v) ntt_st(work, io, i0 + (size_t)(j) * m, log_n, v)
   if constexpr (R == 3) {
-    Fr761 a0 = Fr761::load(p0), a1 = Fr761::load(p0 + st), a2 = Fr761::load(p0 + 2 * st), a3 = Fr761::load(p0 + 3 * st);
-    Fr761 a4 = Fr761::load(p0 + 4 * st), a5 = Fr761::load(p0 + 5 * st), a6 = Fr761::load(p0 + 6 * st), a7 = Fr761::load(p0 + 7 * st);
+    Fr761 a0 = NTT_LD(0), a1 = NTT_LD(1), a2 = NTT_LD(2), a3 = NTT_LD(3), a4 = NTT_LD(4), a5 = NTT_LD(5), a6 = NTT_LD(6), a7 = NTT_LD(7);
     ntt_bf(a0, a4, NTT_K(0, 2), tw); ntt_bf(a1, a5, NTT_K(1, 2), tw); ntt_bf(a2, a6, NTT_K(2, 2), tw); ntt_bf(a3, a7, NTT_K(3, 2), tw);
     ntt_bf(a0, a2, NTT_K(0, 1), tw); ntt_bf(a1, a3, NTT_K(1, 1), tw); ntt_bf(a4, a6, NTT_K(4, 1), tw); ntt_bf(a5, a7, NTT_K(5, 1), tw);
     ntt_bf(a0, a1, NTT_K(0, 0), tw); ntt_bf(a2, a3, NTT_K(2, 0), tw); ntt_bf(a4, a5, NTT_K(4, 0), tw); ntt_bf(a6, a7, NTT_K(6, 0), tw);
-    a0.store(p0); a1.store(p0 + st); a2.store(p0 + 2 * st); a3.store(p0 + 3 * st);
-    a4.store(p0 + 4 * st); a5.store(p0 + 5 * st); a6.store(p0 + 6 * st); a7.store(p0 + 7 * st);
+    NTT_ST(0, a0); NTT_ST(1, a1); NTT_ST(2, a2); NTT_ST(3, a3); NTT_ST(4, a4); NTT_ST(5, a5); NTT_ST(6, a6); NTT_ST(7, a7);
   } else if constexpr (R == 2) {
-    Fr761 a0 = Fr761::load(p0), a1 = Fr761::load(p0 + st), a2 = Fr761::load(p0 + 2 * st), a3 = Fr761::load(p0 + 3 * st);
+    Fr761 a0 = NTT_LD(0), a1 = NTT_LD(1), a2 = NTT_LD(2), a3 = NTT_LD(3);
     ntt_bf(a0, a2, NTT_K(0, 1), tw); ntt_bf(a1, a3, NTT_K(1, 1), tw);
     ntt_bf(a0, a1, NTT_K(0, 0), tw); ntt_bf(a2, a3, NTT_K(2, 0), tw);
-    a0.store(p0); a1.store(p0 + st); a2.store(p0 + 2 * st); a3.store(p0 + 3 * st);
+    NTT_ST(0, a0); NTT_ST(1, a1); NTT_ST(2, a2); NTT_ST(3, a3);
   } else {
-    Fr761 a0 = Fr761::load(p0), a1 = Fr761::load(p0 + st);
+    Fr761 a0 = NTT_LD(0), a1 = NTT_LD(1);
     ntt_bf(a0, a1, NTT_K(0, 0), tw);
-    a0.store(p0); a1.store(p0 + st);
+    NTT_ST(0, a0); NTT_ST(1, a1);
   }
+#undef NTT_LD
+#undef NTT_ST
 #undef NTT_K
 }
 // twiddle exponent of the butterfly at sub-level b inside a radix-2^k group whose elements sit at rows r0 + j * 2^L0 (r0 has those
@@ -134,7 +165,7 @@ template <int NR> __device__ __forceinline__ Fr761 ntt_lds_get4(const uint32_t* 
   ntt_bf(a0, a1, NTT_TK(0, 0), tw); ntt_bf(a2, a3, NTT_TK(2, 0), tw);
 template <int NR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_ntt_tile4(uint32_t* __restrict__ work, const uint32_t* __restrict__ tw,
-                                                                                              uint32_t log_n, int s_top) {
+                                                                                              uint32_t log_n, int s_top, NttIo io) {
   extern __shared__ uint32_t lds[];
   constexpr int LT = 2 * NR;                       // levels per launch = log2(rows per tile)
   constexpr uint32_t C = 1024u >> LT;              // tiles per workgroup
@@ -142,16 +173,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   const uint32_t c = threadIdx.x & (C - 1), u = threadIdx.x / C;       // u in [0, rows / 4)
   const uint32_t inst = blockIdx.x * C + c;
   const uint32_t lo = inst & ((1u << s_lo) - 1), hi = inst >> s_lo;
-  uint32_t* const g0 = work + (((size_t)hi << (s_top + 1)) + lo) * NTT_WORDS;
-  const size_t row_stride = ((size_t)1 << s_lo) * NTT_WORDS;
+  const size_t i0 = ((size_t)hi << (s_top + 1)) + lo;      // row 0 of this lane's tile; row r is element i0 + (r << s_lo)
   Fr761 a0, a1, a2, a3;
 #pragma unroll
   for (int q = NR - 1; q >= 0; q--) {              // round q works on local bits 2q+1, 2q: rows r0 + j * 4^q
     const int L0 = 2 * q;
     const uint32_t r0 = ((u >> L0) << (L0 + 2)) | (u & ((1u << L0) - 1)), d = 1u << L0;
     if (q == NR - 1) {
-      a0 = Fr761::load(g0 + (size_t)r0 * row_stride);           a1 = Fr761::load(g0 + (size_t)(r0 + d) * row_stride);
-      a2 = Fr761::load(g0 + (size_t)(r0 + 2 * d) * row_stride); a3 = Fr761::load(g0 + (size_t)(r0 + 3 * d) * row_stride);
+      a0 = ntt_ld(work, io, i0 + ((size_t)r0 << s_lo), log_n);           a1 = ntt_ld(work, io, i0 + ((size_t)(r0 + d) << s_lo), log_n);
+      a2 = ntt_ld(work, io, i0 + ((size_t)(r0 + 2 * d) << s_lo), log_n); a3 = ntt_ld(work, io, i0 + ((size_t)(r0 + 3 * d) << s_lo), log_n);
     } else {
       __syncthreads();
       a0 = ntt_lds_get4<NR>(lds, r0 * C + c);           a1 = ntt_lds_get4<NR>(lds, (r0 + d) * C + c);
@@ -159,8 +189,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     NTT_RADIX4(a0, a1, a2, a3)
     if (q == 0) {
-      a0.store(g0 + (size_t)r0 * row_stride);           a1.store(g0 + (size_t)(r0 + d) * row_stride);
-      a2.store(g0 + (size_t)(r0 + 2 * d) * row_stride); a3.store(g0 + (size_t)(r0 + 3 * d) * row_stride);
+      ntt_st(work, io, i0 + ((size_t)r0 << s_lo), log_n, a0);           ntt_st(work, io, i0 + ((size_t)(r0 + d) << s_lo), log_n, a1);
+      ntt_st(work, io, i0 + ((size_t)(r0 + 2 * d) << s_lo), log_n, a2); ntt_st(work, io, i0 + ((size_t)(r0 + 3 * d) << s_lo), log_n, a3);
     } else {
       ntt_lds_put4<NR>(lds, r0 * C + c, a0);           ntt_lds_put4<NR>(lds, (r0 + d) * C + c, a1);
       ntt_lds_put4<NR>(lds, (r0 + 2 * d) * C + c, a2); ntt_lds_put4<NR>(lds, (r0 + 3 * d) * C + c, a3);
@@ -208,6 +238,7 @@ class NttEngine {
   NttTimings tm;
   int max_radix_log2 = 3;   // butterfly levels per register-only pass (tuning hook: 1..3)
   bool use_tiles = true;    // LDS-tiled passes (tuning hook)
+  bool fuse_io = true;      // format conversion fused into the first / last butterfly launch (tuning hook)
   // data_dev: n = 2^log_n elements, arkworks Montgomery, DEVICE memory, transformed in place.
   // omega: domain generator of order n (its inverse for an inverse transform).  coset: nullptr or g: x_i *= g^i before
   // (coset_after = 0) or after (1) the transform.  scale: nullptr or a factor applied to every output (n^-1).
@@ -218,28 +249,42 @@ class NttEngine {
     if (prepare(log_n, omega6, coset6, scale6, stream)) return 1;
     uint32_t* glo = coset6 ? small(2) : nullptr;
     uint32_t* ghi = coset6 ? small(3) : nullptr;
+    // plan the butterfly launches: (kind, levels): kind 4/3/2 = k_ntt_tile4<kind>, kind 0 = k_ntt_pass<levels>
+    int kinds[16], lv[16], np = 0;
+    {
+      int s = (int)log_n;
+      if (use_tiles && n >= (uint32_t)NTT_TILE4_ELEMS) {
+        while (s >= 8) { kinds[np] = 4; lv[np++] = 8; s -= 8; }
+        if (s >= 6) { kinds[np] = 3; lv[np++] = 6; s -= 6; }
+        else if (s >= 4) { kinds[np] = 2; lv[np++] = 4; s -= 4; }
+      }
+      while (s > 0) { const int r = s >= max_radix_log2 ? max_radix_log2 : s; kinds[np] = 0; lv[np++] = r; s -= r; }
+    }
+    const bool fused = fuse_io && np >= 2;      // the first launch reads the caller's array, the last one writes it: they must differ
     NTT_HIP_OK(hipEventRecord(ev[0], stream));
-    hipLaunchKernelGGL(k_ntt_load, dim3((n + 255) / 256), dim3(256), 0, stream, data_dev, d_work, n, (coset6 && !coset_after) ? glo : nullptr, ghi);
+    if (!fused) hipLaunchKernelGGL(k_ntt_load, dim3((n + 255) / 256), dim3(256), 0, stream, data_dev, d_work, n, (coset6 && !coset_after) ? glo : nullptr, ghi);
     NTT_HIP_OK(hipEventRecord(ev[1], stream));
-    int s = (int)log_n - 1, np = 0;
-    if (use_tiles && n >= (uint32_t)NTT_TILE4_ELEMS) {     // 1024-element tiles, two workgroups per CU: 8 levels per launch, then 6 or 4
+    int s = (int)log_n - 1;
+    for (int i = 0; i < np; i++) {
+      NttIo io = {nullptr, nullptr, nullptr, nullptr, nullptr};
+      if (fused && i == 0) { io.ark_in = data_dev; if (coset6 && !coset_after) { io.glo = glo; io.ghi = ghi; } }
+      if (fused && i == np - 1) { io.ark_out = data_dev; if (coset6 && coset_after) { io.glo = glo; io.ghi = ghi; } io.scale = scale6 ? small(4) : nullptr; }
       const uint32_t blocks = n / NTT_TILE4_ELEMS;
       const size_t lds_bytes = 14 * NTT_TILE4_ELEMS * 4;
-      while (s + 1 >= 8) { hipLaunchKernelGGL((k_ntt_tile4<4>), dim3(blocks), dim3(256), lds_bytes, stream, d_work, d_tw, log_n, s); s -= 8; np++; }
-      if (s + 1 >= 6) { hipLaunchKernelGGL((k_ntt_tile4<3>), dim3(blocks), dim3(256), lds_bytes, stream, d_work, d_tw, log_n, s); s -= 6; np++; }
-      else if (s + 1 >= 4) { hipLaunchKernelGGL((k_ntt_tile4<2>), dim3(blocks), dim3(256), lds_bytes, stream, d_work, d_tw, log_n, s); s -= 4; np++; }
-    }
-    while (s >= 0) {
-      const int r = s + 1 >= max_radix_log2 ? max_radix_log2 : s + 1;
-      const uint32_t threads = n >> r;
-      if (r == 3) hipLaunchKernelGGL((k_ntt_pass<3>), dim3((threads + 255) / 256), dim3(256), 0, stream, d_work, d_tw, log_n, s);
-      else if (r == 2) hipLaunchKernelGGL((k_ntt_pass<2>), dim3((threads + 255) / 256), dim3(256), 0, stream, d_work, d_tw, log_n, s);
-      else hipLaunchKernelGGL((k_ntt_pass<1>), dim3((threads + 255) / 256), dim3(256), 0, stream, d_work, d_tw, log_n, s);
-      s -= r; np++;
+      if (kinds[i] == 4) hipLaunchKernelGGL((k_ntt_tile4<4>), dim3(blocks), dim3(256), lds_bytes, stream, d_work, d_tw, log_n, s, io);
+      else if (kinds[i] == 3) hipLaunchKernelGGL((k_ntt_tile4<3>), dim3(blocks), dim3(256), lds_bytes, stream, d_work, d_tw, log_n, s, io);
+      else if (kinds[i] == 2) hipLaunchKernelGGL((k_ntt_tile4<2>), dim3(blocks), dim3(256), lds_bytes, stream, d_work, d_tw, log_n, s, io);
+      else {
+        const uint32_t threads = n >> lv[i];
+        if (lv[i] == 3) hipLaunchKernelGGL((k_ntt_pass<3>), dim3((threads + 255) / 256), dim3(256), 0, stream, d_work, d_tw, log_n, s, io);
+        else if (lv[i] == 2) hipLaunchKernelGGL((k_ntt_pass<2>), dim3((threads + 255) / 256), dim3(256), 0, stream, d_work, d_tw, log_n, s, io);
+        else hipLaunchKernelGGL((k_ntt_pass<1>), dim3((threads + 255) / 256), dim3(256), 0, stream, d_work, d_tw, log_n, s, io);
+      }
+      s -= lv[i];
     }
     NTT_HIP_OK(hipEventRecord(ev[2], stream));
-    hipLaunchKernelGGL(k_ntt_store, dim3((n + 255) / 256), dim3(256), 0, stream, d_work, data_dev, log_n, (coset6 && coset_after) ? glo : nullptr, ghi,
-                       scale6 ? small(4) : nullptr);
+    if (!fused) hipLaunchKernelGGL(k_ntt_store, dim3((n + 255) / 256), dim3(256), 0, stream, d_work, data_dev, log_n, (coset6 && coset_after) ? glo : nullptr, ghi,
+                                   scale6 ? small(4) : nullptr);
     NTT_HIP_OK(hipEventRecord(ev[3], stream));
     NTT_HIP_OK(hipStreamSynchronize(stream));
     NTT_HIP_OK(hipGetLastError());

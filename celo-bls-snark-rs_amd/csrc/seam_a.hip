@@ -748,13 +748,26 @@ bool epoch_from_ffi(const EpochBlockFFI& src, EpochBlockHost& e) {  // snark/epo
   e.maximum_non_signers = src.maximum_non_signers; e.maximum_validators = src.maximum_validators;
   e.pubkeys.resize(src.pubkeys_num);
   e.pubkeys_jac.resize(src.pubkeys_num * 36);
-  for (size_t i = 0; i < src.pubkeys_num; i++) {
-    bool inf;
-    if (!g2_decompress(src.pubkeys + 96 * i, e.pubkeys[i], inf) || inf) return false;
-    if (!in_subgroup(e.pubkeys[i])) return false;
-    affine_to_jac(e.pubkeys[i], &e.pubkeys_jac[i * 36]);
+  // one square root in Fq2 + one subgroup check per key (~1 ms each): spread over the host cores for real validator sets
+  std::atomic<bool> ok(true);
+  auto decode = [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi && ok; i++) {
+      bool inf;
+      if (!g2_decompress(src.pubkeys + 96 * i, e.pubkeys[i], inf) || inf || !in_subgroup(e.pubkeys[i])) { ok = false; return; }
+      affine_to_jac(e.pubkeys[i], &e.pubkeys_jac[i * 36]);
+    }
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 32) nt = 32;
+  if (nt > src.pubkeys_num / 2) nt = (unsigned)(src.pubkeys_num / 2);
+  if (nt < 2) decode(0, src.pubkeys_num);
+  else {
+    (void)sqrt_ctx();   // shared constants before the threads start
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(decode, src.pubkeys_num * t / nt, src.pubkeys_num * (t + 1) / nt);
+    for (auto& x : th) x.join();
   }
-  return true;
+  return ok;
 }
 void neg_g2_generator(uint64_t out_xy[24]) {
   Fq_::from_limbs(T377::G2_GEN_X0).to_ark(out_xy);

@@ -1323,20 +1323,29 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
 //   e(A,B) * e(acc,-gamma) * e(C,-delta) * e(-alpha,beta) == 1   through pairing_product_is_one_bw6_761 (GPU).
 bool verify(const uint8_t* vk, uint32_t vk_len, const uint8_t* proof, uint32_t proof_len, EpochBlockFFI first_epoch, EpochBlockFFI last_epoch) {
   if (!vk || !proof || proof_len < 288 || vk_len < 392) return false;
-  EpochBlockHost first, last;
-  if (!epoch_from_ffi(first_epoch, first) || !epoch_from_ffi(last_epoch, last)) { log_err("verify: bad epoch public keys"); return false; }
+  PhaseLog ph("verify");
   // ---- VerifyingKey = alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | u64 len | gamma_abc_g1[len];  Proof = A | B | C
-  Affine<Fw_> alpha, beta, gamma, delta, A, B, Cc;
-  bool inf;
-  if (!bw6_decompress(vk, false, alpha, inf) || inf || !bw6_decompress(vk + 96, true, beta, inf) || inf ||
-      !bw6_decompress(vk + 192, true, gamma, inf) || inf || !bw6_decompress(vk + 288, true, delta, inf) || inf) { log_err("verify: bad vk"); return false; }
   uint64_t nabc;
   memcpy(&nabc, vk + 384, 8);
   if (nabc != 3 || vk_len < 392 + 96 * nabc) { log_err("verify: vk must carry 2 public inputs"); return false; }
-  Affine<Fw_> abc[3];
-  for (int i = 0; i < 3; i++) if (!bw6_decompress(vk + 392 + 96 * i, false, abc[i], inf) || inf) { log_err("verify: bad gamma_abc"); return false; }
-  if (!bw6_decompress(proof, false, A, inf) || inf || !bw6_decompress(proof + 96, true, B, inf) || inf ||
-      !bw6_decompress(proof + 192, false, Cc, inf) || inf) { log_err("verify: bad proof"); return false; }
+  // ten BW6-761 decompressions (a 761-bit square root each) and the two blocks' validator keys: independent, so they share the
+  // host cores instead of queueing on one (they were a fifth of the call)
+  EpochBlockHost first, last;
+  Affine<Fw_> pts[10];                       // alpha, beta, gamma, delta, abc[0..2], A, B, C
+  const uint8_t* src[10] = {vk, vk + 96, vk + 192, vk + 288, vk + 392, vk + 488, vk + 584, proof, proof + 96, proof + 192};
+  const bool on_g2[10] = {false, true, true, true, false, false, false, false, true, false};
+  bool okp[10], ok_first = false, ok_last = false;
+  {
+    std::vector<std::thread> th;
+    th.emplace_back([&]() { ok_first = epoch_from_ffi(first_epoch, first); });
+    th.emplace_back([&]() { ok_last = epoch_from_ffi(last_epoch, last); });
+    for (int i = 0; i < 10; i++) th.emplace_back([&, i]() { bool inf = false; okp[i] = bw6_decompress(src[i], on_g2[i], pts[i], inf) && !inf; });
+    for (auto& x : th) x.join();
+  }
+  if (!ok_first || !ok_last) { log_err("verify: bad epoch public keys"); return false; }
+  for (int i = 0; i < 10; i++) if (!okp[i]) { log_err(i < 7 ? "verify: bad vk" : "verify: bad proof"); return false; }
+  const Affine<Fw_>&alpha = pts[0], &beta = pts[1], &gamma = pts[2], &delta = pts[3], &A = pts[7], &B = pts[8], &Cc = pts[9];
+  const Affine<Fw_>* abc = &pts[4];
   // ---- public inputs: Blake2s("ULforout") of the first epoch and of the last epoch + aggregated key, 512 bits, packed 376|136
   Bits fb, lb;
   epoch_bits_cip22(first, true, fb);
@@ -1362,7 +1371,9 @@ bool verify(const uint8_t* vk, uint32_t vk_len, const uint8_t* proof, uint32_t p
   }
   uint64_t bases[3 * 24], accj[36], accxy[24];
   for (int i = 0; i < 3; i++) bw6_store_xy(abc[i], bases + 24 * i);
+  ph.mark("decode keys, vk, proof; public inputs");
   if (msm_bw6_761_g1(bases, nullptr, scalars, 3, accj) != 0) return false;
+  ph.mark("3-term input MSM (GPU)");
   uint8_t ainf;
   batch_to_affine<Fw_>(accj, 1, accxy, &ainf);
   // ---- the 4-pair product
@@ -1374,6 +1385,7 @@ bool verify(const uint8_t* vk, uint32_t vk_len, const uint8_t* proof, uint32_t p
   bw6_store_xy({alpha.x, fw_neg(alpha.y)}, g1 + 72); bw6_store_xy(beta, g2 + 72);
   int one = 0;
   if (pairing_product_is_one_bw6_761(g1, i1, g2, i2, 4, &one) != 0) return false;
+  ph.mark("4-pair product check (GPU)");
   return one != 0;
 }
 

@@ -1,6 +1,9 @@
 // extern "C" boundary of the gfx950 hot path (include/celo_bls_amd.h).
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <condition_variable>
+#include <vector>
+#include <cstring>
 #include <cstdio>
 #include "../../include/celo_bls_amd.h"
 
@@ -64,12 +67,71 @@ int msm_batch_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t
 int msm_batch_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g2_377(b, inf, s, off, m, out); }
 int msm_batch_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_761(b, inf, s, off, m, out); }
 int msm_batch_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_761(b, inf, s, off, m, out); }
+// Single-product checks from concurrent host threads are COMBINED: bls-snark-sys is synchronous and re-entrant and its callers
+// verify from many threads ("Threading"); one product keeps one lane group of the GPU busy for ~11 ms, so
+// serialising callers behind a mutex would cap the library at ~90 verifications/s.  The first caller to arrive becomes the
+// leader: it drains the queue of pending products, runs them as ONE batched launch, publishes the verdicts and repeats
+// until the queue is empty; the others sleep on a condition variable.
+namespace {
+struct ProductJob {
+  const uint64_t* g1; const uint8_t* inf1; const uint64_t* g2; const uint8_t* inf2; size_t k;
+  int rc = 0; int is_one = 0; bool done = false;
+};
+std::mutex q_mu;
+std::condition_variable q_cv;
+std::vector<ProductJob*> q_pending;
+bool q_leader = false;
+
+void run_products(std::vector<ProductJob*>& jobs) {
+  if (jobs.size() == 1) {
+    ProductJob* j = jobs[0];
+    uint32_t offs[2] = {0, (uint32_t)j->k};
+    uint8_t one = 0;
+    j->rc = pairing_run_377(j->g1, j->inf1, j->g2, j->inf2, offs, 1, &one, nullptr, 0);
+    j->is_one = one;
+    return;
+  }
+  size_t tot = 0;
+  for (ProductJob* j : jobs) tot += j->k;
+  std::vector<uint64_t> g1(tot * 12), g2(tot * 24);
+  std::vector<uint8_t> i1(tot, 0), i2(tot, 0), one(jobs.size(), 0);
+  std::vector<uint32_t> offs(jobs.size() + 1, 0);
+  size_t at = 0;
+  for (size_t p = 0; p < jobs.size(); p++) {
+    ProductJob* j = jobs[p];
+    memcpy(&g1[at * 12], j->g1, j->k * 96);
+    memcpy(&g2[at * 24], j->g2, j->k * 192);
+    if (j->inf1) memcpy(&i1[at], j->inf1, j->k);
+    if (j->inf2) memcpy(&i2[at], j->inf2, j->k);
+    at += j->k;
+    offs[p + 1] = (uint32_t)at;
+  }
+  const int rc = pairing_run_377(g1.data(), i1.data(), g2.data(), i2.data(), offs.data(), jobs.size(), one.data(), nullptr, 0);
+  for (size_t p = 0; p < jobs.size(); p++) { jobs[p]->rc = rc; jobs[p]->is_one = one[p]; }
+}
+}  // namespace
+
 int pairing_product_is_one_bls12_377(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2, size_t k, int* is_one) {
-  uint32_t offs[2] = {0, (uint32_t)k};
-  uint8_t one = 0;
-  int rc = pairing_run_377(g1, inf1, g2, inf2, offs, 1, &one, nullptr, 0);
-  if (rc == 0 && is_one) *is_one = one;
-  return rc;
+  ProductJob job{g1, inf1, g2, inf2, k};
+  std::unique_lock<std::mutex> lk(q_mu);
+  q_pending.push_back(&job);
+  if (q_leader) {
+    q_cv.wait(lk, [&] { return job.done; });
+  } else {
+    q_leader = true;
+    while (!q_pending.empty()) {
+      std::vector<ProductJob*> batch;
+      batch.swap(q_pending);
+      lk.unlock();
+      run_products(batch);
+      lk.lock();
+      for (ProductJob* j : batch) j->done = true;
+      q_cv.notify_all();
+    }
+    q_leader = false;
+  }
+  if (job.rc == 0 && is_one) *is_one = job.is_one;
+  return job.rc;
 }
 int pairing_product_is_one_batch_bls12_377(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2,
                                            const uint32_t* offsets, size_t m, uint8_t* is_one) {

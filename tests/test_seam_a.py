@@ -485,3 +485,43 @@ def test_cached_public_key_deserialisation(sys_lib, golden):
     hb = C.c_void_p()
     ok = lib.deserialize_public_key_cached(bad, 96, C.byref(hb))
     assert ok == lib.deserialize_public_key(bad, 96, C.byref(C.c_void_p()))
+
+
+@pytest.mark.gpu
+def test_concurrent_verifications_are_combined(sys_lib, gpu):
+    """bls-snark-sys is synchronous and re-entrant: 32 host threads verify at once; the library
+    combines their single-product checks into shared launches.  Every verdict must be right (valid / wrong message mixed),
+    and the wall time must show the combining (far below 32 x one call)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    lib = sys_lib
+    for f in ("sign_message", "verify_signature"):
+        getattr(lib, f).restype = C.c_bool
+    sk = _deser(lib, "deserialize_private_key", (0xABCDEF123456789 % ecc.R377).to_bytes(32, "little"))
+    pk = C.c_void_p()
+    assert lib.private_key_to_public_key(sk, C.byref(pk))
+    msgs = [b"message-%03d" % i for i in range(16)]
+    sigs = []
+    for m in msgs:
+        s = C.c_void_p()
+        assert lib.sign_message(sk, m, C.c_int(len(m)), b"", C.c_int(0), C.c_bool(False), C.c_bool(False), C.byref(s))
+        sigs.append(s)
+
+    def one(i):
+        m = msgs[i % 16]
+        claimed = m if i % 5 else b"message-xxx"          # every fifth call verifies the wrong message
+        ok = C.c_bool(False)
+        assert lib.verify_signature(pk, claimed, C.c_int(len(claimed)), b"", C.c_int(0), sigs[i % 16], C.c_bool(False), C.c_bool(False), C.byref(ok))
+        return ok.value == bool(i % 5)
+
+    assert one(1) and one(5)                               # warm-up, serial
+    t0 = time.perf_counter()
+    assert one(2)
+    t_one = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(32) as ex:
+        res = list(ex.map(one, range(256)))
+    t_all = time.perf_counter() - t0
+    assert all(res)
+    print("one call %.1f ms; 256 calls from 32 threads %.1f ms" % (t_one * 1e3, t_all * 1e3))
+    assert t_all < 0.35 * 256 * t_one

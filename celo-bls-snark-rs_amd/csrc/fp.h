@@ -212,7 +212,7 @@ template <class P> struct Fp {
   }
 
   // ---- exact halving mod p: (a + (a odd ? p : 0)) >> 1.  lb = 1, vb -> (vb + 1) / 2.  Used by the lane-parallel pairing
-  // (pairing_quad.h) in place of the multiplications by 1/2 of ark-ec's doubling step: same field element, ~50 VALU ops.
+  // (pairing_lanes.h) in place of the multiplications by 1/2 of ark-ec's doubling step: same field element, ~50 VALU ops.
   HD static Fp half(const Fp& a_) {
     const Fp a = norm(a_);
     const uint32_t odd = 0u - (a.l[0] & 1u);

@@ -10,7 +10,7 @@ typedef QTower<QTri377> QTow;
 #define lanes_store lanes_store<LP377>
 
 // op 0: mul12, 1: sqr12, 2: cyclotomic, 3: mul_by_034 (s from y's first three coefficients), 4: inv12, 5: frob1, 6: conj, 7: identity (load/store)
-__global__ void k_quad_op(int op, const uint32_t* x, const uint32_t* y, uint32_t* out) {
+__global__ void k_lanes_op(int op, const uint32_t* x, const uint32_t* y, uint32_t* out) {
   QTow::E12 a = lanes_load(x), b = lanes_load(y), r;
   switch (op) {
     case 0: r = QTow::mul12(a, b); break;
@@ -41,13 +41,13 @@ __global__ void k_lane_op(int op, const uint32_t* x, const uint32_t* y, uint32_t
   f12_to_ark(r, tmp);
   for (int i = 0; i < 72; i++) ((uint64_t*)out)[i] = tmp[i];
 }
-__global__ void k_quad_canon(const uint32_t* in, uint64_t* out) {
+__global__ void k_lanes_canon(const uint32_t* in, uint64_t* out) {
   QTow::E12 r = lanes_load(in);
   int q = QTri377::lane();
   r.a.to_ark(out + 12 * q); r.b.to_ark(out + 12 * (3 + q));
 }
 // point steps: in: R (3 Fq2 at x, x+32, x+64), Q (y, y+32); out: R' (3 Fq2) then line (3 Fq2) as ark u64 (6*12)
-__global__ void k_quad_step(int add, const uint32_t* x, const uint32_t* y, uint64_t* out) {
+__global__ void k_lanes_step(int add, const uint32_t* x, const uint32_t* y, uint64_t* out) {
   int q = QTri377::lane();
   Fq2 Rc = Fq2::load(x + 32 * q);
   Fq2 Qc = Fq2::load(y + 32 * (q & 1));
@@ -76,8 +76,8 @@ __global__ void k_fill(uint32_t* x, uint64_t seed) {  // six pseudo-random Fq2 (
       }
     }
 }
-// truncated Miller loops: `iters` top iterations of the loop, quad vs one-lane
-__global__ void k_quad_miller(int iters, const uint32_t* x, const uint32_t* y, uint32_t* out) {
+// truncated Miller loops: `iters` top iterations of the loop, lane-parallel vs one-lane
+__global__ void k_lanes_miller(int iters, const uint32_t* x, const uint32_t* y, uint32_t* out) {
   int q = QTri377::lane();
   Fq px = Fq::load(x), py = Fq::load(x + 16);
   Fq2 Qc = Fq2::load(y + 32 * (q & 1));
@@ -114,8 +114,8 @@ int main() {
   int bad = 0;
   const char* names[] = {"mul12", "sqr12", "cyclotomic", "mul_by_034", "inv12", "frob1", "conj", "identity"};
   for (int op = 0; op < 8; op++) {
-    k_quad_op<<<1, 3>>>(op, x, y, oq);
-    k_quad_canon<<<1, 3>>>(oq, c1);
+    k_lanes_op<<<1, 3>>>(op, x, y, oq);
+    k_lanes_canon<<<1, 3>>>(oq, c1);
     k_lane_op<<<1, 1>>>(op, x, y, (uint32_t*)c2);
     std::vector<uint64_t> a(72), b(72);
     hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost); hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost);
@@ -124,7 +124,7 @@ int main() {
     if (!ok) { bad++; for (int c = 0; c < 6; c++) printf("   coeff %d: %s\n", c, memcmp(a.data() + 12 * c, b.data() + 12 * c, 96) ? "diff" : "same"); }
   }
   for (int add = 0; add < 2; add++) {
-    k_quad_step<<<1, 3>>>(add, x, y, c1);
+    k_lanes_step<<<1, 3>>>(add, x, y, c1);
     k_lane_step<<<1, 1>>>(add, x, y, c2);
     std::vector<uint64_t> a(72), b(72);
     hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost); hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost);
@@ -133,8 +133,8 @@ int main() {
     if (!ok) { bad++; const char* nm[] = {"X", "Y", "Z", "l.c0", "l.c1", "l.c2"}; for (int c = 0; c < 6; c++) printf("   %s: %s\n", nm[c], memcmp(a.data() + 12 * c, b.data() + 12 * c, 96) ? "diff" : "same"); }
   }
   for (int iters : {1, 2, 3, 5, 8, 63}) {
-    k_quad_miller<<<1, 3>>>(iters, x, y, oq);
-    k_quad_canon<<<1, 3>>>(oq, c1);
+    k_lanes_miller<<<1, 3>>>(iters, x, y, oq);
+    k_lanes_canon<<<1, 3>>>(oq, c1);
     k_lane_miller<<<1, 1>>>(iters, x, y, c2);
     std::vector<uint64_t> a(72), b(72);
     hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost); hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost);

@@ -1,4 +1,4 @@
-/* celo_bls_amd.h — C ABI of the MI355X (gfx950) MSM / pairing hot path.
+/* celo_bls_amd.h — C ABI of the MI355X (gfx950) MSM / pairing / NTT hot path.
  *
  * "Seam B" of SURVEY.md §8b: the thin extern "C" shim that replaces the arkworks call sites
  * of celo-bls-snark-rs.  Each entry cites the reference interface it stands in for.
@@ -14,7 +14,8 @@
  *     crates/bls-snark-sys/src/lib.rs:21-27 convert_result_to_bool);
  *   - *_dev variants take DEVICE pointers (inputs already resident in HBM) and a hipStream_t
  *     (as void*; NULL = default stream); the result still lands in host memory.
- * All functions are synchronous and may be called from any host thread (internally serialised).
+ * All functions are synchronous and may be called from any host thread.  MSM / NTT / batched calls are serialised internally;
+ * single pairing-product checks from concurrent threads are combined into shared launches.
  */
 #ifndef CELO_BLS_AMD_H
 #define CELO_BLS_AMD_H

@@ -581,13 +581,19 @@ template <class G> class MsmEngine {
     if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; }
     for (int i = 0; i < 6; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
   }
+  // Measured on the MI355X (sweep over c at n = 2^8 .. 2^20, uniform scalars, all groups): with the log-depth bucket reduction
+  // the buckets are cheap and the accumulate lanes are not - few long bucket runs are pure latency - so small and mid-size
+  // inputs want MORE buckets than points, and a window size that DIVIDES the scalar length wins by up to 2x because no ragged
+  // top window (few, heavy buckets) is left: 253 = 11 * 23 and 377 = 13 * 29.
+  //   253-bit scalars (BLS12-377): c = 11 below 2^15 points (0.34 ms at n = 256, was 0.9 with c = 4), 15 below 2^19, then 16
+  //   377-bit scalars (BW6-761):   c = 13 below 2^19 points (6.9 ms at 2^18, was 7.1 with c = 14 and 8.6 with 15), then 16
   static int window_bits(size_t n) {
-    int lg = 0;
-    while ((size_t(1) << (lg + 1)) <= n) lg++;
-    int c = lg - 4;
-    if (c < 4) c = 4;
-    if (c > 16) c = 16;
-    return c;
+    if (G::SCALAR_BITS > 256) {
+      if (n < 512) return 9;
+      return n < (size_t(1) << 19) ? 13 : 16;
+    }
+    if (n < (size_t(1) << 15)) return 11;
+    return n < (size_t(1) << 19) ? 15 : 16;
   }
   int force_c = 0;  // test hook / tuning: 0 = auto
 

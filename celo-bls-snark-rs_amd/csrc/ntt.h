@@ -163,6 +163,33 @@ template <int NR> __device__ __forceinline__ Fr761 ntt_lds_get4(const uint32_t* 
 #define NTT_RADIX4(a0, a1, a2, a3)                                        \
   ntt_bf(a0, a2, NTT_TK(0, 1), tw); ntt_bf(a1, a3, NTT_TK(1, 1), tw);     \
   ntt_bf(a0, a1, NTT_TK(0, 0), tw); ntt_bf(a2, a3, NTT_TK(2, 0), tw);
+// round Q of a tile launch (local row bits 2Q+1, 2Q; rows r0 + j * 4^Q): the first round (Q = NR-1) reads HBM, the last (Q = 0)
+// writes it, the ones in between exchange through LDS.  A template over Q so that every shift count is a compile-time constant.
+template <int NR, int Q>
+__device__ __forceinline__ void ntt_tile_round(uint32_t* lds, uint32_t* __restrict__ work, const uint32_t* __restrict__ tw, const NttIo& io,
+                                               uint32_t log_n, int s_lo, uint32_t lo, size_t i0, uint32_t c, uint32_t u) {
+  constexpr int LT = 2 * NR, L0 = 2 * Q;
+  constexpr uint32_t C = 1024u >> LT, d = 1u << L0;
+  const uint32_t r0 = ((u >> L0) << (L0 + 2)) | (u & ((1u << L0) - 1));
+  Fr761 a0, a1, a2, a3;
+  if constexpr (Q == NR - 1) {
+    a0 = ntt_ld(work, io, i0 + ((size_t)r0 << s_lo), log_n);           a1 = ntt_ld(work, io, i0 + ((size_t)(r0 + d) << s_lo), log_n);
+    a2 = ntt_ld(work, io, i0 + ((size_t)(r0 + 2 * d) << s_lo), log_n); a3 = ntt_ld(work, io, i0 + ((size_t)(r0 + 3 * d) << s_lo), log_n);
+  } else {
+    __syncthreads();
+    a0 = ntt_lds_get4<NR>(lds, r0 * C + c);           a1 = ntt_lds_get4<NR>(lds, (r0 + d) * C + c);
+    a2 = ntt_lds_get4<NR>(lds, (r0 + 2 * d) * C + c); a3 = ntt_lds_get4<NR>(lds, (r0 + 3 * d) * C + c);
+  }
+  NTT_RADIX4(a0, a1, a2, a3)
+  if constexpr (Q == 0) {
+    ntt_st(work, io, i0 + ((size_t)r0 << s_lo), log_n, a0);           ntt_st(work, io, i0 + ((size_t)(r0 + d) << s_lo), log_n, a1);
+    ntt_st(work, io, i0 + ((size_t)(r0 + 2 * d) << s_lo), log_n, a2); ntt_st(work, io, i0 + ((size_t)(r0 + 3 * d) << s_lo), log_n, a3);
+  } else {
+    ntt_lds_put4<NR>(lds, r0 * C + c, a0);           ntt_lds_put4<NR>(lds, (r0 + d) * C + c, a1);
+    ntt_lds_put4<NR>(lds, (r0 + 2 * d) * C + c, a2); ntt_lds_put4<NR>(lds, (r0 + 3 * d) * C + c, a3);
+    ntt_tile_round<NR, Q - 1>(lds, work, tw, io, log_n, s_lo, lo, i0, c, u);
+  }
+}
 template <int NR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_ntt_tile4(uint32_t* __restrict__ work, const uint32_t* __restrict__ tw,
                                                                                               uint32_t log_n, int s_top, NttIo io) {
@@ -174,28 +201,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   const uint32_t inst = blockIdx.x * C + c;
   const uint32_t lo = inst & ((1u << s_lo) - 1), hi = inst >> s_lo;
   const size_t i0 = ((size_t)hi << (s_top + 1)) + lo;      // row 0 of this lane's tile; row r is element i0 + (r << s_lo)
-  Fr761 a0, a1, a2, a3;
-#pragma unroll
-  for (int q = NR - 1; q >= 0; q--) {              // round q works on local bits 2q+1, 2q: rows r0 + j * 4^q
-    const int L0 = 2 * q;
-    const uint32_t r0 = ((u >> L0) << (L0 + 2)) | (u & ((1u << L0) - 1)), d = 1u << L0;
-    if (q == NR - 1) {
-      a0 = ntt_ld(work, io, i0 + ((size_t)r0 << s_lo), log_n);           a1 = ntt_ld(work, io, i0 + ((size_t)(r0 + d) << s_lo), log_n);
-      a2 = ntt_ld(work, io, i0 + ((size_t)(r0 + 2 * d) << s_lo), log_n); a3 = ntt_ld(work, io, i0 + ((size_t)(r0 + 3 * d) << s_lo), log_n);
-    } else {
-      __syncthreads();
-      a0 = ntt_lds_get4<NR>(lds, r0 * C + c);           a1 = ntt_lds_get4<NR>(lds, (r0 + d) * C + c);
-      a2 = ntt_lds_get4<NR>(lds, (r0 + 2 * d) * C + c); a3 = ntt_lds_get4<NR>(lds, (r0 + 3 * d) * C + c);
-    }
-    NTT_RADIX4(a0, a1, a2, a3)
-    if (q == 0) {
-      ntt_st(work, io, i0 + ((size_t)r0 << s_lo), log_n, a0);           ntt_st(work, io, i0 + ((size_t)(r0 + d) << s_lo), log_n, a1);
-      ntt_st(work, io, i0 + ((size_t)(r0 + 2 * d) << s_lo), log_n, a2); ntt_st(work, io, i0 + ((size_t)(r0 + 3 * d) << s_lo), log_n, a3);
-    } else {
-      ntt_lds_put4<NR>(lds, r0 * C + c, a0);           ntt_lds_put4<NR>(lds, (r0 + d) * C + c, a1);
-      ntt_lds_put4<NR>(lds, (r0 + 2 * d) * C + c, a2); ntt_lds_put4<NR>(lds, (r0 + 3 * d) * C + c, a3);
-    }
-  }
+  ntt_tile_round<NR, NR - 1>(lds, work, tw, io, log_n, s_lo, lo, i0, c, u);
 }
 #undef NTT_RADIX4
 #undef NTT_TK

@@ -4,6 +4,7 @@
 #include <vector>
 #include <cstring>
 using namespace celo;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 99; } } while (0)
 typedef QPairing377<QTri377> QPair;
 typedef QTower<QTri377> QTow;
 #define lanes_load lanes_load<LP377>
@@ -109,7 +110,7 @@ __global__ void k_lane_miller(int iters, const uint32_t* x, const uint32_t* y, u
 int main() {
   uint32_t *x, *y, *oq;
   uint64_t *c1, *c2;
-  hipMalloc(&x, 192 * 4); hipMalloc(&y, 192 * 4); hipMalloc(&oq, 192 * 4); hipMalloc(&c1, 72 * 8); hipMalloc(&c2, 72 * 8);
+  CK(hipMalloc(&x, 192 * 4)); CK(hipMalloc(&y, 192 * 4)); CK(hipMalloc(&oq, 192 * 4)); CK(hipMalloc(&c1, 72 * 8)); CK(hipMalloc(&c2, 72 * 8));
   k_fill<<<1, 1>>>(x, 12345); k_fill<<<1, 1>>>(y, 999);
   int bad = 0;
   const char* names[] = {"mul12", "sqr12", "cyclotomic", "mul_by_034", "inv12", "frob1", "conj", "identity"};
@@ -118,7 +119,7 @@ int main() {
     k_lanes_canon<<<1, 3>>>(oq, c1);
     k_lane_op<<<1, 1>>>(op, x, y, (uint32_t*)c2);
     std::vector<uint64_t> a(72), b(72);
-    hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost); hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost);
+    CK(hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost));
     int ok = memcmp(a.data(), b.data(), 576) == 0;
     printf("%-12s %s\n", names[op], ok ? "ok" : "MISMATCH");
     if (!ok) { bad++; for (int c = 0; c < 6; c++) printf("   coeff %d: %s\n", c, memcmp(a.data() + 12 * c, b.data() + 12 * c, 96) ? "diff" : "same"); }
@@ -127,7 +128,7 @@ int main() {
     k_lanes_step<<<1, 3>>>(add, x, y, c1);
     k_lane_step<<<1, 1>>>(add, x, y, c2);
     std::vector<uint64_t> a(72), b(72);
-    hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost); hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost);
+    CK(hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost));
     int ok = memcmp(a.data(), b.data(), 576) == 0;
     printf("%-12s %s\n", add ? "add_step" : "double_step", ok ? "ok" : "MISMATCH");
     if (!ok) { bad++; const char* nm[] = {"X", "Y", "Z", "l.c0", "l.c1", "l.c2"}; for (int c = 0; c < 6; c++) printf("   %s: %s\n", nm[c], memcmp(a.data() + 12 * c, b.data() + 12 * c, 96) ? "diff" : "same"); }
@@ -137,7 +138,7 @@ int main() {
     k_lanes_canon<<<1, 3>>>(oq, c1);
     k_lane_miller<<<1, 1>>>(iters, x, y, c2);
     std::vector<uint64_t> a(72), b(72);
-    hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost); hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost);
+    CK(hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost));
     int ok = memcmp(a.data(), b.data(), 576) == 0;
     printf("miller[%2d]   %s\n", iters, ok ? "ok" : "MISMATCH");
     if (!ok) { bad++; for (int c = 0; c < 6; c++) printf("   coeff %d: %s\n", c, memcmp(a.data() + 12 * c, b.data() + 12 * c, 96) ? "diff" : "same"); }

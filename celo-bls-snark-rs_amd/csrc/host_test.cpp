@@ -4,6 +4,7 @@
 #include "curve.h"
 #include "fp2.h"
 #include "pairing.h"
+#include "curve_lanes.h"
 #include <cstring>
 using namespace celo;
 
@@ -42,9 +43,35 @@ template <class F> static void point_op(int op, const uint64_t* p1, const uint64
     case 5: xyzz_madd(acc, a); break;                       // a + a via madd (doubling branch)
     case 6: { for (uint32_t i = 0; i < k; i++) xyzz_madd(acc, b); } break;  // a + k*b by repeated madd
     case 7: { Xyzz<F> t = acc; xyzz_add(acc, t); } break;   // add-with-self (doubling branch of add)
+    case 8: { for (uint32_t i = 0; i < k; i++) acc = xyzz_dbl(acc); xyzz_madd(acc, b); } break;  // 2^k a + b (a Horner step)
     default: break;
   }
   xyzz_to_jac(acc, out);
+}
+
+// lane-parallel XYZZ arithmetic (curve_lanes.h) on the three-explicit-lanes host backend: the same ops as point_op
+template <class F> static void lane_point_op(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) {
+  typedef QHostT<FieldBase<F>> QB;
+  typedef LanePoint<QB> LP;
+  Affine<F> a = load_aff<F>(p1), b = load_aff<F>(p2);
+  auto lift = [](const Affine<F>& p) { typename LP::P r = {QB::uni(p.x), QB::uni(p.y), QB::uni(F::one()), QB::uni(F::one())}; return r; };
+  typename LP::Pt acc = {lift(a), false};
+  switch (op) {
+    case 0: LP::add(acc, lift(b), false); break;                                            // a + b
+    case 1: LP::dbl(acc); break;                                                            // 2a
+    case 2: { typename LP::Pt t = {lift(b), false}; LP::dbl(t); LP::add(t, lift(a), false); LP::add(acc, t.p, t.inf); } break;  // a + (2b + a)
+    case 4: LP::add(acc, lift(affine_neg(a)), false); break;                                // a - a = 0
+    case 6: { for (uint32_t i = 0; i < k; i++) LP::add(acc, lift(b), false); } break;        // a + k*b
+    case 7: { typename LP::P t = acc.p; LP::add(acc, t, false); } break;                    // a + a through add (doubling branch)
+    case 8: { for (uint32_t i = 0; i < k; i++) LP::dbl(acc); LP::add(acc, lift(b), false); } break;  // 2^k a + b (a Horner step)
+    default: break;
+  }
+  Xyzz<F> r = acc.inf ? Xyzz<F>::identity() : Xyzz<F>{acc.p.X.v[0], acc.p.Y.v[0], acc.p.ZZ.v[0], acc.p.ZZZ.v[0]};
+  for (int l = 1; l < 3 && !acc.inf; l++) {   // the lanes must agree
+    if (!F::norm(F::template sub<64, 1>(F::norm(acc.p.X.v[l]), F::norm(r.X))).is_zero_mod_p() ||
+        !F::norm(F::template sub<64, 1>(F::norm(acc.p.ZZZ.v[l]), F::norm(r.ZZZ))).is_zero_mod_p()) r = Xyzz<F>::identity();
+  }
+  xyzz_to_jac(r, out);
 }
 
 // pairing tower on the host with bounds tracking.  mode 0: product of pairings (GT), 1: Miller-loop product only,
@@ -187,6 +214,9 @@ void ht_fq761(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { fie
 void ht_fq2_377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp2<P377>>(op, a, b, out); }
 void ht_g1_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { point_op<Fp<P377>>(op, p1, p2, k, out); }
 void ht_g2_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { point_op<Fp2<P377>>(op, p1, p2, k, out); }
+void ht_lane_g1_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { lane_point_op<Fp<P377>>(op, p1, p2, k, out); }
+void ht_lane_g2_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { lane_point_op<Fp2<P377>>(op, p1, p2, k, out); }
+void ht_lane_g_761(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { lane_point_op<Fp<P761>>(op, p1, p2, k, out); }
 void ht_g_761(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { point_op<Fp<P761>>(op, p1, p2, k, out); }
 void ht_fq377_canon(const uint64_t* canon, uint64_t* out_ark, uint64_t* out_canon) {
   Fp<P377> x = Fp<P377>::from_canonical(canon);

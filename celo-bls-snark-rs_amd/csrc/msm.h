@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <vector>
 #include "curve.h"
+#include "curve_lanes.h"
 #include "fp2.h"
 
 namespace celo {
@@ -436,7 +437,7 @@ __global__ void __launch_bounds__(128) k_bitsum(const uint32_t* __restrict__ par
 //   k_batch_sort      one workgroup per instance: signed digits, per-window LDS counting sort, runs written to HBM
 //   k_size_* + k_accumulate (shared with the big path): every (instance, window, bucket) run is a work item, longest first
 //   k_batch_reduce    one lane per (instance, window): running sum over its <= 64 buckets
-//   k_batch_horner    one lane per instance: Horner over the windows, Jacobian result in arkworks form
+//   k_batch_horner_lanes  three lanes per instance: Horner over the windows, Jacobian result in arkworks form
 template <int SW, int CB, int NW, int PT>
 __global__ void __launch_bounds__(256) k_batch_sort(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
                                                     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted,
@@ -531,9 +532,9 @@ __global__ void __launch_bounds__(128) k_batch_reduce(const uint32_t* __restrict
     size_t bucket = (size_t)vw * B + b;
     if (plen[bucket]) {
       Xyzz<F> v = IO::load_xyzz(partials + bucket * IO::XYZZ_WORDS);
-      xyzz_add_fn(running, v);
+      xyzz_add(running, v);
     }
-    xyzz_add_fn(acc, running);
+    xyzz_add(acc, running);
   }
   IO::store_xyzz(wsum + (size_t)vw * IO::XYZZ_WORDS, acc);
 }
@@ -558,6 +559,38 @@ __global__ void __launch_bounds__(128) k_batch_horner(const uint32_t* __restrict
     F::mul(acc.X, acc.ZZ).to_ark(o);
     F::mul(acc.Y, acc.ZZZ).to_ark(o + IO::ARK64);
     acc.ZZ.to_ark(o + 2 * IO::ARK64);
+  }
+}
+
+// The same Horner pass with THREE LANES PER INSTANCE (curve_lanes.h): the chain of c * nw dependent doublings is pure latency
+// (136 of them per Batch::verify instance), one lane per instance leaves all but 64 waves of the chip idle, and spreading each
+// doubling's independent products over a lane group more than halves its latency.  21 instances per 64-lane block.
+template <class G>
+__global__ void __launch_bounds__(64) k_batch_horner_lanes(const uint32_t* __restrict__ wsum, uint64_t* __restrict__ out, uint32_t nw,
+                                                           uint32_t c, uint32_t m) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  typedef QTriT<FieldBase<F>> QB;
+  typedef LanePoint<QB> LP;
+  const int g = QB::group();
+  const uint32_t inst = blockIdx.x * 21u + (uint32_t)g;
+  if (g >= 21 || inst >= m) return;
+  typename LP::Pt acc;
+  acc.inf = true;
+  for (int w = (int)nw - 1; w >= 0; w--) {
+    for (uint32_t k = 0; k < c; k++) LP::dbl(acc);
+    const Xyzz<F> v = IO::load_xyzz(wsum + ((size_t)inst * nw + w) * IO::XYZZ_WORDS);     // every lane of the group loads the window sum
+    const typename LP::P b = {v.X, v.Y, v.ZZ, v.ZZZ};
+    LP::add(acc, b, v.is_identity());
+  }
+  if (QB::lane() != 0) return;
+  uint64_t* o = out + (size_t)inst * 3 * IO::ARK64;
+  if (acc.inf || acc.p.ZZ.is_zero_mod_p()) {
+    F::zero().to_ark(o); F::one().to_ark(o + IO::ARK64); F::zero().to_ark(o + 2 * IO::ARK64);
+  } else {
+    F::mul(acc.p.X, acc.p.ZZ).to_ark(o);
+    F::mul(acc.p.Y, acc.p.ZZZ).to_ark(o + IO::ARK64);
+    acc.p.ZZ.to_ark(o + 2 * IO::ARK64);
   }
 }
 
@@ -596,6 +629,7 @@ template <class G> class MsmEngine {
     return n < (size_t(1) << 19) ? 15 : 16;
   }
   int force_c = 0;  // test hook / tuning: 0 = auto
+  bool lane_horner = true;  // batched path: three lanes per instance in the Horner pass (tuning hook)
 
   // bases/scalars/inf are DEVICE pointers (ark layout); result: Jacobian in ark Montgomery form (3*ARK64 u64) on host.
   int run_device(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, uint64_t* out_jac,
@@ -847,7 +881,8 @@ template <class G> class MsmEngine {
                        d_nwork, d_partials);
     HIP_OK(hipEventRecord(ev[3], stream));
     hipLaunchKernelGGL((k_batch_reduce<G>), dim3(((uint32_t)nvw + 127) / 128), dim3(128), 0, stream, d_partials, d_plen, d_wsum, B, (uint32_t)nvw);
-    hipLaunchKernelGGL((k_batch_horner<G>), dim3(((uint32_t)m + 127) / 128), dim3(128), 0, stream, d_wsum, d_out, (uint32_t)nw, (uint32_t)c, (uint32_t)m);
+    if (lane_horner) hipLaunchKernelGGL((k_batch_horner_lanes<G>), dim3(((uint32_t)m + 20) / 21), dim3(64), 0, stream, d_wsum, d_out, (uint32_t)nw, (uint32_t)c, (uint32_t)m);
+    else hipLaunchKernelGGL((k_batch_horner<G>), dim3(((uint32_t)m + 127) / 128), dim3(128), 0, stream, d_wsum, d_out, (uint32_t)nw, (uint32_t)c, (uint32_t)m);
     HIP_OK(hipEventRecord(ev[4], stream));
     HIP_OK(hipMemcpyAsync(out, d_out, m * 3 * IO::ARK64 * 8, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ev[5], stream));

@@ -13,12 +13,10 @@
 // Montgomery passes (~22k instructions); operands live in per-lane private memory and the code stays tens of KB.
 #pragma once
 #include "fp2.h"
+#include "lanes.h"
 
 namespace celo {
 
-typedef Fp<P377> Fq;
-typedef Fp2<P377> Fq2;
-typedef Fp<P761> Fw;  // BW6-761 base field
 
 #if defined(__HIPCC__)
 #define TW_FN __host__ __device__ inline __attribute__((noinline))

@@ -121,3 +121,53 @@ def test_point_ops_bw6(ht, golden):
     assert op(3, A, B, 1000003) == cur.mul(A, 1000003)
     assert op(4, A, B) is None
     assert op(6, A, B, 9) == cur.add(A, cur.mul(B, 9))
+
+
+@pytest.mark.parametrize("kind", ["g1_377", "g2_377"])
+def test_lane_parallel_point_ops(ht, kind):
+    """curve_lanes.h (XYZZ doubling / addition spread over three lanes: the batched MSM's Horner kernel) on the three-explicit-
+    lanes host backend with bounds tracking, against the oracle's group law: addition, doubling, chains, P + P through add,
+    P - P, Horner steps 2^k a + b."""
+    cur, gen, fn, pack, nw = {
+        "g1_377": (ecc.E1_377, ecc.G1_377, ht.ht_lane_g1_377, co.pack_g1_377, 18),
+        "g2_377": (ecc.E2_377, ecc.G2_377, ht.ht_lane_g2_377, co.pack_g2_377, 36),
+    }[kind]
+
+    def op(o, P1, P2, k=0):
+        a, _ = pack([P1])
+        b, _ = pack([P2])
+        out = np.zeros(nw, dtype=np.uint64)
+        fn(o, _p(a), _p(b), C.c_uint32(k), _p(out))
+        return co.jac_to_affine(out, kind)
+
+    rng = ecc.SplitMix64(15)
+    for _ in range(3):
+        A = cur.mul(gen, rng.next())
+        B = cur.mul(gen, rng.next())
+        assert op(0, A, B) == cur.add(A, B)
+        assert op(1, A, B) == cur.add(A, A)
+        assert op(2, A, B) == cur.add(A, cur.add(cur.add(B, B), A))
+        assert op(4, A, B) is None
+        assert op(6, A, B, 21) == cur.add(A, cur.mul(B, 21))
+        assert op(7, A, B) == cur.add(A, A)
+        assert op(8, A, B, 5) == cur.add(cur.mul(A, 32), B)
+        assert op(8, A, B, 136) == cur.add(cur.mul(A, 1 << 136), B)      # a whole Batch::verify doubling chain
+
+
+def test_lane_parallel_point_ops_bw6(ht, golden):
+    from oracle.py import epoch as ep
+    vk = ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))
+    A, B = vk["alpha_g1"], vk["gamma_abc_g1"][1]
+    cur = ecc.E1_761
+
+    def op(o, P1, P2, k=0):
+        a, _ = co.pack_761([P1])
+        b, _ = co.pack_761([P2])
+        out = np.zeros(36, dtype=np.uint64)
+        ht.ht_lane_g_761(o, _p(a), _p(b), C.c_uint32(k), _p(out))
+        return co.jac_to_affine(out, "761")
+
+    assert op(0, A, B) == cur.add(A, B)
+    assert op(1, A, B) == cur.add(A, A)
+    assert op(4, A, B) is None
+    assert op(8, A, B, 13) == cur.add(cur.mul(A, 1 << 13), B)

@@ -17,7 +17,7 @@ LIB = os.path.join(ROOT, "celo-bls-snark-rs_amd", "build", "libcelo_hosttest.so"
 
 @pytest.fixture(scope="module")
 def ht():
-    srcs = [os.path.join(CSRC, f) for f in ("host_test.cpp", "fp.h", "fp2.h", "curve.h", "tower.h", "pairing.h", "pairing_lanes.h", "fp_consts.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("host_test.cpp", "fp.h", "fp2.h", "curve.h", "curve_lanes.h", "lanes.h", "tower.h", "pairing.h", "pairing_lanes.h", "fp_consts.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB, srcs[0]])

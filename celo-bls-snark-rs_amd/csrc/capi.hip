@@ -34,6 +34,8 @@ int pairing_run_377(const uint64_t*, const uint8_t*, const uint64_t*, const uint
 int pairing_timings_377(float*);
 int ntt_run(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const uint64_t*, int, void*);
 int ntt_timings(float*, int*);
+int wire_decompress(int, const uint8_t*, size_t, int, uint64_t*, uint8_t*, int, void*);
+float wire_last_ms();
 int pairing_run_761(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
 }  // namespace celo
 using namespace celo;
@@ -161,6 +163,19 @@ int ntt_bw6_761_fr_dev(uint64_t* d_data, unsigned log_n, const uint64_t omega[6]
   return ntt_run(d_data, log_n, omega, coset, coset_after, scale, 1, hip_stream);
 }
 int celo_amd_ntt_last_timings(float ms[4], int* passes) { return ntt_timings(ms, passes); }
+int decompress_bls12_377_g1(const uint8_t* in, size_t n, int check_subgroup, uint64_t* out_xy, uint8_t* status) {
+  return wire_decompress(0, in, n, check_subgroup, out_xy, status, 0, nullptr);
+}
+int decompress_bls12_377_g2(const uint8_t* in, size_t n, int check_subgroup, uint64_t* out_xy, uint8_t* status) {
+  return wire_decompress(1, in, n, check_subgroup, out_xy, status, 0, nullptr);
+}
+int decompress_bls12_377_g1_dev(const uint8_t* d_in, size_t n, int check_subgroup, uint64_t* d_out_xy, uint8_t* d_status, void* hip_stream) {
+  return wire_decompress(0, d_in, n, check_subgroup, d_out_xy, d_status, 1, hip_stream);
+}
+int decompress_bls12_377_g2_dev(const uint8_t* d_in, size_t n, int check_subgroup, uint64_t* d_out_xy, uint8_t* d_status, void* hip_stream) {
+  return wire_decompress(1, d_in, n, check_subgroup, d_out_xy, d_status, 1, hip_stream);
+}
+int celo_amd_decompress_last_ms(float* ms) { if (!ms) return 2; *ms = wire_last_ms(); return 0; }
 int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]) {
   switch (group) {
     case 0: return msm_timings_g1_377(ms, cfg);

@@ -5,6 +5,7 @@
 #include "fp2.h"
 #include "pairing.h"
 #include "curve_lanes.h"
+#include "wire.h"
 #include <cstring>
 using namespace celo;
 
@@ -203,6 +204,32 @@ static void pairing_op_761(int mode, const uint64_t* g1, const uint64_t* g2, siz
 }
 
 extern "C" {
+// wire.h under bounds tracking: n compressed points -> affine ark limbs + status (the GPU kernels run the same functions)
+void ht_wire_decode(int g2, const uint8_t* in, size_t n, int check, uint64_t* out, uint8_t* status) {
+  const WireConsts& k = wire_consts();
+  for (size_t i = 0; i < n; i++) {
+    uint64_t* o = out + i * (g2 ? 24 : 12);
+    memset(o, 0, (g2 ? 24 : 12) * 8);
+    if (g2) {
+      Affine<Fq2> p = {Fq2::zero(), Fq2::zero()};
+      status[i] = wire_decode_g2(in + i * 96, k, check != 0, p);
+      if (status[i] == WIRE_OK) { p.x.c0.to_ark(o); p.x.c1.to_ark(o + 6); p.y.c0.to_ark(o + 12); p.y.c1.to_ark(o + 18); }
+    } else {
+      Affine<Fq> p = {Fq::zero(), Fq::zero()};
+      status[i] = wire_decode_g1(in + i * 48, k, check != 0, p);
+      if (status[i] == WIRE_OK) { p.x.to_ark(o); p.y.to_ark(o + 6); }
+    }
+  }
+}
+// square root in Fq2 (ark limbs in and out); returns 1 when a root exists
+int ht_wire_fq2_sqrt(const uint64_t* a, uint64_t* out) {
+  Fq2 r;
+  const Fq2 x = {Fq::from_ark(a), Fq::from_ark(a + 6)};
+  if (!wire_fq2_sqrt(x, wire_consts(), r)) return 0;
+  r.c0.to_ark(out);
+  r.c1.to_ark(out + 6);
+  return 1;
+}
 void ht_pairing_761_lanes(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out72, int* is_one) { pairing_op_761_lanes(mode, g1, g2, k, out72, is_one); }
 void ht_pairing_761(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out72, int* is_one) { pairing_op_761(mode, g1, g2, k, out72, is_one); }
 void ht_pairing_377(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include "curve.h"
 #include "fp2.h"
+#include "wire.h"
 #include "../../include/celo_bls_amd.h"
 #include "../../include/celo_bls_snark_sys.h"
 
@@ -73,88 +74,12 @@ bool fq_lex_largest(const Fq_& a) {  // canonical(a) > (p-1)/2
 bool fq_is_zero(const Fq_& a) { return a.is_zero_mod_p(); }
 bool fq_eq(const Fq_& a, const Fq_& b) { return Fq_::eq_mod_p(Fq_::norm(a), Fq_::norm(b)); }
 
-// Tonelli-Shanks over Fq (q - 1 = 2^46 * t)
-struct SqrtCtx {
-  uint64_t t[6], t_plus1_half[6], pm1_half[6];
-  Fq_ z;  // (non-residue)^t
-  SqrtCtx() {
-    uint64_t pm1[6];
-    memcpy(pm1, P377::P64, 48);
-    pm1[0] -= 1;
-    // t = (p-1) >> 46
-    for (int i = 0; i < 6; i++) t[i] = (pm1[i] >> 46) | (i + 1 < 6 ? pm1[i + 1] << 18 : 0);
-    uint64_t tp1[6];
-    memcpy(tp1, t, 48);
-    tp1[0] += 1;  // t odd, no carry out of limb 0 unless all ones (not the case)
-    for (int i = 0; i < 6; i++) t_plus1_half[i] = (tp1[i] >> 1) | (i + 1 < 6 ? tp1[i + 1] << 63 : 0);
-    memcpy(pm1_half, P377::PM1_HALF64, 48);
-    for (uint64_t g = 2;; g++) {
-      uint64_t gw[6] = {g, 0, 0, 0, 0, 0};
-      Fq_ gf = Fq_::from_canonical(gw);
-      Fq_ l = Fq_::pow64(gf, pm1_half, 6);
-      if (!fq_eq(l, Fq_::one())) { z = Fq_::pow64(gf, t, 6); break; }
-    }
-  }
-};
-const SqrtCtx& sqrt_ctx() { static SqrtCtx c; return c; }
-
-bool fq_sqrt(const Fq_& a_, Fq_& out) {
-  const Fq_ a = Fq_::norm(a_);
-  if (fq_is_zero(a)) { out = Fq_::zero(); return true; }
-  const SqrtCtx& c = sqrt_ctx();
-  if (!fq_eq(Fq_::pow64(a, c.pm1_half, 6), Fq_::one())) return false;
-  Fq_ x = Fq_::pow64(a, c.t_plus1_half, 6);
-  Fq_ b = Fq_::pow64(a, c.t, 6);
-  Fq_ zz = c.z;
-  int m = 46;
-  while (!fq_eq(b, Fq_::one())) {
-    int i = 0;
-    Fq_ b2 = b;
-    while (!fq_eq(b2, Fq_::one())) { b2 = Fq_::sqr(b2); i++; }
-    Fq_ g = zz;
-    for (int k = 0; k < m - i - 1; k++) g = Fq_::sqr(g);
-    x = Fq_::mul(x, g);
-    zz = Fq_::sqr(g);
-    b = Fq_::mul(b, zz);
-    m = i;
-  }
-  out = x;
-  return true;
-}
+// square roots, decoding and the subgroup check live in wire.h (shared with the bulk GPU kernels of unit_wire.hip)
+bool fq_sqrt(const Fq_& a, Fq_& out) { return wire_fq_sqrt(a, wire_consts(), out); }
 Fq_ fq_neg(const Fq_& a) { return Fq_::wred(Fq_::norm(Fq_::neg<64, 1>(Fq_::norm(a)))); }  // weak-reduced: keeps the affine-coordinate bound (vb <= 3)
 Fq_ fq_inv_of_small(uint64_t k) {
   uint64_t w[6] = {k, 0, 0, 0, 0, 0};
   return Fq_::inv(Fq_::from_canonical(w));
-}
-// sqrt in Fq2 = Fq[u]/(u^2+5) (complex method generalised to u^2 = -5)
-bool fq2_sqrt(const Fq2_& a, Fq2_& out) {
-  if (a.is_zero_mod_p()) { out = Fq2_::zero(); return true; }
-  static const Fq_ inv2 = fq_inv_of_small(2);
-  static const Fq_ inv5 = fq_inv_of_small(5);
-  Fq_ a0 = Fq_::norm(a.c0), a1 = Fq_::norm(a.c1);
-  if (fq_is_zero(a1)) {
-    Fq_ s;
-    if (fq_sqrt(a0, s)) { out = {s, Fq_::zero()}; return true; }
-    // a0 = -5 t^2  ->  sqrt = t u
-    Fq_ tt = fq_neg(Fq_::mul(a0, inv5));
-    if (!fq_sqrt(tt, s)) return false;
-    out = {Fq_::zero(), s};
-    return true;
-  }
-  // norm = a0^2 + 5 a1^2
-  Fq_ s1 = Fq_::sqr(a1);
-  Fq_ n = Fq_::norm(Fq_::add(Fq_::sqr(a0), Fq_::norm(Fq_::add(Fq_::dbl(Fq_::dbl(s1)), s1))));
-  Fq_ al;
-  if (!fq_sqrt(n, al)) return false;
-  Fq_ d = Fq_::mul(Fq_::norm(Fq_::add(a0, al)), inv2), x0;
-  if (!fq_sqrt(d, x0)) {
-    d = Fq_::mul(Fq_::norm(Fq_::sub<4, 1>(a0, Fq_::norm(al))), inv2);
-    if (!fq_sqrt(d, x0)) return false;
-  }
-  Fq_ x1 = Fq_::mul(a1, Fq_::inv(Fq_::norm(Fq_::dbl(x0))));
-  out = {x0, x1};
-  Fq2_ chk = Fq2_::sqr(out);
-  return fq_eq(chk.c0, a0) && fq_eq(chk.c1, a1);
 }
 bool fq2_lex_largest(const Fq2_& y) {  // arkworks: compare c1 first, then c0
   if (!y.c1.is_zero_mod_p()) return fq_lex_largest(y.c1);
@@ -170,10 +95,7 @@ template <class F> Xyzz<F> scalar_mul_host(const Affine<F>& p, const uint64_t* k
   }
   return acc;
 }
-template <class F> bool in_subgroup(const Affine<F>& p) {
-  Xyzz<F> r = scalar_mul_host(p, R_ORDER, 4);
-  return r.is_identity() || r.ZZ.is_zero_mod_p();
-}
+template <class F> bool in_subgroup(const Affine<F>& p) { return wire_in_subgroup(p, wire_consts()); }
 template <class F> void affine_to_jac(const Affine<F>& p, uint64_t* out) {
   constexpr int A = F::ARK64;
   p.x.to_ark(out);
@@ -209,19 +131,9 @@ bool emit(const std::vector<uint8_t>& v, uint8_t** out_bytes, int* out_len) {
 
 // ---- G1 (48-byte x, flags in the top two bits of the last byte)
 bool g1_decompress(const uint8_t* in, Affine<Fq_>& p, bool& inf) {
-  uint8_t buf[48];
-  memcpy(buf, in, 48);
-  uint8_t flags = buf[47] & 0xC0;
-  buf[47] &= 0x3F;
-  inf = (flags & 0x40) != 0;
-  if (inf) return true;
-  Fq_ x;
-  if (!fq_from_bytes(buf, x)) return false;
-  Fq_ rhs = Fq_::norm(Fq_::add(Fq_::mul(Fq_::sqr(x), x), Fq_::one())), y;
-  if (!fq_sqrt(rhs, y)) return false;
-  if (fq_lex_largest(y) != ((flags & 0x80) != 0)) y = fq_neg(y);
-  p = {Fq_::norm(x), Fq_::norm(y)};
-  return true;
+  const WireStatus st = wire_decode_g1(in, wire_consts(), false, p);
+  inf = st == WIRE_INFINITY;
+  return st != WIRE_INVALID;
 }
 void g1_compress(const Affine<Fq_>& p, bool inf, uint8_t* out) {
   memset(out, 0, 48);
@@ -235,19 +147,9 @@ Fq2_ twist_b() {
   return {Fq_::zero(), fq_neg(inv5)};
 }
 bool g2_decompress(const uint8_t* in, Affine<Fq2_>& p, bool& inf) {
-  uint8_t buf[96];
-  memcpy(buf, in, 96);
-  uint8_t flags = buf[95] & 0xC0;
-  buf[95] &= 0x3F;
-  inf = (flags & 0x40) != 0;
-  if (inf) return true;
-  Fq2_ x;
-  if (!fq_from_bytes(buf, x.c0) || !fq_from_bytes(buf + 48, x.c1)) return false;
-  Fq2_ rhs = Fq2_::norm(Fq2_::add(Fq2_::mul(Fq2_::sqr(x), x), twist_b())), y;
-  if (!fq2_sqrt(rhs, y)) return false;
-  if (fq2_lex_largest(y) != ((flags & 0x80) != 0)) y = {fq_neg(y.c0), fq_neg(y.c1)};
-  p = {Fq2_::norm(x), Fq2_::norm(y)};
-  return true;
+  const WireStatus st = wire_decode_g2(in, wire_consts(), false, p);
+  inf = st == WIRE_INFINITY;
+  return st != WIRE_INVALID;
 }
 void g2_compress(const Affine<Fq2_>& p, bool inf, uint8_t* out) {
   memset(out, 0, 96);
@@ -558,7 +460,7 @@ bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* m
 // Blake2Xs call, a 377-bit square root and a 125-bit cofactor multiplication)
 struct HashJob { const uint8_t* msg; size_t mlen; const uint8_t* extra; size_t elen; uint64_t* out_xy; };
 bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJob>& jobs) {
-  (void)sqrt_ctx();
+  (void)wire_consts();
   if (composite) (void)composite_params();  // initialise shared constants before the threads start
   std::atomic<size_t> next(0);
   std::atomic<bool> ok(true);
@@ -762,7 +664,7 @@ bool epoch_from_ffi(const EpochBlockFFI& src, EpochBlockHost& e) {  // snark/epo
   if (nt > src.pubkeys_num / 2) nt = (unsigned)(src.pubkeys_num / 2);
   if (nt < 2) decode(0, src.pubkeys_num);
   else {
-    (void)sqrt_ctx();   // shared constants before the threads start
+    (void)wire_consts();   // shared constants before the threads start
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++) th.emplace_back(decode, src.pubkeys_num * t / nt, src.pubkeys_num * (t + 1) / nt);
     for (auto& x : th) x.join();
@@ -781,7 +683,7 @@ extern "C" {
 
 bool init(void) {  // lib.rs:28-36: force both lazy hashers (the Bowe-Hopwood generator table) and bring the device up
   (void)composite_params();
-  (void)sqrt_ctx();
+  (void)wire_consts();
   return celo_amd_init(0) == 0;
 }
 

@@ -1,0 +1,192 @@
+// Compressed-point decoding for BLS12-377 G1 / G2 (arkworks 0.1 CanonicalDeserialize: x little-endian, flags in the two top
+// bits of the last byte) as host+device templates: the square root (Tonelli-Shanks over Fq, 2-adicity
+// 46; the norm method over Fq2 = Fq[u]/(u^2+5)), the choice of y by the "lexicographically largest" flag, and the
+// prime-order subgroup check r*P = O that GroupAffine::deserialize performs.  SURVEY.md section 8f row f2: what the
+// reference does once per key in PublicKey::deserialize / Signature::deserialize (crates/bls-crypto/src/bls/public.rs:123-149,
+// signature.rs:31-57) and per validator in EpochBlock::from FFI bytes (crates/bls-snark-sys/src/snark/epoch_block.rs:187-196).
+//
+// One source for both sides: seam_a.hip calls these functions on the host for single keys (a 1 ms latency path), the
+// k_decompress kernels (unit_wire.hip) run them one point per lane for bulk wire data.  A square root is unique up to
+// sign and the sign is fixed by the flag, so every correct implementation decodes to the same canonical coordinates.
+#pragma once
+#include <cstdint>
+#include "curve.h"
+#include "fp2.h"
+#include "lanes.h"
+
+namespace celo {
+
+#if defined(__HIPCC__)
+#define WIRE_FN __host__ __device__ inline __attribute__((noinline))
+#else
+#define WIRE_FN inline
+#endif
+
+struct WireConsts {         // built once on the host (wire_consts()), handed to the kernels by value
+  uint64_t tm1_half[6];     // (t - 1) / 2 where q - 1 = 2^46 t, t odd
+  uint64_t r_order[4];      // r, the prime subgroup order
+  Fq z;                     // c^t for the smallest quadratic non-residue c: a generator of the 2^46-th roots of unity
+  Fq inv2, inv5;
+};
+
+enum WireStatus : uint8_t { WIRE_OK = 0, WIRE_INFINITY = 1, WIRE_INVALID = 2, WIRE_NOT_IN_SUBGROUP = 3 };
+
+HD bool wire_eq(const Fq& a, const Fq& b) { return Fq::eq_mod_p(Fq::norm(a), Fq::norm(b)); }
+HD bool wire_is_one(const Fq& a) { return wire_eq(a, Fq::one()); }
+HD Fq wire_neg(const Fq& a) { return Fq::wred(Fq::norm(Fq::neg<64, 1>(Fq::norm(a)))); }   // weak-reduced: vb <= 3 like a decoded coordinate
+HD int wire_cmp(const uint64_t* a, const uint64_t* b, int n) {
+  for (int i = n - 1; i >= 0; i--) {
+    if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+  }
+  return 0;
+}
+// canonical little-endian bytes -> field element; false when the integer is not below q (Fp::read's from_repr failure)
+HD bool wire_fq_from_bytes(const uint8_t* in, Fq& out) {
+  uint64_t w[6];
+  for (int i = 0; i < 6; i++) {
+    uint64_t v = 0;
+    for (int b = 7; b >= 0; b--) v = (v << 8) | in[8 * i + b];
+    w[i] = v;
+  }
+  if (wire_cmp(w, P377::P64, 6) >= 0) return false;
+  out = Fq::from_canonical(w);
+  return true;
+}
+HD bool wire_lex_largest(const Fq& a) {   // canonical(a) > (q - 1) / 2
+  uint64_t w[6];
+  a.to_canonical(w);
+  return wire_cmp(w, P377::PM1_HALF64, 6) > 0;
+}
+HD bool wire_lex_largest(const Fq2& y) {  // arkworks orders Fq2 by c1 first, then c0
+  if (!y.c1.is_zero_mod_p()) return wire_lex_largest(y.c1);
+  return wire_lex_largest(y.c0);
+}
+
+// Tonelli-Shanks.  One exponentiation w = a^((t-1)/2) gives x = a w = a^((t+1)/2) and b = x w = a^t; b has order 2^46
+// exactly when a is a non-residue, which the order search of the first round detects (no separate Legendre symbol).
+WIRE_FN bool wire_fq_sqrt(const Fq& a_, const WireConsts& k, Fq& out) {
+  const Fq a = Fq::norm(a_);
+  if (a.is_zero_mod_p()) { out = Fq::zero(); return true; }
+  const Fq w = Fq::pow64(a, k.tm1_half, 6);
+  Fq x = Fq::mul(a, w);
+  Fq b = Fq::mul(x, w);
+  Fq zz = k.z;
+  int m = 46;
+  while (!wire_is_one(b)) {
+    int i = 0;
+    Fq b2 = b;
+    while (!wire_is_one(b2)) {
+      if (i == m - 1) return false;
+      b2 = Fq::sqr(b2);
+      i++;
+    }
+    Fq g = zz;
+    for (int j = 0; j < m - i - 1; j++) g = Fq::sqr(g);
+    x = Fq::mul(x, g);
+    zz = Fq::sqr(g);
+    b = Fq::mul(b, zz);
+    m = i;
+  }
+  out = x;
+  return true;
+}
+// sqrt in Fq2 by the norm: for a = a0 + a1 u, alpha = sqrt(a0^2 + 5 a1^2), x0^2 = (a0 +- alpha) / 2, x1 = a1 / (2 x0)
+WIRE_FN bool wire_fq2_sqrt(const Fq2& a, const WireConsts& k, Fq2& out) {
+  if (a.is_zero_mod_p()) { out = Fq2::zero(); return true; }
+  const Fq a0 = Fq::norm(a.c0), a1 = Fq::norm(a.c1);
+  Fq s;
+  if (a1.is_zero_mod_p()) {
+    if (wire_fq_sqrt(a0, k, s)) { out = {s, Fq::zero()}; return true; }
+    const Fq tt = wire_neg(Fq::mul(a0, k.inv5));      // a0 = -5 t^2  ->  sqrt = t u
+    if (!wire_fq_sqrt(tt, k, s)) return false;
+    out = {Fq::zero(), s};
+    return true;
+  }
+  const Fq s1 = Fq::sqr(a1);
+  const Fq n = Fq::norm(Fq::add(Fq::sqr(a0), Fq::norm(Fq::add(Fq::dbl(Fq::dbl(s1)), s1))));
+  Fq al, x0;
+  if (!wire_fq_sqrt(n, k, al)) return false;
+  Fq d = Fq::mul(Fq::norm(Fq::add(a0, al)), k.inv2);
+  if (!wire_fq_sqrt(d, k, x0)) {
+    d = Fq::mul(Fq::norm(Fq::sub<4, 1>(a0, Fq::norm(al))), k.inv2);
+    if (!wire_fq_sqrt(d, k, x0)) return false;
+  }
+  const Fq x1 = Fq::mul(a1, Fq::inv(Fq::norm(Fq::dbl(x0))));
+  out = {x0, x1};
+  const Fq2 chk = Fq2::sqr(out);
+  return wire_eq(chk.c0, a0) && wire_eq(chk.c1, a1);
+}
+
+// r * P == O, MSB-first double-and-add over the 253 bits of r (the reference's is_in_correct_subgroup_assuming_on_curve)
+template <class F> WIRE_FN bool wire_in_subgroup(const Affine<F>& p, const WireConsts& k) {
+  Xyzz<F> acc = Xyzz<F>::from_affine(p);
+  for (int i = 251; i >= 0; i--) {
+    xyzz_dbl_fn(acc);
+    if ((k.r_order[i >> 6] >> (i & 63)) & 1) xyzz_madd(acc, p);
+  }
+  return acc.is_identity() || acc.ZZ.is_zero_mod_p();
+}
+
+// 48 bytes -> affine G1 point (y^2 = x^3 + 1)
+HD WireStatus wire_decode_g1(const uint8_t* in, const WireConsts& k, bool check_subgroup, Affine<Fq>& p) {
+  uint8_t buf[48];
+  for (int i = 0; i < 48; i++) buf[i] = in[i];
+  const uint8_t flags = buf[47] & 0xC0;
+  buf[47] &= 0x3F;
+  if (flags & 0x40) return WIRE_INFINITY;
+  Fq x, y;
+  if (!wire_fq_from_bytes(buf, x)) return WIRE_INVALID;
+  const Fq rhs = Fq::norm(Fq::add(Fq::mul(Fq::sqr(x), x), Fq::one()));
+  if (!wire_fq_sqrt(rhs, k, y)) return WIRE_INVALID;
+  if (wire_lex_largest(y) != ((flags & 0x80) != 0)) y = wire_neg(y);
+  p = {Fq::norm(x), Fq::norm(y)};
+  if (check_subgroup && !wire_in_subgroup(p, k)) return WIRE_NOT_IN_SUBGROUP;
+  return WIRE_OK;
+}
+// 96 bytes (x = c0 || c1, flags on c1's last byte) -> affine G2 point (y^2 = x^3 + B', B' = 1/u = -u/5)
+HD WireStatus wire_decode_g2(const uint8_t* in, const WireConsts& k, bool check_subgroup, Affine<Fq2>& p) {
+  uint8_t buf[96];
+  for (int i = 0; i < 96; i++) buf[i] = in[i];
+  const uint8_t flags = buf[95] & 0xC0;
+  buf[95] &= 0x3F;
+  if (flags & 0x40) return WIRE_INFINITY;
+  Fq2 x, y;
+  if (!wire_fq_from_bytes(buf, x.c0) || !wire_fq_from_bytes(buf + 48, x.c1)) return WIRE_INVALID;
+  const Fq2 tb = {Fq::zero(), wire_neg(k.inv5)};
+  const Fq2 rhs = Fq2::norm(Fq2::add(Fq2::mul(Fq2::sqr(x), x), tb));
+  if (!wire_fq2_sqrt(rhs, k, y)) return WIRE_INVALID;
+  if (wire_lex_largest(y) != ((flags & 0x80) != 0)) y = {wire_neg(y.c0), wire_neg(y.c1)};
+  p = {Fq2::norm(x), Fq2::norm(y)};
+  if (check_subgroup && !wire_in_subgroup(p, k)) return WIRE_NOT_IN_SUBGROUP;
+  return WIRE_OK;
+}
+
+// ---- host: the constants (one search for the smallest non-residue, three exponentiations; first use only)
+inline WireConsts wire_consts_build() {
+  WireConsts k;
+  uint64_t pm1[6], t[6];
+  for (int i = 0; i < 6; i++) pm1[i] = P377::P64[i];
+  pm1[0] -= 1;
+  for (int i = 0; i < 6; i++) t[i] = (pm1[i] >> 46) | (i + 1 < 6 ? pm1[i + 1] << 18 : 0);
+  uint64_t tm1[6];
+  for (int i = 0; i < 6; i++) tm1[i] = t[i];
+  tm1[0] -= 1;   // t is odd
+  for (int i = 0; i < 6; i++) k.tm1_half[i] = (tm1[i] >> 1) | (i + 1 < 6 ? tm1[i + 1] << 63 : 0);
+  const uint64_t r[4] = {0x0a11800000000001ULL, 0x59aa76fed0000001ULL, 0x60b44d1e5c37b001ULL, 0x12ab655e9a2ca556ULL};
+  for (int i = 0; i < 4; i++) k.r_order[i] = r[i];
+  for (uint64_t g = 2;; g++) {
+    const uint64_t gw[6] = {g, 0, 0, 0, 0, 0};
+    const Fq gf = Fq::from_canonical(gw);
+    if (!wire_is_one(Fq::pow64(gf, P377::PM1_HALF64, 6))) { k.z = Fq::pow64(gf, t, 6); break; }
+  }
+  const uint64_t two[6] = {2, 0, 0, 0, 0, 0}, five[6] = {5, 0, 0, 0, 0, 0};
+  k.inv2 = Fq::inv(Fq::from_canonical(two));
+  k.inv5 = Fq::inv(Fq::from_canonical(five));
+  return k;
+}
+inline const WireConsts& wire_consts() {
+  static const WireConsts k = wire_consts_build();
+  return k;
+}
+
+}  // namespace celo

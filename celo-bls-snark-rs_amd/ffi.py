@@ -222,3 +222,32 @@ def pairing_gt_bw6(g1_xy, inf1, g2_xy, inf2, offsets, miller_only=False):
     if rc != 0:
         raise RuntimeError(f"celo_amd_pairing_gt_bw6_761 failed rc={rc}")
     return out
+
+
+def decompress(group, data, check_subgroup=True):
+    """Bulk decoding of compressed points (include/celo_bls_amd.h: decompress_bls12_377_g1/_g2).  group: "g1" (48 B each) or
+    "g2" (96 B each); data: bytes of n concatenated encodings.  Returns (xy, status): xy (n, 12 | 24) uint64 affine arkworks
+    Montgomery limbs (zero rows unless status == 0), status (n,) uint8 (0 ok, 1 infinity, 2 invalid, 3 not in subgroup)."""
+    size, words, fn = {"g1": (48, 12, "decompress_bls12_377_g1"), "g2": (96, 24, "decompress_bls12_377_g2")}[group]
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    assert buf.size % size == 0
+    n = buf.size // size
+    xy = np.zeros((n, words), dtype=np.uint64)
+    st = np.zeros(n, dtype=np.uint8)
+    rc = getattr(lib(), fn)(_p(buf), C.c_size_t(n), C.c_int(1 if check_subgroup else 0), _p(xy), _p(st))
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (fn, rc))
+    return xy, st
+
+
+def decompress_dev(group, d_in, n, d_out, d_status, check_subgroup=True, stream=0):
+    fn = {"g1": "decompress_bls12_377_g1_dev", "g2": "decompress_bls12_377_g2_dev"}[group]
+    rc = getattr(lib(), fn)(C.c_void_p(d_in), C.c_size_t(n), C.c_int(1 if check_subgroup else 0), C.c_void_p(d_out), C.c_void_p(d_status), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (fn, rc))
+
+
+def decompress_last_ms():
+    ms = C.c_float(0)
+    assert lib().celo_amd_decompress_last_ms(C.byref(ms)) == 0
+    return ms.value

@@ -98,6 +98,22 @@ int ntt_bw6_761_fr_dev(uint64_t* d_data, unsigned log_n, const uint64_t omega[6]
 /* ms[4] = {load/convert, butterfly passes, bit-reversal store, total}, passes = number of butterfly launches (last NTT call). */
 int celo_amd_ntt_last_timings(float ms[4], int* passes);
 
+/* ---- bulk decoding of compressed points: n keys or signatures in arkworks 0.1 wire form
+ * (G1: 48 B, G2: 96 B; x little-endian, flag bits 0x80 = "y is the larger root", 0x40 = infinity in the last byte) to
+ * affine (x, y) in arkworks Montgomery limbs - the layout the MSM and pairing entry points take.  One point per GPU lane:
+ * the square root (Tonelli-Shanks in Fq, the norm method in Fq2), the sign choice and, with check_subgroup != 0, r*P == O.
+ * Replaces the per-key work of PublicKey::deserialize / Signature::deserialize (crates/bls-crypto/src/bls/public.rs:123-149,
+ * signature.rs:31-57: GroupAffine::deserialize = get_point_from_x + is_in_correct_subgroup_assuming_on_curve) and of the
+ * per-validator loop of the epoch FFI (crates/bls-snark-sys/src/snark/epoch_block.rs:187-196).
+ * status[i]: 0 = decoded, 1 = the encoding of the point at infinity, 2 = not a valid encoding (x >= q or no y exists),
+ * 3 = on the curve but outside the prime-order subgroup; out_xy[i] is all zero unless status[i] == 0. */
+int decompress_bls12_377_g1(const uint8_t* in /* n x 48 */, size_t n, int check_subgroup, uint64_t* out_xy /* n x 12 */, uint8_t* status /* n */);
+int decompress_bls12_377_g2(const uint8_t* in /* n x 96 */, size_t n, int check_subgroup, uint64_t* out_xy /* n x 24 */, uint8_t* status /* n */);
+int decompress_bls12_377_g1_dev(const uint8_t* d_in, size_t n, int check_subgroup, uint64_t* d_out_xy, uint8_t* d_status, void* hip_stream);
+int decompress_bls12_377_g2_dev(const uint8_t* d_in, size_t n, int check_subgroup, uint64_t* d_out_xy, uint8_t* d_status, void* hip_stream);
+/* kernel time (HIP events) of the last decompress call */
+int celo_amd_decompress_last_ms(float* ms);
+
 /* ---- plain sums of k Jacobian points (host pointers, arkworks layout; host-side, for small k): the fold of per-GPU
  * partial MSM results and small aggregates — Signature::aggregate / PublicKey::aggregate
  * (crates/bls-crypto/src/bls/signature.rs:61-67, public.rs:38-44). */

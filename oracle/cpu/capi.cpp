@@ -237,5 +237,66 @@ double orc_time_msm_bls12_377_g1(const u64* xy, const u64* sc, size_t n, int thr
   msm_impl<Fq377, 4>(xy, nullptr, sc, n, 253, threads, 0, out18);
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
+}  // extern "C"
+
+// ---- compressed-point decoding (arkworks 0.1 GroupAffine::deserialize: x little-endian with the flag bits 0x80 "y is the
+// larger root" / 0x40 infinity in the last byte, get_point_from_x, then is_in_correct_subgroup_assuming_on_curve = r*P == O;
+// crates/bls-crypto/src/bls/public.rs:123-149, signature.rs:31-57).  status: 0 ok, 1 infinity, 2 invalid, 3 not in subgroup.
+namespace {
+const u64 R377_ORDER[4] = {0x0a11800000000001ULL, 0x59aa76fed0000001ULL, 0x60b44d1e5c37b001ULL, 0x12ab655e9a2ca556ULL};
+bool read_fq377(const uint8_t* in, Fq377& out) {
+  u64 w[6];
+  memcpy(w, in, 48);
+  if (big_cmp<6>(w, Fq377::C().p) >= 0) return false;
+  out = Fq377::from_canonical(w);
+  return true;
+}
+template <class F> uint8_t finish_point(const F& x, const F& b, bool greatest, int check, u64* out) {
+  constexpr int L = limbs_of<F>();
+  F y;
+  if (!(x.sqr() * x + b).sqrt(y)) return 2;
+  if (y.lex_largest() != greatest) y = -y;
+  Affine<F> p = {x, y, false};
+  if (check && !Jac<F>::from_affine(p).template mul<4>(R377_ORDER).is_identity()) return 3;
+  store_f(x, out);
+  store_f(y, out + L);
+  return 0;
+}
+uint8_t decode_one(int g2, const uint8_t* in, int check, u64* out) {
+  const int nb = g2 ? 96 : 48;
+  uint8_t buf[96];
+  memcpy(buf, in, nb);
+  const uint8_t flags = buf[nb - 1] & 0xC0;
+  buf[nb - 1] &= 0x3F;
+  memset(out, 0, (g2 ? 24 : 12) * 8);
+  if (flags & 0x40) return 1;
+  if (g2) {
+    Fq2_377 x;
+    if (!read_fq377(buf, x.c0) || !read_fq377(buf + 48, x.c1)) return 2;
+    return finish_point<Fq2_377>(x, Bls12_377::twist_b(), (flags & 0x80) != 0, check, out);
+  }
+  Fq377 x;
+  if (!read_fq377(buf, x)) return 2;
+  return finish_point<Fq377>(x, Fq377::one(), (flags & 0x80) != 0, check, out);
+}
+}  // namespace
+extern "C" {
+int orc_decompress_bls12_377(int g2, const uint8_t* in, size_t n, int check_subgroup, int threads, u64* out_xy, uint8_t* status) {
+  const size_t nb = g2 ? 96 : 48, ow = g2 ? 24 : 12;
+  if (threads < 1) threads = 1;
+  (void)decode_one(g2, in, 0, out_xy);   // lazily built field constants before the threads start
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; t++)
+    th.emplace_back([&, t]() {
+      for (size_t i = n * t / threads; i < n * (t + 1) / threads; i++) status[i] = decode_one(g2, in + i * nb, check_subgroup, out_xy + i * ow);
+    });
+  for (auto& x : th) x.join();
+  return 0;
+}
+double orc_time_decompress_bls12_377(int g2, const uint8_t* in, size_t n, int check_subgroup, int threads, u64* out_xy, uint8_t* status) {
+  auto t0 = std::chrono::steady_clock::now();
+  orc_decompress_bls12_377(g2, in, n, check_subgroup, threads, out_xy, status);
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
 int orc_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
 }

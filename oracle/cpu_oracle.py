@@ -215,3 +215,27 @@ def time_ntt_fq377(data, log_n, omega):
     out = np.ascontiguousarray(data, dtype=np.uint64).copy()
     lib().orc_time_ntt_fq377.restype = C.c_double
     return lib().orc_time_ntt_fq377(_p(out), C.c_uint(log_n), _p(to_mont([omega], Q377)))
+
+
+def decompress(group, data, check_subgroup=True, threads=1):
+    """arkworks GroupAffine::deserialize of n concatenated compressed BLS12-377 points (orc_decompress_bls12_377).
+    group "g1" (48 B) / "g2" (96 B).  Returns (xy (n, 12|24) uint64 Montgomery limbs, status (n,) uint8: 0 ok, 1 infinity,
+    2 invalid, 3 not in the subgroup)."""
+    size, words, g2 = {"g1": (48, 12, 0), "g2": (96, 24, 1)}[group]
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    n = buf.size // size
+    xy = np.zeros((n, words), dtype=np.uint64)
+    st = np.zeros(n, dtype=np.uint8)
+    if n:
+        assert lib().orc_decompress_bls12_377(C.c_int(g2), _p(buf), C.c_size_t(n), C.c_int(1 if check_subgroup else 0), C.c_int(threads), _p(xy), _p(st)) == 0
+    return xy, st
+
+
+def time_decompress(group, data, check_subgroup=True, threads=1):
+    size, words, g2 = {"g1": (48, 12, 0), "g2": (96, 24, 1)}[group]
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    n = buf.size // size
+    xy = np.zeros((n, words), dtype=np.uint64)
+    st = np.zeros(n, dtype=np.uint8)
+    lib().orc_time_decompress_bls12_377.restype = C.c_double
+    return lib().orc_time_decompress_bls12_377(C.c_int(g2), _p(buf), C.c_size_t(n), C.c_int(1 if check_subgroup else 0), C.c_int(threads), _p(xy), _p(st))

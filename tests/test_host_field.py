@@ -171,3 +171,55 @@ def test_lane_parallel_point_ops_bw6(ht, golden):
     assert op(1, A, B) == cur.add(A, A)
     assert op(4, A, B) is None
     assert op(8, A, B, 13) == cur.add(cur.mul(A, 1 << 13), B)
+
+
+def test_wire_decode_under_bounds_tracking(ht, golden):
+    """wire.h (the functions the k_decompress kernels and Seam A's deserialize_* run) on the host with every lazy-reduction
+    bound asserted: the reference's compressed points (hash_to_curve/mod.rs:412-513), both signs, and every failure verdict,
+    against the oracle's C restatement of GroupAffine::deserialize."""
+    h = golden["hash_to_curve"]
+    for group, size, words, encs in (("g1", 48, 12, [bytes.fromhex(x) for k in ("g1_compat", "g1_noncompat") for x in h[k]["points"][:4]]),
+                                     ("g2", 96, 24, [bytes.fromhex(x) for x in h["g2_noncompat"]["points"][:4]])):
+        curve = ecc.E1_377 if group == "g1" else ecc.E2_377
+        flipped = [bytes(b[:-1]) + bytes([b[-1] ^ 0x80]) for b in encs[:2]]          # the other root
+        spoiled = [bytes([b[0] ^ 1]) + bytes(b[1:]) for b in encs] + [bytes([b[0] ^ 2]) + bytes(b[1:]) for b in encs]
+        bad = [ecc.ser_point(curve, None), ecc.Q377.to_bytes(48, "little") * (size // 48)]
+        data = b"".join(encs + flipped + spoiled + bad)
+        n = len(data) // size
+        for check in (1, 0):
+            out = np.zeros((n, words), dtype=np.uint64)
+            st = np.zeros(n, dtype=np.uint8)
+            ht.ht_wire_decode(C.c_int(group == "g2"), data, C.c_size_t(n), C.c_int(check), _p(out), _p(st))
+            wxy, wst = co.decompress(group, data, check_subgroup=bool(check), threads=4)
+            assert np.array_equal(st, wst) and np.array_equal(out, wxy)
+        assert st[:len(encs) + 2].tolist() == [0] * (len(encs) + 2) and st[-2:].tolist() == [1, 2]
+        assert 2 in wst[len(encs) + 2:-2].tolist()          # some spoiled x have no y at all
+
+
+def test_wire_fq2_sqrt_special_branches(ht):
+    """the branches a curve point never reaches: purely real / purely imaginary squares (c1 == 0 in, root in Fq or in Fq*u),
+    zero, and non-squares."""
+    p, f2 = ecc.Q377, ecc.F2_377
+    random.seed(11)
+
+    def root(a):
+        A = co.to_mont(list(a), p).reshape(-1)
+        out = np.zeros(12, dtype=np.uint64)
+        ok = ht.ht_wire_fq2_sqrt(_p(A), _p(out))
+        return tuple(co.from_mont(out, p)) if ok else None
+
+    cases = [(0, 0)]
+    for _ in range(6):
+        t = random.randrange(1, p)
+        cases += [(t * t % p, 0), (-5 * t * t % p, 0)]                      # t^2 and (t u)^2 = -5 t^2
+        cases.append(f2.mul((t, random.randrange(p)), (t, 0)))               # generic
+    nonsq = 0
+    for a in cases + [f2.mul(c, c) for c in cases]:
+        r = root(a)
+        want = f2.sqrt(a)
+        assert (r is None) == (want is None)
+        if r is None:
+            nonsq += 1
+        else:
+            assert f2.mul(r, r) == (a[0] % p, a[1] % p)
+    assert nonsq > 0

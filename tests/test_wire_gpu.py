@@ -1,0 +1,139 @@
+"""GPU (-m gpu): bulk decoding of compressed BLS12-377 points through the C ABI (include/celo_bls_amd.h:
+decompress_bls12_377_g1 / _g2) vs the oracle's restatement of arkworks' GroupAffine::deserialize (oracle/py/ecc.py:
+deser_point) - SURVEY.md section 8f row f2.
+
+What it replaces: the per-key work of PublicKey::deserialize / Signature::deserialize (crates/bls-crypto/src/bls/
+public.rs:123-149, signature.rs:31-57) and of the per-validator loop in crates/bls-snark-sys/src/snark/epoch_block.rs:187-196.
+Pinned on the reference's own compressed points (crates/bls-crypto/src/hash_to_curve/mod.rs:412-513, committed in
+tests/golden/reference_vectors.json): each decodes, lies in the subgroup and re-encodes to the same bytes.  Integer work:
+bit-exact."""
+import numpy as np
+import pytest
+import torch  # before the library: both must share one HIP runtime
+from oracle.py import ecc
+from oracle import cpu_oracle as co
+from helpers import seeded_points
+
+pytestmark = pytest.mark.gpu
+Q = ecc.Q377
+
+
+def _g1_rows(pts):
+    return co.pack_g1_377(pts)[0]
+
+
+def _g2_rows(pts):
+    return co.pack_g2_377(pts)[0]
+
+
+def test_reference_points_decode(gpu, golden):
+    h = golden["hash_to_curve"]
+    g1 = [bytes.fromhex(x) for k in ("g1_compat", "g1_noncompat") if k in h for x in h[k]["points"]]
+    g2 = [bytes.fromhex(x) for x in h["g2_noncompat"]["points"]]
+    assert len(g1) >= 20 and len(g2) >= 10
+    xy, st = gpu.decompress("g1", b"".join(g1))
+    assert st.tolist() == [0] * len(g1)
+    want = [ecc.deser_point(ecc.E1_377, b, check_subgroup=True) for b in g1]
+    assert np.array_equal(xy, _g1_rows(want))
+    xy, st = gpu.decompress("g2", b"".join(g2))
+    assert st.tolist() == [0] * len(g2)
+    want = [ecc.deser_point(ecc.E2_377, b, check_subgroup=True) for b in g2]
+    assert np.array_equal(xy, _g2_rows(want))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 300])
+def test_random_points_round_trip(gpu, n):
+    """encode (oracle) -> decode (GPU) gives the same affine coordinates, both signs of y, ragged launch sizes."""
+    p1 = seeded_points(ecc.E1_377, ecc.G1_377, n, 31 + n)
+    p1 = [P if i % 2 else ecc.E1_377.neg(P) for i, P in enumerate(p1)]
+    xy, st = gpu.decompress("g1", b"".join(ecc.ser_point(ecc.E1_377, P) for P in p1))
+    assert not st.any() and np.array_equal(xy, _g1_rows(p1))
+    m = min(n, 96)
+    p2 = seeded_points(ecc.E2_377, ecc.G2_377, m, 77 + n)
+    p2 = [P if i % 2 else ecc.E2_377.neg(P) for i, P in enumerate(p2)]
+    xy, st = gpu.decompress("g2", b"".join(ecc.ser_point(ecc.E2_377, P) for P in p2))
+    assert not st.any() and np.array_equal(xy, _g2_rows(p2))
+
+
+def _off_subgroup(curve, f2):
+    """an on-curve point outside the prime-order subgroup (cofactor not cleared)"""
+    x = 7
+    while True:
+        X = (x, 1) if f2 else x
+        rhs = curve._add(curve._mul(curve._mul(X, X), X), curve.b)
+        y = curve.f2.sqrt(rhs) if f2 else ecc.sqrt_fp(rhs, Q)
+        if y is not None and not curve.in_subgroup((X, y)):
+            return (X, y)
+        x += 1
+
+
+def _no_y(curve, f2):
+    x = 5
+    while True:
+        X = (x, 3) if f2 else x
+        rhs = curve._add(curve._mul(curve._mul(X, X), X), curve.b)
+        y = curve.f2.sqrt(rhs) if f2 else ecc.sqrt_fp(rhs, Q)
+        if y is None:
+            return X
+        x += 1
+
+
+def test_status_codes_mixed_batch(gpu):
+    """every verdict of GroupAffine::deserialize in ONE launch, neighbours unaffected: ok / infinity / x >= q / x not on the
+    curve / on the curve but outside the subgroup (accepted when the check is off, as deserialize_unchecked would)."""
+    good = seeded_points(ecc.E1_377, ecc.G1_377, 3, 5)
+    off = _off_subgroup(ecc.E1_377, False)
+    enc = [ecc.ser_point(ecc.E1_377, good[0]), ecc.ser_point(ecc.E1_377, None), Q.to_bytes(48, "little"),
+           _no_y(ecc.E1_377, False).to_bytes(48, "little"), ecc.ser_point(ecc.E1_377, off), ecc.ser_point(ecc.E1_377, good[1]),
+           ((1 << 382) - 1).to_bytes(48, "little"), ecc.ser_point(ecc.E1_377, good[2])]
+    xy, st = gpu.decompress("g1", b"".join(enc))
+    assert st.tolist() == [0, 1, 2, 2, 3, 0, 2, 0]
+    assert np.array_equal(xy[[0, 5, 7]], _g1_rows(good)) and not xy[[1, 2, 3, 4, 6]].any()
+    xy, st = gpu.decompress("g1", b"".join(enc), check_subgroup=False)
+    assert st.tolist() == [0, 1, 2, 2, 0, 0, 2, 0] and np.array_equal(xy[4:5], _g1_rows([off]))
+
+    good = seeded_points(ecc.E2_377, ecc.G2_377, 2, 6)
+    off = _off_subgroup(ecc.E2_377, True)
+    nx = _no_y(ecc.E2_377, True)
+    enc = [ecc.ser_point(ecc.E2_377, good[0]), ecc.ser_point(ecc.E2_377, None), (1).to_bytes(48, "little") + Q.to_bytes(48, "little"),
+           nx[0].to_bytes(48, "little") + nx[1].to_bytes(48, "little"), ecc.ser_point(ecc.E2_377, off), ecc.ser_point(ecc.E2_377, good[1])]
+    xy, st = gpu.decompress("g2", b"".join(enc))
+    assert st.tolist() == [0, 1, 2, 2, 3, 0]
+    assert np.array_equal(xy[[0, 5]], _g2_rows(good)) and not xy[1:5].any()
+    xy, st = gpu.decompress("g2", b"".join(enc), check_subgroup=False)
+    assert st.tolist() == [0, 1, 2, 2, 0, 0] and np.array_equal(xy[4:5], _g2_rows([off]))
+
+
+def test_empty_and_many_waves(gpu):
+    """the empty call; 4120 G2 encodings (several waves per SIMD) decode like their 40 distinct sources"""
+    xy, st = gpu.decompress("g2", b"")
+    assert xy.shape == (0, 24) and st.shape == (0,)
+    pts = seeded_points(ecc.E2_377, ecc.G2_377, 40, 9)
+    enc = [ecc.ser_point(ecc.E2_377, P) for P in pts]
+    big = enc * 103  # 4120 points: several waves per SIMD
+    xy, st = gpu.decompress("g2", b"".join(big))
+    assert not st.any()
+    assert np.array_equal(xy, np.tile(_g2_rows(pts), (103, 1)))
+
+
+@pytest.mark.parametrize("group,n", [("g1", 1 << 13), ("g2", 1 << 11)])
+def test_bulk_matches_oracle_c(gpu, group, n):
+    """thousands of distinct encodings with ~3 % spoiled ones (bit flips in x: most land off the curve, some on it but
+    outside the subgroup) against the C restatement: same verdict and same coordinates for every entry."""
+    curve, gen, size = (ecc.E1_377, ecc.G1_377, 48) if group == "g1" else (ecc.E2_377, ecc.G2_377, 96)
+    base = seeded_points(curve, gen, 64, 1000 + n)
+    rng = ecc.SplitMix64(n)
+    enc = []
+    P = base[0]
+    for i in range(n):
+        P = curve.add(P, base[rng.next() % 64])        # a walk through the subgroup: distinct points, cheap to make
+        b = bytearray(ecc.ser_point(curve, P))
+        r = rng.next()
+        if r % 32 == 0:
+            b[(r >> 8) % (size - 1)] ^= 1 << ((r >> 20) % 8)
+        enc.append(bytes(b))
+    data = b"".join(enc)
+    xy, st = gpu.decompress(group, data)
+    wxy, wst = co.decompress(group, data, threads=8)
+    assert np.array_equal(st, wst) and np.array_equal(xy, wxy)
+    assert 0 < int((st != 0).sum()) < n // 8

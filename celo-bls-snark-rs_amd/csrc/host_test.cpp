@@ -6,6 +6,7 @@
 #include "pairing.h"
 #include "curve_lanes.h"
 #include "wire.h"
+#include "hash_direct.h"
 #include <cstring>
 using namespace celo;
 
@@ -220,6 +221,15 @@ void ht_wire_decode(int g2, const uint8_t* in, size_t n, int check, uint64_t* ou
       if (status[i] == WIRE_OK) { p.x.to_ark(o); p.y.to_ark(o + 6); }
     }
   }
+}
+// hash_direct.h under bounds tracking: one try-and-increment hash; returns the attempt counter, -1 when none succeeds
+int ht_hash_to_g1_direct(const uint8_t* dom, const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen, uint64_t* out_xy) {
+  Affine<Fq> p = {Fq::zero(), Fq::zero()};
+  int c = -1;
+  if (!hash_to_g1_direct_tai(dom, msg, mlen, extra, elen, wire_consts(), p, c)) return -1;
+  p.x.to_ark(out_xy);
+  p.y.to_ark(out_xy + 6);
+  return c;
 }
 // square root in Fq2 (ark limbs in and out); returns 1 when a root exists
 int ht_wire_fq2_sqrt(const uint64_t* a, uint64_t* out) {

@@ -461,6 +461,25 @@ bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* m
 struct HashJob { const uint8_t* msg; size_t mlen; const uint8_t* extra; size_t elen; uint64_t* out_xy; };
 bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJob>& jobs) {
   (void)wire_consts();
+  // direct hasher, many messages: one GPU launch (hash_direct.h, a message per lane; ~5 ms for one wave of 64, so the host
+  // cores keep the small calls).  The composite hasher's Pedersen CRH stays on the host.
+  if (!composite && jobs.size() >= 256) {
+    const size_t n = jobs.size();
+    std::vector<uint64_t> moff(n + 1, 0), eoff(n + 1, 0);
+    for (size_t i = 0; i < n; i++) { moff[i + 1] = moff[i] + jobs[i].mlen; eoff[i + 1] = eoff[i] + jobs[i].elen; }
+    std::vector<uint8_t> mb(moff[n] + 1), eb(eoff[n] + 1), att(n);
+    for (size_t i = 0; i < n; i++) {
+      if (jobs[i].mlen) memcpy(&mb[moff[i]], jobs[i].msg, jobs[i].mlen);
+      if (jobs[i].elen) memcpy(&eb[eoff[i]], jobs[i].extra, jobs[i].elen);
+    }
+    std::vector<uint64_t> xy(n * 12);
+    if (hash_to_g1_direct_bls12_377(dom, mb.data(), moff.data(), eb.data(), eoff.data(), n, xy.data(), att.data()) != 0) return false;
+    for (size_t i = 0; i < n; i++) {
+      if (att[i] == 255) return false;
+      memcpy(jobs[i].out_xy, &xy[i * 12], 96);
+    }
+    return true;
+  }
   if (composite) (void)composite_params();  // initialise shared constants before the threads start
   std::atomic<size_t> next(0);
   std::atomic<bool> ok(true);

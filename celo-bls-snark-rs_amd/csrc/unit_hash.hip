@@ -1,0 +1,166 @@
+// Translation unit: batched hash-to-G1 over the direct hasher (see hash_direct.h): rounds of candidate counters, then the
+// cofactor ladder.
+#include "hash_direct.h"
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+
+namespace celo {
+std::mutex& api_mutex();
+int api_ensure_init();
+
+struct HashDom { uint8_t b[8]; };
+struct HashIn { const uint8_t* msgs; const uint64_t* msg_off; const uint8_t* extras; const uint64_t* extra_off; };
+
+// One round of try-and-increment for the messages still without a point.  list: their indices (nullptr = all of 0..count);
+// each gets CAND adjacent lanes trying the counters base .. base + CAND - 1 side by side (CAND = 1, 2, ... 64 divides the wave:
+// many messages -> 1, so every lane's square root is one the serial loop would also have computed; few messages -> up to 16,
+// so a round finds a point with probability 1 - 0.58^16 and the call is two launches deep instead of eight).  The lowest
+// successful counter of the group wins (ballot), its lane stores the curve point BEFORE the cofactor; a group without success
+// appends its message to the next round's list.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_hash_candidates(HashDom dom, HashIn in, const uint32_t* __restrict__ list, uint32_t count, uint32_t cand_log, uint32_t base,
+                  uint64_t* __restrict__ cand_xy, uint8_t* __restrict__ attempts, uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count,
+                  WireConsts k) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = t >> cand_log, s = t & ((1u << cand_log) - 1);
+  const bool live = j < count;
+  const uint32_t i = live ? (list ? list[j] : j) : 0;
+  const uint32_t c = base + s;
+  bool ok = false;
+  Affine<Fq> p = {Fq::zero(), Fq::zero()};
+  if (live && c < 255) {
+    const uint8_t* msg = in.msgs + in.msg_off[i];
+    const size_t mlen = (size_t)(in.msg_off[i + 1] - in.msg_off[i]);
+    const uint8_t* extra = in.extra_off ? in.extras + in.extra_off[i] : nullptr;
+    const size_t elen = in.extra_off ? (size_t)(in.extra_off[i + 1] - in.extra_off[i]) : 0;
+    ok = tai_candidate(dom.b, msg, mlen, extra, elen, (int)c, k, p);
+  }
+  const uint64_t mask = __ballot(ok);
+  const uint32_t lane = threadIdx.x & 63, g0 = lane & ~((1u << cand_log) - 1);
+  const uint64_t gm = (mask >> g0) & (cand_log == 6 ? ~0ull : ((1ull << (1u << cand_log)) - 1));
+  if (!live) return;
+  if (gm) {
+    const uint32_t win = (uint32_t)__builtin_ctzll(gm);
+    if (s == win) {
+      uint64_t* o = cand_xy + (size_t)i * 12;
+      p.x.to_ark(o);
+      p.y.to_ark(o + 6);
+      attempts[i] = (uint8_t)c;
+    }
+  } else if (s == 0) {
+    if (base + (1u << cand_log) >= 255) attempts[i] = 255;                // every counter tried: the reference errs
+    else next_list[atomicAdd(next_count, 1u)] = i;
+  }
+}
+// scale_by_cofactor + normalisation of the winning candidates, one message per lane (uniform: a 124-step ladder and one
+// inversion).  A multiple that is the identity (probability ~2^-125 per message) is flagged for the host's serial loop.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_hash_finish(const uint64_t* __restrict__ cand_xy, const uint8_t* __restrict__ attempts, uint64_t* __restrict__ out, uint8_t* __restrict__ redo, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t* o = out + (size_t)i * 12;
+  redo[i] = 0;
+  if (attempts[i] == 255) { for (int j = 0; j < 12; j++) o[j] = 0; return; }
+  const uint64_t* ci = cand_xy + (size_t)i * 12;
+  const Affine<Fq> p = {Fq::norm(Fq::from_ark(ci)), Fq::norm(Fq::from_ark(ci + 6))};
+  Affine<Fq> r = {Fq::zero(), Fq::zero()};
+  if (tai_finish(p, r)) { r.x.to_ark(o); r.y.to_ark(o + 6); }
+  else { redo[i] = 1; for (int j = 0; j < 12; j++) o[j] = 0; }
+}
+
+static float g_hash_ms = 0.f;
+static int g_hash_rounds = 0;
+
+#define HASH_TRY(x)                                                                                  \
+  do {                                                                                               \
+    hipError_t e_ = (x);                                                                             \
+    if (e_ != hipSuccess) { fprintf(stderr, "[celo-amd] %s: %s\n", #x, hipGetErrorString(e_)); rc = 10; goto done; } \
+  } while (0)
+
+int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* extras, const uint64_t* extra_off,
+                          size_t n, uint64_t* out_xy, uint8_t* attempts) {
+  std::lock_guard<std::mutex> lk(api_mutex());
+  if (int rc0 = api_ensure_init()) return rc0;
+  if (n == 0) return 0;
+  if (!domain || !msg_off || !out_xy || !attempts || n > 0x3fffffffu) return 2;
+  for (size_t i = 0; i < n; i++) {
+    if (msg_off[i + 1] < msg_off[i] || (extra_off && extra_off[i + 1] < extra_off[i])) return 2;
+  }
+  const size_t mb = msg_off[n], eb = extra_off ? extra_off[n] : 0;
+  if ((mb && !msgs) || (eb && !extras)) return 2;
+  const WireConsts& k = wire_consts();
+  HashDom dom;
+  memcpy(dom.b, domain, 8);
+  uint8_t *d_bytes = nullptr, *d_att = nullptr, *d_redo = nullptr;
+  uint64_t *d_off = nullptr, *d_out = nullptr, *d_cand = nullptr;
+  uint32_t *d_list = nullptr, *d_cnt = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::vector<uint8_t> redo(n);
+  int rc = 0;
+  {
+    HASH_TRY(hipMalloc(&d_bytes, mb + eb + 8));
+    HASH_TRY(hipMalloc(&d_off, (n + 1) * 2 * 8));
+    HASH_TRY(hipMalloc(&d_out, n * 12 * 8));
+    HASH_TRY(hipMalloc(&d_cand, n * 12 * 8));
+    HASH_TRY(hipMalloc(&d_att, n));
+    HASH_TRY(hipMalloc(&d_redo, n));
+    HASH_TRY(hipMalloc(&d_list, 2 * n * 4));
+    HASH_TRY(hipMalloc(&d_cnt, 256 * 4));
+    if (mb) HASH_TRY(hipMemcpyAsync(d_bytes, msgs, mb, hipMemcpyHostToDevice, 0));
+    if (eb) HASH_TRY(hipMemcpyAsync(d_bytes + mb, extras, eb, hipMemcpyHostToDevice, 0));
+    HASH_TRY(hipMemcpyAsync(d_off, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, 0));
+    if (extra_off) HASH_TRY(hipMemcpyAsync(d_off + n + 1, extra_off, (n + 1) * 8, hipMemcpyHostToDevice, 0));
+    HASH_TRY(hipMemsetAsync(d_cnt, 0, 256 * 4, 0));
+    HASH_TRY(hipEventCreate(&e0));
+    HASH_TRY(hipEventCreate(&e1));
+    HASH_TRY(hipEventRecord(e0, 0));
+    const HashIn in = {d_bytes, d_off, d_bytes + mb, extra_off ? d_off + n + 1 : nullptr};
+    uint32_t count = (uint32_t)n, base = 0;
+    int round = 0;
+    while (count && base < 255) {
+      uint32_t cand_log = 0;
+      while (cand_log < 4 && ((size_t)count << (cand_log + 1)) <= (1u << 17)) cand_log++;     // fill ~2^17 lanes, at most 16 counters
+      const uint32_t* list = round ? d_list + (size_t)(round & 1) * n : nullptr;
+      uint32_t* next = d_list + (size_t)((round + 1) & 1) * n;
+      const size_t lanes = (size_t)count << cand_log;
+      hipLaunchKernelGGL(k_hash_candidates, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, 0, dom, in, list, count, cand_log, base, d_cand, d_att,
+                         next, d_cnt + round, k);
+      HASH_TRY(hipGetLastError());
+      HASH_TRY(hipMemcpyAsync(&count, d_cnt + round, 4, hipMemcpyDeviceToHost, 0));
+      HASH_TRY(hipStreamSynchronize(0));
+      base += 1u << cand_log;
+      round++;
+    }
+    g_hash_rounds = round;
+    hipLaunchKernelGGL(k_hash_finish, dim3(((uint32_t)n + 63) / 64), dim3(64), 0, 0, d_cand, d_att, d_out, d_redo, (uint32_t)n);
+    HASH_TRY(hipGetLastError());
+    HASH_TRY(hipEventRecord(e1, 0));
+    HASH_TRY(hipMemcpyAsync(out_xy, d_out, n * 12 * 8, hipMemcpyDeviceToHost, 0));
+    HASH_TRY(hipMemcpyAsync(attempts, d_att, n, hipMemcpyDeviceToHost, 0));
+    HASH_TRY(hipMemcpyAsync(redo.data(), d_redo, n, hipMemcpyDeviceToHost, 0));
+    HASH_TRY(hipStreamSynchronize(0));
+    HASH_TRY(hipEventElapsedTime(&g_hash_ms, e0, e1));
+    // the counter whose cofactor multiple was the identity is skipped like the reference's loop does: continue serially after it
+    for (size_t i = 0; i < n; i++) {
+      if (!redo[i]) continue;
+      Affine<Fq> p = {Fq::zero(), Fq::zero()};
+      int c = 255;
+      uint64_t* o = out_xy + i * 12;
+      if (hash_to_g1_direct_tai(domain, msgs + msg_off[i], msg_off[i + 1] - msg_off[i], extra_off ? extras + extra_off[i] : nullptr,
+                                extra_off ? extra_off[i + 1] - extra_off[i] : 0, k, p, c, attempts[i] + 1)) { p.x.to_ark(o); p.y.to_ark(o + 6); attempts[i] = (uint8_t)c; }
+      else { attempts[i] = 255; memset(o, 0, 96); }
+    }
+  }
+done:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  for (void* q : {(void*)d_bytes, (void*)d_off, (void*)d_out, (void*)d_cand, (void*)d_att, (void*)d_redo, (void*)d_list, (void*)d_cnt})
+    if (q) (void)hipFree(q);
+  return rc;
+}
+float hash_last_ms() { return g_hash_ms; }
+int hash_last_rounds() { return g_hash_rounds; }
+}  // namespace celo

@@ -251,3 +251,32 @@ def decompress_last_ms():
     ms = C.c_float(0)
     assert lib().celo_amd_decompress_last_ms(C.byref(ms)) == 0
     return ms.value
+
+
+def hash_to_g1_direct(domain, messages, extras=None):
+    """Batched try-and-increment hash-to-G1 over the direct hasher (include/celo_bls_amd.h: hash_to_g1_direct_bls12_377).
+    domain: 8 bytes; messages / extras: lists of bytes (extras None = no extra data).  Returns (xy (n, 12) uint64 affine
+    arkworks Montgomery limbs, attempts (n,) uint8; 255 = no point)."""
+    n = len(messages)
+    assert len(domain) == 8 and (extras is None or len(extras) == n)
+
+    def pack(items):
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(b) for b in items], dtype=np.uint64) if n else []
+        data = np.frombuffer(b"".join(items) or b"\0", dtype=np.uint8)
+        return data, off
+    mdat, moff = pack(messages)
+    edat, eoff = pack(extras) if extras is not None else (None, None)
+    dom = np.frombuffer(bytes(domain), dtype=np.uint8)
+    xy = np.zeros((n, 12), dtype=np.uint64)
+    att = np.zeros(n, dtype=np.uint8)
+    rc = lib().hash_to_g1_direct_bls12_377(_p(dom), _p(mdat), _p(moff), _p(edat), _p(eoff), C.c_size_t(n), _p(xy), _p(att))
+    if rc != 0:
+        raise RuntimeError("hash_to_g1_direct_bls12_377 failed with code %d" % rc)
+    return xy, att
+
+
+def hash_last_ms():
+    ms = C.c_float(0)
+    assert lib().celo_amd_hash_last_ms(C.byref(ms)) == 0
+    return ms.value

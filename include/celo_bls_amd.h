@@ -114,6 +114,20 @@ int decompress_bls12_377_g2_dev(const uint8_t* d_in, size_t n, int check_subgrou
 /* kernel time (HIP events) of the last decompress call */
 int celo_amd_decompress_last_ms(float* ms);
 
+/* ---- batched hash-to-G1, DIRECT hasher: n messages per launch, one per GPU lane.
+ * Replaces n calls of TryAndIncrement<DirectHasher, G1>::hash_with_attempt(domain, message, extra_data)
+ * (crates/bls-crypto/src/hash_to_curve/try_and_increment.rs:87-139; DirectHasher = Blake2s CRH + Blake2Xs XOF,
+ * crates/bls-crypto/src/hashers/direct.rs:23-80) as Signature::batch_verify issues them (bls/signature.rs:111-114), with the
+ * deployed `compat` bit logic.  domain: the 8-byte personalisation (SIG_DOMAIN "ULforxof" / POP_DOMAIN "ULforpop",
+ * crates/bls-crypto/src/lib.rs:75,78).  msgs / extras: concatenated bytes, message i = msgs[msg_off[i] .. msg_off[i+1]),
+ * likewise extras (extra_off == NULL: no extra data anywhere).  out_xy: n x 12 u64, affine (x, y) in arkworks Montgomery
+ * limbs (the G1 layout of the MSM / pairing entry points); attempts[i]: the counter that produced the point, 255 = no
+ * counter below 255 did (the reference returns an error there; out row zero). */
+int hash_to_g1_direct_bls12_377(const uint8_t domain[8], const uint8_t* msgs, const uint64_t* msg_off /* n+1 */, const uint8_t* extras,
+                                const uint64_t* extra_off /* n+1 or NULL */, size_t n, uint64_t* out_xy /* n x 12 */, uint8_t* attempts /* n */);
+/* kernel time (HIP events) of the last hash_to_g1_direct_bls12_377 call */
+int celo_amd_hash_last_ms(float* ms);
+
 /* ---- plain sums of k Jacobian points (host pointers, arkworks layout; host-side, for small k): the fold of per-GPU
  * partial MSM results and small aggregates — Signature::aggregate / PublicKey::aggregate
  * (crates/bls-crypto/src/bls/signature.rs:61-67, public.rs:38-44). */

@@ -223,3 +223,19 @@ def test_wire_fq2_sqrt_special_branches(ht):
         else:
             assert f2.mul(r, r) == (a[0] % p, a[1] % p)
     assert nonsq > 0
+
+
+def test_hash_to_g1_direct_under_bounds_tracking(ht):
+    """hash_direct.h (what k_hash_to_g1_direct runs per lane) on the host with bounds asserted, against the oracle's
+    TryAndIncrement<DirectHasher, G1>::hash_with_attempt: same point, same attempt counter; message lengths on both sides of
+    the 64-byte Blake2s block."""
+    from oracle.py import hashing as hs
+    rng = np.random.default_rng(3)
+    for mlen, elen in [(0, 0), (5, 0), (31, 2), (62, 1), (63, 0), (64, 0), (100, 27), (127, 0), (128, 64)]:
+        msg = bytes(rng.integers(0, 256, size=mlen, dtype=np.uint8))
+        extra = bytes(rng.integers(0, 256, size=elen, dtype=np.uint8))
+        for dom in (b"ULforxof", b"ULforpop"):
+            out = np.zeros(12, dtype=np.uint64)
+            c = ht.ht_hash_to_g1_direct(dom, msg, C.c_size_t(mlen), extra, C.c_size_t(elen), _p(out))
+            P, wc = hs.hash_to_g1(dom, msg, extra, composite=False)
+            assert c == wc and co.from_mont(out.reshape(2, 6), ecc.Q377) == [P[0], P[1]]

@@ -164,6 +164,7 @@ def main():
         if world == 1 and not args.no_pairing:
             line["pairing"] = pairing_leg(ffi, codec, check_oracle=not args.no_cpu_baseline)
             line["ntt"] = ntt_leg(ffi, check_oracle=not args.no_cpu_baseline)
+            line["wire"] = wire_leg(ffi, check_oracle=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -274,6 +275,50 @@ def ntt_leg(ffi, check_oracle=True):
         if not ok:
             raise SystemExit("PARITY FAILURE: GPU NTT != oracle NTT")
         res.update({"cpu_port_elements_per_s_1core": m / cpu_secs, "parity_2p16_vs_oracle": ok})
+    return res
+
+
+def wire_leg(ffi, check_oracle=True):
+    """Fourth leg (either side of the path): 2^16 compressed G2 keys decoded with the
+    subgroup check (decompress_bls12_377_g2_dev, bytes resident in HBM) and 2^16 32-byte messages hashed to G1 with the direct
+    hasher (hash_to_g1_direct_bls12_377).  Integer-VALU work; algorithmic bytes 96 B in + 192 B out per key, 34 B in + 96 B out
+    per hash."""
+    from oracle import cpu_oracle as co
+    from oracle.py import ecc
+    n = 1 << 16
+    P, enc = ecc.G2_377, []
+    for i in range(64):
+        P = ecc.E2_377.add(ecc.E2_377.add(P, P), ecc.G2_377)
+        enc.append(ecc.ser_point(ecc.E2_377, P if i % 2 else ecc.E2_377.neg(P)))
+    host = np.tile(np.frombuffer(b"".join(enc), dtype=np.uint8), n // 64)
+    d_in = torch.from_numpy(host.copy()).cuda()
+    d_out = torch.zeros((n, 24), dtype=torch.int64, device="cuda")
+    d_st = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    best = None
+    for _ in range(3):
+        ffi.decompress_dev("g2", d_in.data_ptr(), n, d_out.data_ptr(), d_st.data_ptr(), True)
+        ms = ffi.decompress_last_ms()
+        best = ms if best is None or ms < best else best
+    if d_st.any().item():
+        raise SystemExit("PARITY FAILURE: a valid G2 encoding was rejected")
+    res = {"decompress_g2_checked_points_per_s": n / (best * 1e-3), "decompress_ms": best, "decompress_alg_GBps": n * 288 / (best * 1e-3) / 1e9}
+    raw = np.random.default_rng(0x5EED0007).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    msgs = [raw[i].tobytes() for i in range(n)]
+    best = None
+    for _ in range(3):
+        xy, att = ffi.hash_to_g1_direct(b"ULforxof", msgs, [b"\x01\x02"] * n)
+        ms = ffi.hash_last_ms()
+        best = ms if best is None or ms < best else best
+    res.update({"hash_to_g1_direct_hashes_per_s": n / (best * 1e-3), "hash_ms": best, "hash_mean_attempts": float(att.mean()) + 1.0})
+    if check_oracle:
+        m = 128                                           # parity + CPU rate on a sample
+        T = co.lib().orc_hardware_threads()
+        secs = co.time_decompress("g2", host[: m * 96].tobytes(), True, 1)
+        wxy, wst = co.decompress("g2", host[: m * 96].tobytes(), True, min(T, 8))
+        ok = np.array_equal(d_out[:m].cpu().numpy().view(np.uint64), wxy) and not wst.any()
+        if not ok:
+            raise SystemExit("PARITY FAILURE: GPU decompression != oracle")
+        res.update({"cpu_port_decompress_points_per_s_1core": m / secs, "decompress_parity_vs_oracle": ok})
     return res
 
 

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <vector>
 #include "curve.h"
+#include "host64.h"
 #include "curve_lanes.h"
 #include "fp2.h"
 
@@ -399,6 +400,7 @@ struct BitsumJobs {
   uint32_t src[MAXJ];    // point index into the work area (modes 0, 1, 4); unused for the leaf modes
   uint32_t dst[MAXJ];    // point index into the work area
   uint32_t mode[MAXJ];   // 0: in[2i] + in[2i+1]   1: in[4i+1] + in[4i+3]   2, 3: the same on the buckets themselves   4: in[2i+1]
+  uint32_t res_pts;      // outputs below this point index are final (read by the host): stored as arkworks limbs (host64.h)
 };
 template <class G>
 __global__ void __launch_bounds__(128) k_bitsum(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
@@ -426,7 +428,13 @@ __global__ void __launch_bounds__(128) k_bitsum(const uint32_t* __restrict__ par
     if (mode != 4) b = IO::load_xyzz(in + (ia + (mode == 0 ? 1 : 2)) * IO::XYZZ_WORDS);
   }
   if (mode != 4) xyzz_add(a, b);     // inlined for every field: each launch is one addition deep, its latency is the cost
-  IO::store_xyzz(work + ((size_t)jobs.dst[j] + i) * IO::XYZZ_WORDS, a);
+  uint32_t* out = work + ((size_t)jobs.dst[j] + i) * IO::XYZZ_WORDS;
+  if (jobs.dst[j] < jobs.res_pts) {
+    uint64_t* o = reinterpret_cast<uint64_t*>(out);
+    const bool id = a.is_identity();
+    a.X.to_ark(o); a.Y.to_ark(o + IO::ARK64); a.ZZ.to_ark(o + 2 * IO::ARK64); a.ZZZ.to_ark(o + 3 * IO::ARK64);
+    if (id) for (int q = 0; q < IO::ARK64; q++) o[2 * IO::ARK64 + q] = 0;   // ZZ == 0 exactly marks the identity
+  } else IO::store_xyzz(out, a);
 }
 
 // =====================================================================================================================
@@ -734,6 +742,7 @@ template <class G> class MsmEngine {
       for (int t = 1; t <= LB; t++) {
         BitsumJobs jobs;
         jobs.njobs = 0;
+        jobs.res_pts = res_pts;
         uint32_t cursor = half_at[t & 1], total_out = 0;
         auto push = [&](uint32_t src, uint32_t outs_per_window, uint32_t mode, int result_slot) -> uint32_t {
           const uint32_t outs = outs_per_window * (uint32_t)nw;
@@ -780,19 +789,24 @@ template <class G> class MsmEngine {
     (void)hipEventElapsedTime(&tm.reduce, ev[3], ev[4]);
     (void)hipEventElapsedTime(&tm.total, ev[0], ev[5]);
     last_c = c; last_nw = nw; last_buckets = total;
-    // ---- host epilogue: total = sum_w 2^(c w) (node_w + sum_l 2^(LB-l) O_{w,l}): one Horner pass, c doublings and c additions per window
-    Xyzz<F> total_pt = Xyzz<F>::identity();
+    // ---- host epilogue: total = sum_w 2^(c w) (node_w + sum_l 2^(LB-l) O_{w,l}): one Horner pass, c doublings and c additions per
+    // window, on 64-bit limbs (host64.h; the results arrive as arkworks limbs)
+    typedef typename HostField<F>::type HF;
+    const uint64_t* h64 = reinterpret_cast<const uint64_t*>(h_out);
+    constexpr size_t PT64 = (size_t)IO::XYZZ_WORDS / 2;
+    HXyzz<HF> total_pt = HXyzz<HF>::identity();
     for (int w = nw - 1; w >= 0; w--) {
-      total_pt = xyzz_dbl(total_pt);
+      total_pt = hxyzz_dbl(total_pt);
       for (int l = 1; l <= LB; l++) {
-        Xyzz<F> v = IO::load_xyzz(h_out + ((size_t)l * nw + w) * IO::XYZZ_WORDS);
-        total_pt = xyzz_dbl(total_pt);
-        xyzz_add(total_pt, v);
+        total_pt = hxyzz_dbl(total_pt);
+        hxyzz_add(total_pt, HXyzz<HF>::load(h64 + ((size_t)l * nw + w) * PT64, IO::ARK64));
       }
-      Xyzz<F> v = IO::load_xyzz(h_out + (size_t)w * IO::XYZZ_WORDS);
-      xyzz_add(total_pt, v);
+      hxyzz_add(total_pt, HXyzz<HF>::load(h64 + (size_t)w * PT64, IO::ARK64));
     }
-    write_jacobian(total_pt, out_jac);
+    if (total_pt.is_identity()) { write_identity(out_jac); return 0; }
+    (total_pt.X * total_pt.ZZ).store(out_jac);                 // (X ZZ, Y ZZZ, ZZ) is a Jacobian representative with Z = ZZ
+    (total_pt.Y * total_pt.ZZZ).store(out_jac + IO::ARK64);
+    total_pt.ZZ.store(out_jac + 2 * IO::ARK64);
     return 0;
   }
 

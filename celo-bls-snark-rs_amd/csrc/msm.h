@@ -400,7 +400,6 @@ struct BitsumJobs {
   uint32_t src[MAXJ];    // point index into the work area (modes 0, 1, 4); unused for the leaf modes
   uint32_t dst[MAXJ];    // point index into the work area
   uint32_t mode[MAXJ];   // 0: in[2i] + in[2i+1]   1: in[4i+1] + in[4i+3]   2, 3: the same on the buckets themselves   4: in[2i+1]
-  uint32_t res_pts;      // outputs below this point index are final (read by the host): stored as arkworks limbs (host64.h)
 };
 template <class G>
 __global__ void __launch_bounds__(128) k_bitsum(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
@@ -428,13 +427,22 @@ __global__ void __launch_bounds__(128) k_bitsum(const uint32_t* __restrict__ par
     if (mode != 4) b = IO::load_xyzz(in + (ia + (mode == 0 ? 1 : 2)) * IO::XYZZ_WORDS);
   }
   if (mode != 4) xyzz_add(a, b);     // inlined for every field: each launch is one addition deep, its latency is the cost
-  uint32_t* out = work + ((size_t)jobs.dst[j] + i) * IO::XYZZ_WORDS;
-  if (jobs.dst[j] < jobs.res_pts) {
-    uint64_t* o = reinterpret_cast<uint64_t*>(out);
-    const bool id = a.is_identity();
-    a.X.to_ark(o); a.Y.to_ark(o + IO::ARK64); a.ZZ.to_ark(o + 2 * IO::ARK64); a.ZZZ.to_ark(o + 3 * IO::ARK64);
-    if (id) for (int q = 0; q < IO::ARK64; q++) o[2 * IO::ARK64 + q] = 0;   // ZZ == 0 exactly marks the identity
-  } else IO::store_xyzz(out, a);
+  IO::store_xyzz(work + ((size_t)jobs.dst[j] + i) * IO::XYZZ_WORDS, a);
+}
+// the final results (node(0,0) and the O_l of every window), in place: device form -> arkworks limbs for the host's 64-bit
+// Horner pass (host64.h).  Its own tiny launch: inside k_bitsum the conversion doubled the register count of every level.
+template <class G>
+__global__ void __launch_bounds__(64) k_results_to_ark(uint32_t* __restrict__ work, uint32_t res_pts) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= res_pts) return;
+  uint32_t* slot = work + (size_t)t * IO::XYZZ_WORDS;
+  const Xyzz<F> a = IO::load_xyzz(slot);
+  uint64_t* o = reinterpret_cast<uint64_t*>(slot);
+  const bool id = a.is_identity();
+  a.X.to_ark(o); a.Y.to_ark(o + IO::ARK64); a.ZZ.to_ark(o + 2 * IO::ARK64); a.ZZZ.to_ark(o + 3 * IO::ARK64);
+  if (id) for (int q = 0; q < IO::ARK64; q++) o[2 * IO::ARK64 + q] = 0;   // ZZ == 0 exactly marks the identity
 }
 
 // =====================================================================================================================
@@ -742,7 +750,6 @@ template <class G> class MsmEngine {
       for (int t = 1; t <= LB; t++) {
         BitsumJobs jobs;
         jobs.njobs = 0;
-        jobs.res_pts = res_pts;
         uint32_t cursor = half_at[t & 1], total_out = 0;
         auto push = [&](uint32_t src, uint32_t outs_per_window, uint32_t mode, int result_slot) -> uint32_t {
           const uint32_t outs = outs_per_window * (uint32_t)nw;
@@ -777,6 +784,7 @@ template <class G> class MsmEngine {
         hipLaunchKernelGGL((k_bitsum<G>), dim3((total_out + 127) / 128), dim3(128), 0, stream, d_partials, d_counts, d_pfirst, d_piecesof, SEG,
                            d_work, jobs);
       }
+      hipLaunchKernelGGL((k_results_to_ark<G>), dim3((res_pts + 63) / 64), dim3(64), 0, stream, d_work, res_pts);
     }
     HIP_OK(hipEventRecord(ev[4], stream));
     HIP_OK(hipMemcpyAsync(h_out, d_work, (size_t)res_pts * IO::XYZZ_WORDS * 4, hipMemcpyDeviceToHost, stream));

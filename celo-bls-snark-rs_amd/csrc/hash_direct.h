@@ -106,6 +106,26 @@ template <class Src> HD void b2s_stream(uint32_t h[8], const Src& src) {
 
 HD uint64_t b2x_node_offset(uint64_t i, uint32_t xof_len) { return i | ((uint64_t)(xof_len & 0xFFFF) << 32); }
 
+// the first 48 XOF bytes (twelve little-endian words) -> the curve point they select, before the cofactor: the `compat` flag
+// logic of hash_to_curve/mod.rs:146-158 and get_point_from_x.  Shared by every hasher (Seam A's composite path calls it on
+// the host, so the reference's compat hash-to-G1 vectors pin it).  false: not a field element, the flagged zero, or no y.
+HD bool tai_point_from_xof(const uint32_t w12[12], const WireConsts& k, Affine<Fq>& p) {
+  uint32_t b47 = w12[11] >> 24;                                          // byte 47
+  if (b47 & 2) b47 |= 0x80; else b47 &= 0x7F;                            // `compat`: the y-sign flag is taken from bit 377
+  const uint32_t flags = b47 & 0xC0;
+  b47 &= 0x01;                                                           // bits below MODULUS_BITS = 377
+  uint64_t w[6];
+  for (int i = 0; i < 5; i++) w[i] = (uint64_t)w12[2 * i] | ((uint64_t)w12[2 * i + 1] << 32);
+  w[5] = (uint64_t)w12[10] | ((uint64_t)((w12[11] & 0x00FFFFFFu) | (b47 << 24)) << 32);
+  if (wire_cmp(w, P377::P64, 6) >= 0) return false;
+  const Fq x = Fq::from_canonical(w);
+  if (x.is_zero_mod_p() && (flags & 0x40)) return false;                 // the zero point scales to zero
+  Fq y;
+  if (!wire_fq_sqrt(Fq::norm(Fq::add(Fq::mul(Fq::sqr(x), x), Fq::one())), k, y)) return false;
+  if (wire_lex_largest(y) != ((flags & 0x80) != 0)) y = wire_neg(y);    // get_point_from_x(x, greatest)
+  p = {Fq::norm(x), Fq::norm(y)};
+  return true;
+}
 // one attempt: counter c -> the curve point (x, y) the candidate bytes select, before the cofactor; false when the
 // candidate is not a field element, is the flagged zero, or x^3 + 1 is not a square
 HD bool tai_candidate(const uint8_t dom[8], const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen, int c, const WireConsts& k,
@@ -118,23 +138,10 @@ HD bool tai_candidate(const uint8_t dom[8], const uint8_t* msg, size_t mlen, con
   b2s_compress(x0, m, 32, true);
   b2s_init(x1, 32, 0, 0, 32, b2x_node_offset(1, 64), 0, 32, dom);
   b2s_compress(x1, m, 32, true);
-  // bytes 0..47 of the XOF output: x0[0..7] || x1[0..3]; byte 47 = top byte of x1[3]
-  uint32_t b47 = x1[3] >> 24;
-  if (b47 & 2) b47 |= 0x80; else b47 &= 0x7F;                            // `compat`: the y-sign flag is taken from bit 377
-  const uint32_t flags = b47 & 0xC0;
-  b47 &= 0x01;                                                           // bits below MODULUS_BITS = 377
-  uint64_t w[6];
-  for (int i = 0; i < 4; i++) w[i] = (uint64_t)x0[2 * i] | ((uint64_t)x0[2 * i + 1] << 32);
-  w[4] = (uint64_t)x1[0] | ((uint64_t)x1[1] << 32);
-  w[5] = (uint64_t)x1[2] | ((uint64_t)((x1[3] & 0x00FFFFFFu) | (b47 << 24)) << 32);
-  if (wire_cmp(w, P377::P64, 6) >= 0) return false;
-  const Fq x = Fq::from_canonical(w);
-  if (x.is_zero_mod_p() && (flags & 0x40)) return false;                 // the zero point scales to zero
-  Fq y;
-  if (!wire_fq_sqrt(Fq::norm(Fq::add(Fq::mul(Fq::sqr(x), x), Fq::one())), k, y)) return false;
-  if (wire_lex_largest(y) != ((flags & 0x80) != 0)) y = wire_neg(y);    // get_point_from_x(x, greatest)
-  p = {Fq::norm(x), Fq::norm(y)};
-  return true;
+  uint32_t w12[12];
+  for (int i = 0; i < 8; i++) w12[i] = x0[i];
+  for (int i = 0; i < 4; i++) w12[8 + i] = x1[i];
+  return tai_point_from_xof(w12, k, p);
 }
 // scale_by_cofactor + affine normalisation; false when the multiple is the identity (the reference then tries the next counter)
 HD bool tai_finish(const Affine<Fq>& p, Affine<Fq>& out) {

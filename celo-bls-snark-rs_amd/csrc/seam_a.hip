@@ -30,6 +30,7 @@
 #include "curve.h"
 #include "fp2.h"
 #include "wire.h"
+#include "hash_direct.h"
 #include "../../include/celo_bls_amd.h"
 #include "../../include/celo_bls_snark_sys.h"
 
@@ -247,39 +248,11 @@ std::vector<uint8_t> direct_hash(const uint8_t* dom, size_t dlen, const uint8_t*
 }
 const uint8_t SIG_DOMAIN[8] = {'U', 'L', 'f', 'o', 'r', 'x', 'o', 'f'};  // crates/bls-crypto/src/lib.rs:75
 const uint8_t POP_DOMAIN[8] = {'U', 'L', 'f', 'o', 'r', 'p', 'o', 'p'};  // lib.rs:78
-const uint64_t G1_COFACTOR[2] = {0x0000000000000000ULL, 0x170b5d4430000000ULL};  // (x-1)^2/3
 
 // TryAndIncrement<DirectHasher, G1>::hash_with_attempt with the deployed `compat` bit logic
 // (crates/bls-crypto/src/hash_to_curve/try_and_increment.rs:87-139, mod.rs:146-158)
 bool hash_to_g1_direct(const uint8_t* dom, const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen, Affine<Fq_>& out, int& attempt) {
-  std::vector<uint8_t> buf(1 + elen + mlen);
-  if (elen) memcpy(buf.data() + 1, extra, elen);
-  if (mlen) memcpy(buf.data() + 1 + elen, msg, mlen);
-  for (int c = 0; c < 255; c++) {
-    buf[0] = (uint8_t)c;
-    std::vector<uint8_t> cand = direct_hash(dom, 8, buf.data(), buf.size(), 64);  // hash_length(48) = 64
-    cand.resize(48);
-    if (cand[47] & 2) cand[47] |= 0x80; else cand[47] &= 0x7F;
-    uint8_t flags = cand[47] & 0xC0;
-    cand[47] &= 0x01;  // bits below MODULUS_BITS = 377
-    Fq_ x;
-    if (!fq_from_bytes(cand.data(), x)) continue;
-    if (x.is_zero_mod_p() && (flags & 0x40)) continue;  // the zero point scales to zero
-    Fq_ rhs = Fq_::norm(Fq_::add(Fq_::mul(Fq_::sqr(x), x), Fq_::one())), y;
-    if (!fq_sqrt(rhs, y)) continue;
-    // get_point_from_x(x, greatest): greatest selects the lexicographically larger of {y, -y}
-    bool greatest = (flags & 0x80) != 0;
-    if (fq_lex_largest(y) != greatest) y = fq_neg(y);
-    Affine<Fq_> p = {Fq_::norm(x), Fq_::norm(y)};
-    Xyzz<Fq_> s = scalar_mul_host(p, G1_COFACTOR, 2);
-    if (s.is_identity() || s.ZZ.is_zero_mod_p()) continue;
-    Fq_ t = Fq_::inv(Fq_::mul(s.ZZ, s.ZZZ));
-    out.x = Fq_::norm(Fq_::mul(s.X, Fq_::mul(t, s.ZZZ)));
-    out.y = Fq_::norm(Fq_::mul(s.Y, Fq_::mul(t, s.ZZ)));
-    attempt = c;
-    return true;
-  }
-  return false;
+  return hash_to_g1_direct_tai(dom, msg, mlen, extra, elen, wire_consts(), out, attempt);   // hash_direct.h: the source the GPU kernels run
 }
 
 // ---------------------------------------------------------------- CompositeHasher (crates/bls-crypto/src/hashers/composite.rs)
@@ -434,22 +407,11 @@ bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* m
     std::vector<uint8_t> cand;
     if (cip22) cand = direct_xof(dom, 8, buf.data(), buf.size(), 64);
     else { if (!crh(buf.data(), buf.size(), pre)) return false; cand = direct_xof(dom, 8, pre.data(), pre.size(), 64); }
-    cand.resize(48);
-    if (cand[47] & 2) cand[47] |= 0x80; else cand[47] &= 0x7F;
-    uint8_t flags = cand[47] & 0xC0;
-    cand[47] &= 0x01;
-    Fq_ x;
-    if (!fq_from_bytes(cand.data(), x)) continue;
-    if (x.is_zero_mod_p() && (flags & 0x40)) continue;
-    Fq_ rhs = Fq_::norm(Fq_::add(Fq_::mul(Fq_::sqr(x), x), Fq_::one())), y;
-    if (!fq_sqrt(rhs, y)) continue;
-    if (fq_lex_largest(y) != ((flags & 0x80) != 0)) y = fq_neg(y);
-    Affine<Fq_> p = {Fq_::norm(x), Fq_::norm(y)};
-    Xyzz<Fq_> s = scalar_mul_host(p, G1_COFACTOR, 2);
-    if (s.is_identity() || s.ZZ.is_zero_mod_p()) continue;
-    Fq_ t = Fq_::inv(Fq_::mul(s.ZZ, s.ZZZ));
-    out.x = Fq_::norm(Fq_::mul(s.X, Fq_::mul(t, s.ZZZ)));
-    out.y = Fq_::norm(Fq_::mul(s.Y, Fq_::mul(t, s.ZZ)));
+    uint32_t w12[12];
+    memcpy(w12, cand.data(), 48);
+    Affine<Fq_> p = {Fq_::zero(), Fq_::zero()};
+    if (!tai_point_from_xof(w12, wire_consts(), p)) continue;            // hash_direct.h: compat flags, get_point_from_x
+    if (!tai_finish(p, out)) continue;                                   // scale_by_cofactor
     attempt = c;
     return true;
   }

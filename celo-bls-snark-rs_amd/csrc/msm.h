@@ -454,10 +454,22 @@ __global__ void __launch_bounds__(64) k_results_to_ark(uint32_t* __restrict__ wo
 //   k_size_* + k_accumulate (shared with the big path): every (instance, window, bucket) run is a work item, longest first
 //   k_batch_reduce    one lane per (instance, window): running sum over its <= 64 buckets
 //   k_batch_horner_lanes  three lanes per instance: Horner over the windows, Jacobian result in arkworks form
-template <int SW, int CB, int NW, int PT>
+// OR of every scalar, limb by limb: the batch path sizes its window count by the longest scalar actually present (Batch::verify
+// hands over 136-bit exponents in 253-bit containers: 28 windows of 5 bits instead of 51, and no idle lanes in the per-window
+// kernels)
+template <int SW>
+__global__ void __launch_bounds__(256) k_scalar_or(const uint32_t* __restrict__ scalars, size_t words, uint32_t* __restrict__ out) {
+  uint32_t acc = 0;                                   // thread t only ever sees limb position t % SW (the stride is a multiple of SW)
+  const size_t stride = (size_t)gridDim.x * blockDim.x / SW * SW;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= stride) return;
+  for (; i < words; i += stride) acc |= scalars[i];
+  if (acc) atomicOr(out + (blockIdx.x * blockDim.x + threadIdx.x) % SW, acc);
+}
+template <int SW, int CB, int PT>
 __global__ void __launch_bounds__(256) k_batch_sort(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
                                                     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted,
-                                                    uint32_t* __restrict__ pstart, uint32_t* __restrict__ plen) {
+                                                    uint32_t* __restrict__ pstart, uint32_t* __restrict__ plen, const int NW) {
   constexpr uint32_t B = 1u << (CB - 1);
   static_assert(B <= 64, "batch path supports window sizes up to 7 bits");
   __shared__ uint32_t cnt[B], cur[B];
@@ -841,6 +853,7 @@ template <class G> class MsmEngine {
   // through run_host one by one).  out: m Jacobian results (arkworks form).
   static constexpr uint32_t BATCH_MAX_N = 1024;
   MsmTimings tm_batch;
+  int batch_bits = 0;   // length of the longest scalar of the last batched call
   int run_batch_host(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m,
                      uint64_t* out, hipStream_t stream) {
     if (m == 0) return 0;
@@ -865,35 +878,61 @@ template <class G> class MsmEngine {
     if (!force_c) { while (c < 7 && (16u << c) <= max_n) c++; }
     if (c > 7) c = 7;
     if (c < 3) c = 3;
-    const int nw = (G::SCALAR_BITS + c) / c;
+    // stage the inputs at the front of the arena (sized for the full scalar length first), then let the scalars decide the
+    // number of windows: bits = length of the longest scalar present
+    const int nw_max = (G::SCALAR_BITS + c) / c;
     const uint32_t B = 1u << (c - 1);
-    const size_t nvw = m * (size_t)nw, nbuckets = nvw * B, entries = (size_t)total_pts * nw;
-    if (nbuckets >= (size_t(1) << 31) || entries >= (size_t(1) << 32)) return 2;
+    if (m * (size_t)nw_max * B >= (size_t(1) << 31) || (size_t)total_pts * nw_max >= (size_t(1) << 32)) return 2;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
     const size_t o_in_b = take((size_t)total_pts * 2 * IO::ARK64 * 8), o_in_s = take((size_t)total_pts * SW * 4), o_in_i = take(total_pts + 8);
-    const size_t o_off = take((m + 1) * 4);
-    const size_t o_bases = take((size_t)total_pts * IO::AFF_WORDS * 4), o_sorted = take(entries * 4 + 16);
-    const size_t o_pstart = take(nbuckets * 4), o_plen = take(nbuckets * 4), o_order = take(nbuckets * 4);
-    const size_t o_bins = take((size_t)SIZE_BINS * 4 + 256), o_partials = take(nbuckets * IO::XYZZ_WORDS * 4);
-    const size_t o_wsum = take(nvw * IO::XYZZ_WORDS * 4), o_out = take(m * 3 * IO::ARK64 * 8);
-    if (ensure(off)) return 1;
+    const size_t o_off = take((m + 1) * 4), o_or = take(64 * 4);
+    const size_t front = off;
+    auto rest = [&](int nw_, size_t* o) {     // the window-count dependent part of the arena; returns its end
+      size_t save = off;
+      off = front;
+      const size_t nvw_ = m * (size_t)nw_, nb = nvw_ * B, en = (size_t)total_pts * nw_;
+      o[0] = take((size_t)total_pts * IO::AFF_WORDS * 4); o[1] = take(en * 4 + 16);
+      o[2] = take(nb * 4); o[3] = take(nb * 4); o[4] = take(nb * 4);
+      o[5] = take((size_t)SIZE_BINS * 4 + 256); o[6] = take(nb * IO::XYZZ_WORDS * 4);
+      o[7] = take(nvw_ * IO::XYZZ_WORDS * 4); o[8] = take(m * 3 * IO::ARK64 * 8);
+      const size_t end = off;
+      off = save;
+      return end;
+    };
+    size_t o[9];
+    if (ensure(rest(nw_max, o))) return 1;     // sized for full-length scalars: the actual layout below can only be smaller
+    {
+      char* A0 = arena;
+      HIP_OK(hipMemcpyAsync(A0 + o_in_s, scalars, (size_t)total_pts * SW * 4, hipMemcpyHostToDevice, stream));
+      HIP_OK(hipMemsetAsync(A0 + o_or, 0, 64 * 4, stream));
+      hipLaunchKernelGGL((k_scalar_or<SW>), dim3(256), dim3(256), 0, stream, (const uint32_t*)(A0 + o_in_s), (size_t)total_pts * SW, (uint32_t*)(A0 + o_or));
+      uint32_t h_or[SW];
+      HIP_OK(hipMemcpyAsync(h_or, A0 + o_or, SW * 4, hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      int bits = 1;
+      for (int k = SW - 1; k >= 0; k--) if (h_or[k]) { bits = 32 * k + 32 - __builtin_clz(h_or[k]); break; }
+      if (bits > G::SCALAR_BITS) bits = G::SCALAR_BITS;
+      batch_bits = bits;
+    }
+    const int nw = (batch_bits + c) / c;
+    const size_t nvw = m * (size_t)nw, nbuckets = nvw * B;
+    (void)rest(nw, o);
     char* A = arena;
     uint64_t* d_in_b = (uint64_t*)(A + o_in_b); uint32_t* d_in_s = (uint32_t*)(A + o_in_s); uint8_t* d_in_i = (uint8_t*)(A + o_in_i);
     uint32_t* d_off = (uint32_t*)(A + o_off);
-    uint32_t* d_bases = (uint32_t*)(A + o_bases); uint32_t* d_sorted = (uint32_t*)(A + o_sorted);
-    uint32_t* d_pstart = (uint32_t*)(A + o_pstart); uint32_t* d_plen = (uint32_t*)(A + o_plen); uint32_t* d_order = (uint32_t*)(A + o_order);
-    uint32_t* d_bins = (uint32_t*)(A + o_bins); uint32_t* d_nwork = d_bins + SIZE_BINS;
-    uint32_t* d_partials = (uint32_t*)(A + o_partials); uint32_t* d_wsum = (uint32_t*)(A + o_wsum); uint64_t* d_out = (uint64_t*)(A + o_out);
+    uint32_t* d_bases = (uint32_t*)(A + o[0]); uint32_t* d_sorted = (uint32_t*)(A + o[1]);
+    uint32_t* d_pstart = (uint32_t*)(A + o[2]); uint32_t* d_plen = (uint32_t*)(A + o[3]); uint32_t* d_order = (uint32_t*)(A + o[4]);
+    uint32_t* d_bins = (uint32_t*)(A + o[5]); uint32_t* d_nwork = d_bins + SIZE_BINS;
+    uint32_t* d_partials = (uint32_t*)(A + o[6]); uint32_t* d_wsum = (uint32_t*)(A + o[7]); uint64_t* d_out = (uint64_t*)(A + o[8]);
     HIP_OK(hipMemcpyAsync(d_in_b, bases, (size_t)total_pts * 2 * IO::ARK64 * 8, hipMemcpyHostToDevice, stream));
-    HIP_OK(hipMemcpyAsync(d_in_s, scalars, (size_t)total_pts * SW * 4, hipMemcpyHostToDevice, stream));
     if (inf) HIP_OK(hipMemcpyAsync(d_in_i, inf, total_pts, hipMemcpyHostToDevice, stream));
     HIP_OK(hipMemcpyAsync(d_off, offsets, (m + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_OK(hipEventRecord(ev[0], stream));
     hipLaunchKernelGGL((k_convert_bases<G>), dim3((total_pts + 255) / 256), dim3(256), 0, stream, d_in_b, d_bases, (size_t)total_pts);
     HIP_OK(hipEventRecord(ev[1], stream));
     HIP_OK(hipMemsetAsync(d_bins, 0, (size_t)SIZE_BINS * 4 + 256, stream));
-    if (launch_batch_sort(c, max_n, d_in_s, inf ? d_in_i : nullptr, d_off, d_sorted, d_pstart, d_plen, (uint32_t)m, stream)) return 3;
+    if (launch_batch_sort(c, max_n, d_in_s, inf ? d_in_i : nullptr, d_off, d_sorted, d_pstart, d_plen, (uint32_t)m, nw, stream)) return 3;
     const uint32_t slots = (uint32_t)nbuckets;
     hipLaunchKernelGGL((k_size_hist<G>), dim3(slots / 256 < 2048 ? (slots + 255) / 256 : 2048), dim3(256), 0, stream, d_plen, d_bins, slots);
     hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
@@ -970,25 +1009,24 @@ template <class G> class MsmEngine {
   }
 
   template <int CB, int PT> int launch_batch_sort_cp(const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
-                                                     uint32_t* pstart, uint32_t* plen, uint32_t m, hipStream_t st) {
-    constexpr int NW = (G::SCALAR_BITS + CB) / CB;
-    hipLaunchKernelGGL((k_batch_sort<SW, CB, NW, PT>), dim3(m), dim3(256), 0, st, sc, inf, off, sorted, pstart, plen);
+                                                     uint32_t* pstart, uint32_t* plen, uint32_t m, int nw, hipStream_t st) {
+    hipLaunchKernelGGL((k_batch_sort<SW, CB, PT>), dim3(m), dim3(256), 0, st, sc, inf, off, sorted, pstart, plen, nw);
     return 0;
   }
   template <int CB> int launch_batch_sort_c(uint32_t max_n, const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
-                                            uint32_t* pstart, uint32_t* plen, uint32_t m, hipStream_t st) {
-    if (max_n <= 256) return launch_batch_sort_cp<CB, 1>(sc, inf, off, sorted, pstart, plen, m, st);
-    if (max_n <= 512) return launch_batch_sort_cp<CB, 2>(sc, inf, off, sorted, pstart, plen, m, st);
-    return launch_batch_sort_cp<CB, 4>(sc, inf, off, sorted, pstart, plen, m, st);
+                                            uint32_t* pstart, uint32_t* plen, uint32_t m, int nw, hipStream_t st) {
+    if (max_n <= 256) return launch_batch_sort_cp<CB, 1>(sc, inf, off, sorted, pstart, plen, m, nw, st);
+    if (max_n <= 512) return launch_batch_sort_cp<CB, 2>(sc, inf, off, sorted, pstart, plen, m, nw, st);
+    return launch_batch_sort_cp<CB, 4>(sc, inf, off, sorted, pstart, plen, m, nw, st);
   }
   int launch_batch_sort(int c, uint32_t max_n, const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
-                        uint32_t* pstart, uint32_t* plen, uint32_t m, hipStream_t st) {
+                        uint32_t* pstart, uint32_t* plen, uint32_t m, int nw, hipStream_t st) {
     switch (c) {
-      case 3: return launch_batch_sort_c<3>(max_n, sc, inf, off, sorted, pstart, plen, m, st);
-      case 4: return launch_batch_sort_c<4>(max_n, sc, inf, off, sorted, pstart, plen, m, st);
-      case 5: return launch_batch_sort_c<5>(max_n, sc, inf, off, sorted, pstart, plen, m, st);
-      case 6: return launch_batch_sort_c<6>(max_n, sc, inf, off, sorted, pstart, plen, m, st);
-      case 7: return launch_batch_sort_c<7>(max_n, sc, inf, off, sorted, pstart, plen, m, st);
+      case 3: return launch_batch_sort_c<3>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
+      case 4: return launch_batch_sort_c<4>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
+      case 5: return launch_batch_sort_c<5>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
+      case 6: return launch_batch_sort_c<6>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
+      case 7: return launch_batch_sort_c<7>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
       default: return 1;
     }
   }

@@ -317,6 +317,53 @@ def test_sign_verify_flow_on_gpu(sys_lib, gpu, composite, cip22):
     assert not sys_lib.batch_verify_strict(good, C.c_size_t(2), C.c_bool(False), C.c_bool(True), res2) and list(res2) == [False, False]
 
 
+@pytest.mark.gpu
+def test_batch_verify_signature_hashes_many_messages_on_the_gpu(sys_lib, gpu):
+    """From 256 messages up, batch_verify_signature / batch_verify_strict with the direct hasher hash all messages in one GPU
+    call (hash_direct.h) instead of on the host cores: 300 epochs of varying message length accept; one changed message byte,
+    one changed extra-data byte reject - the same verdicts as the per-message host path gives on the first 8."""
+    for f in ("sign_message", "batch_verify_signature", "batch_verify_strict"):
+        getattr(sys_lib, f).restype = C.c_bool
+    rng = ecc.SplitMix64(77)
+    CF, C22 = C.c_bool(False), C.c_bool(False)
+    sk = ecc.random_scalar(rng, ecc.R377)
+    skh = _deser(sys_lib, "deserialize_private_key", sk.to_bytes(32, "little"))
+    pkh = C.c_void_p()
+    assert sys_lib.private_key_to_public_key(skh, C.byref(pkh))
+    n = 300
+    msgs = [bytes([(7 * i + j) & 0xFF for j in range(1 + (i * 5) % 150)]) for i in range(n)]
+    extras = [bytes([i & 0xFF]) * (i % 3) for i in range(n)]
+    sigs = []
+    for m, e in zip(msgs, extras):
+        s = C.c_void_p()
+        assert sys_lib.sign_message(skh, m, C.c_int(len(m)), e, C.c_int(len(e)), CF, C22, C.byref(s))
+        sigs.append(s)
+
+    def run(ms, es, count):
+        arr = (_MessageFFI * count)(*[_MessageFFI(_Buffer(ms[i], len(ms[i])), _Buffer(es[i], len(es[i])), pkh.value, sigs[i].value) for i in range(count)])
+        ok = C.c_bool(False)
+        assert sys_lib.batch_verify_signature(arr, C.c_size_t(count), CF, C22, C.byref(ok))
+        return ok.value
+
+    assert run(msgs, extras, n) and run(msgs, extras, 8)
+    bad = list(msgs)
+    bad[257] = bad[257][:-1] + bytes([bad[257][-1] ^ 1])
+    assert not run(bad, extras, n)
+    bade = list(extras)
+    bade[5] = b"\x99"
+    assert not run(msgs, bade, n) and not run(msgs, bade, 8)
+    # strict batches: 256 one-signer batches, batch 100 signed over a different message
+    keys = (C.c_void_p * 1)(pkh.value)
+    holders, batches = [], []
+    for i in range(256):
+        sg = (C.c_void_p * 1)(sigs[i if i != 100 else 101].value)
+        holders.append(sg)
+        batches.append(_BatchMessageFFI(_Buffer(msgs[i], len(msgs[i])), _Buffer(extras[i], len(extras[i])), keys, 1, sg, 1))
+    res = (C.c_bool * 256)()
+    assert not sys_lib.batch_verify_strict((_BatchMessageFFI * 256)(*batches), C.c_size_t(256), CF, C22, res)
+    assert [i for i in range(256) if not res[i]] == [100]
+
+
 # ---------------------------------------------------------------- snark half of the FFI
 class _EpochBlockFFI(C.Structure):
     _fields_ = [("index", C.c_uint16), ("round", C.c_uint8), ("epoch_entropy", C.c_char_p), ("parent_entropy", C.c_char_p),

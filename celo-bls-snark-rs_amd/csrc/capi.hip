@@ -36,7 +36,7 @@ int ntt_run(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const ui
 int ntt_timings(float*, int*);
 int wire_decompress(int, const uint8_t*, size_t, int, uint64_t*, uint8_t*, int, void*);
 float wire_last_ms();
-int hash_to_g1_direct_run(const uint8_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*, uint8_t*);
+int hash_to_g1_direct_run(const uint8_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*, uint8_t*, int);
 float hash_last_ms();
 int pairing_run_761(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
 }  // namespace celo
@@ -179,7 +179,11 @@ int decompress_bls12_377_g2_dev(const uint8_t* d_in, size_t n, int check_subgrou
 }
 int hash_to_g1_direct_bls12_377(const uint8_t domain[8], const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* extras, const uint64_t* extra_off,
                                 size_t n, uint64_t* out_xy, uint8_t* attempts) {
-  return hash_to_g1_direct_run(domain, msgs, msg_off, extras, extra_off, n, out_xy, attempts);
+  return hash_to_g1_direct_run(domain, msgs, msg_off, extras, extra_off, n, out_xy, attempts, 0);
+}
+int hash_to_g1_cip22_tail_bls12_377(const uint8_t domain[8], const uint8_t* inner, const uint64_t* inner_off, const uint8_t* extras, const uint64_t* extra_off,
+                                    size_t n, uint64_t* out_xy, uint8_t* attempts) {
+  return hash_to_g1_direct_run(domain, inner, inner_off, extras, extra_off, n, out_xy, attempts, 1);
 }
 int celo_amd_hash_last_ms(float* ms) { if (!ms) return 2; *ms = hash_last_ms(); return 0; }
 int celo_amd_decompress_last_ms(float* ms) { if (!ms) return 2; *ms = wire_last_ms(); return 0; }

@@ -127,17 +127,29 @@ HD bool tai_point_from_xof(const uint32_t w12[12], const WireConsts& k, Affine<F
   return true;
 }
 // one attempt: counter c -> the curve point (x, y) the candidate bytes select, before the cofactor; false when the
-// candidate is not a field element, is the flagged zero, or x^3 + 1 is not a square
+// candidate is not a field element, is the flagged zero, or x^3 + 1 is not a square.
+// xof_only = false: TryAndIncrement<DirectHasher>: candidate = xof(crh(c || extra || message))
+// xof_only = true:  the CIP22 loop (try_and_increment_cip22.rs:81-134): `message` is the inner CRH computed once by the
+//                   caller (the composite hasher's 48 bytes), candidate = xof(c || extra || inner) - no CRH per attempt
 HD bool tai_candidate(const uint8_t dom[8], const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen, int c, const WireConsts& k,
-                      Affine<Fq>& p) {
-  uint32_t h[8], m[16], x0[8], x1[8];
-  b2s_init(h, 32, 1, 1, 0, b2x_node_offset(0, 64), 0, 0, dom);           // DirectHasher::crh with hash_length(48) = 64
-  b2s_stream(h, TaiBytes{(uint8_t)c, extra, elen, msg, mlen});
-  for (int i = 0; i < 8; i++) { m[i] = h[i]; m[i + 8] = 0; }
-  b2s_init(x0, 32, 0, 0, 32, b2x_node_offset(0, 64), 0, 32, dom);        // DirectHasher::xof, blocks 0 and 1
-  b2s_compress(x0, m, 32, true);
-  b2s_init(x1, 32, 0, 0, 32, b2x_node_offset(1, 64), 0, 32, dom);
-  b2s_compress(x1, m, 32, true);
+                      Affine<Fq>& p, bool xof_only = false) {
+  uint32_t x0[8], x1[8];
+  const TaiBytes src = {(uint8_t)c, extra, elen, msg, mlen};
+  if (xof_only) {
+    b2s_init(x0, 32, 0, 0, 32, b2x_node_offset(0, 64), 0, 32, dom);
+    b2s_stream(x0, src);
+    b2s_init(x1, 32, 0, 0, 32, b2x_node_offset(1, 64), 0, 32, dom);
+    b2s_stream(x1, src);
+  } else {
+    uint32_t h[8], m[16];
+    b2s_init(h, 32, 1, 1, 0, b2x_node_offset(0, 64), 0, 0, dom);           // DirectHasher::crh with hash_length(48) = 64
+    b2s_stream(h, src);
+    for (int i = 0; i < 8; i++) { m[i] = h[i]; m[i + 8] = 0; }
+    b2s_init(x0, 32, 0, 0, 32, b2x_node_offset(0, 64), 0, 32, dom);        // DirectHasher::xof, blocks 0 and 1
+    b2s_compress(x0, m, 32, true);
+    b2s_init(x1, 32, 0, 0, 32, b2x_node_offset(1, 64), 0, 32, dom);
+    b2s_compress(x1, m, 32, true);
+  }
   uint32_t w12[12];
   for (int i = 0; i < 8; i++) w12[i] = x0[i];
   for (int i = 0; i < 4; i++) w12[8 + i] = x1[i];
@@ -160,10 +172,10 @@ HD bool tai_finish(const Affine<Fq>& p, Affine<Fq>& out) {
 // the serial loop (host single hashes, and the GPU path's fallback from counter c_start): -> affine point of the prime-order
 // subgroup and the attempt counter; false when no counter below 255 succeeds (the reference errs there)
 HD bool hash_to_g1_direct_tai(const uint8_t dom[8], const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen, const WireConsts& k,
-                              Affine<Fq>& out, int& attempt, int c_start = 0) {
+                              Affine<Fq>& out, int& attempt, int c_start = 0, bool xof_only = false) {
   for (int c = c_start; c < 255; c++) {
     Affine<Fq> p = {Fq::zero(), Fq::zero()};
-    if (!tai_candidate(dom, msg, mlen, extra, elen, c, k, p)) continue;
+    if (!tai_candidate(dom, msg, mlen, extra, elen, c, k, p, xof_only)) continue;
     if (!tai_finish(p, out)) continue;
     attempt = c;
     return true;

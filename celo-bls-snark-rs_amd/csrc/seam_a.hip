@@ -423,19 +423,44 @@ bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* m
 struct HashJob { const uint8_t* msg; size_t mlen; const uint8_t* extra; size_t elen; uint64_t* out_xy; };
 bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJob>& jobs) {
   (void)wire_consts();
-  // direct hasher, many messages: one GPU launch (hash_direct.h, a message per lane; ~5 ms for one wave of 64, so the host
-  // cores keep the small calls).  The composite hasher's Pedersen CRH stays on the host.
-  if (!composite && jobs.size() >= 256) {
+  // many messages: the try-and-increment loops run on the GPU (hash_direct.h; a lone wave of 64 needs ~4 ms, so the host
+  // cores keep the small calls) - the whole hash for the direct hasher, everything after the inner Pedersen CRH for the
+  // composite hasher with CIP22 (the CRHs stay on the host cores).  Composite without CIP22 re-hashes per attempt: host.
+  if ((!composite || cip22) && jobs.size() >= 256) {
     const size_t n = jobs.size();
+    std::vector<std::vector<uint8_t>> inner;
+    if (composite) {
+      (void)composite_params();
+      inner.resize(n);
+      std::atomic<size_t> nexti(0);
+      std::atomic<bool> okc(true);
+      unsigned nt = std::thread::hardware_concurrency();
+      if (nt == 0) nt = 1;
+      if (nt > 64) nt = 64;
+      auto crh_work = [&]() {
+        for (;;) {
+          const size_t i = nexti.fetch_add(1);
+          if (i >= n) break;
+          if (!composite_crh(jobs[i].msg, jobs[i].mlen, inner[i])) okc = false;
+        }
+      };
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; t++) th.emplace_back(crh_work);
+      for (auto& t : th) t.join();
+      if (!okc) return false;
+    }
     std::vector<uint64_t> moff(n + 1, 0), eoff(n + 1, 0);
-    for (size_t i = 0; i < n; i++) { moff[i + 1] = moff[i] + jobs[i].mlen; eoff[i + 1] = eoff[i] + jobs[i].elen; }
+    for (size_t i = 0; i < n; i++) { moff[i + 1] = moff[i] + (composite ? inner[i].size() : jobs[i].mlen); eoff[i + 1] = eoff[i] + jobs[i].elen; }
     std::vector<uint8_t> mb(moff[n] + 1), eb(eoff[n] + 1), att(n);
     for (size_t i = 0; i < n; i++) {
-      if (jobs[i].mlen) memcpy(&mb[moff[i]], jobs[i].msg, jobs[i].mlen);
+      const size_t l = (size_t)(moff[i + 1] - moff[i]);
+      if (l) memcpy(&mb[moff[i]], composite ? inner[i].data() : jobs[i].msg, l);
       if (jobs[i].elen) memcpy(&eb[eoff[i]], jobs[i].extra, jobs[i].elen);
     }
     std::vector<uint64_t> xy(n * 12);
-    if (hash_to_g1_direct_bls12_377(dom, mb.data(), moff.data(), eb.data(), eoff.data(), n, xy.data(), att.data()) != 0) return false;
+    const int rc = composite ? hash_to_g1_cip22_tail_bls12_377(dom, mb.data(), moff.data(), eb.data(), eoff.data(), n, xy.data(), att.data())
+                             : hash_to_g1_direct_bls12_377(dom, mb.data(), moff.data(), eb.data(), eoff.data(), n, xy.data(), att.data());
+    if (rc != 0) return false;
     for (size_t i = 0; i < n; i++) {
       if (att[i] == 255) return false;
       memcpy(jobs[i].out_xy, &xy[i * 12], 96);

@@ -21,7 +21,7 @@ struct HashIn { const uint8_t* msgs; const uint64_t* msg_off; const uint8_t* ext
 // successful counter of the group wins (ballot), its lane stores the curve point BEFORE the cofactor; a group without success
 // appends its message to the next round's list.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_hash_candidates(HashDom dom, HashIn in, const uint32_t* __restrict__ list, uint32_t count, uint32_t cand_log, uint32_t base,
+k_hash_candidates(HashDom dom, HashIn in, const uint32_t* __restrict__ list, uint32_t count, uint32_t cand_log, uint32_t base, int xof_only,
                   uint64_t* __restrict__ cand_xy, uint8_t* __restrict__ attempts, uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count,
                   WireConsts k) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -36,7 +36,7 @@ k_hash_candidates(HashDom dom, HashIn in, const uint32_t* __restrict__ list, uin
     const size_t mlen = (size_t)(in.msg_off[i + 1] - in.msg_off[i]);
     const uint8_t* extra = in.extra_off ? in.extras + in.extra_off[i] : nullptr;
     const size_t elen = in.extra_off ? (size_t)(in.extra_off[i + 1] - in.extra_off[i]) : 0;
-    ok = tai_candidate(dom.b, msg, mlen, extra, elen, (int)c, k, p);
+    ok = tai_candidate(dom.b, msg, mlen, extra, elen, (int)c, k, p, xof_only != 0);
   }
   const uint64_t mask = __ballot(ok);
   const uint32_t lane = threadIdx.x & 63, g0 = lane & ~((1u << cand_log) - 1);
@@ -81,7 +81,7 @@ static int g_hash_rounds = 0;
   } while (0)
 
 int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* extras, const uint64_t* extra_off,
-                          size_t n, uint64_t* out_xy, uint8_t* attempts) {
+                          size_t n, uint64_t* out_xy, uint8_t* attempts, int xof_only) {
   std::lock_guard<std::mutex> lk(api_mutex());
   if (int rc0 = api_ensure_init()) return rc0;
   if (n == 0) return 0;
@@ -126,7 +126,7 @@ int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint
       const uint32_t* list = round ? d_list + (size_t)(round & 1) * n : nullptr;
       uint32_t* next = d_list + (size_t)((round + 1) & 1) * n;
       const size_t lanes = (size_t)count << cand_log;
-      hipLaunchKernelGGL(k_hash_candidates, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, 0, dom, in, list, count, cand_log, base, d_cand, d_att,
+      hipLaunchKernelGGL(k_hash_candidates, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, 0, dom, in, list, count, cand_log, base, xof_only, d_cand, d_att,
                          next, d_cnt + round, k);
       HASH_TRY(hipGetLastError());
       HASH_TRY(hipMemcpyAsync(&count, d_cnt + round, 4, hipMemcpyDeviceToHost, 0));
@@ -150,7 +150,7 @@ int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint
       int c = 255;
       uint64_t* o = out_xy + i * 12;
       if (hash_to_g1_direct_tai(domain, msgs + msg_off[i], msg_off[i + 1] - msg_off[i], extra_off ? extras + extra_off[i] : nullptr,
-                                extra_off ? extra_off[i + 1] - extra_off[i] : 0, k, p, c, attempts[i] + 1)) { p.x.to_ark(o); p.y.to_ark(o + 6); attempts[i] = (uint8_t)c; }
+                                extra_off ? extra_off[i + 1] - extra_off[i] : 0, k, p, c, attempts[i] + 1, xof_only != 0)) { p.x.to_ark(o); p.y.to_ark(o + 6); attempts[i] = (uint8_t)c; }
       else { attempts[i] = 255; memset(o, 0, 96); }
     }
   }

@@ -253,10 +253,11 @@ def decompress_last_ms():
     return ms.value
 
 
-def hash_to_g1_direct(domain, messages, extras=None):
-    """Batched try-and-increment hash-to-G1 over the direct hasher (include/celo_bls_amd.h: hash_to_g1_direct_bls12_377).
-    domain: 8 bytes; messages / extras: lists of bytes (extras None = no extra data).  Returns (xy (n, 12) uint64 affine
-    arkworks Montgomery limbs, attempts (n,) uint8; 255 = no point)."""
+def hash_to_g1_direct(domain, messages, extras=None, cip22_tail=False):
+    """Batched try-and-increment hash-to-G1 over the direct hasher (include/celo_bls_amd.h: hash_to_g1_direct_bls12_377), or,
+    with cip22_tail, the CIP22 loop over precomputed inner CRHs (hash_to_g1_cip22_tail_bls12_377: `messages` are the inner
+    hashes).  domain: 8 bytes; messages / extras: lists of bytes (extras None = no extra data).  Returns (xy (n, 12) uint64
+    affine arkworks Montgomery limbs, attempts (n,) uint8; 255 = no point)."""
     n = len(messages)
     assert len(domain) == 8 and (extras is None or len(extras) == n)
 
@@ -270,9 +271,10 @@ def hash_to_g1_direct(domain, messages, extras=None):
     dom = np.frombuffer(bytes(domain), dtype=np.uint8)
     xy = np.zeros((n, 12), dtype=np.uint64)
     att = np.zeros(n, dtype=np.uint8)
-    rc = lib().hash_to_g1_direct_bls12_377(_p(dom), _p(mdat), _p(moff), _p(edat), _p(eoff), C.c_size_t(n), _p(xy), _p(att))
+    fn = lib().hash_to_g1_cip22_tail_bls12_377 if cip22_tail else lib().hash_to_g1_direct_bls12_377
+    rc = fn(_p(dom), _p(mdat), _p(moff), _p(edat), _p(eoff), C.c_size_t(n), _p(xy), _p(att))
     if rc != 0:
-        raise RuntimeError("hash_to_g1_direct_bls12_377 failed with code %d" % rc)
+        raise RuntimeError("hash_to_g1 (%s) failed with code %d" % ("cip22 tail" if cip22_tail else "direct", rc))
     return xy, att
 
 

@@ -125,7 +125,13 @@ int celo_amd_decompress_last_ms(float* ms);
  * counter below 255 did (the reference returns an error there; out row zero). */
 int hash_to_g1_direct_bls12_377(const uint8_t domain[8], const uint8_t* msgs, const uint64_t* msg_off /* n+1 */, const uint8_t* extras,
                                 const uint64_t* extra_off /* n+1 or NULL */, size_t n, uint64_t* out_xy /* n x 12 */, uint8_t* attempts /* n */);
-/* kernel time (HIP events) of the last hash_to_g1_direct_bls12_377 call */
+/* The try-and-increment loop of the CIP22 hashers (crates/bls-crypto/src/hash_to_curve/try_and_increment_cip22.rs:81-134), n
+ * messages per launch: the caller computes the inner CRH of each message once (for the composite hasher: hash_crh of
+ * include/celo_bls_snark_sys.h, 48 bytes), this entry point runs candidate = xof(domain, counter || extra_data || inner) ->
+ * curve point -> cofactor for every message.  Same layout and result conventions as hash_to_g1_direct_bls12_377. */
+int hash_to_g1_cip22_tail_bls12_377(const uint8_t domain[8], const uint8_t* inner, const uint64_t* inner_off /* n+1 */, const uint8_t* extras,
+                                    const uint64_t* extra_off /* n+1 or NULL */, size_t n, uint64_t* out_xy /* n x 12 */, uint8_t* attempts /* n */);
+/* kernel time (HIP events) of the last hash_to_g1_* call */
 int celo_amd_hash_last_ms(float* ms);
 
 /* ---- plain sums of k Jacobian points (host pointers, arkworks layout; host-side, for small k): the fold of per-GPU

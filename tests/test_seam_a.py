@@ -364,6 +364,67 @@ def test_batch_verify_signature_hashes_many_messages_on_the_gpu(sys_lib, gpu):
     assert [i for i in range(256) if not res[i]] == [100]
 
 
+@pytest.mark.gpu
+def test_cip22_tail_on_gpu_reproduces_reference_points(sys_lib, gpu, golden):
+    """hash_to_g1_cip22_tail_bls12_377 (the CIP22 try-and-increment loop on the GPU, inner CRHs from hash_crh) on the inputs of
+    the reference's compat CIP22 vectors (crates/bls-crypto/src/hash_to_curve/mod.rs:438-449): the ten reference points come
+    out byte for byte, with the attempt counters of the host path."""
+    from oracle import cpu_oracle as co
+    gen, _ = _composite_inputs()
+    lib = sys_lib
+    lib.hash_crh.restype = C.c_bool
+    lib.celo_amd_hash_to_g1.restype = C.c_bool
+    pts = golden["hash_to_curve"]["g1_compat_cip22"]["points"]
+    doms, inners, extras, want_att = [], [], [], []
+    for dom, msg, extra in gen(len(pts)):
+        out, n = C.c_void_p(), C.c_int()
+        assert lib.hash_crh(msg, len(msg), 96, C.byref(out), C.byref(n))
+        inners.append(_take(lib, out, n))
+        doms.append(dom); extras.append(extra)
+        o48, att = (C.c_ubyte * 48)(), C.c_int(-1)
+        assert lib.celo_amd_hash_to_g1(True, True, dom, msg, len(msg), extra, len(extra), o48, C.byref(att))
+        want_att.append(att.value)
+    for i, hx in enumerate(pts):                   # the reference draws a fresh 8-byte domain per vector: one call each
+        xy, att = gpu.hash_to_g1_direct(doms[i], [inners[i]] * 3, [extras[i]] * 3, cip22_tail=True)
+        assert att.tolist() == [want_att[i]] * 3
+        vals = co.from_mont(xy.reshape(-1, 6), ecc.Q377)
+        for k in range(3):
+            assert ecc.ser_point(ecc.E1_377, (vals[2 * k], vals[2 * k + 1])).hex() == hx
+
+
+@pytest.mark.gpu
+def test_batch_verify_signature_composite_cip22_many_messages(sys_lib, gpu):
+    """300 messages with the composite CIP22 hasher: inner CRHs on the host cores, the try-and-increment loops in one GPU call;
+    accept, and reject after one changed message byte."""
+    for f in ("sign_message", "batch_verify_signature"):
+        getattr(sys_lib, f).restype = C.c_bool
+    rng = ecc.SplitMix64(78)
+    CF, C22 = C.c_bool(True), C.c_bool(True)
+    sk = ecc.random_scalar(rng, ecc.R377)
+    skh = _deser(sys_lib, "deserialize_private_key", sk.to_bytes(32, "little"))
+    pkh = C.c_void_p()
+    assert sys_lib.private_key_to_public_key(skh, C.byref(pkh))
+    n = 300
+    msgs = [bytes([(3 * i + j) & 0xFF for j in range(1 + (i * 7) % 90)]) for i in range(n)]
+    extras = [bytes([i & 0xFF]) * (i % 4) for i in range(n)]
+    sigs = []
+    for m, e in zip(msgs, extras):
+        s = C.c_void_p()
+        assert sys_lib.sign_message(skh, m, C.c_int(len(m)), e, C.c_int(len(e)), CF, C22, C.byref(s))
+        sigs.append(s)
+
+    def run(ms):
+        arr = (_MessageFFI * n)(*[_MessageFFI(_Buffer(ms[i], len(ms[i])), _Buffer(extras[i], len(extras[i])), pkh.value, sigs[i].value) for i in range(n)])
+        ok = C.c_bool(False)
+        assert sys_lib.batch_verify_signature(arr, C.c_size_t(n), CF, C22, C.byref(ok))
+        return ok.value
+
+    assert run(msgs)
+    bad = list(msgs)
+    bad[299] = bytes([bad[299][0] ^ 0x80]) + bad[299][1:]
+    assert not run(bad)
+
+
 # ---------------------------------------------------------------- snark half of the FFI
 class _EpochBlockFFI(C.Structure):
     _fields_ = [("index", C.c_uint16), ("round", C.c_uint8), ("epoch_entropy", C.c_char_p), ("parent_entropy", C.c_char_p),

@@ -38,6 +38,7 @@ int wire_decompress(int, const uint8_t*, size_t, int, uint64_t*, uint8_t*, int, 
 float wire_last_ms();
 int hash_to_g1_direct_run(const uint8_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*, uint8_t*, int);
 float hash_last_ms();
+int pedersen_crh_run(const uint8_t*, const uint64_t*, size_t, uint8_t*);
 int pairing_run_761(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
 }  // namespace celo
 using namespace celo;
@@ -185,6 +186,7 @@ int hash_to_g1_cip22_tail_bls12_377(const uint8_t domain[8], const uint8_t* inne
                                     size_t n, uint64_t* out_xy, uint8_t* attempts) {
   return hash_to_g1_direct_run(domain, inner, inner_off, extras, extra_off, n, out_xy, attempts, 1);
 }
+int composite_crh_bls12_377(const uint8_t* msgs, const uint64_t* msg_off, size_t n, uint8_t* out48) { return pedersen_crh_run(msgs, msg_off, n, out48); }
 int celo_amd_hash_last_ms(float* ms) { if (!ms) return 2; *ms = hash_last_ms(); return 0; }
 int celo_amd_decompress_last_ms(float* ms) { if (!ms) return 2; *ms = wire_last_ms(); return 0; }
 int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]) {

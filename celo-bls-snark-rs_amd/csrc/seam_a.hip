@@ -31,6 +31,7 @@
 #include "fp2.h"
 #include "wire.h"
 #include "hash_direct.h"
+#include "pedersen.h"
 #include "../../include/celo_bls_amd.h"
 #include "../../include/celo_bls_snark_sys.h"
 
@@ -261,31 +262,6 @@ bool hash_to_g1_direct(const uint8_t* dom, const uint8_t* msg, size_t mlen, cons
 // Blake2s("ULTRALIGHT PRNG SEED", personal "UL_prngs") exactly as rand 0.7 / rand_chacha 0.2 / ark-ff 0.1 consume it, then
 // the Blake2Xs XOF.  Host plumbing; pinned on the reference's CRH vector and its 20 compat hash-to-G1
 // vectors through the oracle restatement (tests/test_oracle_golden.py, tests/test_seam_a.py).
-struct SF {  // "safe" host field element: every result weak-reduced and normalised (speed is irrelevant here)
-  Fq_ v;
-  static SF from(const Fq_& x) { return {Fq_::wred(Fq_::norm(x))}; }
-  SF operator+(const SF& o) const { return from(Fq_::add(v, o.v)); }
-  SF operator-(const SF& o) const { return from(Fq_::sub<4, 1>(v, o.v)); }
-  SF operator*(const SF& o) const { return from(Fq_::mul(v, o.v)); }
-  SF neg() const { return from(Fq_::neg<4, 1>(v)); }
-  SF dbl() const { return from(Fq_::add(v, v)); }
-};
-struct EdPoint { SF X, Y, Z, T; };  // extended twisted Edwards, a = -1
-SF sf_small(uint64_t k) { uint64_t w[6] = {k, 0, 0, 0, 0, 0}; return SF::from(Fq_::from_canonical(w)); }
-EdPoint ed_add(const EdPoint& p, const EdPoint& q) {  // add-2008-hwcd-3 (a = -1)
-  static const SF d2 = sf_small(2 * 79743);
-  SF A = (p.Y - p.X) * (q.Y - q.X), B = (p.Y + p.X) * (q.Y + q.X), C = p.T * d2 * q.T, D = (p.Z * q.Z).dbl();
-  SF E = B - A, F = D - C, G = D + C, H = B + A;
-  return {E * F, G * H, F * G, E * H};
-}
-EdPoint ed_dbl(const EdPoint& p) {  // dbl-2008-hwcd (a = -1)
-  SF A = p.X * p.X, B = p.Y * p.Y, C = (p.Z * p.Z).dbl(), D = A.neg();
-  SF E = (p.X + p.Y) * (p.X + p.Y) - A - B, G = D + B, F = G - C, H = D - B;
-  return {E * F, G * H, F * G, E * H};
-}
-EdPoint ed_neg(const EdPoint& p) { return {p.X.neg(), p.Y, p.Z, p.T.neg()}; }
-EdPoint ed_zero() { return {sf_small(0), sf_small(1), sf_small(1), sf_small(0)}; }
-
 struct ChaCha20Rng {  // rand_chacha 0.2 behind rand_core 0.5 BlockRng: 64-word buffer (4 blocks), 64-bit block counter
   uint32_t key[8]; uint64_t counter = 0; uint32_t buf[64]; int idx = 64;
   static uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
@@ -327,7 +303,7 @@ bool os_seeded_rng(ChaCha20Rng& rng) {
 }
 struct CompositeParams {
   std::vector<EdPoint> gens;  // [NUM_WINDOWS * WINDOW_SIZE]: window-major, generator j = 16^j * base
-  static constexpr int WINDOW_SIZE = 93, NUM_WINDOWS = 560;
+  static constexpr int WINDOW_SIZE = PEDERSEN_WINDOW_SIZE, NUM_WINDOWS = PEDERSEN_NUM_WINDOWS;
   CompositeParams() {
     static const uint8_t PERS[8] = {'U', 'L', '_', 'p', 'r', 'n', 'g', 's'};
     static const char* SEED_MSG = "ULTRALIGHT PRNG SEED";
@@ -370,21 +346,9 @@ struct CompositeParams {
 const CompositeParams& composite_params() { static CompositeParams p; return p; }
 bool composite_crh(const uint8_t* msg, size_t len, std::vector<uint8_t>& out) {  // bowe_hopwood::CRH::evaluate -> affine x, 48 bytes
   const CompositeParams& cp = composite_params();
-  if (len * 8 > (size_t)CompositeParams::WINDOW_SIZE * CompositeParams::NUM_WINDOWS * 3) return false;  // the reference panics
-  size_t nbits = len * 8, nchunks = (nbits + 2) / 3;
-  auto bit = [&](size_t i) -> int { return i < nbits ? (msg[i >> 3] >> (i & 7)) & 1 : 0; };  // LSB-first, zero padded
-  EdPoint total = ed_zero();
-  for (size_t ch = 0; ch < nchunks; ch++) {
-    const EdPoint& g = cp.gens[ch];  // chunk ch of the message uses generator (ch / 93, ch % 93): window-major order
-    EdPoint enc = g;
-    if (bit(3 * ch)) enc = ed_add(enc, g);
-    if (bit(3 * ch + 1)) enc = ed_add(enc, ed_dbl(g));
-    if (bit(3 * ch + 2)) enc = ed_neg(enc);
-    total = ed_add(total, enc);
-  }
-  SF x = total.X * SF::from(Fq_::inv(total.Z.v));
+  if (len * 8 > PEDERSEN_MAX_BITS) return false;  // the reference panics
   out.assign(48, 0);
-  fq_to_bytes(x.v, out.data());
+  pedersen_crh(cp.gens.data(), msg, len, out.data());   // pedersen.h: the source the GPU kernel runs
   return true;
 }
 // generic try-and-increment over {direct, composite} x {plain, cip22} with the `compat` bit logic
@@ -423,38 +387,26 @@ bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* m
 struct HashJob { const uint8_t* msg; size_t mlen; const uint8_t* extra; size_t elen; uint64_t* out_xy; };
 bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJob>& jobs) {
   (void)wire_consts();
-  // many messages: the try-and-increment loops run on the GPU (hash_direct.h; a lone wave of 64 needs ~4 ms, so the host
-  // cores keep the small calls) - the whole hash for the direct hasher, everything after the inner Pedersen CRH for the
-  // composite hasher with CIP22 (the CRHs stay on the host cores).  Composite without CIP22 re-hashes per attempt: host.
+  // many messages: hashing runs on the GPU (a lone wave of 64 needs ~4 ms, so the host cores keep the small calls) - the
+  // whole try-and-increment hash for the direct hasher (hash_direct.h); for the composite hasher with CIP22 the inner
+  // Pedersen CRHs (pedersen.h) and then the loops.  Composite without CIP22 re-hashes per attempt: host cores.
   if ((!composite || cip22) && jobs.size() >= 256) {
     const size_t n = jobs.size();
-    std::vector<std::vector<uint8_t>> inner;
+    std::vector<uint8_t> inner;     // composite: n x 48 bytes, the Pedersen CRH of every message in one GPU launch (pedersen.h)
     if (composite) {
-      (void)composite_params();
-      inner.resize(n);
-      std::atomic<size_t> nexti(0);
-      std::atomic<bool> okc(true);
-      unsigned nt = std::thread::hardware_concurrency();
-      if (nt == 0) nt = 1;
-      if (nt > 64) nt = 64;
-      auto crh_work = [&]() {
-        for (;;) {
-          const size_t i = nexti.fetch_add(1);
-          if (i >= n) break;
-          if (!composite_crh(jobs[i].msg, jobs[i].mlen, inner[i])) okc = false;
-        }
-      };
-      std::vector<std::thread> th;
-      for (unsigned t = 0; t < nt; t++) th.emplace_back(crh_work);
-      for (auto& t : th) t.join();
-      if (!okc) return false;
+      std::vector<uint64_t> coff(n + 1, 0);
+      for (size_t i = 0; i < n; i++) coff[i + 1] = coff[i] + jobs[i].mlen;
+      std::vector<uint8_t> cb(coff[n] + 1);
+      for (size_t i = 0; i < n; i++) if (jobs[i].mlen) memcpy(&cb[coff[i]], jobs[i].msg, jobs[i].mlen);
+      inner.resize(n * 48);
+      if (composite_crh_bls12_377(cb.data(), coff.data(), n, inner.data()) != 0) return false;
     }
     std::vector<uint64_t> moff(n + 1, 0), eoff(n + 1, 0);
-    for (size_t i = 0; i < n; i++) { moff[i + 1] = moff[i] + (composite ? inner[i].size() : jobs[i].mlen); eoff[i + 1] = eoff[i] + jobs[i].elen; }
+    for (size_t i = 0; i < n; i++) { moff[i + 1] = moff[i] + (composite ? 48 : jobs[i].mlen); eoff[i + 1] = eoff[i] + jobs[i].elen; }
     std::vector<uint8_t> mb(moff[n] + 1), eb(eoff[n] + 1), att(n);
     for (size_t i = 0; i < n; i++) {
       const size_t l = (size_t)(moff[i + 1] - moff[i]);
-      if (l) memcpy(&mb[moff[i]], composite ? inner[i].data() : jobs[i].msg, l);
+      if (l) memcpy(&mb[moff[i]], composite ? &inner[i * 48] : jobs[i].msg, l);
       if (jobs[i].elen) memcpy(&eb[eoff[i]], jobs[i].extra, jobs[i].elen);
     }
     std::vector<uint64_t> xy(n * 12);
@@ -684,6 +636,15 @@ void neg_g2_generator(uint64_t out_xy[24]) {
   fq_neg(Fq_::from_limbs(T377::G2_GEN_Y1)).to_ark(out_xy + 18);
 }
 }  // namespace
+
+namespace celo {
+// the composite hasher's generator table for the bulk GPU kernel (unit_hash.hip: k_pedersen_crh)
+const EdPoint* celo_composite_gens(size_t* count) {
+  const CompositeParams& cp = composite_params();
+  *count = cp.gens.size();
+  return cp.gens.data();
+}
+}  // namespace celo
 
 extern "C" {
 

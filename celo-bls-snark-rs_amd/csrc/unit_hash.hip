@@ -1,6 +1,7 @@
 // Translation unit: batched hash-to-G1 over the direct hasher (see hash_direct.h): rounds of candidate counters, then the
 // cofactor ladder.
 #include "hash_direct.h"
+#include "pedersen.h"
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <vector>
@@ -158,6 +159,59 @@ done:
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   for (void* q : {(void*)d_bytes, (void*)d_off, (void*)d_out, (void*)d_cand, (void*)d_att, (void*)d_redo, (void*)d_list, (void*)d_cnt})
+    if (q) (void)hipFree(q);
+  return rc;
+}
+// ---- bulk Pedersen CRH (pedersen.h): one message per lane; the 52080-generator table (11.7 MB) is uploaded on first use
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_pedersen_crh(const EdPoint* __restrict__ gens, const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off, uint8_t* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t h[48];
+  pedersen_crh(gens, msgs + off[i], (size_t)(off[i + 1] - off[i]), h);
+  for (int j = 0; j < 48; j++) out[(size_t)i * 48 + j] = h[j];
+}
+const EdPoint* celo_composite_gens(size_t* count);   // seam_a.hip: the generator table (built once, ChaCha20 stream of the reference)
+
+int pedersen_crh_run(const uint8_t* msgs, const uint64_t* msg_off, size_t n, uint8_t* out48) {
+  size_t ngens = 0;
+  const EdPoint* gens = celo_composite_gens(&ngens);      // before the lock: building the table takes 0.5 s on first use
+  std::lock_guard<std::mutex> lk(api_mutex());
+  if (int rc0 = api_ensure_init()) return rc0;
+  if (n == 0) return 0;
+  if (!msg_off || !out48 || n > 0x7fffffffu) return 2;
+  for (size_t i = 0; i < n; i++) {
+    if (msg_off[i + 1] < msg_off[i] || (msg_off[i + 1] - msg_off[i]) * 8 > PEDERSEN_MAX_BITS) return 2;   // the reference panics on longer messages
+  }
+  const size_t mb = msg_off[n];
+  if (mb && !msgs) return 2;
+  static EdPoint* d_gens = nullptr;
+  uint8_t *d_bytes = nullptr, *d_out = nullptr;
+  uint64_t* d_off = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = 0;
+  if (!d_gens) {
+    HASH_TRY(hipMalloc(&d_gens, ngens * sizeof(EdPoint)));
+    HASH_TRY(hipMemcpy(d_gens, gens, ngens * sizeof(EdPoint), hipMemcpyHostToDevice));
+  }
+  HASH_TRY(hipMalloc(&d_bytes, mb + 8));
+  HASH_TRY(hipMalloc(&d_off, (n + 1) * 8));
+  HASH_TRY(hipMalloc(&d_out, n * 48));
+  if (mb) HASH_TRY(hipMemcpyAsync(d_bytes, msgs, mb, hipMemcpyHostToDevice, 0));
+  HASH_TRY(hipMemcpyAsync(d_off, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, 0));
+  HASH_TRY(hipEventCreate(&e0));
+  HASH_TRY(hipEventCreate(&e1));
+  HASH_TRY(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_pedersen_crh, dim3(((uint32_t)n + 63) / 64), dim3(64), 0, 0, d_gens, d_bytes, d_off, d_out, (uint32_t)n);
+  HASH_TRY(hipGetLastError());
+  HASH_TRY(hipEventRecord(e1, 0));
+  HASH_TRY(hipMemcpyAsync(out48, d_out, n * 48, hipMemcpyDeviceToHost, 0));
+  HASH_TRY(hipStreamSynchronize(0));
+  HASH_TRY(hipEventElapsedTime(&g_hash_ms, e0, e1));
+done:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  for (void* q : {(void*)d_bytes, (void*)d_off, (void*)d_out})
     if (q) (void)hipFree(q);
   return rc;
 }

@@ -282,3 +282,18 @@ def hash_last_ms():
     ms = C.c_float(0)
     assert lib().celo_amd_hash_last_ms(C.byref(ms)) == 0
     return ms.value
+
+
+def composite_crh(messages):
+    """The composite hasher's Pedersen CRH of n messages in one GPU launch (include/celo_bls_amd.h: composite_crh_bls12_377).
+    Returns a list of n 48-byte hashes."""
+    n = len(messages)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    if n:
+        off[1:] = np.cumsum([len(b) for b in messages], dtype=np.uint64)
+    data = np.frombuffer(b"".join(messages) or b"\0", dtype=np.uint8)
+    out = np.zeros((n, 48), dtype=np.uint8)
+    rc = lib().composite_crh_bls12_377(_p(data), _p(off), C.c_size_t(n), _p(out))
+    if rc != 0:
+        raise RuntimeError("composite_crh_bls12_377 failed with code %d" % rc)
+    return [out[i].tobytes() for i in range(n)]

@@ -131,6 +131,11 @@ int hash_to_g1_direct_bls12_377(const uint8_t domain[8], const uint8_t* msgs, co
  * curve point -> cofactor for every message.  Same layout and result conventions as hash_to_g1_direct_bls12_377. */
 int hash_to_g1_cip22_tail_bls12_377(const uint8_t domain[8], const uint8_t* inner, const uint64_t* inner_off /* n+1 */, const uint8_t* extras,
                                     const uint64_t* extra_off /* n+1 or NULL */, size_t n, uint64_t* out_xy /* n x 12 */, uint8_t* attempts /* n */);
+/* The composite hasher's CRH for n messages in one launch: the Bowe-Hopwood-Pedersen hash over ed-on-BW6-761 that
+ * CompositeHasher::crh evaluates (crates/bls-crypto/src/hashers/composite.rs:79-86; hash_crh of the bls-snark-sys ABI,
+ * signatures.rs:169, is the one-message form).  out48: n x 48 bytes, the affine x coordinate little-endian.  A message longer
+ * than 93 * 560 * 3 bits is an error for the whole call (the reference panics). */
+int composite_crh_bls12_377(const uint8_t* msgs, const uint64_t* msg_off /* n+1 */, size_t n, uint8_t* out48 /* n x 48 */);
 /* kernel time (HIP events) of the last hash_to_g1_* call */
 int celo_amd_hash_last_ms(float* ms);
 

@@ -393,6 +393,32 @@ def test_cip22_tail_on_gpu_reproduces_reference_points(sys_lib, gpu, golden):
 
 
 @pytest.mark.gpu
+def test_bulk_pedersen_crh_on_gpu(sys_lib, gpu, golden):
+    """composite_crh_bls12_377 (pedersen.h, one message per lane) against the reference's CRH vector
+    (crates/bls-crypto/src/hashers/composite.rs:105-190, golden "composite_hasher" entries without an XOF length) and against
+    hash_crh, the one-message host path of the same source, for lengths 0 ... 400 (chunk boundaries fall on every bit offset;
+    the last chunk is padded with zero bits)."""
+    _, xs = _composite_inputs()
+    lib = sys_lib
+    lib.hash_crh.restype = C.c_bool
+    ref = [(xs(v["seed0"], v["msg_len"]) if v["seed0"] is not None else b"", v["expected"])
+           for v in golden["composite_hasher"].values() if v["out_bytes"] is None]
+    assert ref
+    got = gpu.composite_crh([m for m, _ in ref])
+    assert [g.hex() for g in got] == [e for _, e in ref]
+    msgs = [bytes([(11 * i + 3 * j) & 0xFF for j in range(l)]) for i, l in enumerate(list(range(0, 70)) + [95, 96, 97, 200, 333, 400])]
+    want = []
+    for m in msgs:
+        out, n = C.c_void_p(), C.c_int()
+        assert lib.hash_crh(m, len(m), 96, C.byref(out), C.byref(n))
+        want.append(_take(lib, out, n))
+    assert gpu.composite_crh(msgs) == want
+    assert gpu.composite_crh([]) == []
+    with pytest.raises(RuntimeError):
+        gpu.composite_crh([bytes(93 * 560 * 3 // 8 + 1)])     # longer than the generator table: the reference panics
+
+
+@pytest.mark.gpu
 def test_batch_verify_signature_composite_cip22_many_messages(sys_lib, gpu):
     """300 messages with the composite CIP22 hasher: inner CRHs on the host cores, the try-and-increment loops in one GPU call;
     accept, and reject after one changed message byte."""

@@ -186,6 +186,17 @@ int hash_to_g1_cip22_tail_bls12_377(const uint8_t domain[8], const uint8_t* inne
                                     size_t n, uint64_t* out_xy, uint8_t* attempts) {
   return hash_to_g1_direct_run(domain, inner, inner_off, extras, extra_off, n, out_xy, attempts, 1);
 }
+int hash_to_g1_composite_bls12_377(const uint8_t domain[8], const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* extras, const uint64_t* extra_off,
+                                   size_t n, int cip22, uint64_t* out_xy, uint8_t* attempts) {
+  if (!cip22) return hash_to_g1_direct_run(domain, msgs, msg_off, extras, extra_off, n, out_xy, attempts, 2);
+  if (n == 0) return 0;
+  if (!msg_off) return 2;
+  std::vector<uint8_t> inner(n * 48);                        // CIP22: one CRH per message, then the loops over xof(c || extra || inner)
+  std::vector<uint64_t> ioff(n + 1);
+  for (size_t i = 0; i <= n; i++) ioff[i] = 48 * i;
+  if (int rc = pedersen_crh_run(msgs, msg_off, n, inner.data())) return rc;
+  return hash_to_g1_direct_run(domain, inner.data(), ioff.data(), extras, extra_off, n, out_xy, attempts, 1);
+}
 int composite_crh_bls12_377(const uint8_t* msgs, const uint64_t* msg_off, size_t n, uint8_t* out48) { return pedersen_crh_run(msgs, msg_off, n, out48); }
 int celo_amd_hash_last_ms(float* ms) { if (!ms) return 2; *ms = hash_last_ms(); return 0; }
 int celo_amd_decompress_last_ms(float* ms) { if (!ms) return 2; *ms = wire_last_ms(); return 0; }

@@ -12,6 +12,7 @@
 // against that implementation and the oracle (tests/test_hash_gpu.py).
 #pragma once
 #include "wire.h"
+#include "pedersen.h"
 
 namespace celo {
 
@@ -128,18 +129,29 @@ HD bool tai_point_from_xof(const uint32_t w12[12], const WireConsts& k, Affine<F
 }
 // one attempt: counter c -> the curve point (x, y) the candidate bytes select, before the cofactor; false when the
 // candidate is not a field element, is the flagged zero, or x^3 + 1 is not a square.
-// xof_only = false: TryAndIncrement<DirectHasher>: candidate = xof(crh(c || extra || message))
-// xof_only = true:  the CIP22 loop (try_and_increment_cip22.rs:81-134): `message` is the inner CRH computed once by the
-//                   caller (the composite hasher's 48 bytes), candidate = xof(c || extra || inner) - no CRH per attempt
+// mode TAI_DIRECT:    TryAndIncrement<DirectHasher>: candidate = xof(crh(c || extra || message)), Blake2s CRH
+// mode TAI_XOF_ONLY:  the CIP22 loop (try_and_increment_cip22.rs:81-134): `message` is the inner CRH computed once by the
+//                     caller (the composite hasher's 48 bytes), candidate = xof(c || extra || inner) - no CRH per attempt
+// mode TAI_COMPOSITE: TryAndIncrement<CompositeHasher> before CIP22: candidate = xof(pedersen_crh(c || extra || message)),
+//                     `gens` = the generator table (pedersen.h)
+enum TaiMode : int { TAI_DIRECT = 0, TAI_XOF_ONLY = 1, TAI_COMPOSITE = 2 };
 HD bool tai_candidate(const uint8_t dom[8], const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen, int c, const WireConsts& k,
-                      Affine<Fq>& p, bool xof_only = false) {
+                      Affine<Fq>& p, int mode = TAI_DIRECT, const EdPoint* gens = nullptr) {
   uint32_t x0[8], x1[8];
   const TaiBytes src = {(uint8_t)c, extra, elen, msg, mlen};
-  if (xof_only) {
+  if (mode == TAI_XOF_ONLY) {
     b2s_init(x0, 32, 0, 0, 32, b2x_node_offset(0, 64), 0, 32, dom);
     b2s_stream(x0, src);
     b2s_init(x1, 32, 0, 0, 32, b2x_node_offset(1, 64), 0, 32, dom);
     b2s_stream(x1, src);
+  } else if (mode == TAI_COMPOSITE) {
+    uint8_t pre[48];
+    pedersen_crh_src(gens, src, pre);
+    const PtrBytes ps = {pre, 48};
+    b2s_init(x0, 32, 0, 0, 32, b2x_node_offset(0, 64), 0, 32, dom);
+    b2s_stream(x0, ps);
+    b2s_init(x1, 32, 0, 0, 32, b2x_node_offset(1, 64), 0, 32, dom);
+    b2s_stream(x1, ps);
   } else {
     uint32_t h[8], m[16];
     b2s_init(h, 32, 1, 1, 0, b2x_node_offset(0, 64), 0, 0, dom);           // DirectHasher::crh with hash_length(48) = 64
@@ -172,10 +184,10 @@ HD bool tai_finish(const Affine<Fq>& p, Affine<Fq>& out) {
 // the serial loop (host single hashes, and the GPU path's fallback from counter c_start): -> affine point of the prime-order
 // subgroup and the attempt counter; false when no counter below 255 succeeds (the reference errs there)
 HD bool hash_to_g1_direct_tai(const uint8_t dom[8], const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen, const WireConsts& k,
-                              Affine<Fq>& out, int& attempt, int c_start = 0, bool xof_only = false) {
+                              Affine<Fq>& out, int& attempt, int c_start = 0, int mode = TAI_DIRECT, const EdPoint* gens = nullptr) {
   for (int c = c_start; c < 255; c++) {
     Affine<Fq> p = {Fq::zero(), Fq::zero()};
-    if (!tai_candidate(dom, msg, mlen, extra, elen, c, k, p, xof_only)) continue;
+    if (!tai_candidate(dom, msg, mlen, extra, elen, c, k, p, mode, gens)) continue;
     if (!tai_finish(p, out)) continue;
     attempt = c;
     return true;

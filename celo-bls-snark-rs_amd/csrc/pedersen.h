@@ -39,15 +39,23 @@ HD EdPoint ed_zero() { return {sf_small(0), sf_small(1), sf_small(1), sf_small(0
 constexpr int PEDERSEN_WINDOW_SIZE = 93, PEDERSEN_NUM_WINDOWS = 560;
 constexpr size_t PEDERSEN_MAX_BITS = (size_t)PEDERSEN_WINDOW_SIZE * PEDERSEN_NUM_WINDOWS * 3;
 
-// out48 = x coordinate of sum_ch enc_ch; the caller has checked len * 8 <= PEDERSEN_MAX_BITS (the reference panics beyond)
-HD void pedersen_crh(const EdPoint* gens, const uint8_t* msg, size_t len, uint8_t out48[48]) {
-  const size_t nbits = len * 8, nchunks = (nbits + 2) / 3;
+// out48 = x coordinate of sum_ch enc_ch over the bytes src(0 .. src.size()); the caller has checked size * 8 <= PEDERSEN_MAX_BITS
+// (the reference panics beyond).  Src: any byte source with size() and operator()(j) (a plain buffer, or the counter || extra ||
+// message string of a try-and-increment attempt).
+struct PtrBytes {
+  const uint8_t* p;
+  size_t n;
+  HD size_t size() const { return n; }
+  HD uint8_t operator()(size_t j) const { return p[j]; }
+};
+template <class Src> HD void pedersen_crh_src(const EdPoint* gens, const Src& src, uint8_t out48[48]) {
+  const size_t len = src.size(), nbits = len * 8, nchunks = (nbits + 2) / 3;
   EdPoint total = ed_zero();
   for (size_t ch = 0; ch < nchunks; ch++) {
     const size_t b = 3 * ch;
     // three message bits, LSB-first within a byte, zero beyond the end
-    uint32_t two = msg[b >> 3];
-    if ((b >> 3) + 1 < len) two |= (uint32_t)msg[(b >> 3) + 1] << 8;
+    uint32_t two = src(b >> 3);
+    if ((b >> 3) + 1 < len) two |= (uint32_t)src((b >> 3) + 1) << 8;
     const uint32_t bits = (two >> (b & 7)) & 7u;
     const EdPoint g = gens[ch];
     EdPoint enc = g;
@@ -61,5 +69,6 @@ HD void pedersen_crh(const EdPoint* gens, const uint8_t* msg, size_t len, uint8_
   x.v.to_canonical(w);
   for (int i = 0; i < 48; i++) out48[i] = (uint8_t)(w[i >> 3] >> (8 * (i & 7)));
 }
+HD void pedersen_crh(const EdPoint* gens, const uint8_t* msg, size_t len, uint8_t out48[48]) { pedersen_crh_src(gens, PtrBytes{msg, len}, out48); }
 
 }  // namespace celo

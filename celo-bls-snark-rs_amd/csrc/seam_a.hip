@@ -387,30 +387,20 @@ bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* m
 struct HashJob { const uint8_t* msg; size_t mlen; const uint8_t* extra; size_t elen; uint64_t* out_xy; };
 bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJob>& jobs) {
   (void)wire_consts();
-  // many messages: hashing runs on the GPU (a lone wave of 64 needs ~4 ms, so the host cores keep the small calls) - the
-  // whole try-and-increment hash for the direct hasher (hash_direct.h); for the composite hasher with CIP22 the inner
-  // Pedersen CRHs (pedersen.h) and then the loops.  Composite without CIP22 re-hashes per attempt: host cores.
-  if ((!composite || cip22) && jobs.size() >= 256) {
+  // many messages: hashing runs on the GPU (a lone wave of 64 needs ~4 ms, so the host cores keep the small calls), for
+  // every hasher: hash_direct.h's try-and-increment rounds over the Blake2s CRH, over precomputed Pedersen CRHs (CIP22), or
+  // with a Pedersen CRH per attempt (composite before CIP22)
+  if (jobs.size() >= 256) {
     const size_t n = jobs.size();
-    std::vector<uint8_t> inner;     // composite: n x 48 bytes, the Pedersen CRH of every message in one GPU launch (pedersen.h)
-    if (composite) {
-      std::vector<uint64_t> coff(n + 1, 0);
-      for (size_t i = 0; i < n; i++) coff[i + 1] = coff[i] + jobs[i].mlen;
-      std::vector<uint8_t> cb(coff[n] + 1);
-      for (size_t i = 0; i < n; i++) if (jobs[i].mlen) memcpy(&cb[coff[i]], jobs[i].msg, jobs[i].mlen);
-      inner.resize(n * 48);
-      if (composite_crh_bls12_377(cb.data(), coff.data(), n, inner.data()) != 0) return false;
-    }
     std::vector<uint64_t> moff(n + 1, 0), eoff(n + 1, 0);
-    for (size_t i = 0; i < n; i++) { moff[i + 1] = moff[i] + (composite ? 48 : jobs[i].mlen); eoff[i + 1] = eoff[i] + jobs[i].elen; }
+    for (size_t i = 0; i < n; i++) { moff[i + 1] = moff[i] + jobs[i].mlen; eoff[i + 1] = eoff[i] + jobs[i].elen; }
     std::vector<uint8_t> mb(moff[n] + 1), eb(eoff[n] + 1), att(n);
     for (size_t i = 0; i < n; i++) {
-      const size_t l = (size_t)(moff[i + 1] - moff[i]);
-      if (l) memcpy(&mb[moff[i]], composite ? &inner[i * 48] : jobs[i].msg, l);
+      if (jobs[i].mlen) memcpy(&mb[moff[i]], jobs[i].msg, jobs[i].mlen);
       if (jobs[i].elen) memcpy(&eb[eoff[i]], jobs[i].extra, jobs[i].elen);
     }
     std::vector<uint64_t> xy(n * 12);
-    const int rc = composite ? hash_to_g1_cip22_tail_bls12_377(dom, mb.data(), moff.data(), eb.data(), eoff.data(), n, xy.data(), att.data())
+    const int rc = composite ? hash_to_g1_composite_bls12_377(dom, mb.data(), moff.data(), eb.data(), eoff.data(), n, cip22 ? 1 : 0, xy.data(), att.data())
                              : hash_to_g1_direct_bls12_377(dom, mb.data(), moff.data(), eb.data(), eoff.data(), n, xy.data(), att.data());
     if (rc != 0) return false;
     for (size_t i = 0; i < n; i++) {

@@ -22,7 +22,7 @@ struct HashIn { const uint8_t* msgs; const uint64_t* msg_off; const uint8_t* ext
 // successful counter of the group wins (ballot), its lane stores the curve point BEFORE the cofactor; a group without success
 // appends its message to the next round's list.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_hash_candidates(HashDom dom, HashIn in, const uint32_t* __restrict__ list, uint32_t count, uint32_t cand_log, uint32_t base, int xof_only,
+k_hash_candidates(HashDom dom, HashIn in, const uint32_t* __restrict__ list, uint32_t count, uint32_t cand_log, uint32_t base, int mode, const EdPoint* __restrict__ gens,
                   uint64_t* __restrict__ cand_xy, uint8_t* __restrict__ attempts, uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count,
                   WireConsts k) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,7 +37,7 @@ k_hash_candidates(HashDom dom, HashIn in, const uint32_t* __restrict__ list, uin
     const size_t mlen = (size_t)(in.msg_off[i + 1] - in.msg_off[i]);
     const uint8_t* extra = in.extra_off ? in.extras + in.extra_off[i] : nullptr;
     const size_t elen = in.extra_off ? (size_t)(in.extra_off[i + 1] - in.extra_off[i]) : 0;
-    ok = tai_candidate(dom.b, msg, mlen, extra, elen, (int)c, k, p, xof_only != 0);
+    ok = tai_candidate(dom.b, msg, mlen, extra, elen, (int)c, k, p, mode, gens);
   }
   const uint64_t mask = __ballot(ok);
   const uint32_t lane = threadIdx.x & 63, g0 = lane & ~((1u << cand_log) - 1);
@@ -72,6 +72,14 @@ k_hash_finish(const uint64_t* __restrict__ cand_xy, const uint8_t* __restrict__ 
   else { redo[i] = 1; for (int j = 0; j < 12; j++) o[j] = 0; }
 }
 
+const EdPoint* celo_composite_gens(size_t* count);   // seam_a.hip: the generator table (built once, ChaCha20 stream of the reference)
+static EdPoint* g_d_gens = nullptr;                  // its device copy (11.7 MB), uploaded on first use under the API lock
+static int ensure_device_gens(const EdPoint* h_gens, size_t ngens) {
+  if (g_d_gens) return 0;
+  if (hipMalloc(&g_d_gens, ngens * sizeof(EdPoint)) != hipSuccess) { g_d_gens = nullptr; return 10; }
+  if (hipMemcpy(g_d_gens, h_gens, ngens * sizeof(EdPoint), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g_d_gens); g_d_gens = nullptr; return 10; }
+  return 0;
+}
 static float g_hash_ms = 0.f;
 static int g_hash_rounds = 0;
 
@@ -82,10 +90,18 @@ static int g_hash_rounds = 0;
   } while (0)
 
 int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* extras, const uint64_t* extra_off,
-                          size_t n, uint64_t* out_xy, uint8_t* attempts, int xof_only) {
+                          size_t n, uint64_t* out_xy, uint8_t* attempts, int mode) {
+  size_t ngens = 0;
+  const EdPoint* h_gens = mode == TAI_COMPOSITE ? celo_composite_gens(&ngens) : nullptr;   // before the lock: 0.5 s on first use
   std::lock_guard<std::mutex> lk(api_mutex());
   if (int rc0 = api_ensure_init()) return rc0;
   if (n == 0) return 0;
+  if (mode == TAI_COMPOSITE) {
+    if (int rcg = ensure_device_gens(h_gens, ngens)) return rcg;
+    for (size_t i = 0; i < n; i++)   // counter || extra || message must fit the generator table (the reference panics)
+      if ((1 + (msg_off ? msg_off[i + 1] - msg_off[i] : 0) + (extra_off ? extra_off[i + 1] - extra_off[i] : 0)) * 8 > PEDERSEN_MAX_BITS) return 2;
+  }
+  const EdPoint* d_gens = mode == TAI_COMPOSITE ? g_d_gens : nullptr;
   if (!domain || !msg_off || !out_xy || !attempts || n > 0x3fffffffu) return 2;
   for (size_t i = 0; i < n; i++) {
     if (msg_off[i + 1] < msg_off[i] || (extra_off && extra_off[i + 1] < extra_off[i])) return 2;
@@ -127,7 +143,7 @@ int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint
       const uint32_t* list = round ? d_list + (size_t)(round & 1) * n : nullptr;
       uint32_t* next = d_list + (size_t)((round + 1) & 1) * n;
       const size_t lanes = (size_t)count << cand_log;
-      hipLaunchKernelGGL(k_hash_candidates, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, 0, dom, in, list, count, cand_log, base, xof_only, d_cand, d_att,
+      hipLaunchKernelGGL(k_hash_candidates, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, 0, dom, in, list, count, cand_log, base, mode, d_gens, d_cand, d_att,
                          next, d_cnt + round, k);
       HASH_TRY(hipGetLastError());
       HASH_TRY(hipMemcpyAsync(&count, d_cnt + round, 4, hipMemcpyDeviceToHost, 0));
@@ -151,7 +167,7 @@ int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint
       int c = 255;
       uint64_t* o = out_xy + i * 12;
       if (hash_to_g1_direct_tai(domain, msgs + msg_off[i], msg_off[i + 1] - msg_off[i], extra_off ? extras + extra_off[i] : nullptr,
-                                extra_off ? extra_off[i + 1] - extra_off[i] : 0, k, p, c, attempts[i] + 1, xof_only != 0)) { p.x.to_ark(o); p.y.to_ark(o + 6); attempts[i] = (uint8_t)c; }
+                                extra_off ? extra_off[i + 1] - extra_off[i] : 0, k, p, c, attempts[i] + 1, mode, h_gens)) { p.x.to_ark(o); p.y.to_ark(o + 6); attempts[i] = (uint8_t)c; }
       else { attempts[i] = 255; memset(o, 0, 96); }
     }
   }
@@ -171,7 +187,6 @@ k_pedersen_crh(const EdPoint* __restrict__ gens, const uint8_t* __restrict__ msg
   pedersen_crh(gens, msgs + off[i], (size_t)(off[i + 1] - off[i]), h);
   for (int j = 0; j < 48; j++) out[(size_t)i * 48 + j] = h[j];
 }
-const EdPoint* celo_composite_gens(size_t* count);   // seam_a.hip: the generator table (built once, ChaCha20 stream of the reference)
 
 int pedersen_crh_run(const uint8_t* msgs, const uint64_t* msg_off, size_t n, uint8_t* out48) {
   size_t ngens = 0;
@@ -185,15 +200,12 @@ int pedersen_crh_run(const uint8_t* msgs, const uint64_t* msg_off, size_t n, uin
   }
   const size_t mb = msg_off[n];
   if (mb && !msgs) return 2;
-  static EdPoint* d_gens = nullptr;
   uint8_t *d_bytes = nullptr, *d_out = nullptr;
   uint64_t* d_off = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = 0;
-  if (!d_gens) {
-    HASH_TRY(hipMalloc(&d_gens, ngens * sizeof(EdPoint)));
-    HASH_TRY(hipMemcpy(d_gens, gens, ngens * sizeof(EdPoint), hipMemcpyHostToDevice));
-  }
+  if (int rcg = ensure_device_gens(gens, ngens)) return rcg;
+  EdPoint* d_gens = g_d_gens;
   HASH_TRY(hipMalloc(&d_bytes, mb + 8));
   HASH_TRY(hipMalloc(&d_off, (n + 1) * 8));
   HASH_TRY(hipMalloc(&d_out, n * 48));

@@ -253,7 +253,13 @@ def decompress_last_ms():
     return ms.value
 
 
-def hash_to_g1_direct(domain, messages, extras=None, cip22_tail=False):
+def hash_to_g1_composite(domain, messages, extras=None, cip22=False):
+    """Batched hash-to-G1 with the composite hasher (include/celo_bls_amd.h: hash_to_g1_composite_bls12_377); same conventions
+    as hash_to_g1_direct."""
+    return hash_to_g1_direct(domain, messages, extras, composite=(2 if cip22 else 1))
+
+
+def hash_to_g1_direct(domain, messages, extras=None, cip22_tail=False, composite=0):
     """Batched try-and-increment hash-to-G1 over the direct hasher (include/celo_bls_amd.h: hash_to_g1_direct_bls12_377), or,
     with cip22_tail, the CIP22 loop over precomputed inner CRHs (hash_to_g1_cip22_tail_bls12_377: `messages` are the inner
     hashes).  domain: 8 bytes; messages / extras: lists of bytes (extras None = no extra data).  Returns (xy (n, 12) uint64
@@ -271,8 +277,11 @@ def hash_to_g1_direct(domain, messages, extras=None, cip22_tail=False):
     dom = np.frombuffer(bytes(domain), dtype=np.uint8)
     xy = np.zeros((n, 12), dtype=np.uint64)
     att = np.zeros(n, dtype=np.uint8)
-    fn = lib().hash_to_g1_cip22_tail_bls12_377 if cip22_tail else lib().hash_to_g1_direct_bls12_377
-    rc = fn(_p(dom), _p(mdat), _p(moff), _p(edat), _p(eoff), C.c_size_t(n), _p(xy), _p(att))
+    if composite:
+        rc = lib().hash_to_g1_composite_bls12_377(_p(dom), _p(mdat), _p(moff), _p(edat), _p(eoff), C.c_size_t(n), C.c_int(composite - 1), _p(xy), _p(att))
+    else:
+        fn = lib().hash_to_g1_cip22_tail_bls12_377 if cip22_tail else lib().hash_to_g1_direct_bls12_377
+        rc = fn(_p(dom), _p(mdat), _p(moff), _p(edat), _p(eoff), C.c_size_t(n), _p(xy), _p(att))
     if rc != 0:
         raise RuntimeError("hash_to_g1 (%s) failed with code %d" % ("cip22 tail" if cip22_tail else "direct", rc))
     return xy, att

@@ -131,6 +131,13 @@ int hash_to_g1_direct_bls12_377(const uint8_t domain[8], const uint8_t* msgs, co
  * curve point -> cofactor for every message.  Same layout and result conventions as hash_to_g1_direct_bls12_377. */
 int hash_to_g1_cip22_tail_bls12_377(const uint8_t domain[8], const uint8_t* inner, const uint64_t* inner_off /* n+1 */, const uint8_t* extras,
                                     const uint64_t* extra_off /* n+1 or NULL */, size_t n, uint64_t* out_xy /* n x 12 */, uint8_t* attempts /* n */);
+/* Batched hash-to-G1 with the COMPOSITE hasher (Pedersen CRH + Blake2Xs XOF), n messages per call: cip22 == 0:
+ * TryAndIncrement<CompositeHasher, G1>::hash_with_attempt (try_and_increment.rs:87-139: a CRH of counter || extra || message per
+ * attempt); cip22 != 0: the CIP22 form (try_and_increment_cip22.rs:81-134: one CRH per message, then
+ * hash_to_g1_cip22_tail_bls12_377).  What hash_composite / hash_composite_cip22 of the bls-snark-sys ABI compute for one
+ * message (signatures.rs:143,215).  Layout and results as hash_to_g1_direct_bls12_377. */
+int hash_to_g1_composite_bls12_377(const uint8_t domain[8], const uint8_t* msgs, const uint64_t* msg_off /* n+1 */, const uint8_t* extras,
+                                   const uint64_t* extra_off /* n+1 or NULL */, size_t n, int cip22, uint64_t* out_xy /* n x 12 */, uint8_t* attempts /* n */);
 /* The composite hasher's CRH for n messages in one launch: the Bowe-Hopwood-Pedersen hash over ed-on-BW6-761 that
  * CompositeHasher::crh evaluates (crates/bls-crypto/src/hashers/composite.rs:79-86; hash_crh of the bls-snark-sys ABI,
  * signatures.rs:169, is the one-message form).  out48: n x 48 bytes, the affine x coordinate little-endian.  A message longer

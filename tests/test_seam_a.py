@@ -393,6 +393,22 @@ def test_cip22_tail_on_gpu_reproduces_reference_points(sys_lib, gpu, golden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("key,cip22", [("g1_compat", False), ("g1_compat_cip22", True)])
+def test_composite_hash_to_g1_on_gpu_reproduces_reference_points(gpu, golden, key, cip22):
+    """hash_to_g1_composite_bls12_377 - Pedersen CRH, XOF, try-and-increment and cofactor all on the GPU - on the inputs of the
+    reference's compat vectors (crates/bls-crypto/src/hash_to_curve/mod.rs:412-449): the reference's twenty points byte for
+    byte, before and after CIP22."""
+    from oracle import cpu_oracle as co
+    gen, _ = _composite_inputs()
+    pts = golden["hash_to_curve"][key]["points"]
+    for (dom, msg, extra), hx in zip(gen(len(pts)), pts):
+        xy, att = gpu.hash_to_g1_composite(dom, [msg, msg], [extra, extra], cip22=cip22)
+        assert att[0] == att[1] < 255
+        vals = co.from_mont(xy.reshape(-1, 6), ecc.Q377)
+        assert ecc.ser_point(ecc.E1_377, (vals[0], vals[1])).hex() == hx and vals[2:] == vals[:2]
+
+
+@pytest.mark.gpu
 def test_bulk_pedersen_crh_on_gpu(sys_lib, gpu, golden):
     """composite_crh_bls12_377 (pedersen.h, one message per lane) against the reference's CRH vector
     (crates/bls-crypto/src/hashers/composite.rs:105-190, golden "composite_hasher" entries without an XOF length) and against

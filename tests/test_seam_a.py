@@ -435,13 +435,14 @@ def test_bulk_pedersen_crh_on_gpu(sys_lib, gpu, golden):
 
 
 @pytest.mark.gpu
-def test_batch_verify_signature_composite_cip22_many_messages(sys_lib, gpu):
-    """300 messages with the composite CIP22 hasher: inner CRHs on the host cores, the try-and-increment loops in one GPU call;
-    accept, and reject after one changed message byte."""
+@pytest.mark.parametrize("cip22", [False, True])
+def test_batch_verify_signature_composite_many_messages(sys_lib, gpu, cip22):
+    """300 messages with the composite hasher, before and after CIP22: all hashing (Pedersen CRHs, try-and-increment rounds) on
+    the GPU; accept, and reject after one changed message byte."""
     for f in ("sign_message", "batch_verify_signature"):
         getattr(sys_lib, f).restype = C.c_bool
     rng = ecc.SplitMix64(78)
-    CF, C22 = C.c_bool(True), C.c_bool(True)
+    CF, C22 = C.c_bool(True), C.c_bool(cip22)
     sk = ecc.random_scalar(rng, ecc.R377)
     skh = _deser(sys_lib, "deserialize_private_key", sk.to_bytes(32, "little"))
     pkh = C.c_void_p()

@@ -36,6 +36,7 @@ int ntt_run(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const ui
 int ntt_timings(float*, int*);
 int wire_decompress(int, const uint8_t*, size_t, int, uint64_t*, uint8_t*, int, void*);
 float wire_last_ms();
+int wire_normalize(int, const uint64_t*, size_t, uint64_t*, uint8_t*);
 int hash_to_g1_direct_run(const uint8_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*, uint8_t*, int);
 float hash_last_ms();
 int pedersen_crh_run(const uint8_t*, const uint64_t*, size_t, uint8_t*);
@@ -199,6 +200,8 @@ int hash_to_g1_composite_bls12_377(const uint8_t domain[8], const uint8_t* msgs,
 }
 int composite_crh_bls12_377(const uint8_t* msgs, const uint64_t* msg_off, size_t n, uint8_t* out48) { return pedersen_crh_run(msgs, msg_off, n, out48); }
 int celo_amd_hash_last_ms(float* ms) { if (!ms) return 2; *ms = hash_last_ms(); return 0; }
+int normalize_bls12_377_g1(const uint64_t* jac, size_t n, uint64_t* out_xy, uint8_t* inf) { return wire_normalize(0, jac, n, out_xy, inf); }
+int normalize_bls12_377_g2(const uint64_t* jac, size_t n, uint64_t* out_xy, uint8_t* inf) { return wire_normalize(1, jac, n, out_xy, inf); }
 int celo_amd_decompress_last_ms(float* ms) { if (!ms) return 2; *ms = wire_last_ms(); return 0; }
 int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]) {
   switch (group) {

@@ -31,6 +31,48 @@ template <bool G2> __global__ void __launch_bounds__(64) __attribute__((amdgpu_w
   }
 }
 
+// Jacobian -> affine for n points (ProjectiveCurve::batch_normalization_into_affine, called at crates/bls-crypto/src/bls/
+// signature.rs:82 and public.rs:58 before every MSM): Montgomery's trick inside a lane over K consecutive points - one field
+// inversion per K points, 3 products per point for the prefix / suffix products, then x = X z^-2, y = Y z^-3.  in: n x 3
+// coordinates (arkworks Montgomery limbs, identity = Z == 0); out: n x (x, y), zero rows + inf[i] = 1 for the identity.
+// Points that are already affine (Z == 1: everything that came off the wire) take part with z = 1; their x, y come out unchanged.
+template <class F, int K> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_normalize(const uint64_t* __restrict__ jac, uint64_t* __restrict__ out, uint8_t* __restrict__ inf, uint32_t n) {
+  constexpr int A = F::ARK64;
+  const uint32_t lo = (blockIdx.x * blockDim.x + threadIdx.x) * K;
+  if (lo >= n) return;
+  const uint32_t cnt = n - lo < (uint32_t)K ? n - lo : (uint32_t)K;
+  F z[K], pre[K];
+  bool id[K];
+  F acc = F::one();
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    id[j] = true;
+    z[j] = F::one();
+    if ((uint32_t)j < cnt) {
+      const F zj = F::norm(F::from_ark(jac + ((size_t)lo + j) * 3 * A + 2 * A));
+      id[j] = zj.is_zero_mod_p();
+      if (!id[j]) z[j] = zj;
+    }
+    pre[j] = acc;
+    acc = F::norm(F::mul(acc, z[j]));
+  }
+  F inv = F::norm(F::inv(acc));
+#pragma unroll
+  for (int j = K - 1; j >= 0; j--) {
+    if ((uint32_t)j >= cnt) continue;
+    const F zi = F::norm(F::mul(inv, pre[j]));
+    inv = F::norm(F::mul(inv, z[j]));
+    uint64_t* o = out + ((size_t)lo + j) * 2 * A;
+    inf[lo + j] = id[j] ? 1 : 0;
+    if (id[j]) { for (int q = 0; q < 2 * A; q++) o[q] = 0; continue; }
+    const uint64_t* src = jac + ((size_t)lo + j) * 3 * A;
+    const F zi2 = F::norm(F::sqr(zi));
+    F::mul(F::from_ark(src), zi2).to_ark(o);
+    F::mul(F::from_ark(src + A), F::norm(F::mul(zi2, zi))).to_ark(o + A);
+  }
+}
+
 static float g_wire_ms = 0.f;
 
 #define WIRE_TRY(x)                                                                                  \
@@ -75,6 +117,39 @@ done:
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   if (!dev) { if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); if (d_st) (void)hipFree(d_st); }
+  return rc;
+}
+int wire_normalize(int g2, const uint64_t* jac, size_t n, uint64_t* out_xy, uint8_t* inf) {
+  std::lock_guard<std::mutex> lk(api_mutex());
+  if (int rc0 = api_ensure_init()) return rc0;
+  if (n == 0) return 0;
+  if (!jac || !out_xy || !inf || n > 0x7fffffffu) return 2;
+  const size_t cw = g2 ? 12 : 6;
+  uint64_t *d_in = nullptr, *d_out = nullptr;
+  uint8_t* d_inf = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = 0;
+  WIRE_TRY(hipMalloc(&d_in, n * 3 * cw * 8));
+  WIRE_TRY(hipMalloc(&d_out, n * 2 * cw * 8));
+  WIRE_TRY(hipMalloc(&d_inf, n));
+  WIRE_TRY(hipMemcpyAsync(d_in, jac, n * 3 * cw * 8, hipMemcpyHostToDevice, 0));
+  WIRE_TRY(hipEventCreate(&e0));
+  WIRE_TRY(hipEventCreate(&e1));
+  WIRE_TRY(hipEventRecord(e0, 0));
+  if (g2) hipLaunchKernelGGL((k_normalize<Fq2, 4>), dim3(((uint32_t)((n + 3) / 4) + 63) / 64), dim3(64), 0, 0, d_in, d_out, d_inf, (uint32_t)n);
+  else hipLaunchKernelGGL((k_normalize<Fq, 8>), dim3(((uint32_t)((n + 7) / 8) + 63) / 64), dim3(64), 0, 0, d_in, d_out, d_inf, (uint32_t)n);
+  WIRE_TRY(hipGetLastError());
+  WIRE_TRY(hipEventRecord(e1, 0));
+  WIRE_TRY(hipMemcpyAsync(out_xy, d_out, n * 2 * cw * 8, hipMemcpyDeviceToHost, 0));
+  WIRE_TRY(hipMemcpyAsync(inf, d_inf, n, hipMemcpyDeviceToHost, 0));
+  WIRE_TRY(hipStreamSynchronize(0));
+  WIRE_TRY(hipEventElapsedTime(&g_wire_ms, e0, e1));
+done:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (d_inf) (void)hipFree(d_inf);
   return rc;
 }
 float wire_last_ms() { return g_wire_ms; }

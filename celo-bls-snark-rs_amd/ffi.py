@@ -306,3 +306,17 @@ def composite_crh(messages):
     if rc != 0:
         raise RuntimeError("composite_crh_bls12_377 failed with code %d" % rc)
     return [out[i].tobytes() for i in range(n)]
+
+
+def normalize(group, jac):
+    """Jacobian -> affine for n points in one GPU launch (include/celo_bls_amd.h: normalize_bls12_377_g1/_g2).  jac: (n, 18 | 36)
+    uint64; returns (xy (n, 12 | 24) uint64, inf (n,) uint8)."""
+    words, fn = {"g1": (6, "normalize_bls12_377_g1"), "g2": (12, "normalize_bls12_377_g2")}[group]
+    j = np.ascontiguousarray(jac, dtype=np.uint64).reshape(-1, 3 * words)
+    n = j.shape[0]
+    xy = np.zeros((n, 2 * words), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    rc = getattr(lib(), fn)(_p(j), C.c_size_t(n), _p(xy), _p(inf))
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (fn, rc))
+    return xy, inf

@@ -111,7 +111,13 @@ int decompress_bls12_377_g1(const uint8_t* in /* n x 48 */, size_t n, int check_
 int decompress_bls12_377_g2(const uint8_t* in /* n x 96 */, size_t n, int check_subgroup, uint64_t* out_xy /* n x 24 */, uint8_t* status /* n */);
 int decompress_bls12_377_g1_dev(const uint8_t* d_in, size_t n, int check_subgroup, uint64_t* d_out_xy, uint8_t* d_status, void* hip_stream);
 int decompress_bls12_377_g2_dev(const uint8_t* d_in, size_t n, int check_subgroup, uint64_t* d_out_xy, uint8_t* d_status, void* hip_stream);
-/* kernel time (HIP events) of the last decompress call */
+/* Jacobian -> affine for n points in one launch (Montgomery's trick inside each lane): replaces
+ * ProjectiveCurve::batch_normalization_into_affine as called before every MSM (crates/bls-crypto/src/bls/signature.rs:82,
+ * public.rs:58).  jac: n x (X, Y, Z) arkworks Montgomery limbs (G1: 18 u64, G2: 36 u64 per point; identity = Z == 0);
+ * out_xy: n x (x, y) in the layout the MSM / pairing entry points take, a zero row and inf[i] = 1 for the identity. */
+int normalize_bls12_377_g1(const uint64_t* jac /* n x 18 */, size_t n, uint64_t* out_xy /* n x 12 */, uint8_t* inf /* n */);
+int normalize_bls12_377_g2(const uint64_t* jac /* n x 36 */, size_t n, uint64_t* out_xy /* n x 24 */, uint8_t* inf /* n */);
+/* kernel time (HIP events) of the last decompress / normalize call */
 int celo_amd_decompress_last_ms(float* ms);
 
 /* ---- batched hash-to-G1, DIRECT hasher: n messages per launch, one per GPU lane.

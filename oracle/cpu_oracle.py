@@ -239,3 +239,17 @@ def time_decompress(group, data, check_subgroup=True, threads=1):
     st = np.zeros(n, dtype=np.uint8)
     lib().orc_time_decompress_bls12_377.restype = C.c_double
     return lib().orc_time_decompress_bls12_377(C.c_int(g2), _p(buf), C.c_size_t(n), C.c_int(1 if check_subgroup else 0), C.c_int(threads), _p(xy), _p(st))
+
+
+def normalize(kind, jac):
+    """ProjectiveCurve::batch_normalization_into_affine restated (orc_normalize_*): jac (n, 18 | 36) uint64 Jacobian Montgomery
+    limbs -> (xy (n, 12 | 24), inf (n,) uint8).  kind: 'g1_377' | 'g2_377'."""
+    words, fn = {"g1_377": (6, "orc_normalize_bls12_377_g1"), "g2_377": (12, "orc_normalize_bls12_377_g2")}[kind]
+    j = np.ascontiguousarray(jac, dtype=np.uint64).reshape(-1, 3 * words)
+    n = j.shape[0]
+    xy = np.zeros((n, 2 * words), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    if n:
+        assert getattr(lib(), fn)(_p(j), C.c_size_t(n), _p(xy), _p(inf)) == 0
+    xy[inf != 0] = 0
+    return xy, inf

@@ -137,3 +137,41 @@ def test_bulk_matches_oracle_c(gpu, group, n):
     wxy, wst = co.decompress(group, data, threads=8)
     assert np.array_equal(st, wst) and np.array_equal(xy, wxy)
     assert 0 < int((st != 0).sum()) < n // 8
+
+
+@pytest.mark.parametrize("group,n", [("g1", 1), ("g1", 7), ("g1", 8), ("g1", 9), ("g1", 1000), ("g2", 1), ("g2", 5), ("g2", 333)])
+def test_batch_normalisation_matches_oracle(gpu, group, n):
+    """normalize_bls12_377_g1/_g2 (Montgomery's trick inside a lane over 8 / 4 points) vs the oracle's restatement of
+    batch_normalization_into_affine: random Jacobian representatives (x z^2, y z^3, z), identities (Z = 0) and already-affine
+    points (Z = 1) mixed, ragged group sizes; and the affine values are the points we started from."""
+    curve, gen, kind, words, pack = ((ecc.E1_377, ecc.G1_377, "g1_377", 6, co.pack_g1_377) if group == "g1"
+                                     else (ecc.E2_377, ecc.G2_377, "g2_377", 12, co.pack_g2_377))
+    rng = ecc.SplitMix64(4000 + n)
+    base = seeded_points(curve, gen, 16, 17)
+    q = ecc.Q377
+    pts, rows = [], []
+    P = base[0]
+    for i in range(n):
+        P = curve.add(P, base[rng.next() % 16])
+        r = rng.next() % 8
+        z = 1 if r == 0 else ecc.random_scalar(rng, q - 1) + 1
+        if r == 1:
+            pts.append(None)
+            rows.append([rng.next(), rng.next(), 0] if group == "g1" else [rng.next(), 1, rng.next(), 2, 0, 0])   # arbitrary X, Y with Z = 0
+            continue
+        pts.append(P)
+        if group == "g1":
+            rows.append([P[0] * z * z % q, P[1] * z * z * z % q, z])
+        else:
+            f2 = ecc.F2_377
+            zz = (z, 0)
+            z2 = f2.mul(zz, zz)
+            X, Y = f2.mul(P[0], z2), f2.mul(P[1], f2.mul(z2, zz))
+            rows.append([X[0], X[1], Y[0], Y[1], z, 0])
+    jac = co.to_mont([v for r in rows for v in r], q).reshape(n, 3 * words)
+    xy, inf = gpu.normalize(group, jac)
+    wxy, winf = co.normalize(kind, jac)
+    assert np.array_equal(inf, winf) and np.array_equal(xy, wxy)
+    exy, einf = pack(pts)
+    exy[einf != 0] = 0
+    assert np.array_equal(inf, einf) and np.array_equal(xy, exy)

@@ -47,4 +47,21 @@ for group, curve, gen, size, words in (("g1", ecc.E1_377, ecc.G1_377, 48, 12), (
             res["cpu_port_allcores_checked_points_per_s"] = m2 / co.time_decompress(group, host[: m2 * size].tobytes(), True, T)
             res["cpu_threads"] = T
         out[f"{group}_2^{log_n}"] = res
+# Jacobian -> affine (normalize_bls12_377_g1/_g2; host buffers, kernel time from HIP events): field arithmetic only, so random
+# field elements serve as coordinates
+rng = np.random.default_rng(3)
+for group, words in (("g1", 6), ("g2", 12)):
+    n = 1 << 20
+    jac = rng.integers(0, 1 << 62, size=(n, 3 * words), dtype=np.int64).astype(np.uint64)
+    jac[:, 5::6] &= np.uint64((1 << 56) - 1)
+    best = None
+    for _ in range(3):
+        xy, inf = ffi.normalize(group, jac)
+        ms = ffi.decompress_last_ms()
+        best = ms if best is None or ms < best else best
+    res = {"kernel_ms": best, "points_per_s": n / (best * 1e-3), "alg_GBps": n * 5 * words * 8 / (best * 1e-3) / 1e9}
+    m = 1 << 14
+    import time
+    t0 = time.perf_counter(); co.normalize("g1_377" if group == "g1" else "g2_377", jac[:m]); res["cpu_port_1core_points_per_s"] = m / (time.perf_counter() - t0)
+    out[f"normalize_{group}_2^20"] = res
 print(json.dumps(out))

@@ -231,6 +231,18 @@ int ht_hash_to_g1_direct(const uint8_t* dom, const uint8_t* msg, size_t mlen, co
   p.y.to_ark(out_xy + 6);
   return c;
 }
+// table-driven root vs the Tonelli-Shanks loop on one Fq element (ark limbs): returns 1 + 2*(roots agree up to sign) when a root
+// exists for both, 0 when both say non-residue, -1 on disagreement
+int ht_wire_fq_sqrt_both(const uint64_t* a, uint64_t* out) {
+  const Fq x = Fq::from_ark(a);
+  Fq r1, r2;
+  const bool o1 = wire_fq_sqrt(x, wire_consts(), r1), o2 = wire_fq_sqrt_ts(x, wire_consts(), r2);
+  if (o1 != o2) return -1;
+  if (!o1) return 0;
+  r1.to_ark(out);
+  const bool same = wire_eq(r1, r2) || wire_eq(r1, wire_neg(r2));
+  return wire_eq(Fq::sqr(r1), x) && same ? 3 : -1;
+}
 // square root in Fq2 (ark limbs in and out); returns 1 when a root exists
 int ht_wire_fq2_sqrt(const uint64_t* a, uint64_t* out) {
   Fq2 r;

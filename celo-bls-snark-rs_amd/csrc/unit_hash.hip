@@ -11,6 +11,7 @@
 namespace celo {
 std::mutex& api_mutex();
 int api_ensure_init();
+int wire_consts_device(WireConsts& out);   // unit_wire.hip
 
 struct HashDom { uint8_t b[8]; };
 struct HashIn { const uint8_t* msgs; const uint64_t* msg_off; const uint8_t* extras; const uint64_t* extra_off; };
@@ -108,7 +109,9 @@ int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint
   }
   const size_t mb = msg_off[n], eb = extra_off ? extra_off[n] : 0;
   if ((mb && !msgs) || (eb && !extras)) return 2;
-  const WireConsts& k = wire_consts();
+  const WireConsts& kh = wire_consts();   // host tables (the serial fallback below)
+  WireConsts k;
+  if (int rck = wire_consts_device(k)) return rck;
   HashDom dom;
   memcpy(dom.b, domain, 8);
   uint8_t *d_bytes = nullptr, *d_att = nullptr, *d_redo = nullptr;
@@ -167,7 +170,7 @@ int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint
       int c = 255;
       uint64_t* o = out_xy + i * 12;
       if (hash_to_g1_direct_tai(domain, msgs + msg_off[i], msg_off[i + 1] - msg_off[i], extra_off ? extras + extra_off[i] : nullptr,
-                                extra_off ? extra_off[i + 1] - extra_off[i] : 0, k, p, c, attempts[i] + 1, mode, h_gens)) { p.x.to_ark(o); p.y.to_ark(o + 6); attempts[i] = (uint8_t)c; }
+                                extra_off ? extra_off[i + 1] - extra_off[i] : 0, kh, p, c, attempts[i] + 1, mode, h_gens)) { p.x.to_ark(o); p.y.to_ark(o + 6); attempts[i] = (uint8_t)c; }
       else { attempts[i] = 255; memset(o, 0, 96); }
     }
   }

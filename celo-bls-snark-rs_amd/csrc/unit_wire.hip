@@ -73,6 +73,17 @@ k_normalize(const uint64_t* __restrict__ jac, uint64_t* __restrict__ out, uint8_
   }
 }
 
+// the constants with the discrete-log tables in device memory (uploaded once; callers hold the API lock)
+int wire_consts_device(WireConsts& out) {
+  static WireTables* d_tab = nullptr;
+  out = wire_consts();
+  if (!d_tab) {
+    if (hipMalloc(&d_tab, sizeof(WireTables)) != hipSuccess) { d_tab = nullptr; return 10; }
+    if (hipMemcpy(d_tab, out.tab, sizeof(WireTables), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_tab); d_tab = nullptr; return 10; }
+  }
+  out.tab = d_tab;
+  return 0;
+}
 static float g_wire_ms = 0.f;
 
 #define WIRE_TRY(x)                                                                                  \
@@ -86,7 +97,8 @@ int wire_decompress(int g2, const uint8_t* in, size_t n, int check, uint64_t* ou
   if (int rc0 = api_ensure_init()) return rc0;
   if (n == 0) return 0;
   if (!in || !out || !status || n > 0x7fffffffu) return 2;
-  const WireConsts& k = wire_consts();
+  WireConsts k;
+  if (int rck = wire_consts_device(k)) return rck;
   const size_t ib = g2 ? 96 : 48, ow = g2 ? 24 : 12;
   hipStream_t stream = (hipStream_t)stream_;
   uint8_t *d_in = nullptr, *d_st = nullptr;

@@ -22,11 +22,17 @@ namespace celo {
 #define WIRE_FN inline
 #endif
 
+struct WireTables {         // for the discrete logarithm in the 2^46-th roots of unity (wire_fq_sqrt); 36 KB, host copy + device copy
+  Fq t8[256];               // reduce(h^j), h = z^(2^38): the 256-th roots of unity by exponent (the 64-th ones are every 4th entry)
+  Fq bt[12][16];            // z^(-j 2^(4m)): removes nibble m of the logarithm from b
+  Fq ht[12][16];            // z^(-j 2^(4m) / 2): the matching correction of the root (m = 0: even j only)
+};
 struct WireConsts {         // built once on the host (wire_consts()), handed to the kernels by value
   uint64_t tm1_half[6];     // (t - 1) / 2 where q - 1 = 2^46 t, t odd
   uint64_t r_order[4];      // r, the prime subgroup order
   Fq z;                     // c^t for the smallest quadratic non-residue c: a generator of the 2^46-th roots of unity
   Fq inv2, inv5;
+  const WireTables* tab;    // in the memory space of whoever runs the functions below (unit_wire.hip: wire_consts_device())
 };
 
 enum WireStatus : uint8_t { WIRE_OK = 0, WIRE_INFINITY = 1, WIRE_INVALID = 2, WIRE_NOT_IN_SUBGROUP = 3 };
@@ -62,9 +68,44 @@ HD bool wire_lex_largest(const Fq2& y) {  // arkworks orders Fq2 by c1 first, th
   return wire_lex_largest(y.c0);
 }
 
-// Tonelli-Shanks.  One exponentiation w = a^((t-1)/2) gives x = a w = a^((t+1)/2) and b = x w = a^t; b has order 2^46
-// exactly when a is a non-residue, which the order search of the first round detects (no separate Legendre symbol).
+// Square root in Fq (q - 1 = 2^46 t).  One exponentiation w = a^((t-1)/2) gives x = a w = a^((t+1)/2) and b = x w = a^t, a
+// 2^46-th root of unity: b = z^e, and a is a square exactly when e is even, with root x z^(-e/2).  e is found digit by
+// digit (Pohlig-Hellman, five 8-bit digits and one of 6 bits, least significant first): b^(2^(46 - s - w)) is a 2^w-th root
+// of unity whose exponent is the next digit - read off a table of the 256-th roots - and the digit is then divided out of b
+// while x collects the half power.  110 squarings and <= 24 products after the exponentiation, the same for every input:
+// the classic Tonelli-Shanks order search it replaces takes ~550 squarings on average and ~1000 for the slowest lane of a
+// wave.  An odd first digit means a non-residue.
 WIRE_FN bool wire_fq_sqrt(const Fq& a_, const WireConsts& k, Fq& out) {
+  const Fq a = Fq::norm(a_);
+  if (a.is_zero_mod_p()) { out = Fq::zero(); return true; }
+  const Fq w = Fq::pow64(a, k.tm1_half, 6);
+  Fq x = Fq::mul(a, w);
+  Fq b = Fq::mul(x, w);
+  const WireTables& T = *k.tab;
+  for (int i = 0; i < 6; i++) {
+    const int s = 8 * i, wd = i == 5 ? 6 : 8, stride = i == 5 ? 4 : 1;
+    Fq u = b;
+    for (int q = 0; q < 46 - s - wd; q++) u = Fq::sqr(u);
+    u = Fq::reduce(u);
+    int e = -1;
+    for (int j = 0; j < (1 << wd); j++) {
+      const Fq& c = T.t8[j * stride];
+      if (c.l[0] != u.l[0] || c.l[1] != u.l[1]) continue;
+      bool same = true;
+      for (int q = 2; q < P377::L; q++) same = same && c.l[q] == u.l[q];
+      if (same) { e = j; break; }
+    }
+    if (e < 0) return false;                 // cannot happen: b is a 2^46-th root of unity
+    if (i == 0 && (e & 1)) return false;     // odd logarithm: a is a non-residue
+    const int lo = e & 15, hi = e >> 4;
+    if (lo) { b = Fq::mul(b, T.bt[2 * i][lo]); x = Fq::mul(x, T.ht[2 * i][lo]); }
+    if (hi) { b = Fq::mul(b, T.bt[2 * i + 1][hi]); x = Fq::mul(x, T.ht[2 * i + 1][hi]); }
+  }
+  out = x;
+  return true;
+}
+// The textbook Tonelli-Shanks loop (order search): kept as the cross-check of the table-driven root (tests/test_host_field.py)
+WIRE_FN bool wire_fq_sqrt_ts(const Fq& a_, const WireConsts& k, Fq& out) {
   const Fq a = Fq::norm(a_);
   if (a.is_zero_mod_p()) { out = Fq::zero(); return true; }
   const Fq w = Fq::pow64(a, k.tm1_half, 6);
@@ -182,6 +223,30 @@ inline WireConsts wire_consts_build() {
   const uint64_t two[6] = {2, 0, 0, 0, 0, 0}, five[6] = {5, 0, 0, 0, 0, 0};
   k.inv2 = Fq::inv(Fq::from_canonical(two));
   k.inv5 = Fq::inv(Fq::from_canonical(five));
+  // the discrete-log tables of wire_fq_sqrt
+  static WireTables T;
+  Fq h = k.z;
+  for (int i = 0; i < 38; i++) h = Fq::sqr(h);                       // z^(2^38): a primitive 256-th root of unity
+  Fq p = Fq::one();
+  for (int j = 0; j < 256; j++) { T.t8[j] = Fq::reduce(p); p = Fq::mul(p, h); }
+  const Fq zi = Fq::inv(k.z);
+  Fq base = zi;                                                       // z^-(2^(4m)) for m = 0, 1, ...
+  Fq half = zi;                                                       // z^-(2^(4m - 1)) for m >= 1 (m = 0 handled below)
+  for (int m = 0; m < 12; m++) {
+    Fq pb = Fq::one(), ph = Fq::one();
+    for (int j = 0; j < 16; j++) {
+      T.bt[m][j] = Fq::wred(Fq::norm(pb));
+      pb = Fq::mul(pb, base);
+      if (m == 0) { T.ht[0][j] = Fq::wred(Fq::norm(ph)); if (j & 1) ph = Fq::mul(ph, zi); }   // entry j (even) = z^-(j/2); odd entries unused
+      else { T.ht[m][j] = Fq::wred(Fq::norm(ph)); ph = Fq::mul(ph, half); }
+    }
+    // next m: base <- base^16; half <- z^-(2^(4(m+1) - 1)) = base^8
+    Fq b8 = base;
+    for (int q = 0; q < 3; q++) b8 = Fq::sqr(b8);
+    half = b8;
+    base = Fq::sqr(b8);
+  }
+  k.tab = &T;
   return k;
 }
 inline const WireConsts& wire_consts() {

@@ -239,3 +239,33 @@ def test_hash_to_g1_direct_under_bounds_tracking(ht):
             c = ht.ht_hash_to_g1_direct(dom, msg, C.c_size_t(mlen), extra, C.c_size_t(elen), _p(out))
             P, wc = hs.hash_to_g1(dom, msg, extra, composite=False)
             assert c == wc and co.from_mont(out.reshape(2, 6), ecc.Q377) == [P[0], P[1]]
+
+
+def test_table_driven_square_root_agrees_with_tonelli_shanks(ht):
+    """wire_fq_sqrt (discrete log in the 2^46-th roots of unity by 8-bit digits) vs the textbook Tonelli-Shanks loop, under bounds
+    tracking: same verdict, same root up to sign, root^2 == a; squares of elements of every 2-power order (z^(2^k) for the
+    2-Sylow generator: logarithms with long runs of zero digits), 0, 1, and random residues / non-residues."""
+    p = ecc.Q377
+    random.seed(5)
+    t = (p - 1) >> 46
+    c = 2
+    while pow(c, (p - 1) // 2, p) == 1:
+        c += 1
+    z = pow(c, t, p)
+    cases = [0, 1, p - 1, 4, c, c * c % p]
+    cases += [pow(z, 1 << k, p) for k in range(0, 47)]                  # every 2-power order; k = 0 (and odd powers of z) are non-residues
+    cases += [pow(z, (1 << k) * 3, p) * 9 % p for k in range(0, 46, 5)]
+    cases += [random.randrange(p) for _ in range(40)]
+    n_res = 0
+    for a in cases:
+        A = co.to_mont([a], p).reshape(-1)
+        out = np.zeros(6, dtype=np.uint64)
+        rc = ht.ht_wire_fq_sqrt_both(_p(A), _p(out))
+        want = ecc.sqrt_fp(a, p)
+        assert rc in (0, 3), a
+        assert (rc == 3) == (want is not None)
+        if rc == 3:
+            n_res += 1
+            r = co.from_mont(out, p)[0]
+            assert r * r % p == a
+    assert 20 < n_res < len(cases)

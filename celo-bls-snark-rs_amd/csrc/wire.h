@@ -1,5 +1,5 @@
 // Compressed-point decoding for BLS12-377 G1 / G2 (arkworks 0.1 CanonicalDeserialize: x little-endian, flags in the two top
-// bits of the last byte) as host+device templates: the square root (Tonelli-Shanks over Fq, 2-adicity
+// bits of the last byte) as host+device templates: the square root (Fq: a discrete log in the 2-Sylow subgroup, 2-adicity
 // 46; the norm method over Fq2 = Fq[u]/(u^2+5)), the choice of y by the "lexicographically largest" flag, and the
 // prime-order subgroup check r*P = O that GroupAffine::deserialize performs.  SURVEY.md section 8f row f2: what the
 // reference does once per key in PublicKey::deserialize / Signature::deserialize (crates/bls-crypto/src/bls/public.rs:123-149,

@@ -101,7 +101,7 @@ int celo_amd_ntt_last_timings(float ms[4], int* passes);
 /* ---- bulk decoding of compressed points: n keys or signatures in arkworks 0.1 wire form
  * (G1: 48 B, G2: 96 B; x little-endian, flag bits 0x80 = "y is the larger root", 0x40 = infinity in the last byte) to
  * affine (x, y) in arkworks Montgomery limbs - the layout the MSM and pairing entry points take.  One point per GPU lane:
- * the square root (Tonelli-Shanks in Fq, the norm method in Fq2), the sign choice and, with check_subgroup != 0, r*P == O.
+ * the square root (table-driven in Fq, the norm method in Fq2), the sign choice and, with check_subgroup != 0, r*P == O.
  * Replaces the per-key work of PublicKey::deserialize / Signature::deserialize (crates/bls-crypto/src/bls/public.rs:123-149,
  * signature.rs:31-57: GroupAffine::deserialize = get_point_from_x + is_in_correct_subgroup_assuming_on_curve) and of the
  * per-validator loop of the epoch FFI (crates/bls-snark-sys/src/snark/epoch_block.rs:187-196).

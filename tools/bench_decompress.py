@@ -14,7 +14,7 @@ ffi.init(0)
 out = {}
 sizes = [int(a) for a in sys.argv[1:]] or [10, 14, 16, 18, 20]
 for group, curve, gen, size, words in (("g1", ecc.E1_377, ecc.G1_377, 48, 12), ("g2", ecc.E2_377, ecc.G2_377, 96, 24)):
-    # 256 distinct valid encodings, tiled (the work per point does not depend on the point beyond the Tonelli-Shanks trip counts)
+    # 256 distinct valid encodings, tiled (the work per point does not depend on the point)
     P, enc = gen, []
     for i in range(256):
         P = curve.add(curve.add(P, P), gen)

@@ -176,7 +176,7 @@ HD bool tai_finish(const Affine<Fq>& p, Affine<Fq>& out) {
     if ((cof[i >> 6] >> (i & 63)) & 1) xyzz_madd(s, p);
   }
   if (s.is_identity() || s.ZZ.is_zero_mod_p()) return false;
-  const Fq t = Fq::inv(Fq::mul(s.ZZ, s.ZZZ));
+  const Fq t = wire_inv(Fq::mul(s.ZZ, s.ZZZ));
   out.x = Fq::norm(Fq::mul(s.X, Fq::mul(t, s.ZZZ)));
   out.y = Fq::norm(Fq::mul(s.Y, Fq::mul(t, s.ZZ)));
   return true;

@@ -64,7 +64,7 @@ template <class Src> HD void pedersen_crh_src(const EdPoint* gens, const Src& sr
     if (bits & 4) enc = ed_neg(enc);
     total = ed_add(total, enc);
   }
-  const SF x = total.X * SF::from(Fq::inv(total.Z.v));
+  const SF x = total.X * SF::from(wire_inv(total.Z.v));
   uint64_t w[6];
   x.v.to_canonical(w);
   for (int i = 0; i < 48; i++) out48[i] = (uint8_t)(w[i >> 3] >> (8 * (i & 7)));

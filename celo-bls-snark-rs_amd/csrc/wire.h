@@ -68,6 +68,32 @@ HD bool wire_lex_largest(const Fq2& y) {  // arkworks orders Fq2 by c1 first, th
   return wire_lex_largest(y.c0);
 }
 
+// a^e for a multi-limb exponent, fixed 4-bit windows (MSB first): ~25 % fewer products than square-and-multiply for the
+// 331- and 377-bit exponents of the root and the inversion.  The 15-entry table lives in private memory (dynamic index).
+WIRE_FN Fq wire_pow_w4(const Fq& a_, const uint64_t* e, int nlimbs) {
+  Fq tab[16];
+  tab[0] = Fq::one();
+  tab[1] = Fq::norm(a_);
+  for (int j = 2; j < 16; j++) tab[j] = Fq::mul(tab[j - 1], tab[1]);
+  Fq r = Fq::one();
+  bool started = false;
+  for (int i = nlimbs * 16 - 1; i >= 0; i--) {
+    const uint32_t nib = (uint32_t)(e[i >> 4] >> (4 * (i & 15))) & 15u;
+    if (started) { r = Fq::sqr(r); r = Fq::sqr(r); r = Fq::sqr(r); r = Fq::sqr(r); }
+    if (nib) {
+      r = started ? Fq::mul(r, tab[nib]) : tab[nib];
+      started = true;
+    }
+  }
+  return r;
+}
+WIRE_FN Fq wire_inv(const Fq& a) {   // a^(q - 2)
+  uint64_t e[6];
+  for (int i = 0; i < 6; i++) e[i] = P377::P64[i];
+  e[0] -= 2;
+  return wire_pow_w4(a, e, 6);
+}
+
 // Square root in Fq (q - 1 = 2^46 t).  One exponentiation w = a^((t-1)/2) gives x = a w = a^((t+1)/2) and b = x w = a^t, a
 // 2^46-th root of unity: b = z^e, and a is a square exactly when e is even, with root x z^(-e/2).  e is found digit by
 // digit (Pohlig-Hellman, five 8-bit digits and one of 6 bits, least significant first): b^(2^(46 - s - w)) is a 2^w-th root
@@ -78,7 +104,7 @@ HD bool wire_lex_largest(const Fq2& y) {  // arkworks orders Fq2 by c1 first, th
 WIRE_FN bool wire_fq_sqrt(const Fq& a_, const WireConsts& k, Fq& out) {
   const Fq a = Fq::norm(a_);
   if (a.is_zero_mod_p()) { out = Fq::zero(); return true; }
-  const Fq w = Fq::pow64(a, k.tm1_half, 6);
+  const Fq w = wire_pow_w4(a, k.tm1_half, 6);
   Fq x = Fq::mul(a, w);
   Fq b = Fq::mul(x, w);
   const WireTables& T = *k.tab;
@@ -152,7 +178,7 @@ WIRE_FN bool wire_fq2_sqrt(const Fq2& a, const WireConsts& k, Fq2& out) {
     d = Fq::mul(Fq::norm(Fq::sub<4, 1>(a0, Fq::norm(al))), k.inv2);
     if (!wire_fq_sqrt(d, k, x0)) return false;
   }
-  const Fq x1 = Fq::mul(a1, Fq::inv(Fq::norm(Fq::dbl(x0))));
+  const Fq x1 = Fq::mul(a1, wire_inv(Fq::norm(Fq::dbl(x0))));
   out = {x0, x1};
   const Fq2 chk = Fq2::sqr(out);
   return wire_eq(chk.c0, a0) && wire_eq(chk.c1, a1);

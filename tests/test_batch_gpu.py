@@ -40,6 +40,31 @@ def test_batch_g1_mixed_sizes_136bit(gpu):
     _check_batch(gpu, "bls12_377_g1", "g1_377", ecc.E1_377, ecc.G1_377, co.pack_g1_377, [1, 17, 256, 0, 300, 64], 136, 1)
 
 
+@pytest.mark.parametrize("bits", [1, 4, 5, 6, 31, 32, 33, 64, 65, 135, 137, 252])
+def test_batch_window_count_follows_the_longest_scalar(gpu, bits):
+    """the batch path sizes its window count by the longest scalar present (k_scalar_or): lengths on both sides of the 5-bit
+    window and 32-bit limb boundaries, one instance whose top scalar is exactly 2^bits - 1 among shorter ones"""
+    _check_batch(gpu, "bls12_377_g1", "g1_377", ecc.E1_377, ecc.G1_377, co.pack_g1_377, [9, 40, 1, 130], bits, 100 + bits)
+    rng = ecc.SplitMix64(900 + bits)
+    pts = [ecc.E1_377.mul(ecc.G1_377, rng.next() | 1) for _ in range(20)]
+    sc = [ecc.random_scalar(rng, 1 << max(1, bits - 3)) for _ in range(20)]
+    sc[13] = (1 << bits) - 1
+    xy, inf = co.pack_g1_377(pts)
+    s_np = H.scalars_np(sc, 4)
+    offs = np.array([0, 12, 20], dtype=np.uint32)
+    got = gpu.msm_batch("bls12_377_g1", xy, inf, s_np, offs)
+    for i in range(2):
+        lo, hi = int(offs[i]), int(offs[i + 1])
+        assert co.jac_to_affine(got[i], "g1_377") == co.jac_to_affine(co.msm("bls12_377_g1", xy[lo:hi], inf[lo:hi], s_np[lo:hi], threads=1), "g1_377")
+
+
+def test_batch_all_zero_scalars(gpu):
+    pts = [ecc.E1_377.mul(ecc.G1_377, 5 + i) for i in range(10)]
+    xy, inf = co.pack_g1_377(pts)
+    got = gpu.msm_batch("bls12_377_g1", xy, inf, H.scalars_np([0] * 10, 4), np.array([0, 4, 10], dtype=np.uint32))
+    assert co.jac_to_affine(got[0], "g1_377") is None and co.jac_to_affine(got[1], "g1_377") is None
+
+
 def test_batch_g1_full_scalars(gpu):
     _check_batch(gpu, "bls12_377_g1", "g1_377", ecc.E1_377, ecc.G1_377, co.pack_g1_377, [33, 256, 700], 252, 2)
 

@@ -23,6 +23,10 @@ EXPORTS = [
     "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
     "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
+    "ntt_bw6_761_fr", "ntt_bw6_761_fr_dev",
+    "decompress_bls12_377_g1", "decompress_bls12_377_g2", "decompress_bls12_377_g1_dev", "decompress_bls12_377_g2_dev",
+    "normalize_bls12_377_g1", "normalize_bls12_377_g2",
+    "hash_to_g1_direct_bls12_377", "hash_to_g1_composite_bls12_377", "hash_to_g1_cip22_tail_bls12_377", "composite_crh_bls12_377",
 ]
 
 _lib = None

@@ -41,3 +41,16 @@ def test_no_device_fails_loudly():
     sc = np.ones((2, 4), dtype=np.uint64)
     with pytest.raises(RuntimeError):
         ffi.msm("bls12_377_g1", xy, None, sc)
+    # the rows either side of the path refuse as well: decoding, normalisation, hashing, the NTT
+    with pytest.raises(RuntimeError):
+        ffi.decompress("g1", bytes(48))
+    with pytest.raises(RuntimeError):
+        ffi.normalize("g1", np.zeros((1, 18), dtype=np.uint64))
+    with pytest.raises(RuntimeError):
+        ffi.hash_to_g1_direct(b"ULforxof", [b"m"])
+    with pytest.raises(RuntimeError):
+        ffi.hash_to_g1_composite(b"ULforxof", [b"m"], cip22=True)
+    with pytest.raises(RuntimeError):
+        ffi.composite_crh([b"m"])
+    with pytest.raises(RuntimeError):
+        ffi.ntt(np.zeros((2, 6), dtype=np.uint64), 1, np.zeros(6, dtype=np.uint64))

@@ -1,23 +1,46 @@
 // extern "C" boundary of the gfx950 hot path (include/celo_bls_amd.h).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <mutex>
 #include <condition_variable>
 #include <vector>
 #include <cstring>
 #include <cstdio>
 #include "../../include/celo_bls_amd.h"
+#include "runtime.h"
 
 namespace celo {
-std::mutex& api_mutex() { static std::mutex m; return m; }
-static bool g_inited = false;
-int api_ensure_init() {
-  if (g_inited) return 0;
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+// Device binding.  HIP's current device is a per-thread setting, and this library is entered from many host threads (and
+// starts its own): every entry point passes through api_enter(), which applies the calling thread's device - the one bound
+// with celo_amd_use_device(), else the process default chosen by celo_amd_init() (device 0 if init was never called).
+static std::atomic<int> g_device_count{-1};
+static std::atomic<int> g_default_device{0};
+static thread_local int t_bound_device = -1;
+static thread_local int t_applied_device = -1;
+static int device_count() {
+  int n = g_device_count.load();
+  if (n >= 0) return n;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  if (n > MAX_DEVICES) n = MAX_DEVICES;
+  g_device_count.store(n);
+  return n;
+}
+int api_device() { return t_bound_device >= 0 ? t_bound_device : g_default_device.load(); }
+int api_enter() {
+  if (device_count() == 0) {
     fprintf(stderr, "[celo-amd] no HIP device: the MSM/pairing path has no CPU fallback\n");
     return 100;
   }
-  g_inited = true;
+  const int dev = api_device();
+  if (t_applied_device != dev) {
+    if (hipSetDevice(dev) != hipSuccess) return 102;
+    t_applied_device = dev;
+  }
+  return 0;
+}
+int api_bind_thread(int device) {
+  if (device < 0 || device >= device_count()) return 101;
+  t_bound_device = device;
   return 0;
 }
 #define DECL(TAG)                                                                                     \
@@ -26,8 +49,10 @@ int api_ensure_init() {
   int msm_batch_host_##TAG(const uint64_t*, const uint8_t*, const uint64_t*, const uint32_t*, size_t, uint64_t*); \
   int msm_timings_##TAG(float*, int*);                                                                \
   int msm_set_c_##TAG(int);                                                                           \
-  int gen_points_##TAG(void*, size_t, uint64_t, const uint64_t*, void*);                              \
+  int gen_points_##TAG(void*, size_t, uint64_t, const uint64_t*, size_t, uint32_t, void*);                              \
   int sum_jac_##TAG(const uint64_t*, size_t, uint64_t*);                                              \
+  int msm_multi_host_##TAG(const int*, int, const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*); \
+  int msm_multi_dev_##TAG(const int*, int, const void* const*, const void* const*, const void* const*, const size_t*, uint64_t*); \
   void msm_note_big_call_##TAG();
 DECL(g1_377) DECL(g2_377) DECL(761)
 int pairing_run_377(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
@@ -41,26 +66,48 @@ int hash_to_g1_direct_run(const uint8_t*, const uint8_t*, const uint64_t*, const
 float hash_last_ms();
 int pedersen_crh_run(const uint8_t*, const uint64_t*, size_t, uint8_t*);
 int pairing_run_761(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
+int batch_verify_377_run(const void*, const void*, const void*, int, const uint32_t*, const void*, const uint64_t*, size_t, uint8_t*);
 }  // namespace celo
 using namespace celo;
 
 extern "C" {
 int celo_amd_init(int device) {
-  std::lock_guard<std::mutex> lk(api_mutex());
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return 100;
+  const int n = device_count();
+  if (n == 0) return 100;
   if (device < 0 || device >= n) return 101;
-  if (hipSetDevice(device) != hipSuccess) return 102;
-  g_inited = true;
-  return 0;
+  g_default_device.store(device);      // every thread that has not bound itself to a device uses this one from now on
+  t_bound_device = -1;
+  return api_enter();
+}
+int celo_amd_use_device(int device) {
+  if (device_count() == 0) return 100;
+  if (int rc = api_bind_thread(device)) return rc;
+  return api_enter();
+}
+int celo_amd_device_count(int* count) {
+  if (!count) return 2;
+  *count = device_count();
+  return *count ? 0 : 100;
 }
 int celo_amd_device_name(char* buf, size_t buflen) {
+  if (int rc = api_enter()) return rc;
   hipDeviceProp_t p;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 100;
+  if (hipGetDeviceProperties(&p, api_device()) != hipSuccess) return 100;
   snprintf(buf, buflen, "%s", p.gcnArchName);
   return 0;
 }
+#define MULTI(NAME, TAG)                                                                                                              \
+  int NAME##_multi(const int* devices, int ndev, const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { \
+    msm_note_big_call_##TAG();                                                                                                        \
+    return msm_multi_host_##TAG(devices, ndev, b, inf, s, n, out);                                                                    \
+  }                                                                                                                                   \
+  int NAME##_multi_dev(const int* devices, int ndev, const void* const* b, const void* const* inf, const void* const* s,              \
+                       const size_t* n_per, uint64_t* out) {                                                                          \
+    msm_note_big_call_##TAG();                                                                                                        \
+    return msm_multi_dev_##TAG(devices, ndev, b, inf, s, n_per, out);                                                                 \
+  }
+MULTI(msm_bls12_377_g1, g1_377) MULTI(msm_bls12_377_g2, g2_377) MULTI(msm_bw6_761_g1, 761) MULTI(msm_bw6_761_g2, 761)
+#undef MULTI
 int msm_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g1_377(); return msm_host_g1_377(b, inf, s, n, out); }
 int msm_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g2_377(); return msm_host_g2_377(b, inf, s, n, out); }
 int msm_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_761(); return msm_host_761(b, inf, s, n, out); }
@@ -76,8 +123,8 @@ int msm_batch_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* 
 // Single-product checks from concurrent host threads are COMBINED: bls-snark-sys is synchronous and re-entrant and its callers
 // verify from many threads ("Threading"); one product keeps one lane group of the GPU busy for ~11 ms, so
 // serialising callers behind a mutex would cap the library at ~90 verifications/s.  The first caller to arrive becomes the
-// leader: it drains the queue of pending products, runs them as ONE batched launch, publishes the verdicts and repeats
-// until the queue is empty; the others sleep on a condition variable.
+// leader of a round: it takes the queue of pending products, runs them as ONE batched launch and publishes the verdicts; the
+// others sleep on a condition variable, and one of those still waiting leads the next round.
 namespace {
 struct ProductJob {
   const uint64_t* g1; const uint8_t* inf1; const uint64_t* g2; const uint8_t* inf2; size_t k;
@@ -121,21 +168,22 @@ int pairing_product_is_one_bls12_377(const uint64_t* g1, const uint8_t* inf1, co
   ProductJob job{g1, inf1, g2, inf2, k};
   std::unique_lock<std::mutex> lk(q_mu);
   q_pending.push_back(&job);
-  if (q_leader) {
-    q_cv.wait(lk, [&] { return job.done; });
-  } else {
+  while (!job.done) {
+    if (q_leader) { q_cv.wait(lk); continue; }
+    // lead ONE round: everything pending right now (this job included) becomes one launch; whoever is still waiting when
+    // it is over leads the next round, so no caller serves the queue for longer than its own verdict takes
     q_leader = true;
-    while (!q_pending.empty()) {
-      std::vector<ProductJob*> batch;
-      batch.swap(q_pending);
-      lk.unlock();
-      run_products(batch);
-      lk.lock();
-      for (ProductJob* j : batch) j->done = true;
-      q_cv.notify_all();
-    }
+    std::vector<ProductJob*> batch;
+    batch.swap(q_pending);
+    lk.unlock();
+    try { run_products(batch); }
+    catch (...) { for (ProductJob* j : batch) j->rc = 103; }     // e.g. std::bad_alloc while staging: every job of the round fails
+    lk.lock();
+    for (ProductJob* j : batch) j->done = true;
     q_leader = false;
+    q_cv.notify_all();
   }
+  lk.unlock();
   if (job.rc == 0 && is_one) *is_one = job.is_one;
   return job.rc;
 }
@@ -157,6 +205,14 @@ int pairing_product_is_one_bw6_761(const uint64_t* g1, const uint8_t* inf1, cons
 int celo_amd_pairing_gt_bw6_761(const uint64_t* g1, const uint8_t* inf1, const uint64_t* g2, const uint8_t* inf2, const uint32_t* offsets,
                                 size_t m, int miller_only, uint64_t* gt72) {
   return pairing_run_761(g1, inf1, g2, inf2, offsets, m, nullptr, gt72, miller_only ? 1 : 0);
+}
+int batch_verify_bls12_377(const uint64_t* pk_xy, const uint64_t* sig_xy, const uint64_t* exponents, const uint32_t* offsets, const uint64_t* hash_xy,
+                           const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
+  return batch_verify_377_run(pk_xy, sig_xy, exponents, 0, offsets, hash_xy, neg_g2_xy, m, out_ok);
+}
+int batch_verify_bls12_377_dev(const void* d_pk_xy, const void* d_sig_xy, const void* d_exponents, const uint32_t* offsets, const void* d_hash_xy,
+                               const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
+  return batch_verify_377_run(d_pk_xy, d_sig_xy, d_exponents, 1, offsets, d_hash_xy, neg_g2_xy, m, out_ok);
 }
 int celo_amd_pairing_last_timings(float ms[4]) { return pairing_timings_377(ms); }
 int ntt_bw6_761_fr(uint64_t* data, unsigned log_n, const uint64_t omega[6], const uint64_t* coset, int coset_after, const uint64_t* scale) {
@@ -223,7 +279,13 @@ int celo_amd_msm_set_window_bits(int group, int c) {
 int celo_amd_sum_jacobian_bls12_377_g1(const uint64_t* j, size_t k, uint64_t* out) { return sum_jac_g1_377(j, k, out); }
 int celo_amd_sum_jacobian_bls12_377_g2(const uint64_t* j, size_t k, uint64_t* out) { return sum_jac_g2_377(j, k, out); }
 int celo_amd_sum_jacobian_bw6_761(const uint64_t* j, size_t k, uint64_t* out) { return sum_jac_761(j, k, out); }
-int celo_amd_gen_points_bls12_377_g1_dev(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) { return gen_points_g1_377(d, n, seed, g, st); }
-int celo_amd_gen_points_bls12_377_g2_dev(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) { return gen_points_g2_377(d, n, seed, g, st); }
-int celo_amd_gen_points_bw6_761_dev(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) { return gen_points_761(d, n, seed, g, st); }
+int celo_amd_gen_points_bls12_377_g1_dev(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) { return gen_points_g1_377(d, n, seed, g, 1, 0, st); }
+int celo_amd_gen_points_bls12_377_g2_dev(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) { return gen_points_g2_377(d, n, seed, g, 1, 0, st); }
+int celo_amd_gen_points_bw6_761_dev(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) { return gen_points_761(d, n, seed, g, 1, 0, st); }
+int celo_amd_gen_points_grouped_bls12_377_g1_dev(void* d, size_t n, uint64_t seed, const uint64_t* gens, size_t ngens, uint32_t per, void* st) {
+  return gen_points_g1_377(d, n, seed, gens, ngens, per, st);
+}
+int celo_amd_gen_points_grouped_bls12_377_g2_dev(void* d, size_t n, uint64_t seed, const uint64_t* gens, size_t ngens, uint32_t per, void* st) {
+  return gen_points_g2_377(d, n, seed, gens, ngens, per, st);
+}
 }

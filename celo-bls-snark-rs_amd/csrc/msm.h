@@ -29,6 +29,7 @@
 #include "host64.h"
 #include "curve_lanes.h"
 #include "fp2.h"
+#include "runtime.h"
 
 namespace celo {
 
@@ -657,6 +658,7 @@ template <class G> class MsmEngine {
     return n < (size_t(1) << 19) ? 15 : 16;
   }
   int force_c = 0;  // test hook / tuning: 0 = auto
+  hipStream_t own_stream() { return stream_.get(); }   // this engine's non-blocking stream (host-pointer entry points)
   bool lane_horner = true;  // batched path: three lanes per instance in the Horner pass (tuning hook)
 
   // bases/scalars/inf are DEVICE pointers (ark layout); result: Jacobian in ark Montgomery form (3*ARK64 u64) on host.
@@ -706,6 +708,7 @@ template <class G> class MsmEngine {
     const size_t o_partials = take((size_t)slots * IO::XYZZ_WORDS * 4);
     const size_t o_work = take(((size_t)res_pts + 2 * (size_t)half_pts + 64) * IO::XYZZ_WORDS * 4);
     if (ensure(off)) return 1;
+    if (res_pts > H_OUT_POINTS) return 2;
     char* A = arena;
     uint32_t* d_bases = (uint32_t*)(A + o_bases);
     uint16_t* d_digits = (uint16_t*)(A + o_digits);
@@ -856,6 +859,14 @@ template <class G> class MsmEngine {
   int batch_bits = 0;   // length of the longest scalar of the last batched call
   int run_batch_host(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m,
                      uint64_t* out, hipStream_t stream) {
+    return run_batch(bases, inf, scalars, 0, offsets, m, out, nullptr, stream);
+  }
+  // resident = 0: bases / inf / scalars are HOST pointers (staged into the arena); 1: DEVICE pointers (used in place).
+  // out: host buffer for the m Jacobian results, or nullptr to leave them on the device: *d_out_ret then points at them (in this
+  // engine's arena, valid until its next call) and the call returns with the work ENQUEUED on `stream`, not finished - the
+  // caller chains its consumer behind it (batch verification: normalise + pairing inputs without a host round trip).
+  int run_batch(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, int resident, const uint32_t* offsets, size_t m,
+                uint64_t* out, uint64_t** d_out_ret, hipStream_t stream) {
     if (m == 0) return 0;
     const uint32_t total_pts = offsets[m];
     uint32_t max_n = 0;
@@ -864,6 +875,7 @@ template <class G> class MsmEngine {
       if (k > max_n) max_n = k;
     }
     if (max_n > BATCH_MAX_N || total_pts == 0) {  // fall back to instance-at-a-time on the big pipeline (still the GPU)
+      if (resident || !out) return 2;             // the chained / resident form is for Batch::verify-sized instances
       for (size_t p = 0; p < m; p++) {
         uint32_t lo = offsets[p], k = offsets[p + 1] - lo;
         int rc = run_host(bases + (size_t)lo * 2 * IO::ARK64, inf ? inf + lo : nullptr, scalars + (size_t)lo * (SW / 2), k,
@@ -885,7 +897,8 @@ template <class G> class MsmEngine {
     if (m * (size_t)nw_max * B >= (size_t(1) << 31) || (size_t)total_pts * nw_max >= (size_t(1) << 32)) return 2;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
-    const size_t o_in_b = take((size_t)total_pts * 2 * IO::ARK64 * 8), o_in_s = take((size_t)total_pts * SW * 4), o_in_i = take(total_pts + 8);
+    const size_t o_in_b = take(resident ? 0 : (size_t)total_pts * 2 * IO::ARK64 * 8), o_in_s = take(resident ? 0 : (size_t)total_pts * SW * 4),
+                 o_in_i = take(resident ? 0 : total_pts + 8);
     const size_t o_off = take((m + 1) * 4), o_or = take(64 * 4);
     const size_t front = off;
     auto rest = [&](int nw_, size_t* o) {     // the window-count dependent part of the arena; returns its end
@@ -904,9 +917,10 @@ template <class G> class MsmEngine {
     if (ensure(rest(nw_max, o))) return 1;     // sized for full-length scalars: the actual layout below can only be smaller
     {
       char* A0 = arena;
-      HIP_OK(hipMemcpyAsync(A0 + o_in_s, scalars, (size_t)total_pts * SW * 4, hipMemcpyHostToDevice, stream));
+      if (!resident) HIP_OK(hipMemcpyAsync(A0 + o_in_s, scalars, (size_t)total_pts * SW * 4, hipMemcpyHostToDevice, stream));
       HIP_OK(hipMemsetAsync(A0 + o_or, 0, 64 * 4, stream));
-      hipLaunchKernelGGL((k_scalar_or<SW>), dim3(256), dim3(256), 0, stream, (const uint32_t*)(A0 + o_in_s), (size_t)total_pts * SW, (uint32_t*)(A0 + o_or));
+      hipLaunchKernelGGL((k_scalar_or<SW>), dim3(256), dim3(256), 0, stream, resident ? (const uint32_t*)scalars : (const uint32_t*)(A0 + o_in_s),
+                         (size_t)total_pts * SW, (uint32_t*)(A0 + o_or));
       uint32_t h_or[SW];
       HIP_OK(hipMemcpyAsync(h_or, A0 + o_or, SW * 4, hipMemcpyDeviceToHost, stream));
       HIP_OK(hipStreamSynchronize(stream));
@@ -919,14 +933,18 @@ template <class G> class MsmEngine {
     const size_t nvw = m * (size_t)nw, nbuckets = nvw * B;
     (void)rest(nw, o);
     char* A = arena;
-    uint64_t* d_in_b = (uint64_t*)(A + o_in_b); uint32_t* d_in_s = (uint32_t*)(A + o_in_s); uint8_t* d_in_i = (uint8_t*)(A + o_in_i);
+    const uint64_t* d_in_b = resident ? bases : (const uint64_t*)(A + o_in_b);
+    const uint32_t* d_in_s = resident ? (const uint32_t*)scalars : (const uint32_t*)(A + o_in_s);
+    const uint8_t* d_in_i = resident ? inf : (const uint8_t*)(A + o_in_i);
     uint32_t* d_off = (uint32_t*)(A + o_off);
     uint32_t* d_bases = (uint32_t*)(A + o[0]); uint32_t* d_sorted = (uint32_t*)(A + o[1]);
     uint32_t* d_pstart = (uint32_t*)(A + o[2]); uint32_t* d_plen = (uint32_t*)(A + o[3]); uint32_t* d_order = (uint32_t*)(A + o[4]);
     uint32_t* d_bins = (uint32_t*)(A + o[5]); uint32_t* d_nwork = d_bins + SIZE_BINS;
     uint32_t* d_partials = (uint32_t*)(A + o[6]); uint32_t* d_wsum = (uint32_t*)(A + o[7]); uint64_t* d_out = (uint64_t*)(A + o[8]);
-    HIP_OK(hipMemcpyAsync(d_in_b, bases, (size_t)total_pts * 2 * IO::ARK64 * 8, hipMemcpyHostToDevice, stream));
-    if (inf) HIP_OK(hipMemcpyAsync(d_in_i, inf, total_pts, hipMemcpyHostToDevice, stream));
+    if (!resident) {
+      HIP_OK(hipMemcpyAsync(A + o_in_b, bases, (size_t)total_pts * 2 * IO::ARK64 * 8, hipMemcpyHostToDevice, stream));
+      if (inf) HIP_OK(hipMemcpyAsync(A + o_in_i, inf, total_pts, hipMemcpyHostToDevice, stream));
+    }
     HIP_OK(hipMemcpyAsync(d_off, offsets, (m + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_OK(hipEventRecord(ev[0], stream));
     hipLaunchKernelGGL((k_convert_bases<G>), dim3((total_pts + 255) / 256), dim3(256), 0, stream, d_in_b, d_bases, (size_t)total_pts);
@@ -945,17 +963,23 @@ template <class G> class MsmEngine {
     if (lane_horner) hipLaunchKernelGGL((k_batch_horner_lanes<G>), dim3(((uint32_t)m + 20) / 21), dim3(64), 0, stream, d_wsum, d_out, (uint32_t)nw, (uint32_t)c, (uint32_t)m);
     else hipLaunchKernelGGL((k_batch_horner<G>), dim3(((uint32_t)m + 127) / 128), dim3(128), 0, stream, d_wsum, d_out, (uint32_t)nw, (uint32_t)c, (uint32_t)m);
     HIP_OK(hipEventRecord(ev[4], stream));
-    HIP_OK(hipMemcpyAsync(out, d_out, m * 3 * IO::ARK64 * 8, hipMemcpyDeviceToHost, stream));
+    if (out) HIP_OK(hipMemcpyAsync(out, d_out, m * 3 * IO::ARK64 * 8, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ev[5], stream));
+    last_c = c; last_nw = nw; last_buckets = (uint32_t)nbuckets;
+    if (d_out_ret) *d_out_ret = d_out;
+    if (!out) { HIP_OK(hipGetLastError()); return 0; }     // chained form: the caller synchronises and may call collect_batch_timings()
     HIP_OK(hipStreamSynchronize(stream));
     HIP_OK(hipGetLastError());
+    collect_batch_timings();
+    return 0;
+  }
+  void collect_batch_timings() {     // after the stream has drained
     (void)hipEventElapsedTime(&tm_batch.convert, ev[0], ev[1]);
     (void)hipEventElapsedTime(&tm_batch.sort, ev[1], ev[2]);
     (void)hipEventElapsedTime(&tm_batch.accumulate, ev[2], ev[3]);
     (void)hipEventElapsedTime(&tm_batch.reduce, ev[3], ev[4]);
     (void)hipEventElapsedTime(&tm_batch.total, ev[0], ev[5]);
-    tm = tm_batch; last_c = c; last_nw = nw; last_buckets = (uint32_t)nbuckets;
-    return 0;
+    tm = tm_batch;
   }
 
   MsmTimings tm;
@@ -987,6 +1011,8 @@ template <class G> class MsmEngine {
   uint64_t* d_in_scalars = nullptr;
   uint8_t* d_in_inf = nullptr;
   uint32_t* h_out = nullptr;
+  static constexpr size_t H_OUT_POINTS = 17 * 64;   // pinned result buffer: (LB + 1) * windows points; checked per call
+  OwnedStream stream_;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap_in = 0;
 
@@ -994,7 +1020,7 @@ template <class G> class MsmEngine {
     if (!ev[0])
       for (int i = 0; i < 6; i++) HIP_OK(hipEventCreate(&ev[i]));
     if (!h_out) {
-      HIP_OK(hipHostMalloc(&h_out, (size_t)17 * 64 * IO::XYZZ_WORDS * 4));
+      HIP_OK(hipHostMalloc(&h_out, H_OUT_POINTS * IO::XYZZ_WORDS * 4));
       // the LDS histograms use up to 128 KB of dynamic LDS (2^15 counters)
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_count<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

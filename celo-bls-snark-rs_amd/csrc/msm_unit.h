@@ -1,11 +1,12 @@
 // One translation unit per group (parallel builds; each unit instantiates the MSM pipeline for one group).
 #pragma once
 #include "msm.h"
+#include "runtime.h"
 #include <mutex>
+#include <thread>
+#include <atomic>
 
 namespace celo {
-std::mutex& api_mutex();
-int api_ensure_init();
 
 __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t i) {
   uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
@@ -14,13 +15,15 @@ __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t i) {
   return z ^ (z >> 31);
 }
 
-// P_i = k_i * G, k_i = splitmix64(seed, i) | 1, affine output in arkworks layout
+// P_i = k_i * G_{i / per}, k_i = splitmix64(seed, i) | 1, affine output in arkworks layout.  per = 0: one generator for all
+// points.  per > 0: point i uses generator i / per - the synthetic Batch::verify workload (signature j of batch b =
+// k_{b, j} * H(m_b), its key = k_{b, j} * g2 with the same seed).
 template <class F>
-__global__ void __launch_bounds__(128) k_gen_points(uint64_t* __restrict__ out, size_t n, uint64_t seed, const uint32_t* __restrict__ gen_dev) {
+__global__ void __launch_bounds__(128) k_gen_points(uint64_t* __restrict__ out, size_t n, uint64_t seed, const uint32_t* __restrict__ gen_dev, uint32_t per) {
   typedef PointIO<F> IO;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Affine<F> g = IO::load_affine(gen_dev);
+  Affine<F> g = IO::load_affine(gen_dev + (per ? (i / per) * IO::AFF_WORDS : 0));
   uint64_t k = splitmix64_at(seed, i) | 1ULL;
   Xyzz<F> acc = Xyzz<F>::identity();
   for (int b = 63; b >= 0; b--) {
@@ -35,17 +38,21 @@ __global__ void __launch_bounds__(128) k_gen_points(uint64_t* __restrict__ out, 
   y.to_ark(o + IO::ARK64);
 }
 
-template <class F> int gen_points_impl(void* d_out, size_t n, uint64_t seed, const uint64_t* gen_xy, void* stream) {
+// gen_xy: ngens generators (HOST, arkworks layout); per = points per generator (0 with ngens = 1: one generator for all)
+template <class F> int gen_points_impl(void* d_out, size_t n, uint64_t seed, const uint64_t* gen_xy, size_t ngens, uint32_t per, void* stream) {
   typedef PointIO<F> IO;
-  std::lock_guard<std::mutex> lk(api_mutex());
-  if (int rc = api_ensure_init()) return rc;
-  Affine<F> g = {F::from_ark(gen_xy), F::from_ark(gen_xy + IO::ARK64)};
-  uint32_t h[IO::AFF_WORDS];
-  IO::store_affine(h, g);
+  if (int rc = api_enter()) return rc;
+  if (n == 0) return 0;
+  if (!gen_xy || ngens == 0 || (per == 0 && ngens != 1) || (per && (n + per - 1) / per > ngens)) return 2;
+  std::vector<uint32_t> h(ngens * IO::AFF_WORDS);
+  for (size_t q = 0; q < ngens; q++) {
+    Affine<F> g = {F::from_ark(gen_xy + q * 2 * IO::ARK64), F::from_ark(gen_xy + q * 2 * IO::ARK64 + IO::ARK64)};
+    IO::store_affine(h.data() + q * IO::AFF_WORDS, g);
+  }
   uint32_t* d_gen = nullptr;
-  HIP_OK(hipMalloc(&d_gen, sizeof h));
-  HIP_OK(hipMemcpy(d_gen, h, sizeof h, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL((k_gen_points<F>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, (uint64_t*)d_out, n, seed, d_gen);
+  HIP_OK(hipMalloc(&d_gen, h.size() * 4));
+  HIP_OK(hipMemcpy(d_gen, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL((k_gen_points<F>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, (uint64_t*)d_out, n, seed, d_gen, per);
   HIP_OK(hipStreamSynchronize((hipStream_t)stream));
   HIP_OK(hipGetLastError());
   HIP_OK(hipFree(d_gen));
@@ -75,61 +82,156 @@ template <class F> int sum_jacobian_impl(const uint64_t* jac, size_t k, uint64_t
   acc.ZZ.to_ark(out + 2 * A);
   return 0;
 }
+
+// "last call" record of a group (what celo_amd_msm_last_timings reports); engines are pooled, so the record is a copy
+struct MsmLast {
+  std::mutex mu;
+  MsmTimings tm;
+  int c = 0, nw = 0;
+  uint32_t buckets = 0;
+  template <class E> void note(const E& e) {
+    std::lock_guard<std::mutex> lk(mu);
+    tm = e.tm; c = e.last_c; nw = e.last_nw; buckets = e.last_buckets;
+  }
+  void read(float ms[5], int cfg[3]) {
+    std::lock_guard<std::mutex> lk(mu);
+    ms[0] = tm.convert; ms[1] = tm.sort; ms[2] = tm.accumulate; ms[3] = tm.reduce; ms[4] = tm.total;
+    cfg[0] = c; cfg[1] = nw; cfg[2] = (int)buckets;
+  }
+};
+
+// One MSM sharded by index range over several devices of THIS process (the reference's callers are one
+// process: crates/bls-snark-sys/src/signatures.rs:343, crates/epoch-snark/src/api/prover.rs:78).  One host thread per device
+// binds to it, leases an engine there and computes the partial sum of its contiguous slice; the 144/288-byte Jacobian
+// partials are folded on the host (EC addition is not a collective's reduction op, and ndev points are nothing to fold).
+// A device may be listed more than once (two engines on one GPU: how the path is exercised on a 1-GPU box).
+// resident = 0: host pointers, slices cut from [0, n);  resident = 1: per-shard DEVICE pointers + per-shard sizes.
+template <class G, class Pool>
+int msm_multi_impl(Pool& pool, int force_c, const int* devices, int ndev, int resident, const void* const* bases, const void* const* infs,
+                   const void* const* scalars, const size_t* n_per, uint64_t* out, MsmLast* last) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  if (ndev <= 0 || ndev > 64 || !devices || !bases || !scalars || !n_per || !out) return 2;
+  std::vector<uint64_t> partial((size_t)ndev * 3 * IO::ARK64, 0);
+  std::vector<int> rcs((size_t)ndev, 0);
+  std::vector<std::thread> th;
+  for (int d = 0; d < ndev; d++) {
+    th.emplace_back([&, d] {
+      int rc = api_bind_thread(devices[d]);
+      if (!rc) rc = api_enter();
+      if (!rc) {
+        auto e = pool.lease();
+        e->force_c = force_c;
+        uint64_t* o = partial.data() + (size_t)d * 3 * IO::ARK64;
+        if (resident) rc = e->run_device((const uint64_t*)bases[d], infs ? (const uint8_t*)infs[d] : nullptr, (const uint32_t*)scalars[d], n_per[d], o, e->own_stream());
+        else rc = e->run_host((const uint64_t*)bases[d], infs ? (const uint8_t*)infs[d] : nullptr, (const uint64_t*)scalars[d], n_per[d], o, e->own_stream());
+        if (!rc && last && d == 0) last->note(*e);
+      }
+      rcs[(size_t)d] = rc;
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int rc : rcs) if (rc) return rc;
+  return sum_jacobian_impl<F>(partial.data(), (size_t)ndev, out);
+}
+template <class G, class Pool>
+int msm_multi_host_impl(Pool& pool, int force_c, const int* devices, int ndev, const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n,
+                        uint64_t* out, MsmLast* last) {
+  typedef PointIO<typename G::F> IO;
+  if (ndev <= 0 || ndev > 64) return 2;
+  std::vector<const void*> pb((size_t)ndev), pi((size_t)ndev), ps((size_t)ndev);
+  std::vector<size_t> np((size_t)ndev);
+  for (int d = 0; d < ndev; d++) {
+    const size_t lo = n * (size_t)d / (size_t)ndev, hi = n * (size_t)(d + 1) / (size_t)ndev;
+    pb[(size_t)d] = b + lo * 2 * IO::ARK64; pi[(size_t)d] = inf ? inf + lo : nullptr; ps[(size_t)d] = s + lo * (G::SCALAR_WORDS / 2); np[(size_t)d] = hi - lo;
+  }
+  return msm_multi_impl<G>(pool, force_c, devices, ndev, 0, pb.data(), inf ? pi.data() : nullptr, ps.data(), np.data(), out, last);
+}
 }  // namespace celo
 
 // The large-MSM engine and the auxiliary entry points (batched MSMs, generators, host sums) are separate macros so that
 // each group compiles as two translation units in parallel (the 28-limb instantiations are the long pole of the build).
 #define CELO_DEFINE_MSM_UNIT(G, TAG)                                                                                     \
   namespace celo {                                                                                                       \
-  static MsmEngine<G> eng_##TAG;                                                                                         \
+  static EnginePool<MsmEngine<G>>& pool_##TAG() { static auto* p = new EnginePool<MsmEngine<G>>(); return *p; }          \
+  static MsmLast& last_##TAG() { static auto* p = new MsmLast(); return *p; }                                            \
+  static std::atomic<int> force_c_##TAG{0};                                                                              \
   int msm_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) {                \
-    std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
-    if (int rc = api_ensure_init()) return rc;                                                                           \
-    return eng_##TAG.run_host(b, inf, s, n, out, nullptr);                                                               \
+    if (int rc = api_enter()) return rc;                                                                                 \
+    auto e = pool_##TAG().lease();                                                                                       \
+    e->force_c = force_c_##TAG.load();                                                                                   \
+    const int rc = e->run_host(b, inf, s, n, out, e->own_stream());                                                      \
+    if (!rc && n) last_##TAG().note(*e);                                                                                 \
+    return rc;                                                                                                           \
   }                                                                                                                      \
   int msm_dev_##TAG(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) {                  \
-    std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
-    if (int rc = api_ensure_init()) return rc;                                                                           \
-    return eng_##TAG.run_device((const uint64_t*)b, (const uint8_t*)inf, (const uint32_t*)s, n, out, (hipStream_t)st);   \
+    if (int rc = api_enter()) return rc;                                                                                 \
+    auto e = pool_##TAG().lease();                                                                                       \
+    e->force_c = force_c_##TAG.load();                                                                                   \
+    const int rc = e->run_device((const uint64_t*)b, (const uint8_t*)inf, (const uint32_t*)s, n, out, (hipStream_t)st);  \
+    if (!rc && n) last_##TAG().note(*e);                                                                                 \
+    return rc;                                                                                                           \
   }                                                                                                                      \
-  void msm_big_timings_##TAG(float ms[5], int cfg[3]) {                                                                  \
-    const MsmTimings& t = eng_##TAG.tm;                                                                                  \
-    ms[0] = t.convert; ms[1] = t.sort; ms[2] = t.accumulate; ms[3] = t.reduce; ms[4] = t.total;                          \
-    cfg[0] = eng_##TAG.last_c; cfg[1] = eng_##TAG.last_nw; cfg[2] = (int)eng_##TAG.last_buckets;                         \
+  int msm_multi_host_##TAG(const int* devs, int nd, const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { \
+    return msm_multi_host_impl<G>(pool_##TAG(), force_c_##TAG.load(), devs, nd, b, inf, s, n, out, &last_##TAG());       \
   }                                                                                                                      \
-  void msm_big_set_c_##TAG(int c) { eng_##TAG.force_c = c; }                                                             \
+  int msm_multi_dev_##TAG(const int* devs, int nd, const void* const* b, const void* const* inf, const void* const* s,   \
+                          const size_t* n_per, uint64_t* out) {                                                          \
+    return msm_multi_impl<G>(pool_##TAG(), force_c_##TAG.load(), devs, nd, 1, b, inf, s, n_per, out, &last_##TAG());     \
+  }                                                                                                                      \
+  void msm_big_timings_##TAG(float ms[5], int cfg[3]) { last_##TAG().read(ms, cfg); }                                    \
+  void msm_big_set_c_##TAG(int c) { force_c_##TAG.store(c); }                                                            \
   }
 
 #define CELO_DEFINE_MSM_AUX_UNIT(G, TAG)                                                                                 \
   namespace celo {                                                                                                       \
-  static MsmEngine<G> eng_aux_##TAG;                                                                                     \
-  static int last_was_batch_##TAG = 0;                                                                                   \
+  static EnginePool<MsmEngine<G>>& pool_aux_##TAG() { static auto* p = new EnginePool<MsmEngine<G>>(); return *p; }      \
+  static MsmLast& last_aux_##TAG() { static auto* p = new MsmLast(); return *p; }                                        \
+  static std::atomic<int> force_c_aux_##TAG{0};                                                                          \
+  static std::atomic<int> last_was_batch_##TAG{0};                                                                       \
   void msm_big_timings_##TAG(float ms[5], int cfg[3]);                                                                   \
   void msm_big_set_c_##TAG(int c);                                                                                       \
   int msm_batch_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { \
-    std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
-    if (int rc = api_ensure_init()) return rc;                                                                           \
-    last_was_batch_##TAG = 1;                                                                                            \
-    return eng_aux_##TAG.run_batch_host(b, inf, s, off, m, out, nullptr);                                                \
+    if (int rc = api_enter()) return rc;                                                                                 \
+    auto e = pool_aux_##TAG().lease();                                                                                   \
+    e->force_c = force_c_aux_##TAG.load();                                                                               \
+    last_was_batch_##TAG.store(1);                                                                                       \
+    const int rc = e->run_batch_host(b, inf, s, off, m, out, e->own_stream());                                           \
+    if (!rc && m) last_aux_##TAG().note(*e);                                                                             \
+    return rc;                                                                                                           \
   }                                                                                                                      \
-  int msm_timings_##TAG(float ms[5], int cfg[3]) {                                                                       \
-    std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
-    if (last_was_batch_##TAG) {                                                                                          \
-      const MsmTimings& t = eng_aux_##TAG.tm;                                                                            \
-      ms[0] = t.convert; ms[1] = t.sort; ms[2] = t.accumulate; ms[3] = t.reduce; ms[4] = t.total;                        \
-      cfg[0] = eng_aux_##TAG.last_c; cfg[1] = eng_aux_##TAG.last_nw; cfg[2] = (int)eng_aux_##TAG.last_buckets;           \
-    } else msm_big_timings_##TAG(ms, cfg);                                                                               \
+  int msm_batch_begin_##TAG(const void* b, const void* inf, const void* s, int resident, const uint32_t* off, size_t m, BatchRun* run) { \
+    if (int rc = api_enter()) return rc;                                                                                 \
+    typedef EnginePool<MsmEngine<G>>::Lease L;                                                                           \
+    L* l = new L(pool_aux_##TAG().lease());                                                                              \
+    (*l)->force_c = force_c_aux_##TAG.load();                                                                            \
+    uint64_t* d_out = nullptr;                                                                                           \
+    const int rc = (*l)->run_batch((const uint64_t*)b, (const uint8_t*)inf, (const uint64_t*)s, resident, off, m, nullptr, &d_out, (*l)->own_stream()); \
+    if (rc) { delete l; return rc; }                                                                                     \
+    run->lease = l; run->d_out = d_out; run->stream = (*l)->own_stream();                                                \
     return 0;                                                                                                            \
   }                                                                                                                      \
-  void msm_note_big_call_##TAG() { last_was_batch_##TAG = 0; }                                                           \
+  void msm_batch_end_##TAG(BatchRun* run, int drained) {                                                                 \
+    typedef EnginePool<MsmEngine<G>>::Lease L;                                                                           \
+    L* l = (L*)run->lease;                                                                                               \
+    if (!l) return;                                                                                                      \
+    if (drained) { (*l)->collect_batch_timings(); last_was_batch_##TAG.store(1); last_aux_##TAG().note(**l); }           \
+    delete l;                                                                                                            \
+    run->lease = nullptr;                                                                                                \
+  }                                                                                                                      \
+  int msm_timings_##TAG(float ms[5], int cfg[3]) {                                                                       \
+    if (last_was_batch_##TAG.load()) last_aux_##TAG().read(ms, cfg);                                                     \
+    else msm_big_timings_##TAG(ms, cfg);                                                                                 \
+    return 0;                                                                                                            \
+  }                                                                                                                      \
+  void msm_note_big_call_##TAG() { last_was_batch_##TAG.store(0); }                                                      \
   int msm_set_c_##TAG(int c) {                                                                                           \
-    std::lock_guard<std::mutex> lk(api_mutex());                                                                         \
-    eng_aux_##TAG.force_c = c;                                                                                           \
+    force_c_aux_##TAG.store(c);                                                                                          \
     msm_big_set_c_##TAG(c);                                                                                              \
     return 0;                                                                                                            \
   }                                                                                                                      \
-  int gen_points_##TAG(void* d, size_t n, uint64_t seed, const uint64_t* g, void* st) {                                  \
-    return gen_points_impl<G::F>(d, n, seed, g, st);                                                                     \
+  int gen_points_##TAG(void* d, size_t n, uint64_t seed, const uint64_t* g, size_t ngens, uint32_t per, void* st) {      \
+    return gen_points_impl<G::F>(d, n, seed, g, ngens, per, st);                                                         \
   }                                                                                                                      \
   int sum_jac_##TAG(const uint64_t* jac, size_t k, uint64_t* out) { return sum_jacobian_impl<G::F>(jac, k, out); }       \
   }

@@ -25,6 +25,7 @@
 #include <cstring>
 #include "fp.h"
 #include "fp_consts.h"
+#include "runtime.h"
 
 namespace celo {
 
@@ -242,6 +243,7 @@ class NttEngine {
     for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
   }
   NttTimings tm;
+  hipStream_t own_stream() { return stream_.get(); }
   int max_radix_log2 = 3;   // butterfly levels per register-only pass (tuning hook: 1..3)
   bool use_tiles = true;    // LDS-tiled passes (tuning hook)
   bool fuse_io = true;      // format conversion fused into the first / last butterfly launch (tuning hook)
@@ -323,6 +325,7 @@ class NttEngine {
   uint32_t* d_small = nullptr;       // 5 x 1024 elements: twiddle lo/hi power tables, coset lo/hi power tables, [4][0] = scale
   uint64_t* d_io = nullptr; size_t cap_io = 0;
   unsigned tw_log_n = 0; uint64_t tw_omega[6] = {0, 0, 0, 0, 0, 0};
+  OwnedStream stream_;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* small(int i) { return d_small + (size_t)i * 1024 * NTT_WORDS; }
 

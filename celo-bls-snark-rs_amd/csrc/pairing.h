@@ -20,6 +20,7 @@
 #pragma once
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#include "runtime.h"
 #endif
 #include <cstdio>
 #include "tower.h"
@@ -322,6 +323,7 @@ template <class PP> class PairingEngine {
     for (int i = 0; i < 4; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
   }
   PairingTimings tm;
+  hipStream_t own_stream() { return stream_.get(); }
   // Host pointers.  m products; product p covers pairs [offsets[p], offsets[p+1]) (offsets[m] = total pairs k).
   // mode: 0 = full check (Miller + final exp), 1 = Miller loop product only (no final exp; test hook)
   // out_is_one[m] (may be null), out_gt[m*72] in arkworks Montgomery form (may be null).
@@ -329,32 +331,51 @@ template <class PP> class PairingEngine {
           uint8_t* out_is_one, uint64_t* out_gt, int mode, hipStream_t stream) {
     if (m == 0) return 0;
     const uint32_t k = offsets[m];
+    Staged st;
+    if (stage(k, m, &st)) return 1;
+    if (k) {
+      PAIR_HIP_OK(hipMemcpyAsync(st.d_g1, g1, (size_t)k * PP::G1_ARK64 * 8, hipMemcpyHostToDevice, stream));
+      PAIR_HIP_OK(hipMemcpyAsync(st.d_g2, g2, (size_t)k * PP::G2_ARK64 * 8, hipMemcpyHostToDevice, stream));
+      if (inf1) PAIR_HIP_OK(hipMemcpyAsync(st.d_i1, inf1, k, hipMemcpyHostToDevice, stream));
+      if (inf2) PAIR_HIP_OK(hipMemcpyAsync(st.d_i2, inf2, k, hipMemcpyHostToDevice, stream));
+    }
+    return run_staged(offsets, m, inf1 != nullptr, inf2 != nullptr, out_is_one, out_gt, mode, stream);
+  }
+  // The two halves of run(), for callers whose pairs are produced ON the device (batch verification: the normalised MSM
+  // results are written straight into the input slots): stage() lays out the workspace for k pairs in m products and hands
+  // out the device input slots; run_staged() runs the check on whatever those slots hold by then (stream order).
+  struct Staged { uint64_t* d_g1; uint64_t* d_g2; uint8_t* d_i1; uint8_t* d_i2; };
+  int stage(uint32_t k, size_t m, Staged* st) {
     const size_t W = IO::WORDS;
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += (b + 255) & ~size_t(255); return o; };
-    const size_t o_g1 = take((size_t)k * PP::G1_ARK64 * 8 + 8), o_g2 = take((size_t)k * PP::G2_ARK64 * 8 + 8), o_i1 = take(k + 8), o_i2 = take(k + 8);
-    const size_t o_off = take((m + 1) * 4), o_f = take(((size_t)k + 1) * W * 4), o_f2 = take(((size_t)k / 2 + 2) * W * 4);
-    const size_t o_prod = take((size_t)m * W * 4), o_one = take(m + 8), o_gt = take((size_t)m * 72 * 8);
+    lay.k = k; lay.m = m;
+    lay.o_g1 = take((size_t)k * PP::G1_ARK64 * 8 + 8); lay.o_g2 = take((size_t)k * PP::G2_ARK64 * 8 + 8); lay.o_i1 = take(k + 8); lay.o_i2 = take(k + 8);
+    lay.o_off = take((m + 1) * 4); lay.o_f = take(((size_t)k + 1) * W * 4); lay.o_f2 = take(((size_t)k / 2 + 2) * W * 4);
+    lay.o_prod = take((size_t)m * W * 4); lay.o_one = take(m + 8); lay.o_gt = take((size_t)m * 72 * 8);
     if (ensure(off)) return 1;
     char* A = arena;
-    uint64_t* d_g1 = (uint64_t*)(A + o_g1); uint64_t* d_g2 = (uint64_t*)(A + o_g2);
-    uint8_t* d_i1 = (uint8_t*)(A + o_i1); uint8_t* d_i2 = (uint8_t*)(A + o_i2);
-    uint32_t* d_off = (uint32_t*)(A + o_off); uint32_t* d_f = (uint32_t*)(A + o_f); uint32_t* d_f2 = (uint32_t*)(A + o_f2);
-    uint32_t* d_prod = (uint32_t*)(A + o_prod); uint8_t* d_one = (uint8_t*)(A + o_one); uint64_t* d_gt = (uint64_t*)(A + o_gt);
-    if (k) {
-      PAIR_HIP_OK(hipMemcpyAsync(d_g1, g1, (size_t)k * PP::G1_ARK64 * 8, hipMemcpyHostToDevice, stream));
-      PAIR_HIP_OK(hipMemcpyAsync(d_g2, g2, (size_t)k * PP::G2_ARK64 * 8, hipMemcpyHostToDevice, stream));
-      if (inf1) PAIR_HIP_OK(hipMemcpyAsync(d_i1, inf1, k, hipMemcpyHostToDevice, stream));
-      if (inf2) PAIR_HIP_OK(hipMemcpyAsync(d_i2, inf2, k, hipMemcpyHostToDevice, stream));
-    }
+    *st = {(uint64_t*)(A + lay.o_g1), (uint64_t*)(A + lay.o_g2), (uint8_t*)(A + lay.o_i1), (uint8_t*)(A + lay.o_i2)};
+    return 0;
+  }
+  int run_staged(const uint32_t* offsets, size_t m, bool has_inf1, bool has_inf2, uint8_t* out_is_one, uint64_t* out_gt, int mode, hipStream_t stream) {
+    if (m == 0) return 0;
+    if (m != lay.m || offsets[m] != lay.k) return 2;
+    const uint32_t k = lay.k;
+    const size_t W = IO::WORDS;
+    char* A = arena;
+    uint64_t* d_g1 = (uint64_t*)(A + lay.o_g1); uint64_t* d_g2 = (uint64_t*)(A + lay.o_g2);
+    uint8_t* d_i1 = (uint8_t*)(A + lay.o_i1); uint8_t* d_i2 = (uint8_t*)(A + lay.o_i2);
+    uint32_t* d_off = (uint32_t*)(A + lay.o_off); uint32_t* d_f = (uint32_t*)(A + lay.o_f); uint32_t* d_f2 = (uint32_t*)(A + lay.o_f2);
+    uint32_t* d_prod = (uint32_t*)(A + lay.o_prod); uint8_t* d_one = (uint8_t*)(A + lay.o_one); uint64_t* d_gt = (uint64_t*)(A + lay.o_gt);
     PAIR_HIP_OK(hipMemcpyAsync(d_off, offsets, (m + 1) * 4, hipMemcpyHostToDevice, stream));
     PAIR_HIP_OK(hipEventRecord(ev[0], stream));
     // shared-accumulator mode: one lane group per product (<= 4 pairs each) when the products alone fill the chip
-    bool shared = m >= 16384;
+    bool shared = m >= SHARED_MIN_PRODUCTS;
     for (size_t p = 0; p < m && shared; p++) shared = offsets[p + 1] - offsets[p] <= 4;
     typedef typename PP::LL LL;
-    if (shared) LL::miller_product(d_g1, inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
-    else if (k) LL::miller(d_g1, inf1 ? d_i1 : nullptr, d_g2, inf2 ? d_i2 : nullptr, d_f, k, stream);
+    if (shared) LL::miller_product(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
+    else if (k) LL::miller(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_f, k, stream);
     PAIR_HIP_OK(hipEventRecord(ev[1], stream));
     if (shared) {
       // products already formed by the Miller kernel
@@ -383,10 +404,13 @@ template <class PP> class PairingEngine {
     (void)hipEventElapsedTime(&tm.total, ev[0], ev[3]);
     return 0;
   }
+  static constexpr size_t SHARED_MIN_PRODUCTS = 16384;
 
  private:
+  struct Layout { uint32_t k = 0; size_t m = 0, o_g1 = 0, o_g2 = 0, o_i1 = 0, o_i2 = 0, o_off = 0, o_f = 0, o_f2 = 0, o_prod = 0, o_one = 0, o_gt = 0; } lay;
   char* arena = nullptr;
   size_t arena_bytes = 0;
+  OwnedStream stream_;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int ensure(size_t bytes) {
     if (!ev[0])

@@ -1,0 +1,83 @@
+// Process-wide runtime of the gfx950 library: device binding per host thread and pools of engine instances.
+//
+// The reference's callers are synchronous, re-entrant and multi-threaded (bls-snark-sys is called from Go/Rust worker threads:
+// crates/bls-snark-sys/src/cache.rs:5, signatures.rs:343-400; epoch-snark's prover runs its MSMs from rayon tasks,
+// crates/epoch-snark/src/api/prover.rs:78).  So there is no global API lock: every entry point
+//   1. api_enter()          binds the calling thread to its device (HIP's current device is per thread),
+//   2. EnginePool::lease()  checks out an engine instance of that device (workspace arena, pinned staging, events and its
+//                           own non-blocking HIP stream); a new one is created when all are busy (up to MAX_PER_DEVICE,
+//                           then callers wait),
+//   3. runs, copies its timings to the per-kind "last call" record, and returns the engine.
+// Independent calls therefore overlap on the GPU (separate streams) and several devices can be driven from one process:
+// celo_amd_use_device() binds a host thread to a device, the msm_*_multi entry points do that internally (one thread per device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+namespace celo {
+
+constexpr int MAX_DEVICES = 16;
+
+int api_enter();                 // 0, or 100 (no device).  Applies the thread's device.
+int api_device();                // device of the calling thread (after api_enter)
+int api_bind_thread(int device); // celo_amd_use_device: 0 or 101
+
+template <class E> class EnginePool {
+ public:
+  static constexpr int MAX_PER_DEVICE = 8;
+  class Lease {
+   public:
+    Lease(EnginePool* p, int dev, E* e) : pool(p), device(dev), eng(e) {}
+    Lease(Lease&& o) noexcept : pool(o.pool), device(o.device), eng(o.eng) { o.eng = nullptr; }
+    Lease(const Lease&) = delete;
+    ~Lease() { if (eng) pool->give_back(device, eng); }
+    E* operator->() { return eng; }
+    E& operator*() { return *eng; }
+    explicit operator bool() const { return eng != nullptr; }
+   private:
+    EnginePool* pool; int device; E* eng;
+  };
+  // the calling thread must have passed api_enter()
+  Lease lease() {
+    const int dev = api_device();
+    std::unique_lock<std::mutex> lk(mu);
+    Slot& s = slots[dev];
+    for (;;) {
+      if (!s.free_list.empty()) { E* e = s.free_list.back(); s.free_list.pop_back(); return Lease(this, dev, e); }
+      if (s.created < MAX_PER_DEVICE) { s.created++; lk.unlock(); return Lease(this, dev, new E()); }   // engines live for the process
+      cv.wait(lk);
+    }
+  }
+ private:
+  struct Slot { std::vector<E*> free_list; int created = 0; };
+  Slot slots[MAX_DEVICES];
+  std::mutex mu;
+  std::condition_variable cv;
+  void give_back(int dev, E* e) {
+    { std::lock_guard<std::mutex> lk(mu); slots[dev].free_list.push_back(e); }
+    cv.notify_one();
+  }
+};
+
+// an engine-owned stream: non-blocking, so that engines of different calls do not serialise through the null stream
+struct OwnedStream {
+  hipStream_t s = nullptr;
+  hipStream_t get() {
+    if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    return s;
+  }
+};
+
+
+// ---- chaining engines on the device (batch verification: MSM results -> normalise -> pairing inputs, no host round trip)
+// A batched MSM that has been ENQUEUED on its engine's stream: d_out = m Jacobian results (arkworks form) in the engine's
+// arena; the engine stays leased until msm_batch_end_*.
+struct BatchRun { void* lease = nullptr; uint64_t* d_out = nullptr; hipStream_t stream = nullptr; };
+// A pairing engine whose input slots (k pairs in m products) are handed to a producer kernel; pairing_run_staged_* runs the
+// check on what the slots hold (stream order) and returns the engine.
+struct PairingStage { void* lease = nullptr; uint64_t* d_g1 = nullptr; uint64_t* d_g2 = nullptr; uint8_t* d_i1 = nullptr; uint8_t* d_i2 = nullptr; hipStream_t stream = nullptr; };
+
+}  // namespace celo

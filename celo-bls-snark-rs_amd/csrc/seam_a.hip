@@ -1,12 +1,11 @@
 // Seam A: the bls-snark-sys C ABI, rebuilt on top of the gfx950 hot path.
 //
-// This file provides the handle / wire-format / aggregation half of `crates/bls-snark-sys/src/{serialization,signatures}.rs`
-// (opaque PrivateKey / PublicKey / Signature handles, arkworks CanonicalSerialize encodings, aggregate_*), plus the GPU
-// verification cores that the reference's verify_* symbols reduce to once the message has been hashed to G1.
-// Not yet exported: the hashers (Blake2Xs try-and-increment, Bowe-Hopwood composite),
-// hence verify_signature / verify_pop / batch_verify_signature / batch_verify_strict / sign_* / hash_* under their
-// reference names, and the epoch-encoding symbols.  Everything here is host orchestration; group arithmetic that is on
-// the hot path (MSM, pairings) goes to the kernels, the rest (one decompression, one subgroup check) is plumbing.
+// This file provides all 36 symbols of `crates/bls-snark-sys/src/{serialization,signatures}.rs` and `src/snark/{mod,epoch_block}.rs`
+// under their reference names: opaque PrivateKey / PublicKey / Signature handles, arkworks CanonicalSerialize encodings,
+// aggregate_*, both hashers (Blake2Xs try-and-increment, the Bowe-Hopwood composite hasher, before and after CIP22),
+// sign_* / verify_* / batch_verify_*, the Groth16 `verify` and the epoch encoders.  Everything here is host orchestration:
+// group arithmetic on the hot path (MSM, pairings, bulk hashing from 256 messages up) goes to the kernels through the
+// Seam B entry points, the rest (one decompression, one subgroup check, one hash) is latency-path plumbing on the host.
 //
 // Ownership mirrors the reference: handles come from new/delete behind destroy_*; byte buffers are malloc'd and released
 // by free_vec(ptr, len) (crates/bls-snark-sys/src/serialization.rs:120-140, 224-268).  Every entry returns `false`
@@ -32,6 +31,7 @@
 #include "wire.h"
 #include "hash_direct.h"
 #include "pedersen.h"
+#include "runtime.h"
 #include "../../include/celo_bls_amd.h"
 #include "../../include/celo_bls_snark_sys.h"
 
@@ -385,8 +385,12 @@ bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* m
 // hash many messages on all host cores (hash-to-curve is host plumbing for now; one attempt costs a
 // Blake2Xs call, a 377-bit square root and a 125-bit cofactor multiplication)
 struct HashJob { const uint8_t* msg; size_t mlen; const uint8_t* extra; size_t elen; uint64_t* out_xy; };
-bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJob>& jobs) {
+// failed (optional, one flag per job): a message that cannot be hashed marks its own job and the call goes on (the caller
+// decides what one bad message means); without it the first failure fails the call.
+bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJob>& jobs, std::vector<uint8_t>* failed = nullptr) {
   (void)wire_consts();
+  if (failed) failed->assign(jobs.size(), 0);
+  bool gpu_done = false;
   // many messages: hashing runs on the GPU (a lone wave of 64 needs ~4 ms, so the host cores keep the small calls), for
   // every hasher: hash_direct.h's try-and-increment rounds over the Blake2s CRH, over precomputed Pedersen CRHs (CIP22), or
   // with a Pedersen CRH per attempt (composite before CIP22)
@@ -402,13 +406,17 @@ bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJ
     std::vector<uint64_t> xy(n * 12);
     const int rc = composite ? hash_to_g1_composite_bls12_377(dom, mb.data(), moff.data(), eb.data(), eoff.data(), n, cip22 ? 1 : 0, xy.data(), att.data())
                              : hash_to_g1_direct_bls12_377(dom, mb.data(), moff.data(), eb.data(), eoff.data(), n, xy.data(), att.data());
-    if (rc != 0) return false;
-    for (size_t i = 0; i < n; i++) {
-      if (att[i] == 255) return false;
-      memcpy(jobs[i].out_xy, &xy[i * 12], 96);
+    if (rc != 0 && !failed) return false;
+    if (rc == 0) {
+      for (size_t i = 0; i < n; i++) {
+        if (att[i] == 255) { if (!failed) return false; (*failed)[i] = 1; continue; }
+        memcpy(jobs[i].out_xy, &xy[i * 12], 96);
+      }
+      gpu_done = true;
     }
-    return true;
+    // rc != 0 with per-job flags wanted (e.g. ONE oversized composite message): the host loop below sorts out which
   }
+  if (gpu_done) return true;
   if (composite) (void)composite_params();  // initialise shared constants before the threads start
   std::atomic<size_t> next(0);
   std::atomic<bool> ok(true);
@@ -421,7 +429,10 @@ bool hash_many(bool composite, bool cip22, const uint8_t* dom, std::vector<HashJ
       size_t i = next.fetch_add(1);
       if (i >= jobs.size()) break;
       Affine<Fq_> h; int c;
-      if (!hash_to_g1(composite, cip22, dom, jobs[i].msg, jobs[i].mlen, jobs[i].extra, jobs[i].elen, h, c)) { ok = false; continue; }
+      if (!hash_to_g1(composite, cip22, dom, jobs[i].msg, jobs[i].mlen, jobs[i].extra, jobs[i].elen, h, c)) {
+        if (failed) (*failed)[i] = 1; else ok = false;
+        continue;
+      }
       h.x.to_ark(jobs[i].out_xy); h.y.to_ark(jobs[i].out_xy + 6);
     }
   };
@@ -1023,7 +1034,7 @@ bool batch_verify_signature(const MessageFFI* messages, size_t n, bool composite
   batch_to_affine<Fq2_>(pkj.data(), n, g2.data() + 24, i2.data() + 1);
   std::vector<HashJob> jobs(n);
   for (size_t i = 0; i < n; i++) jobs[i] = {messages[i].data.ptr, messages[i].data.len, messages[i].extra.ptr, messages[i].extra.len, &g1[(i + 1) * 12]};
-  if (n && !hash_many(composite, cip22, SIG_DOMAIN, jobs)) return false;
+  if (n && !hash_many(composite, cip22, SIG_DOMAIN, jobs)) { *verified = false; return true; }   // a message that does not hash: not verified, not an error
   int one = 0;
   if (pairing_product_is_one_bls12_377(g1.data(), i1.data(), g2.data(), i2.data(), n + 1, &one) != 0) return false;
   *verified = one != 0;
@@ -1045,12 +1056,15 @@ struct PhaseLog {  // CELO_AMD_LOG=1: wall time of the host / device phases of o
 bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composite, bool cip22, bool* out_results) {   /* signatures.rs:343 */
   if ((!batches && m) || !out_results) return false;
   PhaseLog ph("batch_verify_strict");
-  if (!composite && cip22) { for (size_t i = 0; i < m; i++) out_results[i] = false; return false; }  // per-batch false (signatures.rs:387)
+  for (size_t i = 0; i < m; i++) out_results[i] = false;      // always filled: every early return below leaves "not verified"
+  if (!composite && cip22) return false;                      // per-batch false (signatures.rs:387)
   if (m == 0) return true;
   std::vector<uint32_t> offs(m + 1, 0);
+  std::vector<size_t> blen(m);
   for (size_t b = 0; b < m; b++) {
-    if (batches[b].public_keys_len != batches[b].signatures_len) return false;  // the reference panics here (batch.rs:71,78)
-    offs[b + 1] = offs[b] + (uint32_t)batches[b].public_keys_len;
+    // Batch::verify zips keys with signatures (batch.rs:60-64): a longer side is truncated to the shorter
+    blen[b] = batches[b].public_keys_len < batches[b].signatures_len ? batches[b].public_keys_len : batches[b].signatures_len;
+    offs[b + 1] = offs[b] + (uint32_t)blen[b];
   }
   const size_t tot = offs[m];
   // staging: one grow-only PINNED host buffer kept by the library (allocating and releasing ~0.5 GB of pageable memory per call
@@ -1061,7 +1075,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   static size_t stage_cap = 0;
   const size_t need = tot * (24 + 12 + 4) * 8 + 2 * tot + 4096;
   if (need > stage_cap) {
-    if (celo_amd_init(0) != 0) return false;
+    if (api_enter() != 0) return false;
     if (stage) (void)hipHostFree(stage);
     stage = nullptr; stage_cap = 0;
     if (hipHostMalloc((void**)&stage, need + need / 4, hipHostMallocDefault) != hipSuccess) { log_err("batch_verify_strict: pinned staging allocation failed"); return false; }
@@ -1075,7 +1089,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   ChaCha20Rng master;
   if (!os_seeded_rng(master)) { log_err("batch_verify_strict: no OS randomness"); return false; }
   for (size_t b = 0; b < m; b++)
-    for (size_t i = 0; i < batches[b].public_keys_len; i++)
+    for (size_t i = 0; i < blen[b]; i++)
       if (!batches[b].public_keys[i] || !batches[b].signatures[i]) return false;
   ph.mark("validate + allocate");
   // the message hashes depend on nothing computed here: they run on the host cores while the GPU does the two MSMs
@@ -1083,7 +1097,8 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   std::vector<HashJob> jobs(m);
   for (size_t b = 0; b < m; b++) jobs[b] = {batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, &g1[(2 * b + 1) * 12]};
   bool hash_ok = false;
-  std::thread hasher([&]() { hash_ok = hash_many(composite, cip22, SIG_DOMAIN, jobs); });
+  std::vector<uint8_t> hash_failed;
+  std::thread hasher([&]() { hash_ok = hash_many(composite, cip22, SIG_DOMAIN, jobs, &hash_failed); });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } hasher_guard{hasher};   // early returns must not leave it running
   // gather: ranges of batches across host threads; every thread draws its exponents from its own ChaCha20 stream (keys taken
   // from the OS-seeded master stream).  Handles with Z = 1 (everything that came from the wire) are copied straight into the
@@ -1101,7 +1116,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     ChaCha20Rng& rng = rngs[t];
     std::vector<uint32_t> pk_todo, sg_todo;
     for (size_t b = b_lo; b < b_hi; b++) {
-      const size_t n = batches[b].public_keys_len;
+      const size_t n = blen[b];
       size_t lg = 0;
       while (((size_t)1 << lg) < n) lg++;                               // ark_std::log2 = ceil(log2)
       size_t nbytes = (128 + lg + 7) / 8;                               // byte_count_from_target_batch_size (batch.rs:23-28)
@@ -1145,11 +1160,17 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     for (auto& x : th) x.join();
   }
   ph.mark("gather handles -> affine, exponents");
+  // the two batch MSMs are independent calls on independent engines: both in flight at once (their sorts, tails and copies
+  // overlap on the GPU; the message hashing started above is a third concurrent stream of work)
   std::vector<uint64_t> bpk(m * 36), bsg(m * 18);
-  if (msm_batch_bls12_377_g2(pk_xy, pk_inf, sc, offs.data(), m, bpk.data()) != 0) return false;
-  ph.mark("G2 batch MSM (GPU)");
-  if (msm_batch_bls12_377_g1(sg_xy, sg_inf, sc, offs.data(), m, bsg.data()) != 0) return false;
-  ph.mark("G1 batch MSM (GPU)");
+  int rc_g1 = 0;
+  {
+    std::thread g1_msm([&]() { rc_g1 = msm_batch_bls12_377_g1(sg_xy, sg_inf, sc, offs.data(), m, bsg.data()); });
+    const int rc_g2 = msm_batch_bls12_377_g2(pk_xy, pk_inf, sc, offs.data(), m, bpk.data());
+    g1_msm.join();
+    if (rc_g2 != 0 || rc_g1 != 0) return false;
+  }
+  ph.mark("G2 + G1 batch MSMs (GPU, concurrent)");
   std::vector<uint64_t> tmp1(m * 12), tmp2(m * 24);
   std::vector<uint8_t> i1(2 * m, 0), i2(2 * m, 0), t1(m), t2(m);
   batch_to_affine<Fq_>(bsg.data(), m, tmp1.data(), t1.data());
@@ -1164,6 +1185,8 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   ph.mark("pack pairs");
   hasher.join();
   if (!hash_ok) return false;
+  for (size_t b = 0; b < m; b++)        // a batch whose message does not hash is "not verified" (the other batches are unaffected)
+    if (hash_failed[b]) i1[2 * b + 1] = 1;   // no H(m): the pair is left out of the launch, the verdict is forced below
   ph.mark("wait for the hashes");
   std::vector<uint32_t> po(m + 1);
   for (size_t b = 0; b <= m; b++) po[b] = (uint32_t)(2 * b);
@@ -1171,7 +1194,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   if (pairing_product_is_one_batch_bls12_377(g1.data(), i1.data(), g2.data(), i2.data(), po.data(), m, ok.data()) != 0) return false;
   ph.mark("pairing checks (GPU)");
   bool all = true;
-  for (size_t b = 0; b < m; b++) { out_results[b] = ok[b] != 0; all = all && out_results[b]; }
+  for (size_t b = 0; b < m; b++) { out_results[b] = ok[b] != 0 && !hash_failed[b]; all = all && out_results[b]; }
   ph.mark("results");
   return all;
 }

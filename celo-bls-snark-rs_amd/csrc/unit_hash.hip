@@ -8,9 +8,9 @@
 #include <cstring>
 #include <cstdio>
 
+#include "runtime.h"
 namespace celo {
-std::mutex& api_mutex();
-int api_ensure_init();
+static std::mutex hash_mu;                 // bulk calls, serialised per process (each fills the GPU; buffers are per call)
 int wire_consts_device(WireConsts& out);   // unit_wire.hip
 
 struct HashDom { uint8_t b[8]; };
@@ -74,7 +74,8 @@ k_hash_finish(const uint64_t* __restrict__ cand_xy, const uint8_t* __restrict__ 
 }
 
 const EdPoint* celo_composite_gens(size_t* count);   // seam_a.hip: the generator table (built once, ChaCha20 stream of the reference)
-static EdPoint* g_d_gens = nullptr;                  // its device copy (11.7 MB), uploaded on first use under the API lock
+static EdPoint* g_d_gens_dev[MAX_DEVICES] = {};      // its device copies (11.7 MB each), uploaded on first use (under hash_mu)
+#define g_d_gens g_d_gens_dev[api_device()]
 static int ensure_device_gens(const EdPoint* h_gens, size_t ngens) {
   if (g_d_gens) return 0;
   if (hipMalloc(&g_d_gens, ngens * sizeof(EdPoint)) != hipSuccess) { g_d_gens = nullptr; return 10; }
@@ -94,8 +95,8 @@ int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint
                           size_t n, uint64_t* out_xy, uint8_t* attempts, int mode) {
   size_t ngens = 0;
   const EdPoint* h_gens = mode == TAI_COMPOSITE ? celo_composite_gens(&ngens) : nullptr;   // before the lock: 0.5 s on first use
-  std::lock_guard<std::mutex> lk(api_mutex());
-  if (int rc0 = api_ensure_init()) return rc0;
+  if (int rc0 = api_enter()) return rc0;
+  std::lock_guard<std::mutex> lk(hash_mu);
   if (n == 0) return 0;
   if (mode == TAI_COMPOSITE) {
     if (int rcg = ensure_device_gens(h_gens, ngens)) return rcg;
@@ -194,8 +195,8 @@ k_pedersen_crh(const EdPoint* __restrict__ gens, const uint8_t* __restrict__ msg
 int pedersen_crh_run(const uint8_t* msgs, const uint64_t* msg_off, size_t n, uint8_t* out48) {
   size_t ngens = 0;
   const EdPoint* gens = celo_composite_gens(&ngens);      // before the lock: building the table takes 0.5 s on first use
-  std::lock_guard<std::mutex> lk(api_mutex());
-  if (int rc0 = api_ensure_init()) return rc0;
+  if (int rc0 = api_enter()) return rc0;
+  std::lock_guard<std::mutex> lk(hash_mu);
   if (n == 0) return 0;
   if (!msg_off || !out48 || n > 0x7fffffffu) return 2;
   for (size_t i = 0; i < n; i++) {

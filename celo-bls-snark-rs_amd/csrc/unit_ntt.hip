@@ -3,21 +3,23 @@
 #include <mutex>
 
 namespace celo {
-std::mutex& api_mutex();
-int api_ensure_init();
-static NttEngine eng_ntt;
+static EnginePool<NttEngine>& pool_ntt() { static auto* p = new EnginePool<NttEngine>(); return *p; }
+static std::mutex tm_mu_ntt;
+static NttTimings tm_last_ntt;
 
 int ntt_run(uint64_t* data, unsigned log_n, const uint64_t* omega, const uint64_t* coset, int coset_after, const uint64_t* scale, int dev, void* stream) {
-  std::lock_guard<std::mutex> lk(api_mutex());
-  if (int rc = api_ensure_init()) return rc;
+  if (int rc = api_enter()) return rc;
   if (!data || !omega) return 2;
-  return dev ? eng_ntt.run_device(data, log_n, omega, coset, coset_after, scale, (hipStream_t)stream)
-             : eng_ntt.run_host(data, log_n, omega, coset, coset_after, scale, nullptr);
+  auto e = pool_ntt().lease();      // an engine keeps the twiddle table of its last (omega, n): repeated transforms reuse it
+  const int rc = dev ? e->run_device(data, log_n, omega, coset, coset_after, scale, (hipStream_t)stream)
+                     : e->run_host(data, log_n, omega, coset, coset_after, scale, e->own_stream());
+  if (!rc) { std::lock_guard<std::mutex> lk(tm_mu_ntt); tm_last_ntt = e->tm; }
+  return rc;
 }
 int ntt_timings(float ms[4], int* passes) {
-  std::lock_guard<std::mutex> lk(api_mutex());
-  ms[0] = eng_ntt.tm.load; ms[1] = eng_ntt.tm.passes; ms[2] = eng_ntt.tm.store; ms[3] = eng_ntt.tm.total;
-  if (passes) *passes = eng_ntt.tm.npasses;
+  std::lock_guard<std::mutex> lk(tm_mu_ntt);
+  ms[0] = tm_last_ntt.load; ms[1] = tm_last_ntt.passes; ms[2] = tm_last_ntt.store; ms[3] = tm_last_ntt.total;
+  if (passes) *passes = tm_last_ntt.npasses;
   return 0;
 }
 }  // namespace celo

@@ -2,10 +2,12 @@
 #include "wire.h"
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include "runtime.h"
 
 namespace celo {
-std::mutex& api_mutex();
-int api_ensure_init();
+// decode / normalise calls allocate their buffers per call and run on the caller's stream (or the null stream); calls from
+// several host threads are serialised per process by this lock (they are bulk calls: one fills the GPU)
+static std::mutex wire_mu;
 
 // in: n x 48 (G1) / n x 96 (G2) wire bytes.  out: n x 12 / n x 24 u64, affine (x, y) in arkworks Montgomery limbs (the layout
 // the MSM and pairing entry points take), zeros unless status == WIRE_OK.  Control flow is uniform apart from the table scans of the square
@@ -73,9 +75,12 @@ k_normalize(const uint64_t* __restrict__ jac, uint64_t* __restrict__ out, uint8_
   }
 }
 
-// the constants with the discrete-log tables in device memory (uploaded once; callers hold the API lock)
+// the constants with the discrete-log tables in device memory: one copy per device, uploaded on first use there
 int wire_consts_device(WireConsts& out) {
-  static WireTables* d_tab = nullptr;
+  static std::mutex mu;
+  static WireTables* d_tabs[MAX_DEVICES] = {};
+  std::lock_guard<std::mutex> lk(mu);
+  WireTables*& d_tab = d_tabs[api_device()];
   out = wire_consts();
   if (!d_tab) {
     if (hipMalloc(&d_tab, sizeof(WireTables)) != hipSuccess) { d_tab = nullptr; return 10; }
@@ -93,8 +98,8 @@ static float g_wire_ms = 0.f;
   } while (0)
 
 int wire_decompress(int g2, const uint8_t* in, size_t n, int check, uint64_t* out, uint8_t* status, int dev, void* stream_) {
-  std::lock_guard<std::mutex> lk(api_mutex());
-  if (int rc0 = api_ensure_init()) return rc0;
+  if (int rc0 = api_enter()) return rc0;
+  std::lock_guard<std::mutex> lk(wire_mu);
   if (n == 0) return 0;
   if (!in || !out || !status || n > 0x7fffffffu) return 2;
   WireConsts k;
@@ -132,8 +137,8 @@ done:
   return rc;
 }
 int wire_normalize(int g2, const uint64_t* jac, size_t n, uint64_t* out_xy, uint8_t* inf) {
-  std::lock_guard<std::mutex> lk(api_mutex());
-  if (int rc0 = api_ensure_init()) return rc0;
+  if (int rc0 = api_enter()) return rc0;
+  std::lock_guard<std::mutex> lk(wire_mu);
   if (n == 0) return 0;
   if (!jac || !out_xy || !inf || n > 0x7fffffffu) return 2;
   const size_t cw = g2 ? 12 : 6;

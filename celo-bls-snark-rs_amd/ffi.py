@@ -14,7 +14,9 @@ GROUP_ID = {"bls12_377_g1": 0, "bls12_377_g2": 1, "bw6_761_g1": 2, "bw6_761_g2":
 GROUP_SHAPE = {"bls12_377_g1": (12, 4, 18), "bls12_377_g2": (24, 4, 36), "bw6_761_g1": (24, 6, 36), "bw6_761_g2": (24, 6, 36)}
 
 EXPORTS = [
-    "celo_amd_init", "celo_amd_device_name",
+    "celo_amd_init", "celo_amd_use_device", "celo_amd_device_count", "celo_amd_device_name",
+    "msm_bls12_377_g1_multi", "msm_bls12_377_g2_multi", "msm_bw6_761_g1_multi", "msm_bw6_761_g2_multi",
+    "msm_bls12_377_g1_multi_dev", "msm_bls12_377_g2_multi_dev", "msm_bw6_761_g1_multi_dev", "msm_bw6_761_g2_multi_dev",
     "msm_bls12_377_g1", "msm_bls12_377_g2", "msm_bw6_761_g1", "msm_bw6_761_g2",
     "msm_batch_bls12_377_g1", "msm_batch_bls12_377_g2", "msm_batch_bw6_761_g1", "msm_batch_bw6_761_g2",
     "msm_bls12_377_g1_dev", "msm_bls12_377_g2_dev", "msm_bw6_761_g1_dev", "msm_bw6_761_g2_dev",
@@ -23,6 +25,8 @@ EXPORTS = [
     "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
     "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
+    "celo_amd_gen_points_grouped_bls12_377_g1_dev", "celo_amd_gen_points_grouped_bls12_377_g2_dev",
+    "batch_verify_bls12_377", "batch_verify_bls12_377_dev",
     "ntt_bw6_761_fr", "ntt_bw6_761_fr_dev",
     "decompress_bls12_377_g1", "decompress_bls12_377_g2", "decompress_bls12_377_g1_dev", "decompress_bls12_377_g2_dev",
     "normalize_bls12_377_g1", "normalize_bls12_377_g2",
@@ -51,6 +55,53 @@ def init(device=0):
     rc = lib().celo_amd_init(C.c_int(device))
     if rc != 0:
         raise RuntimeError(f"celo_amd_init({device}) failed rc={rc} (no gfx950 device?)")
+
+
+def use_device(device):
+    """Binds the CALLING thread to a device (celo_amd_use_device)."""
+    rc = lib().celo_amd_use_device(C.c_int(device))
+    if rc != 0:
+        raise RuntimeError(f"celo_amd_use_device({device}) failed rc={rc}")
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().celo_amd_device_count(C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"celo_amd_device_count failed rc={rc} (no gfx950 device?)")
+    return n.value
+
+
+def msm_multi(group, devices, bases_xy, inf, scalars):
+    """One MSM sharded by index range over `devices` (list of ordinals, repeats allowed) inside this process; host buffers."""
+    A, S, O = GROUP_SHAPE[group]
+    bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = bases_xy.size // A
+    assert bases_xy.size == n * A and scalars.size == n * S, "bases / scalars length mismatch"
+    devs = (C.c_int * len(devices))(*devices)
+    out = np.zeros(O, dtype=np.uint64)
+    rc = getattr(lib(), "msm_" + group + "_multi")(devs, C.c_int(len(devices)), _p(bases_xy), _p(inf), _p(scalars), C.c_size_t(n), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"msm_{group}_multi failed rc={rc}")
+    return out
+
+
+def msm_multi_dev(group, devices, d_bases, d_infs, d_scalars, n_per):
+    """One MSM over shards already resident on their devices: d_bases / d_scalars / d_infs (or None) are lists of integer
+    device addresses, n_per the terms per shard."""
+    O = GROUP_SHAPE[group][2]
+    k = len(devices)
+    devs = (C.c_int * k)(*devices)
+    pb = (C.c_void_p * k)(*d_bases)
+    ps = (C.c_void_p * k)(*d_scalars)
+    pi = (C.c_void_p * k)(*[x or 0 for x in d_infs]) if d_infs is not None else None
+    np_ = (C.c_size_t * k)(*n_per)
+    out = np.zeros(O, dtype=np.uint64)
+    rc = getattr(lib(), "msm_" + group + "_multi_dev")(devs, C.c_int(k), pb, pi, ps, np_, _p(out))
+    if rc != 0:
+        raise RuntimeError(f"msm_{group}_multi_dev failed rc={rc}")
+    return out
 
 
 def msm(group, bases_xy, inf, scalars):
@@ -100,6 +151,48 @@ def gen_points_dev(group, d_out, n, seed, gen_xy, stream=0):
     rc = getattr(lib(), name)(C.c_void_p(d_out), C.c_size_t(n), C.c_uint64(seed), _p(gen_xy), C.c_void_p(stream or 0))
     if rc != 0:
         raise RuntimeError(f"{name} failed rc={rc}")
+
+
+def gen_points_grouped_dev(group, d_out, n, seed, gens_xy, per, stream=0):
+    """P_i = k_i * gens[i // per] into device memory (celo_amd_gen_points_grouped_*): gens_xy (ngens, A) uint64 host limbs."""
+    name = {"bls12_377_g1": "celo_amd_gen_points_grouped_bls12_377_g1_dev", "bls12_377_g2": "celo_amd_gen_points_grouped_bls12_377_g2_dev"}[group]
+    A = GROUP_SHAPE[group][0]
+    gens_xy = np.ascontiguousarray(gens_xy, dtype=np.uint64).reshape(-1, A)
+    rc = getattr(lib(), name)(C.c_void_p(d_out), C.c_size_t(n), C.c_uint64(seed), _p(gens_xy), C.c_size_t(gens_xy.shape[0]), C.c_uint32(per),
+                              C.c_void_p(stream or 0))
+    if rc != 0:
+        raise RuntimeError(f"{name} failed rc={rc}")
+
+
+def batch_verify(pk_xy, sig_xy, exponents, offsets, hash_xy, neg_g2_xy):
+    """Batch::verify for m batches, host buffers (batch_verify_bls12_377).  Returns uint8 [m] verdicts."""
+    pk_xy = np.ascontiguousarray(pk_xy, dtype=np.uint64)
+    sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
+    exponents = np.ascontiguousarray(exponents, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    hash_xy = np.ascontiguousarray(hash_xy, dtype=np.uint64)
+    ng2 = np.ascontiguousarray(neg_g2_xy, dtype=np.uint64).reshape(24)
+    m = offsets.size - 1
+    tot = int(offsets[-1])
+    assert pk_xy.size == tot * 24 and sig_xy.size == tot * 12 and exponents.size == tot * 4 and hash_xy.size == m * 12
+    out = np.zeros(m, dtype=np.uint8)
+    rc = lib().batch_verify_bls12_377(_p(pk_xy), _p(sig_xy), _p(exponents), _p(offsets), _p(hash_xy), _p(ng2), C.c_size_t(m), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"batch_verify_bls12_377 failed rc={rc}")
+    return out
+
+
+def batch_verify_dev(d_pk, d_sig, d_exp, offsets, d_hash, neg_g2_xy):
+    """The same on inputs resident in HBM (integer device addresses); offsets: host uint32 [m+1]."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    ng2 = np.ascontiguousarray(neg_g2_xy, dtype=np.uint64).reshape(24)
+    m = offsets.size - 1
+    out = np.zeros(m, dtype=np.uint8)
+    rc = lib().batch_verify_bls12_377_dev(C.c_void_p(d_pk), C.c_void_p(d_sig), C.c_void_p(d_exp), _p(offsets), C.c_void_p(d_hash), _p(ng2),
+                                          C.c_size_t(m), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"batch_verify_bls12_377_dev failed rc={rc}")
+    return out
 
 
 def sum_jacobian(group, jac):

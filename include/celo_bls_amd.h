@@ -14,8 +14,13 @@
  *     crates/bls-snark-sys/src/lib.rs:21-27 convert_result_to_bool);
  *   - *_dev variants take DEVICE pointers (inputs already resident in HBM) and a hipStream_t
  *     (as void*; NULL = default stream); the result still lands in host memory.
- * All functions are synchronous and may be called from any host thread.  MSM / NTT / batched calls are serialised internally;
- * single pairing-product checks from concurrent threads are combined into shared launches.
+ * Threading (the reference's callers are synchronous, re-entrant and multi-threaded -
+ * crates/bls-snark-sys/src/cache.rs:5, signatures.rs:343-400): every function is synchronous and may be called from any host
+ * thread at any time.  There is no global lock: each MSM / pairing / NTT call checks an engine instance (workspace, pinned
+ * staging, its own non-blocking HIP stream) out of a per-device pool, so independent calls overlap on the GPU; single
+ * pairing-product checks from concurrent threads are combined into shared launches.  Bulk decode / hash calls are serialised
+ * among themselves only.  Several devices can be driven from one process: celo_amd_use_device() binds the calling thread to a
+ * device, the msm_*_multi entry points shard one MSM over a device list internally.
  */
 #ifndef CELO_BLS_AMD_H
 #define CELO_BLS_AMD_H
@@ -25,8 +30,14 @@
 extern "C" {
 #endif
 
-/* Selects the HIP device for this process (one process per GPU). Returns 0, or non-zero if no gfx950 device. */
+/* Selects the process's DEFAULT device: the one every host thread uses unless it bound itself to another with
+ * celo_amd_use_device (HIP's current device is per thread; each entry point re-applies the right one on its calling thread).
+ * Returns 0, or non-zero if there is no gfx950 device (100) or `device` is out of range (101).  Never calling it = device 0. */
 int celo_amd_init(int device);
+/* Binds the CALLING host thread to `device` for all its later calls (engines, tables and streams are per device). */
+int celo_amd_use_device(int device);
+/* Number of HIP devices visible to the process (at most 16 are used). */
+int celo_amd_device_count(int* count);
 /* "gfx950:..." string of the active device into buf; returns 0. */
 int celo_amd_device_name(char* buf, size_t buflen);
 
@@ -47,6 +58,23 @@ int msm_bls12_377_g2_dev(const void* d_bases_xy, const void* d_inf, const void* 
 int msm_bw6_761_g1_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
 int msm_bw6_761_g2_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
 
+/* ---- one MSM sharded over several devices of this process (index-range shards, no data-path collective;
+ * the reference's callers are ONE process - crates/bls-snark-sys/src/signatures.rs:343, crates/epoch-snark/src/api/prover.rs:78).
+ * devices[ndev]: device ordinals (a device may appear more than once: that many engines run on it concurrently); one host
+ * thread per entry computes the partial sum of its contiguous slice on its device, the Jacobian partials (144 / 288 bytes
+ * each) are folded on the host.  Same conventions and results as the single-device entry points.
+ * _multi: HOST pointers, n terms cut into ndev equal index ranges.
+ * _multi_dev: per-shard DEVICE pointers (shard d resident on devices[d]: d_bases[d], d_inf[d] or d_inf == NULL, d_scalars[d],
+ * n_per[d] terms). */
+int msm_bls12_377_g1_multi(const int* devices, int ndev, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[18]);
+int msm_bls12_377_g2_multi(const int* devices, int ndev, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bw6_761_g1_multi(const int* devices, int ndev, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bw6_761_g2_multi(const int* devices, int ndev, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bls12_377_g1_multi_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, const size_t* n_per, uint64_t out_xyz[18]);
+int msm_bls12_377_g2_multi_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, const size_t* n_per, uint64_t out_xyz[36]);
+int msm_bw6_761_g1_multi_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, const size_t* n_per, uint64_t out_xyz[36]);
+int msm_bw6_761_g2_multi_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, const size_t* n_per, uint64_t out_xyz[36]);
+
 /* ---- batched MSMs: m independent instances in one call; instance p owns points/scalars [offsets[p], offsets[p+1])
  * (offsets has m+1 entries), out_xyz holds m Jacobian results back to back.  This is the shape of Batch::verify
  * (crates/bls-crypto/src/bls/batch.rs:69,76 — one G2 and one G1 MSM over the batch's signers) when
@@ -57,6 +85,20 @@ int msm_batch_bls12_377_g1(const uint64_t* bases_xy, const uint8_t* inf, const u
 int msm_batch_bls12_377_g2(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*36 */);
 int msm_batch_bw6_761_g1(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*36 */);
 int msm_batch_bw6_761_g2(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*36 */);
+
+/* ---- Batch::verify for m batches in one call, chained on the device (crates/bls-crypto/src/bls/batch.rs:44-84: per batch
+ * P = sum_j e_j pk_j (G2 MSM), S = sum_j e_j sig_j (G1 MSM), accept iff e(S, -g2) * e(H(m), P) == 1; the FFI loops over batches
+ * serially, crates/bls-snark-sys/src/signatures.rs:358).  Batch b owns keys / signatures / exponents [offsets[b], offsets[b+1])
+ * (at most 1024 each); hash_xy[b] = H(m_b) affine; neg_g2_xy = the negated G2 generator, affine (the caller's constant; the
+ * library restates no curve constant here).  Both batch MSMs run concurrently on two engines; their Jacobian results are
+ * normalised ON the device straight into the pairing engine's input slots - nothing returns to the host but the m verdicts
+ * out_ok[b] in {0, 1}.  Exponents: canonical 4 x u64 (Batch::verify draws 128 + log2(n) random bits; the window count adapts
+ * to the longest one present).  _dev: every pointer except offsets, neg_g2_xy and out_ok is a DEVICE pointer. */
+int batch_verify_bls12_377(const uint64_t* pk_xy /* tot x 24 */, const uint64_t* sig_xy /* tot x 12 */, const uint64_t* exponents /* tot x 4 */,
+                           const uint32_t* offsets /* m+1 */, const uint64_t* hash_xy /* m x 12 */, const uint64_t neg_g2_xy[24], size_t m,
+                           uint8_t* out_ok /* m */);
+int batch_verify_bls12_377_dev(const void* d_pk_xy, const void* d_sig_xy, const void* d_exponents, const uint32_t* offsets, const void* d_hash_xy,
+                               const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok /* m */);
 
 /* ---- pairing product check.  Replaces `Bls12_377::product_of_pairings(&pairs) == Fq12::one()` at
  *   crates/bls-crypto/src/bls/public.rs:102    (PublicKey::verify_sig: 2 pairs)
@@ -172,6 +214,11 @@ int celo_amd_msm_set_window_bits(int group, int c);
 int celo_amd_gen_points_bls12_377_g1_dev(void* d_out_xy, size_t n, uint64_t seed, const uint64_t* gen_xy, void* stream);
 int celo_amd_gen_points_bls12_377_g2_dev(void* d_out_xy, size_t n, uint64_t seed, const uint64_t* gen_xy, void* stream);
 int celo_amd_gen_points_bw6_761_dev(void* d_out_xy, size_t n, uint64_t seed, const uint64_t* gen_xy, void* stream);
+/* The same with one generator per group of `per` consecutive points: P_i = k_i * gens[i / per] (ngens >= ceil(n / per) affine
+ * generators, HOST pointer).  Builds VALID Batch::verify inputs without a host big-int loop: the
+ * signatures of batch b = k_{b,j} * H(m_b) with gens = the message hashes, the keys = k_{b,j} * g2 from the same seed. */
+int celo_amd_gen_points_grouped_bls12_377_g1_dev(void* d_out_xy, size_t n, uint64_t seed, const uint64_t* gens_xy, size_t ngens, uint32_t per, void* stream);
+int celo_amd_gen_points_grouped_bls12_377_g2_dev(void* d_out_xy, size_t n, uint64_t seed, const uint64_t* gens_xy, size_t ngens, uint32_t per, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,18 @@ def _worker(rank, world, port, q):
     # folding identity partials must be a no-op
     ident = np.zeros((1, 18), dtype=np.uint64)
     total2 = ffi.sum_jacobian("bls12_377_g1", np.concatenate([parts, ident]))
-    q.put((rank, got == exp, co.jac_to_affine(total2, "g1_377") == exp))
+    # bench.py's own N > 1 plumbing (host-staged here): the Folder every MSM step goes through and the one-off gather of the
+    # inputs to rank 0 behind the full-size parity check
+    import bench
+    cx = bench.Ctx()
+    cx.world, cx.rank, cx.xdev = world, rank, "cpu"
+    total3 = bench.Folder(cx, "bls12_377_g1", 18)(part)
+    allxy = bench.gather_to_rank0(cx, torch.from_numpy(xy.view(np.int64).copy()))
+    gathered_ok = True
+    if rank == 0:
+        full, _ = co.pack_g1_377(pts)
+        gathered_ok = np.array_equal(allxy, full)
+    q.put((rank, got == exp, co.jac_to_affine(total2, "g1_377") == exp and co.jac_to_affine(total3, "g1_377") == exp and gathered_ok))
     dist.barrier()
     dist.destroy_process_group()
 

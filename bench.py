@@ -442,7 +442,7 @@ class MixedConfig:
 def pairing_leg(ffi, check_oracle=True):
     """"+ pairings/sec" of BASELINE.json's metric: m independent 2-pair checks e(sig,-g2)*e(H,pk) == 1 (PublicKey::verify /
     Batch::verify's final check) in one launch; Miller loops/s with one final exponentiation per 2 loops."""
-    m = 86016                                 # one 3-lane group per product, 21 groups per wave: 4096 waves = two full rounds of 2 waves/SIMD
+    m = 81920                                 # one 6-lane group per product, 10 groups per wave: 8192 waves = four full rounds of 2 waves/SIMD
     g1, g2, offs, expect = verify_shaped_products(m, 0x5EED0005)
     ffi.pairing_product_is_one_batch(g1, None, g2, None, offs)          # warm-up
     best, got = None, None

@@ -395,6 +395,46 @@ template <class P> struct Fp {
     TRK(r.lb = 1; r.vb = NEG ? 3 : 2;)
     return r;
   }
+  // (a*b + c*d)/R + p with c handed over as SIGNED limbs cs[i] (|cs[i]| <= 5 * 2^W): one instruction stream for both halves of an
+  // Fq2 product when the two halves sit in two different lanes (lanes.h, QHex: c0 = a0 b0 - 5 a1 b1 takes cs = -5 a1, c1 =
+  // a0 b1 + a1 b0 takes cs = a1; v_mad_i64_i32 costs what v_mad_u64_u32 costs).  a, b, d normalised.  Column bound as mul2k<-5>.
+  HD static Fp mul2s(const Fp& a, const Fp& b, const int32_t* cs, const Fp& d) {
+    TRK(assert(a.lb <= 1 && b.lb <= 1 && d.lb <= 1); assert(a.vb * b.vb + 5 * 64 * d.vb <= 32768.0);)
+    Fp r;
+    uint32_t m[L];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc += (uint64_t)a.l[i] * b.l[k - i];
+        acc += (uint64_t)((int64_t)cs[i] * (int64_t)(int32_t)d.l[k - i]);
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      uint32_t lo = (uint32_t)acc;
+      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      acc += (uint64_t)m[k] * P::P[0];
+      acc = (uint64_t)((int64_t)acc >> W);
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) {
+        acc += (uint64_t)a.l[i] * b.l[k - i];
+        acc += (uint64_t)((int64_t)cs[i] * (int64_t)(int32_t)d.l[k - i]);
+      }
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      acc += P::P[k - L];  // + p after the division by R keeps the result positive
+      r.l[k - L] = (uint32_t)acc & MASK;
+      acc = (uint64_t)((int64_t)acc >> W);
+    }
+    acc += P::P[L - 1];
+    r.l[L - 1] = (uint32_t)acc;
+    TRK(r.lb = 1; r.vb = 3;)
+    return r;
+  }
   template <bool SUB5> HD static Fp mul2(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {  // inputs normalised (Fp2)
     TRK(assert(a.lb <= 1 && b.lb <= 1 && c.lb <= 1 && d.lb <= 1);)
     return mul2k<SUB5 ? -5 : 1>(a, b, c, d);

@@ -111,63 +111,83 @@ static void pairing_op(int mode, const uint64_t* g1, const uint64_t* g2, size_t 
   if (is_one) *is_one = f12_is_one(r) ? 1 : 0;
 }
 
-// the lane-parallel pairing (pairing_lanes.h) on its three-explicit-lanes host backend; same modes as pairing_op
-typedef QTower<QHost377> HQT;
-typedef QPairing377<QHost377> HQP;
-static HQT::E12 lanes_from_f12(const Fq12& x) {
-  HQT::E12 e;
-  const Fq2* c[6] = {&x.c0.c0, &x.c0.c1, &x.c0.c2, &x.c1.c0, &x.c1.c1, &x.c1.c2};
-  for (int j = 0; j < 3; j++) { e.a.v[j] = *c[j]; e.b.v[j] = *c[3 + j]; }
-  return e;
-}
-static Fq12 lanes_to_f12(const HQT::E12& e) {
-  Fq12 x;
-  Fq2* c[6] = {&x.c0.c0, &x.c0.c1, &x.c0.c2, &x.c1.c0, &x.c1.c1, &x.c1.c2};
-  for (int j = 0; j < 3; j++) { *c[j] = e.a.v[j]; *c[3 + j] = e.b.v[j]; }
-  return x;
-}
-static void pairing_op_lanes(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
-                            uint64_t* out72, int* is_one) {
-  HQT::E12 r;
+// the lane-parallel pairing (pairing_lanes.h) on its explicit-lanes host backends - three lanes per pairing (an Fq2 per lane)
+// and six (half an Fq2 per lane); same modes as pairing_op
+struct HostTri {
+  typedef QHost377 QB;
+  static QB::V v2(const Fq2& lane0, const Fq2& lane1, const Fq2& lane2) { QB::V r; r.v[0] = lane0; r.v[1] = lane1; r.v[2] = lane2; return r; }
+  static QB::F f1(const Fq& x) { QB::F r; for (int l = 0; l < 3; l++) r.v[l] = x; return r; }
+  static Fq2 get(const QB::V& v, int j) { return v.v[j]; }
+};
+struct HostHex {
+  typedef QHostHex377 QB;
+  static QB::V v2(const Fq2& lane0, const Fq2& lane1, const Fq2& lane2) {
+    QB::V r;
+    const Fq2* s[3] = {&lane0, &lane1, &lane2};
+    for (int j = 0; j < 3; j++) { r.v[2 * j] = s[j]->c0; r.v[2 * j + 1] = s[j]->c1; }
+    return r;
+  }
+  static QB::F f1(const Fq& x) { QB::F r; for (int l = 0; l < 6; l++) r.v[l] = x; return r; }
+  static Fq2 get(const QB::V& v, int j) { return {v.v[2 * j], v.v[2 * j + 1]}; }
+};
+template <class H> static void pairing_op_lanes_t(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
+                                                  uint64_t* out72, int* is_one) {
+  typedef typename H::QB QB;
+  typedef QTower<QB> HQT;
+  typedef QPairing377<QB> HQP;
+  auto from_f12 = [](const Fq12& x) {
+    typename HQT::E12 e;
+    e.a = H::v2(x.c0.c0, x.c0.c1, x.c0.c2);
+    e.b = H::v2(x.c1.c0, x.c1.c1, x.c1.c2);
+    return e;
+  };
+  auto to_f12 = [](const typename HQT::E12& e) {
+    Fq12 x;
+    x.c0.c0 = H::get(e.a, 0); x.c0.c1 = H::get(e.a, 1); x.c0.c2 = H::get(e.a, 2);
+    x.c1.c0 = H::get(e.b, 0); x.c1.c1 = H::get(e.b, 1); x.c1.c2 = H::get(e.b, 2);
+    return x;
+  };
+  auto load_pair = [&](size_t i, typename QB::F& px, typename QB::F& py, typename QB::V& Qc) {
+    px = H::f1(Fq::from_ark(g1 + i * 12)); py = H::f1(Fq::from_ark(g1 + i * 12 + 6));
+    const Fq2 qx = Fq2::from_ark(g2 + i * 24), qy = Fq2::from_ark(g2 + i * 24 + 12);
+    Qc = H::v2(qx, qy, qx);                                      // lanes 0, 2: Q.x; lane 1: Q.y
+  };
+  typename HQT::E12 r;
   if (mode == 10 || mode == 11) {  // whole product in one group with a shared accumulator (k <= 4); 10: GT value, 11: Miller value
-    QHost377::F px[4], py[4];
-    QHost377::V Qc[4];
-    for (size_t i = 0; i < k && i < 4; i++)
-      for (int l = 0; l < 3; l++) {
-        px[i].v[l] = Fq::from_ark(g1 + i * 12); py[i].v[l] = Fq::from_ark(g1 + i * 12 + 6);
-        Qc[i].v[l] = Fq2::from_ark(g2 + i * 24 + (l & 1) * 12);
-      }
-    HQT::E12 acc = HQP::miller_multi<4>((int)k, px, py, Qc);
+    typename QB::F px[4], py[4];
+    typename QB::V Qc[4];
+    for (size_t i = 0; i < k && i < 4; i++) load_pair(i, px[i], py[i], Qc[i]);
+    typename HQT::E12 acc = HQP::template miller_multi<4>((int)k, px, py, Qc);
     r = mode == 10 ? HQP::final_exponentiation(acc) : acc;
   } else if (mode <= 1) {
-    HQT::E12 acc = HQT::one12();
+    typename HQT::E12 acc = HQT::one12();
     for (size_t i = 0; i < k; i++) {
-      QHost377::F px, py;
-      QHost377::V Qc;
-      for (int l = 0; l < 3; l++) {
-        px.v[l] = Fq::from_ark(g1 + i * 12); py.v[l] = Fq::from_ark(g1 + i * 12 + 6);
-        Qc.v[l] = Fq2::from_ark(g2 + i * 24 + (l & 1) * 12);
-      }
+      typename QB::F px, py;
+      typename QB::V Qc;
+      load_pair(i, px, py, Qc);
       acc = HQT::mul12(acc, HQP::miller(px, py, Qc));
     }
     r = mode == 0 ? HQP::final_exponentiation(acc) : acc;
   } else {
-    HQT::E12 a = lanes_from_f12(f12_from_ark(in72));
+    typename HQT::E12 a = from_f12(f12_from_ark(in72));
     switch (mode) {
       case 2: r = HQP::final_exponentiation(a); break;
-      case 3: r = HQT::mul12(a, lanes_from_f12(f12_from_ark(in72b))); break;
+      case 3: r = HQT::mul12(a, from_f12(f12_from_ark(in72b))); break;
       case 4: r = HQT::inv12(a); break;
       case 5: r = HQT::cyclotomic_sqr(a); break;
-      case 6: r = HQP::frob12<1>(a); break;
-      case 7: r = HQP::frob12<2>(a); break;
-      case 8: r = HQP::frob12<3>(a); break;
+      case 6: r = HQP::template frob12<1>(a); break;
+      case 7: r = HQP::template frob12<2>(a); break;
+      case 8: r = HQP::template frob12<3>(a); break;
       default: r = HQT::sqr12(a); break;
     }
   }
-  f12_to_ark(lanes_to_f12(r), out72);
+  f12_to_ark(to_f12(r), out72);
   if (is_one) *is_one = HQT::is_one12(r) ? 1 : 0;
 }
-
+static void pairing_op_lanes(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
+                             uint64_t* out72, int* is_one) { pairing_op_lanes_t<HostTri>(mode, g1, g2, k, in72, in72b, out72, is_one); }
+static void pairing_op_hex(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
+                           uint64_t* out72, int* is_one) { pairing_op_lanes_t<HostHex>(mode, g1, g2, k, in72, in72b, out72, is_one); }
 static void pairing_op_761_lanes(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, uint64_t* out72, int* is_one) {
   typedef QTower<QHost761> T6;
   typedef QPairing761<QHost761> P6;
@@ -258,6 +278,8 @@ void ht_pairing_377(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, 
                     uint64_t* out72, int* is_one) { pairing_op(mode, g1, g2, k, in72, in72b, out72, is_one); }
 void ht_pairing_377_lanes(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
                          uint64_t* out72, int* is_one) { pairing_op_lanes(mode, g1, g2, k, in72, in72b, out72, is_one); }
+void ht_pairing_377_hex(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
+                       uint64_t* out72, int* is_one) { pairing_op_hex(mode, g1, g2, k, in72, in72b, out72, is_one); }
 void ht_fq377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp<P377>>(op, a, b, out); }
 void ht_fq761(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp<P761>>(op, a, b, out); }
 void ht_fq2_377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp2<P377>>(op, a, b, out); }

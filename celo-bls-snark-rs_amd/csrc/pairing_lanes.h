@@ -72,6 +72,196 @@ struct QTri761 : QTriT<Base761> {
 };
 #endif
 
+// ================================================================== BLS12-377, SIX lanes per pairing ("hex" backends)
+// The three-lane layout keeps an Fq2 (28 words) per value and lane; the tower routines hold 8-10 such values at once, which
+// does not fit 256 VGPRs: every step spills ~2.3 KB per lane to scratch, and with 2048 waves resident the spill set (~330 MB)
+// lives in HBM, not in a cache (rocprof: 124 GB of traffic per 86016-product launch).  Here the two halves (c0, c1) of every Fq2
+// sit in two ADJACENT lanes: lane 2j + h of a group of six holds half h of tower lane j.  A value is 14 words, the whole live
+// state of a Miller step fits the register file, and a lane executes half the instructions per pairing (half the latency of a
+// lone verification).  An Fq2 product is ONE signed two-product Montgomery pass per lane (Fp::mul2s):
+//     half 0:  a0 b0 + (-5 a1) b1          half 1:  a0 b1 + a1 b0
+// after one exchange of the operands with the partner lane (lane ^ 1).  Multiplication by the non-residue u swaps the halves
+// ((x0, x1) u = (-5 x1, x0)).  QTower / QPairing377 below run unchanged on these backends: same field elements at every step.
+namespace hex {
+// lane-local pieces; h = the half this lane holds, *o = the partner lane's value.  All host+device, bounds-tracked on the host.
+HD Fq mul(const Fq& a_, const Fq& b_, const Fq& ao_, const Fq& bo_, int h) {     // inputs: any lazy form with lb <= 15
+  const Fq a = Fq::norm(a_), b = Fq::norm(b_), ao = Fq::norm(ao_), bo = Fq::norm(bo_);
+  int32_t cs[14];
+  Fq Y, D;
+#pragma unroll
+  for (int i = 0; i < 14; i++) {
+    cs[i] = h ? (int32_t)ao.l[i] : -5 * (int32_t)ao.l[i];
+    Y.l[i] = h ? bo.l[i] : b.l[i];
+    D.l[i] = h ? b.l[i] : bo.l[i];
+  }
+  TRK(Y.lb = 1; D.lb = 1; Y.vb = h ? bo.vb : b.vb; D.vb = h ? b.vb : bo.vb; assert(ao.vb <= 64);)
+  return Fq::mul2s(a, Y, cs, D);
+}
+// (x0 + x1 u) u = -5 x1 + x0 u: half 0 takes -5 * (partner), half 1 takes the partner as it is.  Needs vb(partner) <= 12.
+HD Fq mul_nr(const Fq& xo, int h) {
+  if (h) return xo;
+  const Fq t = Fq::norm(xo);
+  const Fq t5 = Fq::norm(Fq::add(Fq::dbl(Fq::dbl(t)), t));
+  return Fq::norm(Fq::neg<64, 1>(t5));
+}
+HD Fq conj(const Fq& x, int h) { return h ? Fq::wred(Fq::norm(Fq::neg<4, 1>(x))) : x; }
+// B' x for the twist constant B' = (0, b1): (-5 b1 x1, b1 x0); p = b1 * (own half), po = the partner's p
+HD Fq twist_own(const Fq& x) { return Fq::mul(Fq::norm(x), Fq::from_limbs(T377::TWIST_B_C1)); }
+HD Fq twist_fin(const Fq& po, int h) {
+  if (h) return po;
+  const Fq p5 = Fq::norm(Fq::add(Fq::dbl(Fq::dbl(po)), po));
+  return Fq::wred(Fq::norm(Fq::neg<16, 1>(p5)));
+}
+// Fq2 inverse: n = x0^2 + 5 x1^2 from the two squares, then x0 / n and -x1 / n
+HD Fq inv_norm(const Fq& s, const Fq& so, int h) {
+  const Fq s1 = h ? s : so, s0 = h ? so : s;
+  return Fq::norm(Fq::add(s0, Fq::add(Fq::dbl(Fq::dbl(s1)), s1)));
+}
+HD Fq inv_fin(const Fq& x, const Fq& ni, int h) {
+  const Fq r = Fq::mul(Fq::norm(x), ni);
+  return h ? Fq::norm(Fq::neg<4, 1>(r)) : r;
+}
+HD bool is_one_half(const Fq& a, int h) { return h ? a.is_zero_mod_p() : Fq::sub<64, 1>(Fq::norm(a), Fq::one()).is_zero_mod_p(); }
+HD Fq add(const Fq& a, const Fq& b) { return Fq::norm(Fq::add(a, b)); }
+HD Fq dbl(const Fq& a) { return Fq::norm(Fq::add(a, a)); }
+HD Fq tpl(const Fq& a) { return Fq::norm(Fq::add(Fq::add(a, a), a)); }
+template <int K> HD Fq sub(const Fq& a, const Fq& b) { return Fq::norm(Fq::sub<K, 1>(a, b)); }
+template <int K> HD Fq neg(const Fq& a) { return Fq::norm(Fq::neg<K, 1>(a)); }
+}  // namespace hex
+
+// host backend: six explicit lanes, index 2 j + h
+struct QHostHex377 {
+  static constexpr int NL = 3;
+  struct V { Fq v[6]; };
+  typedef V F;                                            // P's coordinates: the same Fq in every lane
+  template <class Fn> static V map1(const V& a, Fn fn) { V r; for (int i = 0; i < 6; i++) r.v[i] = fn(a.v[i], i & 1); return r; }
+  template <class Fn> static V map2(const V& a, const V& b, Fn fn) { V r; for (int i = 0; i < 6; i++) r.v[i] = fn(a.v[i], b.v[i]); return r; }
+  static V swap(const V& a) { V r; for (int i = 0; i < 6; i++) r.v[i] = a.v[i ^ 1]; return r; }
+  static V uni2(const Fq& c0, const Fq& c1) { V r; for (int i = 0; i < 6; i++) r.v[i] = (i & 1) ? c1 : c0; return r; }
+  static V mul(const V& a, const V& b) { V r; for (int i = 0; i < 6; i++) r.v[i] = hex::mul(a.v[i], b.v[i], a.v[i ^ 1], b.v[i ^ 1], i & 1); return r; }
+  static V add(const V& a, const V& b) { return map2(a, b, [](const Fq& x, const Fq& y) { return hex::add(x, y); }); }
+  static V dbl(const V& a) { return map1(a, [](const Fq& x, int) { return hex::dbl(x); }); }
+  static V tpl(const V& a) { return map1(a, [](const Fq& x, int) { return hex::tpl(x); }); }
+  template <int K> static V sub(const V& a, const V& b) { return map2(a, b, [](const Fq& x, const Fq& y) { return hex::sub<K>(x, y); }); }
+  template <int K> static V neg(const V& a) { return map1(a, [](const Fq& x, int) { return hex::neg<K>(x); }); }
+  static V wred(const V& a) { return map1(a, [](const Fq& x, int) { return Fq::wred(x); }); }
+  static V half(const V& a) { return map1(a, [](const Fq& x, int) { return Fq::half(x); }); }
+  static V mul_nr(const V& a) { V r; for (int i = 0; i < 6; i++) r.v[i] = hex::mul_nr(a.v[i ^ 1], i & 1); return r; }
+  static V conj(const V& a) { return map1(a, [](const Fq& x, int h) { return hex::conj(x, h); }); }
+  static V mul_fp(const V& a, const F& k) { return map2(a, k, [](const Fq& x, const Fq& y) { return Fq::mul(Fq::norm(x), y); }); }
+  static V twist_mul(const V& a) {
+    V p = map1(a, [](const Fq& x, int) { return hex::twist_own(x); }), r;
+    for (int i = 0; i < 6; i++) r.v[i] = hex::twist_fin(p.v[i ^ 1], i & 1);
+    return r;
+  }
+  static V inv(const V& a) {
+    V s = map1(a, [](const Fq& x, int) { return Fq::sqr(Fq::norm(x)); }), r;
+    for (int i = 0; i < 6; i++) r.v[i] = hex::inv_fin(a.v[i], Fq::inv(hex::inv_norm(s.v[i], s.v[i ^ 1], i & 1)), i & 1);
+    return r;
+  }
+  template <int CTRL> static V perm(const V& x) { V r; for (int i = 0; i < 6; i++) r.v[i] = x.v[2 * ((CTRL >> (2 * (i >> 1))) & 3) + (i & 1)]; return r; }
+  template <int K> static V bcast(const V& x) { return perm<QP(K, K, K)>(x); }
+  template <int K> static V sel(const V& onk, const V& other) { V r; for (int i = 0; i < 6; i++) r.v[i] = ((i >> 1) == K) ? onk.v[i] : other.v[i]; return r; }
+  static V pick(const V& a0, const V& a1, const V& a2) { V r; for (int i = 0; i < 6; i++) r.v[i] = (i >> 1) == 0 ? a0.v[i] : (i >> 1) == 1 ? a1.v[i] : a2.v[i]; return r; }
+  static F pickf(const F& a0, const F& a1, const F& a2) { return pick(a0, a1, a2); }
+  static V zero() { return uni2(Fq::zero(), Fq::zero()); }
+  static V one() { return uni2(Fq::one(), Fq::zero()); }
+  static V constant(const uint32_t* c0, const uint32_t* c1) { return uni2(Fq::from_limbs(c0), Fq::from_limbs(c1)); }
+  static bool is_zero_u(const V& a) { return a.v[0].is_zero_mod_p() && a.v[1].is_zero_mod_p(); }
+  static bool is_one3(const V& a, const V& b) {
+    bool ok = hex::is_one_half(a.v[0], 0) && a.v[1].is_zero_mod_p();
+    for (int i = 2; i < 6; i++) ok = ok && a.v[i].is_zero_mod_p();
+    for (int i = 0; i < 6; i++) ok = ok && b.v[i].is_zero_mod_p();
+    return ok;
+  }
+};
+
+#if defined(__HIPCC__)
+// device backend: groups of six adjacent lanes, 10 groups per wave64 (lanes 60..63 idle)
+struct QHex377 {
+  typedef Fq T;
+  typedef Fq V;
+  typedef Fq F;
+  static constexpr int NL = 3, GROUPS_PER_WAVE = 10, NWORDS = 14;
+  QDEV static int wave_lane() { return (int)__lane_id(); }
+  QDEV static int group() { return (wave_lane() * 43) >> 8; }            // lane / 6 for lane < 64
+  QDEV static int sub() { return wave_lane() - 6 * group(); }
+  QDEV static int lane() { return sub() >> 1; }                          // tower lane j
+  QDEV static int hsel() { return wave_lane() & 1; }                     // which half of the Fq2 (6 g is even)
+  QDEV static V from_addr(const V& x, int addr) {
+    V r;
+#pragma unroll
+    for (int i = 0; i < NWORDS; i++) r.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)x.l[i]);
+    return r;
+  }
+  QDEV static V swap(const V& x) { return from_addr(x, (wave_lane() ^ 1) << 2); }
+  QDEV static V choose(bool c, const V& a, const V& b) {
+    V r;
+#pragma unroll
+    for (int i = 0; i < NWORDS; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+  }
+  QDEV static V mul(const V& a, const V& b) {
+    const V an = Fq::norm(a), bn = Fq::norm(b);
+    return hex::mul(an, bn, swap(an), swap(bn), hsel());
+  }
+  QDEV static V add(const V& a, const V& b) { return hex::add(a, b); }
+  QDEV static V dbl(const V& a) { return hex::dbl(a); }
+  QDEV static V tpl(const V& a) { return hex::tpl(a); }
+  template <int K> QDEV static V sub(const V& a, const V& b) { return hex::sub<K>(a, b); }
+  template <int K> QDEV static V neg(const V& a) { return hex::neg<K>(a); }
+  QDEV static V wred(const V& a) { return Fq::wred(a); }
+  QDEV static V half(const V& a) { return Fq::half(a); }
+  QDEV static V mul_nr(const V& a) {
+    const V o = swap(a);
+    return choose(hsel() != 0, o, hex::mul_nr(o, 0));
+  }
+  QDEV static V conj(const V& a) { return choose(hsel() != 0, hex::conj(a, 1), a); }
+  QDEV static V mul_fp(const V& a, const F& k) { return Fq::mul(Fq::norm(a), k); }
+  QDEV static V twist_mul(const V& a) {
+    const V po = swap(hex::twist_own(a));
+    return choose(hsel() != 0, po, hex::twist_fin(po, 0));
+  }
+  QDEV static V inv(const V& a) {
+    const V s = Fq::sqr(Fq::norm(a));
+    const V so = swap(s);
+    const V n = choose(hsel() != 0, hex::inv_norm(s, so, 1), hex::inv_norm(s, so, 0));
+    const V r = Fq::mul(Fq::norm(a), Fq::inv(n));
+    return choose(hsel() != 0, Fq::norm(Fq::neg<4, 1>(r)), r);
+  }
+  template <int CTRL> QDEV static V perm(const V& x) {
+    const int j = lane();
+    return from_addr(x, (wave_lane() - sub() + 2 * ((CTRL >> (2 * j)) & 3) + hsel()) << 2);
+  }
+  template <int K> QDEV static V bcast(const V& x) { return perm<QP(K, K, K)>(x); }
+  template <int K> QDEV static V sel(const V& onk, const V& other) { return choose(lane() == K, onk, other); }
+  QDEV static V pick(const V& a0, const V& a1, const V& a2) {
+    const int q = lane();
+    V r;
+#pragma unroll
+    for (int i = 0; i < NWORDS; i++) r.l[i] = q == 0 ? a0.l[i] : q == 1 ? a1.l[i] : a2.l[i];
+    return r;
+  }
+  QDEV static F pickf(const F& a0, const F& a1, const F& a2) { return pick(a0, a1, a2); }
+  QDEV static V zero() { return Fq::zero(); }
+  QDEV static V one() { return choose(hsel() != 0, Fq::zero(), Fq::one()); }
+  QDEV static V constant(const uint32_t* c0, const uint32_t* c1) { return choose(hsel() != 0, Fq::from_limbs(c1), Fq::from_limbs(c0)); }
+  QDEV static bool is_zero_u(const V& a) {                               // group-uniform Fq2: zero iff both halves are
+    const int z = a.is_zero_mod_p() ? 1 : 0;
+    return (z & __builtin_amdgcn_ds_bpermute((wave_lane() ^ 1) << 2, z)) != 0;
+  }
+  QDEV static bool is_one3(const V& a, const V& b) {
+    const bool first = sub() == 0;
+    int ok = ((first ? hex::is_one_half(a, 0) : a.is_zero_mod_p()) && b.is_zero_mod_p()) ? 1 : 0;
+    const int base = (wave_lane() - sub()) << 2;
+    int all = 1;
+#pragma unroll
+    for (int i = 0; i < 6; i++) all &= __builtin_amdgcn_ds_bpermute(base + 4 * i, ok);
+    return all != 0;
+  }
+};
+#endif
+
 // ================================================================== tower arithmetic, one Fq12 per lane group
 template <class QB> struct QTower {
   typedef typename QB::V V;

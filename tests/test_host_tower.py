@@ -22,7 +22,7 @@ def ht():
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB, srcs[0]])
     lib = C.CDLL(LIB)
-    if not hasattr(lib, "ht_pairing_761_lanes"):
+    if not hasattr(lib, "ht_pairing_377_hex"):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB, srcs[0]])
         lib = C.CDLL(LIB)
     return lib
@@ -38,7 +38,7 @@ class _Hook:
         self.fn = getattr(lib, name)
 
 
-@pytest.fixture(params=["ht_pairing_377", "ht_pairing_377_lanes"])
+@pytest.fixture(params=["ht_pairing_377", "ht_pairing_377_lanes", "ht_pairing_377_hex"])
 def hk(ht, request):
     return _Hook(ht, request.param)
 
@@ -143,9 +143,10 @@ def test_shared_accumulator_product_matches_oracle(ht):
     Q = [ecc.E2_377.mul(ecc.G2_377, rng.next()) for _ in range(3)]
     g1, _ = co.pack_g1_377(P)
     g2, _ = co.pack_g2_377(Q)
-    hook = _Hook(ht, "ht_pairing_377_lanes")
-    for k in (1, 2, 3):
-        ml, _ = hp(hook, 11, g1[:k], g2[:k], k)
-        assert np.array_equal(ml, co.miller_loop_377(g1[:k], None, g2[:k], None))
-        gt, one = hp(hook, 10, g1[:k], g2[:k], k)
-        assert np.array_equal(gt, co.pairing_product_377(g1[:k], None, g2[:k], None)[0]) and not one
+    for name in ("ht_pairing_377_lanes", "ht_pairing_377_hex"):      # three lanes per pairing, six lanes per pairing
+        hook = _Hook(ht, name)
+        for k in (1, 2, 3):
+            ml, _ = hp(hook, 11, g1[:k], g2[:k], k)
+            assert np.array_equal(ml, co.miller_loop_377(g1[:k], None, g2[:k], None)), name
+            gt, one = hp(hook, 10, g1[:k], g2[:k], k)
+            assert np.array_equal(gt, co.pairing_product_377(g1[:k], None, g2[:k], None)[0]) and not one, name

@@ -118,12 +118,13 @@ def test_many_independent_products(gpu):
     print("pairing timings:", gpu.pairing_timings())
 
 
-def test_lane_parallel_pieces_match_one_lane_twins(gpu):
-    """build/lanes_selftest (tools/lanes_selftest.hip): every piece of the lane-parallel pairing (Fq12 product / square /
-    cyclotomic square / sparse line product / inverse / Frobenius, the point steps, truncated and full Miller loops) against
-    its one-lane twin from pairing.h, both on the GPU, canonical Fq12 limbs compared."""
+@pytest.mark.parametrize("exe_name", ["lanes_selftest", "hex_selftest"])
+def test_lane_parallel_pieces_match_one_lane_twins(gpu, exe_name):
+    """build/lanes_selftest, build/hex_selftest (tools/lanes_selftest.hip for three / six lanes per pairing): every piece of the
+    lane-parallel pairing (Fq12 product / square / cyclotomic square / sparse line product / inverse / Frobenius, the point steps,
+    truncated and full Miller loops) against its one-lane twin from pairing.h, both on the GPU, canonical Fq12 limbs compared."""
     import os, subprocess
-    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "celo-bls-snark-rs_amd", "build", "lanes_selftest")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "celo-bls-snark-rs_amd", "build", exe_name)
     assert os.path.exists(exe), "run `make -C celo-bls-snark-rs_amd/csrc` (or __graft_entry__.build()) first"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "MISMATCH" not in r.stdout and r.stdout.count(" ok") >= 16, r.stdout + r.stderr

@@ -5,10 +5,17 @@
 #include <cstring>
 using namespace celo;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 99; } } while (0)
-typedef QPairing377<QTri377> QPair;
-typedef QTower<QTri377> QTow;
-#define lanes_load lanes_load<LP377>
-#define lanes_store lanes_store<LP377>
+#ifdef SELFTEST_HEX
+typedef LPH377 LPX;          // six lanes per pairing
+#else
+typedef LP377 LPX;           // three lanes per pairing
+#endif
+typedef LPX::QB QBX;
+typedef LPX::Pair QPair;
+typedef LPX::Tow QTow;
+constexpr int NLANES = LPX::GROUPS == 21 ? 3 : 6;
+#define lanes_load LPX::load12
+#define lanes_store LPX::store12
 
 // op 0: mul12, 1: sqr12, 2: cyclotomic, 3: mul_by_034 (s from y's first three coefficients), 4: inv12, 5: frob1, 6: conj, 7: identity (load/store)
 __global__ void k_lanes_op(int op, const uint32_t* x, const uint32_t* y, uint32_t* out) {
@@ -17,7 +24,7 @@ __global__ void k_lanes_op(int op, const uint32_t* x, const uint32_t* y, uint32_
     case 0: r = QTow::mul12(a, b); break;
     case 1: r = QTow::sqr12(a); break;
     case 2: r = QTow::cyclotomic_sqr(a); break;
-    case 3: { Fq2 s0 = Fq2::load(y), s3 = Fq2::load(y + 32), s4 = Fq2::load(y + 64); r = a; QTow::mul_by_034(r, s0, s3, s4); } break;
+    case 3: { QBX::V s0 = LPX::load_v(y), s3 = LPX::load_v(y + 32), s4 = LPX::load_v(y + 64); r = a; QTow::mul_by_034(r, s0, s3, s4); } break;
     case 4: r = QTow::inv12(a); break;
     case 5: r = QPair::frob12<1>(a); break;
     case 6: r = QTow::conj12(a); break;
@@ -44,18 +51,17 @@ __global__ void k_lane_op(int op, const uint32_t* x, const uint32_t* y, uint32_t
 }
 __global__ void k_lanes_canon(const uint32_t* in, uint64_t* out) {
   QTow::E12 r = lanes_load(in);
-  int q = QTri377::lane();
-  r.a.to_ark(out + 12 * q); r.b.to_ark(out + 12 * (3 + q));
+  LPX::to_ark12(r, out);
 }
 // point steps: in: R (3 Fq2 at x, x+32, x+64), Q (y, y+32); out: R' (3 Fq2) then line (3 Fq2) as ark u64 (6*12)
 __global__ void k_lanes_step(int add, const uint32_t* x, const uint32_t* y, uint64_t* out) {
-  int q = QTri377::lane();
-  Fq2 Rc = Fq2::load(x + 32 * q);
-  Fq2 Qc = Fq2::load(y + 32 * (q & 1));
+  int q = QBX::lane();
+  QBX::V Rc = LPX::load_v(x + 32 * q);
+  QBX::V Qc = LPX::load_v(y + 32 * (q & 1));
   QPair::Line l;
   if (add) QPair::add_step(Rc, Qc, l); else QPair::double_step(Rc, l);
-  Rc.to_ark(out + 12 * q);
-  if (q == 0) { l.c0.to_ark(out + 36); l.c1.to_ark(out + 48); l.c2.to_ark(out + 60); }
+  LPX::to_ark_v(Rc, out + 12 * q);
+  if (q == 0) { LPX::to_ark_v(l.c0, out + 36); LPX::to_ark_v(l.c1, out + 48); LPX::to_ark_v(l.c2, out + 60); }
 }
 __global__ void k_lane_step(int add, const uint32_t* x, const uint32_t* y, uint64_t* out) {
   G2Proj r = {Fq2::load(x), Fq2::load(x + 32), Fq2::load(x + 64)};
@@ -79,10 +85,10 @@ __global__ void k_fill(uint32_t* x, uint64_t seed) {  // six pseudo-random Fq2 (
 }
 // truncated Miller loops: `iters` top iterations of the loop, lane-parallel vs one-lane
 __global__ void k_lanes_miller(int iters, const uint32_t* x, const uint32_t* y, uint32_t* out) {
-  int q = QTri377::lane();
+  int q = QBX::lane();
   Fq px = Fq::load(x), py = Fq::load(x + 16);
-  Fq2 Qc = Fq2::load(y + 32 * (q & 1));
-  Fq2 Rc = QTri377::sel<2>(QTri377::one(), Qc);
+  QBX::V Qc = LPX::load_v(y + 32 * (q & 1));
+  QBX::V Rc = QBX::sel<2>(QBX::one(), Qc);
   QTow::E12 f = QTow::one12();
   QPair::Line l;
 #pragma unroll 1
@@ -115,8 +121,8 @@ int main() {
   int bad = 0;
   const char* names[] = {"mul12", "sqr12", "cyclotomic", "mul_by_034", "inv12", "frob1", "conj", "identity"};
   for (int op = 0; op < 8; op++) {
-    k_lanes_op<<<1, 3>>>(op, x, y, oq);
-    k_lanes_canon<<<1, 3>>>(oq, c1);
+    k_lanes_op<<<1, NLANES>>>(op, x, y, oq);
+    k_lanes_canon<<<1, NLANES>>>(oq, c1);
     k_lane_op<<<1, 1>>>(op, x, y, (uint32_t*)c2);
     std::vector<uint64_t> a(72), b(72);
     CK(hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost));
@@ -125,7 +131,7 @@ int main() {
     if (!ok) { bad++; for (int c = 0; c < 6; c++) printf("   coeff %d: %s\n", c, memcmp(a.data() + 12 * c, b.data() + 12 * c, 96) ? "diff" : "same"); }
   }
   for (int add = 0; add < 2; add++) {
-    k_lanes_step<<<1, 3>>>(add, x, y, c1);
+    k_lanes_step<<<1, NLANES>>>(add, x, y, c1);
     k_lane_step<<<1, 1>>>(add, x, y, c2);
     std::vector<uint64_t> a(72), b(72);
     CK(hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost));
@@ -134,8 +140,8 @@ int main() {
     if (!ok) { bad++; const char* nm[] = {"X", "Y", "Z", "l.c0", "l.c1", "l.c2"}; for (int c = 0; c < 6; c++) printf("   %s: %s\n", nm[c], memcmp(a.data() + 12 * c, b.data() + 12 * c, 96) ? "diff" : "same"); }
   }
   for (int iters : {1, 2, 3, 5, 8, 63}) {
-    k_lanes_miller<<<1, 3>>>(iters, x, y, oq);
-    k_lanes_canon<<<1, 3>>>(oq, c1);
+    k_lanes_miller<<<1, NLANES>>>(iters, x, y, oq);
+    k_lanes_canon<<<1, NLANES>>>(oq, c1);
     k_lane_miller<<<1, 1>>>(iters, x, y, c2);
     std::vector<uint64_t> a(72), b(72);
     CK(hipMemcpy(a.data(), c1, 576, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), c2, 576, hipMemcpyDeviceToHost));

@@ -66,7 +66,10 @@ int hash_to_g1_direct_run(const uint8_t*, const uint8_t*, const uint64_t*, const
 float hash_last_ms();
 int pedersen_crh_run(const uint8_t*, const uint64_t*, size_t, uint8_t*);
 int pairing_run_761(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
-int batch_verify_377_run(const void*, const void*, const void*, int, const uint32_t*, const void*, const uint64_t*, size_t, uint8_t*);
+int batch_verify_377_run(const void*, const void*, const void*, const void*, const void*, int, const uint32_t*, const void*, const void*, const uint64_t*, size_t, uint8_t*);
+int witness_map_run(uint64_t*, uint64_t*, uint64_t*, unsigned, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, int, int, void*);
+int groth16_prove_761_run(const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, const uint64_t*,
+                          const uint64_t*, size_t, size_t, const uint64_t*, size_t, uint64_t*, uint64_t*, uint64_t*);
 }  // namespace celo
 using namespace celo;
 
@@ -206,13 +209,13 @@ int celo_amd_pairing_gt_bw6_761(const uint64_t* g1, const uint8_t* inf1, const u
                                 size_t m, int miller_only, uint64_t* gt72) {
   return pairing_run_761(g1, inf1, g2, inf2, offsets, m, nullptr, gt72, miller_only ? 1 : 0);
 }
-int batch_verify_bls12_377(const uint64_t* pk_xy, const uint64_t* sig_xy, const uint64_t* exponents, const uint32_t* offsets, const uint64_t* hash_xy,
-                           const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
-  return batch_verify_377_run(pk_xy, sig_xy, exponents, 0, offsets, hash_xy, neg_g2_xy, m, out_ok);
+int batch_verify_bls12_377(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* sig_xy, const uint8_t* sig_inf, const uint64_t* exponents,
+                           const uint32_t* offsets, const uint64_t* hash_xy, const uint8_t* hash_inf, const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
+  return batch_verify_377_run(pk_xy, pk_inf, sig_xy, sig_inf, exponents, 0, offsets, hash_xy, hash_inf, neg_g2_xy, m, out_ok);
 }
-int batch_verify_bls12_377_dev(const void* d_pk_xy, const void* d_sig_xy, const void* d_exponents, const uint32_t* offsets, const void* d_hash_xy,
-                               const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
-  return batch_verify_377_run(d_pk_xy, d_sig_xy, d_exponents, 1, offsets, d_hash_xy, neg_g2_xy, m, out_ok);
+int batch_verify_bls12_377_dev(const void* d_pk_xy, const void* d_pk_inf, const void* d_sig_xy, const void* d_sig_inf, const void* d_exponents,
+                               const uint32_t* offsets, const void* d_hash_xy, const void* d_hash_inf, const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
+  return batch_verify_377_run(d_pk_xy, d_pk_inf, d_sig_xy, d_sig_inf, d_exponents, 1, offsets, d_hash_xy, d_hash_inf, neg_g2_xy, m, out_ok);
 }
 int celo_amd_pairing_last_timings(float ms[4]) { return pairing_timings_377(ms); }
 int ntt_bw6_761_fr(uint64_t* data, unsigned log_n, const uint64_t omega[6], const uint64_t* coset, int coset_after, const uint64_t* scale) {
@@ -223,6 +226,21 @@ int ntt_bw6_761_fr_dev(uint64_t* d_data, unsigned log_n, const uint64_t omega[6]
   return ntt_run(d_data, log_n, omega, coset, coset_after, scale, 1, hip_stream);
 }
 int celo_amd_ntt_last_timings(float ms[4], int* passes) { return ntt_timings(ms, passes); }
+int groth16_witness_map_bw6_761(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, const uint64_t omega[6], const uint64_t omega_inv[6], const uint64_t coset[6],
+                                const uint64_t coset_inv[6], const uint64_t size_inv[6], const uint64_t vanishing_inv[6], int out_canonical) {
+  return witness_map_run(a, b, c, log_n, omega, omega_inv, coset, coset_inv, size_inv, vanishing_inv, out_canonical, 0, nullptr);
+}
+int groth16_witness_map_bw6_761_dev(uint64_t* d_a, uint64_t* d_b, uint64_t* d_c, unsigned log_n, const uint64_t omega[6], const uint64_t omega_inv[6],
+                                    const uint64_t coset[6], const uint64_t coset_inv[6], const uint64_t size_inv[6], const uint64_t vanishing_inv[6],
+                                    int out_canonical, void* hip_stream) {
+  return witness_map_run(d_a, d_b, d_c, log_n, omega, omega_inv, coset, coset_inv, size_inv, vanishing_inv, out_canonical, 1, hip_stream);
+}
+int groth16_prove_bw6_761(const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh, const uint64_t* l_query,
+                          size_t nl, const uint64_t alpha_g1[24], const uint64_t beta_g2[24], const uint64_t* assignment, size_t n_assignment, size_t n_aux,
+                          const uint64_t* h, size_t n_h, uint64_t out_a[36], uint64_t out_b[36], uint64_t out_c[36]) {
+  msm_note_big_call_761();
+  return groth16_prove_761_run(a_query, na, b_g2_query, nb, h_query, nh, l_query, nl, alpha_g1, beta_g2, assignment, n_assignment, n_aux, h, n_h, out_a, out_b, out_c);
+}
 int decompress_bls12_377_g1(const uint8_t* in, size_t n, int check_subgroup, uint64_t* out_xy, uint8_t* status) {
   return wire_decompress(0, in, n, check_subgroup, out_xy, status, 0, nullptr);
 }

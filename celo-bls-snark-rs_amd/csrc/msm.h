@@ -301,8 +301,18 @@ __global__ void __launch_bounds__(1024) k_size_scatter(const uint32_t* __restric
 }
 
 // ---- 4. one lane per piece: XYZZ sum of its run of (signed) points
+// Occupancy A/B (round 2, 2^20 terms): the 28-word fields (G2 of BLS12-377, BW6-761) take 256 VGPRs + ~160 AGPRs = ONE wave per
+// SIMD.  Forcing two (-DCELO_ACC_OCC2: 520-744 B/lane of scratch instead of the AGPRs) is SLOWER - G2 8.69 -> 10.0 ms, BW6-761
+// 16.0 -> 17.1 ms - because the one-wave kernels already issue an instruction every 5.1-5.3 cycles (the v_mad_u64_u32 rate:
+// ~16-19k instructions per mixed addition x 2^20 x windows / 1024 SIMDs): their instruction stream has the independent work a
+// second wave would bring.  What is left is the instruction count.
+#ifdef CELO_ACC_OCC2
+#define ACC_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define ACC_OCC
+#endif
 template <class G>
-__global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(256) ACC_OCC k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ plen,
                                                     const uint32_t* __restrict__ order, const uint32_t* __restrict__ nwork,
                                                     uint32_t* __restrict__ partials) {

@@ -84,8 +84,11 @@ struct QTri761 : QTriT<Base761> {
 // ((x0, x1) u = (-5 x1, x0)).  QTower / QPairing377 below run unchanged on these backends: same field elements at every step.
 namespace hex {
 // lane-local pieces; h = the half this lane holds, *o = the partner lane's value.  All host+device, bounds-tracked on the host.
-HD Fq mul(const Fq& a_, const Fq& b_, const Fq& ao_, const Fq& bo_, int h) {     // inputs: any lazy form with lb <= 15
-  const Fq a = Fq::norm(a_), b = Fq::norm(b_), ao = Fq::norm(ao_), bo = Fq::norm(bo_);
+// Every value of these backends is kept with normalised limbs (each operation below ends in a carry propagation or is a
+// Montgomery product), so the products take their operands as they are: no carry pass per operand (that was 6 x 42 of the
+// ~1400 instructions of a product half).  The bounds-tracking host build asserts it (Fp::mul2s: lb <= 1).
+HD Fq mul(const Fq& a, const Fq& b, const Fq& ao, const Fq& bo, int h) {
+  TRK(assert(ao.lb <= 1);)
   int32_t cs[14];
   Fq Y, D;
 #pragma unroll
@@ -100,13 +103,12 @@ HD Fq mul(const Fq& a_, const Fq& b_, const Fq& ao_, const Fq& bo_, int h) {    
 // (x0 + x1 u) u = -5 x1 + x0 u: half 0 takes -5 * (partner), half 1 takes the partner as it is.  Needs vb(partner) <= 12.
 HD Fq mul_nr(const Fq& xo, int h) {
   if (h) return xo;
-  const Fq t = Fq::norm(xo);
-  const Fq t5 = Fq::norm(Fq::add(Fq::dbl(Fq::dbl(t)), t));
+  const Fq t5 = Fq::norm(Fq::add(Fq::dbl(Fq::dbl(xo)), xo));
   return Fq::norm(Fq::neg<64, 1>(t5));
 }
 HD Fq conj(const Fq& x, int h) { return h ? Fq::wred(Fq::norm(Fq::neg<4, 1>(x))) : x; }
 // B' x for the twist constant B' = (0, b1): (-5 b1 x1, b1 x0); p = b1 * (own half), po = the partner's p
-HD Fq twist_own(const Fq& x) { return Fq::mul(Fq::norm(x), Fq::from_limbs(T377::TWIST_B_C1)); }
+HD Fq twist_own(const Fq& x) { return Fq::mul(x, Fq::from_limbs(T377::TWIST_B_C1)); }
 HD Fq twist_fin(const Fq& po, int h) {
   if (h) return po;
   const Fq p5 = Fq::norm(Fq::add(Fq::dbl(Fq::dbl(po)), po));
@@ -148,7 +150,7 @@ struct QHostHex377 {
   static V half(const V& a) { return map1(a, [](const Fq& x, int) { return Fq::half(x); }); }
   static V mul_nr(const V& a) { V r; for (int i = 0; i < 6; i++) r.v[i] = hex::mul_nr(a.v[i ^ 1], i & 1); return r; }
   static V conj(const V& a) { return map1(a, [](const Fq& x, int h) { return hex::conj(x, h); }); }
-  static V mul_fp(const V& a, const F& k) { return map2(a, k, [](const Fq& x, const Fq& y) { return Fq::mul(Fq::norm(x), y); }); }
+  static V mul_fp(const V& a, const F& k) { return map2(a, k, [](const Fq& x, const Fq& y) { return Fq::mul(x, y); }); }
   static V twist_mul(const V& a) {
     V p = map1(a, [](const Fq& x, int) { return hex::twist_own(x); }), r;
     for (int i = 0; i < 6; i++) r.v[i] = hex::twist_fin(p.v[i ^ 1], i & 1);
@@ -201,10 +203,7 @@ struct QHex377 {
     for (int i = 0; i < NWORDS; i++) r.l[i] = c ? a.l[i] : b.l[i];
     return r;
   }
-  QDEV static V mul(const V& a, const V& b) {
-    const V an = Fq::norm(a), bn = Fq::norm(b);
-    return hex::mul(an, bn, swap(an), swap(bn), hsel());
-  }
+  QDEV static V mul(const V& a, const V& b) { return hex::mul(a, b, swap(a), swap(b), hsel()); }
   QDEV static V add(const V& a, const V& b) { return hex::add(a, b); }
   QDEV static V dbl(const V& a) { return hex::dbl(a); }
   QDEV static V tpl(const V& a) { return hex::tpl(a); }
@@ -217,7 +216,7 @@ struct QHex377 {
     return choose(hsel() != 0, o, hex::mul_nr(o, 0));
   }
   QDEV static V conj(const V& a) { return choose(hsel() != 0, hex::conj(a, 1), a); }
-  QDEV static V mul_fp(const V& a, const F& k) { return Fq::mul(Fq::norm(a), k); }
+  QDEV static V mul_fp(const V& a, const F& k) { return Fq::mul(a, k); }
   QDEV static V twist_mul(const V& a) {
     const V po = swap(hex::twist_own(a));
     return choose(hsel() != 0, po, hex::twist_fin(po, 0));

@@ -1160,39 +1160,22 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     for (auto& x : th) x.join();
   }
   ph.mark("gather handles -> affine, exponents");
-  // the two batch MSMs are independent calls on independent engines: both in flight at once (their sorts, tails and copies
-  // overlap on the GPU; the message hashing started above is a third concurrent stream of work)
-  std::vector<uint64_t> bpk(m * 36), bsg(m * 18);
-  int rc_g1 = 0;
-  {
-    std::thread g1_msm([&]() { rc_g1 = msm_batch_bls12_377_g1(sg_xy, sg_inf, sc, offs.data(), m, bsg.data()); });
-    const int rc_g2 = msm_batch_bls12_377_g2(pk_xy, pk_inf, sc, offs.data(), m, bpk.data());
-    g1_msm.join();
-    if (rc_g2 != 0 || rc_g1 != 0) return false;
-  }
-  ph.mark("G2 + G1 batch MSMs (GPU, concurrent)");
-  std::vector<uint64_t> tmp1(m * 12), tmp2(m * 24);
-  std::vector<uint8_t> i1(2 * m, 0), i2(2 * m, 0), t1(m), t2(m);
-  batch_to_affine<Fq_>(bsg.data(), m, tmp1.data(), t1.data());
-  batch_to_affine<Fq2_>(bpk.data(), m, tmp2.data(), t2.data());
-  uint64_t ng2[24];
-  neg_g2_generator(ng2);
-  for (size_t b = 0; b < m; b++) {
-    memcpy(&g1[(2 * b) * 12], &tmp1[b * 12], 96); i1[2 * b] = t1[b];
-    memcpy(&g2[(2 * b) * 24], ng2, 192);
-    memcpy(&g2[(2 * b + 1) * 24], &tmp2[b * 24], 192); i2[2 * b + 1] = t2[b];
-  }
-  ph.mark("pack pairs");
+  // everything between the gathered handles and the verdicts is ONE chained device call (batch_verify_bls12_377): both batch MSMs
+  // in flight together on two engines, their sums normalised on the device into the pairing engine's input slots, m two-pair
+  // products.  The message hashes (started above, GPU or host cores) are joined just before it.
   hasher.join();
   if (!hash_ok) return false;
-  for (size_t b = 0; b < m; b++)        // a batch whose message does not hash is "not verified" (the other batches are unaffected)
-    if (hash_failed[b]) i1[2 * b + 1] = 1;   // no H(m): the pair is left out of the launch, the verdict is forced below
   ph.mark("wait for the hashes");
-  std::vector<uint32_t> po(m + 1);
-  for (size_t b = 0; b <= m; b++) po[b] = (uint32_t)(2 * b);
-  std::vector<uint8_t> ok(m, 0);
-  if (pairing_product_is_one_batch_bls12_377(g1.data(), i1.data(), g2.data(), i2.data(), po.data(), m, ok.data()) != 0) return false;
-  ph.mark("pairing checks (GPU)");
+  std::vector<uint64_t> hxy(m * 12);
+  std::vector<uint8_t> hinf(m, 0), ok(m, 0);
+  for (size_t b = 0; b < m; b++) {
+    if (hash_failed[b]) hinf[b] = 1;                       // no H(m): that pair is left out, the verdict is forced below
+    else memcpy(&hxy[b * 12], &g1[(2 * b + 1) * 12], 96);
+  }
+  uint64_t ng2[24];
+  neg_g2_generator(ng2);
+  if (batch_verify_bls12_377(pk_xy, pk_inf, sg_xy, sg_inf, sc, offs.data(), hxy.data(), hinf.data(), ng2, m, ok.data()) != 0) return false;
+  ph.mark("G2 + G1 batch MSMs -> pairs -> pairing checks (GPU, chained)");
   bool all = true;
   for (size_t b = 0; b < m; b++) { out_results[b] = ok[b] != 0 && !hash_failed[b]; all = all && out_results[b]; }
   ph.mark("results");

@@ -66,8 +66,9 @@ k_pack_verify_pairs(const uint64_t* __restrict__ sig_sum /* m x 18 */, const uin
 }
 
 // resident = 1: d_* are DEVICE pointers; 0: host pointers (staged by the engines).  offsets, out_ok: host.
-int batch_verify_377_run(const void* pk_xy, const void* sig_xy, const void* exponents, int resident, const uint32_t* offsets, const void* hash_xy,
-                         const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
+// pk_inf / sig_inf / hash_inf: optional byte-per-point "is the identity" arrays (host or device like the points).
+int batch_verify_377_run(const void* pk_xy, const void* pk_inf, const void* sig_xy, const void* sig_inf, const void* exponents, int resident,
+                         const uint32_t* offsets, const void* hash_xy, const void* hash_inf, const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
   if (int rc = api_enter()) return rc;
   if (m == 0) return 0;
   if (!pk_xy || !sig_xy || !exponents || !offsets || !hash_xy || !neg_g2_xy || !out_ok || m > 0x3fffffffu) return 2;
@@ -77,11 +78,12 @@ int batch_verify_377_run(const void* pk_xy, const void* sig_xy, const void* expo
   const int dev = api_device();
   {
     // each begin has one host round trip (the exponents' bit length sizes the window count): two threads keep both in flight
-    std::thread t1([&] { rc1 = api_bind_thread(dev); if (!rc1) rc1 = msm_batch_begin_g1_377(sig_xy, nullptr, exponents, resident, offsets, m, &r1); });
-    rc2 = msm_batch_begin_g2_377(pk_xy, nullptr, exponents, resident, offsets, m, &r2);
+    std::thread t1([&] { rc1 = api_bind_thread(dev); if (!rc1) rc1 = msm_batch_begin_g1_377(sig_xy, sig_inf, exponents, resident, offsets, m, &r1); });
+    rc2 = msm_batch_begin_g2_377(pk_xy, pk_inf, exponents, resident, offsets, m, &r2);
     t1.join();
   }
   uint64_t* d_hash = nullptr;
+  uint8_t* d_hinf = nullptr;
   hipEvent_t e1 = nullptr, e2 = nullptr;
   bool drained = false;
   std::vector<uint32_t> po;
@@ -94,11 +96,15 @@ int batch_verify_377_run(const void* pk_xy, const void* sig_xy, const void* expo
   if (!resident) {   // the message hashes: a small upload of our own
     if (hipMalloc(&d_hash, m * 96) != hipSuccess) { rc = 1; goto done; }
     if (hipMemcpyAsync(d_hash, hash_xy, m * 96, hipMemcpyHostToDevice, ps.stream) != hipSuccess) { rc = 1; goto done; }
+    if (hash_inf) {
+      if (hipMalloc(&d_hinf, m) != hipSuccess) { rc = 1; goto done; }
+      if (hipMemcpyAsync(d_hinf, hash_inf, m, hipMemcpyHostToDevice, ps.stream) != hipSuccess) { rc = 1; goto done; }
+    }
   }
   if (hipEventRecord(e1, r1.stream) != hipSuccess || hipEventRecord(e2, r2.stream) != hipSuccess ||
       hipStreamWaitEvent(ps.stream, e1, 0) != hipSuccess || hipStreamWaitEvent(ps.stream, e2, 0) != hipSuccess) { rc = 1; goto done; }
   hipLaunchKernelGGL(k_pack_verify_pairs, dim3((2 * m_pad + 63) / 64), dim3(64), 0, ps.stream, r1.d_out, r2.d_out,
-                     resident ? (const uint64_t*)hash_xy : d_hash, (const uint8_t*)nullptr, ng2, (uint32_t)m, m_pad, ps.d_g1, ps.d_g2, ps.d_i1, ps.d_i2);
+                     resident ? (const uint64_t*)hash_xy : d_hash, resident ? (const uint8_t*)hash_inf : d_hinf, ng2, (uint32_t)m, m_pad, ps.d_g1, ps.d_g2, ps.d_i1, ps.d_i2);
   po.resize(m + 1);
   for (size_t b = 0; b <= m; b++) po[b] = (uint32_t)(2 * b);
   rc = pairing_run_staged_377(&ps, po.data(), m, out_ok);     // synchronises ps.stream: both MSM streams have drained by then
@@ -114,6 +120,7 @@ done:
   if (e1) (void)hipEventDestroy(e1);
   if (e2) (void)hipEventDestroy(e2);
   if (d_hash) (void)hipFree(d_hash);
+  if (d_hinf) (void)hipFree(d_hinf);
   return rc;
 }
 }  // namespace celo

@@ -28,6 +28,7 @@ EXPORTS = [
     "celo_amd_gen_points_grouped_bls12_377_g1_dev", "celo_amd_gen_points_grouped_bls12_377_g2_dev",
     "batch_verify_bls12_377", "batch_verify_bls12_377_dev",
     "ntt_bw6_761_fr", "ntt_bw6_761_fr_dev",
+    "groth16_witness_map_bw6_761", "groth16_witness_map_bw6_761_dev", "groth16_prove_bw6_761",
     "decompress_bls12_377_g1", "decompress_bls12_377_g2", "decompress_bls12_377_g1_dev", "decompress_bls12_377_g2_dev",
     "normalize_bls12_377_g1", "normalize_bls12_377_g2",
     "hash_to_g1_direct_bls12_377", "hash_to_g1_composite_bls12_377", "hash_to_g1_cip22_tail_bls12_377", "composite_crh_bls12_377",
@@ -176,7 +177,7 @@ def batch_verify(pk_xy, sig_xy, exponents, offsets, hash_xy, neg_g2_xy):
     tot = int(offsets[-1])
     assert pk_xy.size == tot * 24 and sig_xy.size == tot * 12 and exponents.size == tot * 4 and hash_xy.size == m * 12
     out = np.zeros(m, dtype=np.uint8)
-    rc = lib().batch_verify_bls12_377(_p(pk_xy), _p(sig_xy), _p(exponents), _p(offsets), _p(hash_xy), _p(ng2), C.c_size_t(m), _p(out))
+    rc = lib().batch_verify_bls12_377(_p(pk_xy), None, _p(sig_xy), None, _p(exponents), _p(offsets), _p(hash_xy), None, _p(ng2), C.c_size_t(m), _p(out))
     if rc != 0:
         raise RuntimeError(f"batch_verify_bls12_377 failed rc={rc}")
     return out
@@ -188,7 +189,7 @@ def batch_verify_dev(d_pk, d_sig, d_exp, offsets, d_hash, neg_g2_xy):
     ng2 = np.ascontiguousarray(neg_g2_xy, dtype=np.uint64).reshape(24)
     m = offsets.size - 1
     out = np.zeros(m, dtype=np.uint8)
-    rc = lib().batch_verify_bls12_377_dev(C.c_void_p(d_pk), C.c_void_p(d_sig), C.c_void_p(d_exp), _p(offsets), C.c_void_p(d_hash), _p(ng2),
+    rc = lib().batch_verify_bls12_377_dev(C.c_void_p(d_pk), None, C.c_void_p(d_sig), None, C.c_void_p(d_exp), _p(offsets), C.c_void_p(d_hash), None, _p(ng2),
                                           C.c_size_t(m), _p(out))
     if rc != 0:
         raise RuntimeError(f"batch_verify_bls12_377_dev failed rc={rc}")
@@ -267,6 +268,43 @@ def ntt_dev(d_ptr, log_n, omega6, coset6=None, coset_after=False, scale6=None, s
     rc = lib().ntt_bw6_761_fr_dev(C.c_void_p(d_ptr), C.c_uint(log_n), _p(w), _p(g), C.c_int(1 if coset_after else 0), _p(sc), C.c_void_p(stream))
     if rc != 0:
         raise RuntimeError("ntt_bw6_761_fr_dev failed with code %d" % rc)
+
+
+def witness_map(a, b, c, log_n, consts, canonical=False):
+    """R1CStoQAP::witness_map from the QAP evaluations (groth16_witness_map_bw6_761).  a, b, c: (n, 6) uint64 arkworks Montgomery
+    limbs (copied); consts: dict of (6,) uint64 Montgomery limbs: omega, omega_inv, coset, coset_inv, size_inv, vanishing_inv.
+    Returns h (n, 6): field elements, or canonical integers with canonical=True."""
+    bufs = [np.ascontiguousarray(x, dtype=np.uint64).copy() for x in (a, b, c)]
+    assert all(x.shape == (1 << log_n, 6) for x in bufs)
+    k = [np.ascontiguousarray(consts[n], dtype=np.uint64) for n in ("omega", "omega_inv", "coset", "coset_inv", "size_inv", "vanishing_inv")]
+    rc = lib().groth16_witness_map_bw6_761(_p(bufs[0]), _p(bufs[1]), _p(bufs[2]), C.c_uint(log_n), *[_p(x) for x in k], C.c_int(1 if canonical else 0))
+    if rc != 0:
+        raise RuntimeError("groth16_witness_map_bw6_761 failed with code %d" % rc)
+    return bufs[0]
+
+
+def witness_map_dev(d_a, d_b, d_c, log_n, consts, canonical=False, stream=0):
+    k = [np.ascontiguousarray(consts[n], dtype=np.uint64) for n in ("omega", "omega_inv", "coset", "coset_inv", "size_inv", "vanishing_inv")]
+    rc = lib().groth16_witness_map_bw6_761_dev(C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c), C.c_uint(log_n), *[_p(x) for x in k],
+                                               C.c_int(1 if canonical else 0), C.c_void_p(stream or 0))
+    if rc != 0:
+        raise RuntimeError("groth16_witness_map_bw6_761_dev failed with code %d" % rc)
+
+
+def groth16_prove(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, assignment, n_aux, h):
+    """create_proof_no_zk's group arithmetic (groth16_prove_bw6_761).  queries: (k, 24) uint64; alpha / beta: (24,); assignment,
+    h: (k, 6) uint64 canonical scalars.  Returns (A, B, C) Jacobian limbs (36 u64 each)."""
+    arrs = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 24) for x in (a_query, b_g2_query, h_query, l_query)]
+    al, be = (np.ascontiguousarray(x, dtype=np.uint64).reshape(24) for x in (alpha_g1, beta_g2))
+    asg = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 6)
+    hh = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 6)
+    out = [np.zeros(36, dtype=np.uint64) for _ in range(3)]
+    rc = lib().groth16_prove_bw6_761(_p(arrs[0]), C.c_size_t(arrs[0].shape[0]), _p(arrs[1]), C.c_size_t(arrs[1].shape[0]), _p(arrs[2]), C.c_size_t(arrs[2].shape[0]),
+                                     _p(arrs[3]), C.c_size_t(arrs[3].shape[0]), _p(al), _p(be), _p(asg), C.c_size_t(asg.shape[0]), C.c_size_t(n_aux),
+                                     _p(hh), C.c_size_t(hh.shape[0]), _p(out[0]), _p(out[1]), _p(out[2]))
+    if rc != 0:
+        raise RuntimeError("groth16_prove_bw6_761 failed with code %d" % rc)
+    return out
 
 
 def ntt_timings():

@@ -92,13 +92,16 @@ int msm_batch_bw6_761_g2(const uint64_t* bases_xy, const uint8_t* inf, const uin
  * (at most 1024 each); hash_xy[b] = H(m_b) affine; neg_g2_xy = the negated G2 generator, affine (the caller's constant; the
  * library restates no curve constant here).  Both batch MSMs run concurrently on two engines; their Jacobian results are
  * normalised ON the device straight into the pairing engine's input slots - nothing returns to the host but the m verdicts
- * out_ok[b] in {0, 1}.  Exponents: canonical 4 x u64 (Batch::verify draws 128 + log2(n) random bits; the window count adapts
+ * out_ok[b] in {0, 1}.  *_inf: optional byte-per-point identity flags (NULL = none; a batch whose hash is flagged is checked without
+ * that pair).  Exponents: canonical 4 x u64 (Batch::verify draws 128 + log2(n) random bits; the window count adapts
  * to the longest one present).  _dev: every pointer except offsets, neg_g2_xy and out_ok is a DEVICE pointer. */
-int batch_verify_bls12_377(const uint64_t* pk_xy /* tot x 24 */, const uint64_t* sig_xy /* tot x 12 */, const uint64_t* exponents /* tot x 4 */,
-                           const uint32_t* offsets /* m+1 */, const uint64_t* hash_xy /* m x 12 */, const uint64_t neg_g2_xy[24], size_t m,
+int batch_verify_bls12_377(const uint64_t* pk_xy /* tot x 24 */, const uint8_t* pk_inf /* tot or NULL */, const uint64_t* sig_xy /* tot x 12 */,
+                           const uint8_t* sig_inf /* tot or NULL */, const uint64_t* exponents /* tot x 4 */, const uint32_t* offsets /* m+1 */,
+                           const uint64_t* hash_xy /* m x 12 */, const uint8_t* hash_inf /* m or NULL */, const uint64_t neg_g2_xy[24], size_t m,
                            uint8_t* out_ok /* m */);
-int batch_verify_bls12_377_dev(const void* d_pk_xy, const void* d_sig_xy, const void* d_exponents, const uint32_t* offsets, const void* d_hash_xy,
-                               const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok /* m */);
+int batch_verify_bls12_377_dev(const void* d_pk_xy, const void* d_pk_inf, const void* d_sig_xy, const void* d_sig_inf, const void* d_exponents,
+                               const uint32_t* offsets, const void* d_hash_xy, const void* d_hash_inf, const uint64_t neg_g2_xy[24], size_t m,
+                               uint8_t* out_ok /* m */);
 
 /* ---- pairing product check.  Replaces `Bls12_377::product_of_pairings(&pairs) == Fq12::one()` at
  *   crates/bls-crypto/src/bls/public.rs:102    (PublicKey::verify_sig: 2 pairs)
@@ -139,6 +142,32 @@ int ntt_bw6_761_fr_dev(uint64_t* d_data, unsigned log_n, const uint64_t omega[6]
                        const uint64_t* scale, void* hip_stream);
 /* ms[4] = {load/convert, butterfly passes, bit-reversal store, total}, passes = number of butterfly launches (last NTT call). */
 int celo_amd_ntt_last_timings(float ms[4], int* passes);
+
+/* ---- Groth16 prover over BW6-761 after R1CS synthesis: what ark_groth16::create_proof_no_zk does
+ * with the constraint evaluations and the proving key, as called at crates/epoch-snark/src/api/prover.rs:78,112.
+ *
+ * groth16_witness_map_bw6_761: R1CStoQAP::witness_map (ark-groth16 0.1 r1cs_to_qap.rs) from the point where a, b, c hold the
+ * evaluations of the QAP polynomials over the domain (n = 2^log_n elements each, arkworks Montgomery limbs; the caller builds
+ * them from its constraint system, including the input-consistency rows): ifft(a, b, c); coset_fft(a, b, c);
+ * ab = (a o b - c) * vanishing_inv; coset_ifft(ab).  On return a holds h (n coefficients; b and c are scratch) - as field
+ * elements, or with out_canonical != 0 as canonical integers (Fr::into_repr(), what the h MSM takes).  Domain constants from the
+ * caller (nothing of ark-poly is restated): omega = group_gen, omega_inv, coset = the coset offset (F::multiplicative_generator()),
+ * coset_inv, size_inv = n^-1, vanishing_inv = (coset^n - 1)^-1 - all arkworks Montgomery limbs.
+ *
+ * groth16_prove_bw6_761: the proof with r = s = 0 (create_proof_no_zk):
+ *   A = a_query[0] + MSM(a_query[1..], assignment) + alpha_g1          B = b_g2_query[0] + MSM(b_g2_query[1..], assignment) + beta_g2
+ *   C = MSM(l_query, aux) + MSM(h_query, h)
+ * queries: affine points (24 u64 each); assignment: n_assignment canonical scalars (public inputs without the leading 1, then the
+ * witness), aux = its last n_aux entries; h: n_h canonical scalars.  As in VariableBaseMSM::multi_scalar_mul the shorter of bases
+ * and scalars decides each MSM's length.  The four MSMs run concurrently on four engines.  Results: Jacobian, arkworks layout. */
+int groth16_witness_map_bw6_761(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, const uint64_t omega[6], const uint64_t omega_inv[6], const uint64_t coset[6],
+                                const uint64_t coset_inv[6], const uint64_t size_inv[6], const uint64_t vanishing_inv[6], int out_canonical);
+int groth16_witness_map_bw6_761_dev(uint64_t* d_a, uint64_t* d_b, uint64_t* d_c, unsigned log_n, const uint64_t omega[6], const uint64_t omega_inv[6],
+                                    const uint64_t coset[6], const uint64_t coset_inv[6], const uint64_t size_inv[6], const uint64_t vanishing_inv[6],
+                                    int out_canonical, void* hip_stream);
+int groth16_prove_bw6_761(const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh, const uint64_t* l_query,
+                          size_t nl, const uint64_t alpha_g1[24], const uint64_t beta_g2[24], const uint64_t* assignment, size_t n_assignment, size_t n_aux,
+                          const uint64_t* h, size_t n_h, uint64_t out_a[36], uint64_t out_b[36], uint64_t out_c[36]);
 
 /* ---- bulk decoding of compressed points: n keys or signatures in arkworks 0.1 wire form
  * (G1: 48 B, G2: 96 B; x little-endian, flag bits 0x80 = "y is the larger root", 0x40 = infinity in the last byte) to

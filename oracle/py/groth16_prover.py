@@ -1,0 +1,55 @@
+"""ORACLE (test infrastructure only): the Groth16 prover's arithmetic after R1CS synthesis, restated from ark-groth16 0.1.0
+(arkworks-rs/groth16#d8acb2b2, Cargo.lock:175-177; source absent from /root/reference) as the reference calls it through
+`create_proof_no_zk` at crates/epoch-snark/src/api/prover.rs:78,112.
+
+  witness_map      R1CStoQAP::witness_map (r1cs_to_qap.rs) from `domain.ifft_in_place(&mut a)` on: three inverse FFTs, three coset
+                   FFTs, ab = a o b - c, division by the vanishing polynomial on the coset (the constant g^n - 1), one coset
+                   inverse FFT.  The FFTs are the oracle's own C++ decimation-in-time restatement (orc_ntt_fq377).
+  prove_no_zk      create_proof with r = s = 0 (prover.rs): calculate_coeff(0, query, vk_param, assignment) = query[0] + MSM + vk_param
+                   for A (G1) and B (G2), C = MSM(l_query, aux) + MSM(h_query, h); MSMs by the oracle's arkworks-windowed Pippenger.
+PARITY UNPINNED against the reference (it holds no proving key and no proof-generation vector; its Groth16 vector pins the VERIFIER):
+pinned here by the definition - h(x) * (x^n - 1) == a(x) b(x) - c(x) as polynomials (tests/test_prover.py) - and by the group law."""
+import numpy as np
+
+from . import ecc
+from .. import cpu_oracle as co
+
+Q = ecc.Q377          # Fr(BW6-761) = Fq(BLS12-377)
+
+
+def domain_constants(log_n, omega, coset):
+    n = 1 << log_n
+    return {"omega": omega, "omega_inv": pow(omega, -1, Q), "coset": coset, "coset_inv": pow(coset, -1, Q), "size_inv": pow(n, -1, Q),
+            "vanishing_inv": pow((pow(coset, n, Q) - 1) % Q, -1, Q)}
+
+
+def witness_map(a, b, c, log_n, omega, coset):
+    """a, b, c: lists of n canonical ints (QAP evaluations over the domain).  Returns h as a list of n canonical ints."""
+    k = domain_constants(log_n, omega, coset)
+    def ifft(v):
+        return co.ntt_fq377(co.to_mont(v, Q), log_n, k["omega_inv"], scale=k["size_inv"])
+    def coset_fft(m):
+        return co.ntt_fq377(m, log_n, omega, coset=coset)
+    A, B, C = (co.from_mont(coset_fft(ifft(v)), Q) for v in (a, b, c))
+    ab = [((x * y - z) * k["vanishing_inv"]) % Q for x, y, z in zip(A, B, C)]
+    h = co.ntt_fq377(co.to_mont(ab, Q), log_n, k["omega_inv"], coset=k["coset_inv"], coset_after=True, scale=k["size_inv"])
+    return co.from_mont(h, Q)
+
+
+def prove_no_zk(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, assignment, n_aux, h, threads=8):
+    """queries: (k, 24) uint64 affine Montgomery limbs; alpha / beta: (24,) limbs; assignment / h: lists of canonical ints.
+    Returns (A, B, C) as affine python points (or None)."""
+    def msm(bases, scalars):
+        k = min(len(bases), len(scalars))
+        if k == 0:
+            return None
+        return co.jac_to_affine(co.msm("bw6_761_g1", np.ascontiguousarray(bases[:k]), None, co.ints_to_limbs(scalars[:k], 6), threads=threads), "761")
+    def pt(limbs):
+        x, y = co.from_mont(np.asarray(limbs).reshape(2, 12), ecc.Q761)
+        return (x, y)
+    E = ecc.E1_761                       # G2's group law is the same (a = 0; b is never used by it)
+    aux = assignment[len(assignment) - n_aux:]
+    A = E.add(E.add(pt(a_query[0]), msm(a_query[1:], assignment)), pt(alpha_g1))
+    B = E.add(E.add(pt(b_g2_query[0]), msm(b_g2_query[1:], assignment)), pt(beta_g2))
+    Cc = E.add(msm(l_query, aux), msm(h_query, h))
+    return A, B, Cc

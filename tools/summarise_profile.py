@@ -11,7 +11,10 @@ def short(n):
     n = n.replace("void celo::", "").replace("celo::", "")
     return n.split("(")[0]
 
-lines = [f"# rocprofv3 summary — {tag}", "", "Command: `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` (7 MSM launches of 2^20 terms), MI355X gfx950.", "",
+cmd = "python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+if os.path.exists(os.path.join(src, "command.txt")):
+    cmd = open(os.path.join(src, "command.txt")).read().strip().replace(root + "/", "")
+lines = [f"# rocprofv3 summary — {tag}", "", f"Command: `{cmd}`, MI355X gfx950.", "",
          "## kernel trace (`rocprofv3 --kernel-trace --stats`)", "", "| kernel | calls | avg µs | total ms | % |", "|---|---|---|---|---|"]
 with open(os.path.join(src, "trace", "trace_kernel_stats.csv")) as f:
     for r in csv.DictReader(f):

@@ -296,6 +296,8 @@ struct PP761 {
     static void miller(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, uint32_t* f, uint32_t n, hipStream_t s); \
     static void miller_product(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off,  \
                                uint32_t* prod, uint32_t m, hipStream_t s);                                                         \
+    static void miller_product2(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off, \
+                                uint32_t* prod, uint32_t m, hipStream_t s);   /* every product has <= 2 pairs */                   \
     static void gt_product(const uint32_t* f, const uint32_t* off, uint32_t* prod, uint32_t m, hipStream_t s);                     \
     static void gt_tree(const uint32_t* in, uint32_t* out, uint32_t n_in, hipStream_t s);                                          \
     static void final_exp(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint32_t m, int do_fe, hipStream_t s);              \
@@ -372,9 +374,11 @@ template <class PP> class PairingEngine {
     PAIR_HIP_OK(hipEventRecord(ev[0], stream));
     // shared-accumulator mode: one lane group per product (<= 4 pairs each) when the products alone fill the chip
     bool shared = m >= SHARED_MIN_PRODUCTS;
-    for (size_t p = 0; p < m && shared; p++) shared = offsets[p + 1] - offsets[p] <= 4;
+    uint32_t most = 0;
+    for (size_t p = 0; p < m && shared; p++) { const uint32_t c = offsets[p + 1] - offsets[p]; shared = c <= 4; most = c > most ? c : most; }
     typedef typename PP::LL LL;
-    if (shared) LL::miller_product(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
+    if (shared && most <= 2) LL::miller_product2(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
+    else if (shared) LL::miller_product(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
     else if (k) LL::miller(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_f, k, stream);
     PAIR_HIP_OK(hipEventRecord(ev[1], stream));
     if (shared) {

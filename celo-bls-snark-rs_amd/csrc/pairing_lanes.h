@@ -289,7 +289,8 @@ template <class QB> struct QTower {
     V rhs = QB::template sel<2>(vr, xw);
     return QB::wred(QB::add(lhs, rhs));
   }
-  QNI static E12 mul12(const E12& x, const E12& y) {
+  QNI static E12 mul12(const E12& x, const E12& y) { return mul12_inl(x, y); }
+  QFN static E12 mul12_inl(const E12& x, const E12& y) {
     V v0 = mul6(x.a, y.a);
     V v1 = mul6(x.b, y.b);
     V t = mul6(QB::add(x.a, x.b), QB::add(y.a, y.b));
@@ -321,7 +322,8 @@ template <class QB> struct QTower {
     f.a = QB::wred(QB::add(A, mul_by_gen(b)));
   }
   // Granger-Scott cyclotomic squaring: lane k squares the Fq4 pair k: (a0, b1), (b0, a2), (a1, b2)
-  QNI static E12 cyclotomic_sqr(const E12& f) {
+  QNI static E12 cyclotomic_sqr(const E12& f) { return cyclotomic_sqr_inl(f); }
+  QFN static E12 cyclotomic_sqr_inl(const E12& f) {
     V x = QB::template sel<1>(QB::template perm<QP(0, 0, 1)>(f.b), QB::template perm<QP(0, 0, 1)>(f.a));
     V y = QB::template sel<1>(QB::template perm<QP(1, 2, 2)>(f.a), QB::template perm<QP(1, 1, 2)>(f.b));
     V tmp = QB::mul(x, y);
@@ -383,26 +385,31 @@ template <class QB> struct QPairing377 {
     return {QB::mul(a, ca), QB::mul(b, cb)};
   }
 
-  // ark-ec bls12/g2.rs doubling_step on R = (X, Y, Z), one coordinate per lane
+  // ark-ec bls12/g2.rs doubling_step on R = (X, Y, Z), one coordinate per lane.  Statement order keeps few values alive across
+  // the three product rounds (each value is 14-28 registers): the line coefficients are finished as soon as their inputs exist and
+  // the operands of round 3 are picked per lane before anything else is computed.
   QFN static void double_step(V& Rc, Line& l) {
-    V r1 = QB::mul(Rc, Rc);                                           // X^2, Y^2, Z^2
-    V b = QB::template bcast<1>(r1), c = QB::template bcast<2>(r1);
-    V e = QB::twist_mul(QB::tpl(c));                                  // B' * 3c: two Fq products, every lane
+    V b, e;
+    {
+      const V r1 = QB::mul(Rc, Rc);                                   // X^2, Y^2, Z^2
+      l.c1 = QB::wred(QB::tpl(QB::template bcast<0>(r1)));
+      b = QB::template bcast<1>(r1);
+      e = QB::twist_mul(QB::tpl(QB::template bcast<2>(r1)));          // B' * 3 Z^2: two Fq products, every lane
+    }
     // round 2: lane 0: Y Z, lane 1: X Y, lane 2: e^2
-    V r2 = QB::mul(QB::pick(QB::template bcast<1>(Rc), QB::template bcast<0>(Rc), e), QB::pick(QB::template bcast<2>(Rc), QB::template bcast<1>(Rc), e));
-    V h = QB::dbl(QB::template bcast<0>(r2));          // 2YZ = (Y+Z)^2 - (b + c); vb 6
-    V f3 = QB::tpl(e);                                 // vb 9
-    V g = QB::half(QB::add(b, f3));                    // vb 6.5
-    V a = QB::half(QB::template bcast<1>(r2));         // XY / 2
-    V i = QB::template sub<4>(e, b);
-    V e2 = QB::template bcast<2>(r2);
-    // round 3: lane 0: a (b - f3) = X', lane 1: g^2, lane 2: b h = Z'
-    V r3 = QB::mul(QB::pick(a, g, b), QB::pick(QB::template sub<16>(b, f3), g, h));
-    V y3 = QB::wred(QB::template sub<16>(r3, QB::tpl(e2)));   // lane 1: g^2 - 3 e^2
-    Rc = QB::template sel<1>(y3, r3);
+    const V r2 = QB::mul(QB::pick(QB::template bcast<1>(Rc), QB::template bcast<0>(Rc), e), QB::pick(QB::template bcast<2>(Rc), QB::template bcast<1>(Rc), e));
+    const V h = QB::dbl(QB::template bcast<0>(r2));    // 2YZ = (Y+Z)^2 - (b + c); vb 6
     l.c0 = QB::wred(QB::template neg<16>(h));
-    l.c1 = QB::wred(QB::tpl(QB::template bcast<0>(r1)));
-    l.c2 = QB::wred(i);
+    l.c2 = QB::wred(QB::template sub<4>(e, b));
+    const V f3 = QB::tpl(e);                           // vb 9
+    const V e23 = QB::tpl(QB::template bcast<2>(r2));  // 3 e^2
+    // round 3: lane 0: (XY/2) (b - f3) = X', lane 1: g^2 with g = (b + f3)/2, lane 2: b h = Z'
+    const V g = QB::half(QB::add(b, f3));              // vb 6.5
+    const V opA = QB::pick(QB::half(QB::template bcast<1>(r2)), g, b);
+    const V opB = QB::pick(QB::template sub<16>(b, f3), g, h);
+    const V r3 = QB::mul(opA, opB);
+    const V y3 = QB::wred(QB::template sub<16>(r3, e23));   // lane 1: g^2 - 3 e^2
+    Rc = QB::template sel<1>(y3, r3);
   }
   // ark-ec bls12/g2.rs addition_step; Qc: lane 0 = Q.x, lane 1 = Q.y
   QFN static void add_step(V& Rc, const V& Qc, Line& l) {
@@ -481,8 +488,10 @@ template <class QB> struct QPairing377 {
     }
     return acc;
   }
-  // ark-ec bls12 final_exponentiation (same chain as pairing.h)
-  QFN static E12 final_exponentiation(const E12& f) {
+  // ark-ec bls12 final_exponentiation (same chain as pairing.h).  EX: the exp_by_x routine (the kernels bring one that keeps its
+  // accumulator in LDS instead of passing Fq12 values through private memory).
+  QFN static E12 final_exponentiation(const E12& f) { return final_exponentiation_t(f, [](const E12& v) { return exp_by_x(v); }); }
+  template <class EX> QFN static E12 final_exponentiation_t(const E12& f, EX exp_by_x) {
     E12 f2 = TW::inv12(f);
     E12 r = TW::mul12(TW::conj12(f), f2);
     f2 = r;

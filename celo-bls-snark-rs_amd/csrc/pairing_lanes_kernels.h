@@ -149,6 +149,252 @@ __global__ void __launch_bounds__(64) LANES_OCC k_final_exp_lanes(const uint32_t
   if (gt_ark) LP::to_ark12(r, gt_ark + (size_t)p * 72);
 }
 
+// ================================================================== hex kernels with the Fq12 accumulator in LDS
+// The out-of-line tower routines take their Fq12 operands by reference, i.e. through per-lane private memory: ~0.3-0.7 KB per
+// call and lane, and with 2048 waves resident that working set does not stay in L2 (rocprof r2: 30 GB of HBM traffic per
+// 81920-product Miller launch, 33 GB per final-exponentiation launch, all of it argument passing).  With six lanes per pairing an
+// Fq12 is 28 words per lane, so a wave's accumulator is 7 KB: it lives in LDS (two slots per wave: 14 KB, 8 waves per CU = 112 of
+// the 160 KB) and the out-of-line routines take slot numbers; the G2 point travels in registers (14 words in, 14 out).
+//   slot 0: f (Miller) / acc (exp_by_x)        slot 1: (P.x, P.y) of the current pair (Miller) / the base f (exp_by_x)
+// Word-planar layout (word i of lane t at i * 64 + t): every ds_read/ds_write hits 64 distinct banks.
+template <class LP> struct Slots {
+  typedef typename LP::QB QB;
+  typedef typename QB::V V;
+  typedef typename LP::Tow Tow;
+  typedef typename Tow::E12 E12;
+  typedef typename LP::Pair Pair;
+  static constexpr int NW = QB::NWORDS;
+  static constexpr int SLOT_WORDS = 2 * NW * 64;
+  static constexpr unsigned LDS_BYTES = 2 * SLOT_WORDS * 4;
+  __device__ __forceinline__ static uint32_t* at(int slot, int which) {
+    extern __shared__ uint32_t lanes_lds[];
+    return lanes_lds + slot * SLOT_WORDS + which * NW * 64 + threadIdx.x;
+  }
+  __device__ __forceinline__ static V ldv(int slot, int which) {
+    const uint32_t* p = at(slot, which);
+    V r;
+#pragma unroll
+    for (int i = 0; i < NW; i++) r.l[i] = p[i * 64];
+    return r;
+  }
+  __device__ __forceinline__ static void stv(int slot, int which, const V& v) {
+    uint32_t* p = at(slot, which);
+#pragma unroll
+    for (int i = 0; i < NW; i++) p[i * 64] = v.l[i];
+  }
+  __device__ __forceinline__ static E12 ld12(int slot) { return {ldv(slot, 0), ldv(slot, 1)}; }
+  __device__ __forceinline__ static void st12(int slot, const E12& f) { stv(slot, 0, f.a); stv(slot, 1, f.b); }
+
+  // LDS is the spill space: a fence keeps the compiler from hoisting the (cheap) LDS loads of a whole Fq12 above the work that
+  // does not need it yet, or from keeping a value in registers that can be re-read where it is used again
+  __device__ __forceinline__ static void fence() { asm volatile("" ::: "memory"); }
+  // f *= line(P): mul_by_034 with the operands of each product group read from the slot where they are used
+  // commit = false: everything is computed and nothing is stored (a lane group without a live pair in this round of a
+  // multi-pair product keeps its accumulator; LDS stores are per lane, so leaving them out IS the undo)
+  template <class PF> __device__ __forceinline__ static void ell_slot(int sf, PF ldp, const typename Pair::Line& l, bool commit) {
+    typedef typename LP::QB QB;
+    fence();
+    const V t = QB::mul_fp(QB::template sel<0>(l.c0, l.c1), QB::pickf(ldp(1), ldp(0), ldp(0)));
+    const V s0 = QB::template bcast<0>(t), s3 = QB::template bcast<1>(t), s4 = l.c2;
+    fence();
+    const V A = QB::mul(ldv(sf, 0), s0);
+    fence();
+    const V b = Tow::mul6_by_01(ldv(sf, 1), s3, s4);
+    fence();
+    const V e = Tow::mul6_by_01(QB::add(ldv(sf, 0), ldv(sf, 1)), QB::add(s0, s3), s4);
+    const V nb = QB::wred(QB::template sub<4>(QB::template sub<4>(e, A), b)), na = QB::wred(QB::add(A, Tow::mul_by_gen(b)));
+    if (commit) { stv(sf, 1, nb); stv(sf, 0, na); }
+    fence();
+  }
+  // The routines of the inner loops are INLINED into them: an out-of-line call on gfx950 saves and restores the callee-saved
+  // half of the ~250 live VGPRs (77 dwords each way per call, measured in the ISA) - the very private-memory traffic the slots
+  // are there to remove.  Only whole loops (exp_loop: 63 squarings + 6 products) are out of line.
+  __device__ __forceinline__ static void sqr12(int s) { st12(s, Tow::sqr12(ld12(s))); }
+  template <class PF> __device__ __forceinline__ static V step_double(V Rc, int sf, PF ldp, bool commit = true) {
+    typename Pair::Line l;
+    Pair::double_step(Rc, l);
+    ell_slot(sf, ldp, l, commit);
+    return Rc;
+  }
+  template <class PF> __device__ __forceinline__ static V step_add(V Rc, V Qc, int sf, PF ldp, bool commit = true) {
+    typename Pair::Line l;
+    Pair::add_step(Rc, Qc, l);
+    ell_slot(sf, ldp, l, commit);
+    return Rc;
+  }
+  // P = (x, y) of up to MAXK pairs per group, stored ONCE per group behind the two Fq12 slots (the six lanes of a group read the
+  // same words: a broadcast): word i of coordinate c of pair p of group g at ((p * 2 + c) * NW + i) * 16 + g
+  // (the multi-pair kernel keeps f in slot 0 and the running points R_p in slots 1 ..: R_p = half (p & 1) of slot 1 + p / 2)
+  static constexpr int product_slots(int maxk) { return 1 + (maxk + 1) / 2; }
+  template <int NSLOTS> __device__ __forceinline__ static uint32_t* p_area() { extern __shared__ uint32_t lanes_lds[]; return lanes_lds + NSLOTS * SLOT_WORDS; }
+  static constexpr unsigned product_lds_bytes(int maxk) { return (unsigned)(product_slots(maxk) * SLOT_WORDS * 4 + maxk * 2 * NW * 16 * 4); }
+  template <int NSLOTS> __device__ __forceinline__ static void st_p(int pair, int coord, const V& v) {   // every lane of the group stores the same value
+    uint32_t* q = p_area<NSLOTS>() + (pair * 2 + coord) * NW * 16 + QB::group();
+#pragma unroll
+    for (int i = 0; i < NW; i++) q[i * 16] = v.l[i];
+  }
+  template <int NSLOTS> __device__ __forceinline__ static V ld_p(int pair, int coord) {
+    const uint32_t* q = p_area<NSLOTS>() + (pair * 2 + coord) * NW * 16 + QB::group();
+    V r;
+#pragma unroll
+    for (int i = 0; i < NW; i++) r.l[i] = q[i * 16];
+    return r;
+  }
+  __device__ __forceinline__ static void mul12(int dst, int a, int b) {     // Tow::mul12_inl, operands re-read per Fq6 product
+    typedef typename LP::QB QB;
+    const V v0 = Tow::mul6(ldv(a, 0), ldv(b, 0));
+    fence();
+    const V v1 = Tow::mul6(ldv(a, 1), ldv(b, 1));
+    fence();
+    const V t = Tow::mul6(QB::add(ldv(a, 0), ldv(a, 1)), QB::add(ldv(b, 0), ldv(b, 1)));
+    fence();
+    stv(dst, 1, QB::wred(QB::template sub<4>(QB::template sub<4>(t, v0), v1)));
+    stv(dst, 0, QB::wred(QB::add(v0, Tow::mul_by_gen(v1))));
+  }
+  __device__ __forceinline__ static void cyclo(int s) {        // Tow::cyclotomic_sqr_inl with f re-read for the last step
+    typedef typename LP::QB QB;
+    V x, y;
+    {
+      const V fa = ldv(s, 0), fb = ldv(s, 1);
+      x = QB::template sel<1>(QB::template perm<QP(0, 0, 1)>(fb), QB::template perm<QP(0, 0, 1)>(fa));
+      y = QB::template sel<1>(QB::template perm<QP(1, 2, 2)>(fa), QB::template perm<QP(1, 1, 2)>(fb));
+    }
+    fence();
+    const V tmp = QB::mul(x, y);
+    const V m = QB::mul(QB::add(x, y), QB::add(QB::mul_nr(y), x));
+    const V o0 = QB::wred(QB::template sub<64>(QB::template sub<4>(m, tmp), QB::mul_nr(tmp)));
+    const V o1 = QB::dbl(tmp);
+    V u = QB::template perm<QP(2, 0, 1)>(o1);
+    u = QB::template sel<0>(QB::wred(QB::mul_nr(u)), u);
+    fence();
+    const V za = QB::wred(QB::add(QB::dbl(QB::template sub<4>(o0, ldv(s, 0))), o0));
+    const V zb = QB::wred(QB::add(QB::dbl(QB::add(u, ldv(s, 1))), u));
+    stv(s, 0, za); stv(s, 1, zb);
+  }
+  __device__ __attribute__((noinline)) static void exp_loop() {        // slot 0 <- slot 1 ^ x
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+      cyclo(0);
+      if ((T377::X >> i) & 1) mul12(0, 0, 1);
+    }
+  }
+  __device__ __forceinline__ static E12 exp_by_x(const E12& f) {       // acc in slot 0, the base in slot 1
+    st12(0, f); st12(1, f);
+    exp_loop();
+    return ld12(0);
+  }
+};
+
+template <class LP>
+__global__ void __launch_bounds__(64) LANES_OCC k_miller_slots(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1,
+                                                               const uint64_t* __restrict__ g2, const uint8_t* __restrict__ inf2,
+                                                               uint32_t* __restrict__ f_out, uint32_t n) {
+  typedef Slots<LP> S;
+  typedef typename LP::Tow Tow;
+  typedef typename LP::QB QB;
+  const int gi = lanes_group_index<LP>();
+  const bool live = gi >= 0 && (uint32_t)gi < n;
+  const uint32_t i = live ? (uint32_t)gi : 0;                 // idle groups walk pair 0 and store nothing (no early exit: LDS slots are per wave)
+  S::stv(1, 0, LP::load_p(g1 + (size_t)i * LP::G1W, 0));
+  S::stv(1, 1, LP::load_p(g1 + (size_t)i * LP::G1W, 1));
+  const typename QB::V Qc = LP::load_q(g2 + (size_t)i * LP::G2W);
+  typename QB::V Rc = QB::template sel<2>(QB::one(), Qc);
+  S::st12(0, Tow::one12());
+#pragma unroll 1
+  for (int b = 62; b >= 0; b--) {
+    S::sqr12(0);
+    Rc = S::step_double(Rc, 0, [](int c) { return S::ldv(1, c); });
+    if ((T377::X >> b) & 1) Rc = S::step_add(Rc, Qc, 0, [](int c) { return S::ldv(1, c); });
+  }
+  if (!live) return;
+  typename Tow::E12 f = S::ld12(0);
+  if ((inf1 && inf1[i]) || (inf2 && inf2[i])) f = Tow::one12();
+  LP::store12(f_out + (size_t)i * lanes_gt_words<LP>(), f);
+}
+// one group per PRODUCT of <= MAXK pairs with a shared accumulator (ark-ec's multi-Miller loop: one squaring of f per iteration
+// for all its pairs).  Nothing per pair lives in private memory: f in slot 0, the running points R_p in slots 1 .. (14 words per
+// lane each), P_p in the per-group LDS area, Q_p re-read from global memory at the six addition steps.  MAXK is 2 for the verify /
+// Batch::verify shapes (16 KB of LDS per wave: 8 waves per CU) and 4 otherwise (25 KB: 6 waves).  Pairs with a point at infinity are left out (they contribute 1); a group with fewer
+// live pairs than MAXK computes the surplus steps without committing them.
+// the p loops, unrolled by recursion (a `#pragma unroll` over bodies of this size is refused by the optimizer)
+template <class LP, int MAXK, int P = 0> struct PairSteps {
+  typedef Slots<LP> S;
+  typedef typename LP::QB::V V;
+  static constexpr int NS = S::product_slots(MAXK);
+  __device__ __forceinline__ static void init(uint32_t (&idx)[MAXK], int k, uint32_t i, const uint64_t* g1, const uint64_t* g2) {
+    if (P == k) {
+      idx[P] = i;
+      S::template st_p<NS>(P, 0, LP::load_p(g1 + (size_t)i * LP::G1W, 0));
+      S::template st_p<NS>(P, 1, LP::load_p(g1 + (size_t)i * LP::G1W, 1));
+      S::stv(1 + P / 2, P & 1, LP::QB::template sel<2>(LP::QB::one(), LP::load_q(g2 + (size_t)i * LP::G2W)));
+    }
+    PairSteps<LP, MAXK, P + 1>::init(idx, k, i, g1, g2);
+  }
+  __device__ __forceinline__ static void dbl(int k) {
+    const V r = S::step_double(S::ldv(1 + P / 2, P & 1), 0, [](int c) { return S::template ld_p<NS>(P, c); }, P < k);
+    S::stv(1 + P / 2, P & 1, r);                  // a surplus slot may advance its dummy point: only f must not change
+    S::fence();
+    PairSteps<LP, MAXK, P + 1>::dbl(k);
+  }
+  __device__ __forceinline__ static void add(const uint32_t (&idx)[MAXK], int k, const uint64_t* g2) {
+    const V Qc = LP::load_q(g2 + (size_t)idx[P] * LP::G2W);
+    const V r = S::step_add(S::ldv(1 + P / 2, P & 1), Qc, 0, [](int c) { return S::template ld_p<NS>(P, c); }, P < k);
+    S::stv(1 + P / 2, P & 1, r);
+    S::fence();
+    PairSteps<LP, MAXK, P + 1>::add(idx, k, g2);
+  }
+};
+template <class LP, int MAXK> struct PairSteps<LP, MAXK, MAXK> {
+  __device__ __forceinline__ static void init(uint32_t (&)[MAXK], int, uint32_t, const uint64_t*, const uint64_t*) {}
+  __device__ __forceinline__ static void dbl(int) {}
+  __device__ __forceinline__ static void add(const uint32_t (&)[MAXK], int, const uint64_t*) {}
+};
+template <class LP, int MAXK>
+__global__ void __launch_bounds__(64) LANES_OCC k_miller_product_slots(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1,
+                                                                       const uint64_t* __restrict__ g2, const uint8_t* __restrict__ inf2,
+                                                                       const uint32_t* __restrict__ offsets, uint32_t* __restrict__ prod, uint32_t m) {
+  typedef Slots<LP> S;
+  typedef typename LP::Tow Tow;
+  typedef typename LP::QB QB;
+  const int gi = lanes_group_index<LP>();
+  const bool live = gi >= 0 && (uint32_t)gi < m;
+  const uint32_t lo = live ? offsets[gi] : 0, hi = live ? offsets[gi + 1] : 0;
+  typedef PairSteps<LP, MAXK> PS;
+  uint32_t idx[MAXK];                                        // the pair behind slot p (its Q is re-read at the addition steps)
+  // every slot starts on pair 0 of the input (any valid pair); the live pairs of the product then take slots 0 .. k - 1 and the
+  // surplus slots walk their dummy pair uncommitted
+  for (int q = 0; q < MAXK; q++) PS::init(idx, q, 0, g1, g2);
+  int k = 0;
+  for (uint32_t i = lo; i < hi && k < MAXK; i++) {
+    if ((inf1 && inf1[i]) || (inf2 && inf2[i])) continue;
+    PS::init(idx, k, i, g1, g2);
+    k++;
+  }
+  S::st12(0, Tow::one12());
+#pragma unroll 1
+  for (int b = 62; b >= 0; b--) {
+    S::sqr12(0);
+    PS::dbl(k);
+    if ((T377::X >> b) & 1) PS::add(idx, k, g2);
+  }
+  if (live) LP::store12(prod + (size_t)gi * lanes_gt_words<LP>(), S::ld12(0));
+}
+template <class LP>
+__global__ void __launch_bounds__(64) LANES_OCC k_final_exp_slots(const uint32_t* __restrict__ prod, uint8_t* __restrict__ is_one,
+                                                                  uint64_t* __restrict__ gt_ark, uint32_t m, int do_final_exp) {
+  typedef Slots<LP> S;
+  typedef typename LP::Tow Tow;
+  const int gi = lanes_group_index<LP>();
+  const bool live = gi >= 0 && (uint32_t)gi < m;
+  const uint32_t p = live ? (uint32_t)gi : 0;
+  typename Tow::E12 r = LP::load12(prod + (size_t)p * lanes_gt_words<LP>());
+  if (do_final_exp) r = LP::Pair::final_exponentiation_t(r, [](const typename Tow::E12& v) { return S::exp_by_x(v); });
+  const bool one = Tow::is_one12(r);
+  if (!live) return;
+  if (is_one && LP::writer()) is_one[p] = one ? 1 : 0;
+  if (gt_ark) LP::to_ark12(r, gt_ark + (size_t)p * 72);
+}
+
 // launcher definitions (declared in pairing.h as LaneLaunch<CURVE>)
 #define CELO_DEFINE_LANE_MILLER_LAUNCHERS(LL, LP)                                                                                        \
   void LL::miller(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, uint32_t* f, uint32_t n, hipStream_t s) { \
@@ -159,12 +405,40 @@ __global__ void __launch_bounds__(64) LANES_OCC k_final_exp_lanes(const uint32_t
     hipLaunchKernelGGL((k_miller_product_lanes<LP>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64), 0, s, g1, i1, g2, i2, off,    \
                        prod, m);                                                                                                          \
   }                                                                                                                                       \
+  void LL::miller_product2(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off,             \
+                           uint32_t* prod, uint32_t m, hipStream_t s) { miller_product(g1, i1, g2, i2, off, prod, m, s); }                \
   void LL::gt_product(const uint32_t* f, const uint32_t* off, uint32_t* prod, uint32_t m, hipStream_t s) {                               \
     hipLaunchKernelGGL((k_gt_product_lanes<LP>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64), 0, s, f, off, prod, m);           \
   }                                                                                                                                       \
   void LL::gt_tree(const uint32_t* in, uint32_t* out, uint32_t n_in, hipStream_t s) {                                                     \
     const uint32_t n_out = (n_in + 1) / 2;                                                                                                \
     hipLaunchKernelGGL((k_gt_tree_lanes<LP>), dim3((n_out + LP::GROUPS - 1) / LP::GROUPS), dim3(64), 0, s, in, out, n_in);            \
+  }
+// the same launchers on the LDS-slot kernels (hex layout)
+#define CELO_DEFINE_SLOT_MILLER_LAUNCHERS(LL, LP)                                                                                        \
+  void LL::miller(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, uint32_t* f, uint32_t n, hipStream_t s) { \
+    hipLaunchKernelGGL((k_miller_slots<LP>), dim3((n + LP::GROUPS - 1) / LP::GROUPS), dim3(64), Slots<LP>::LDS_BYTES, s, g1, i1, g2, i2, f, n); \
+  }                                                                                                                                       \
+  void LL::miller_product(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off,              \
+                          uint32_t* prod, uint32_t m, hipStream_t s) {                                                                    \
+    hipLaunchKernelGGL((k_miller_product_slots<LP, 4>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64),                               \
+                       Slots<LP>::product_lds_bytes(4), s, g1, i1, g2, i2, off, prod, m);                                    \
+  }                                                                                                                                       \
+  void LL::miller_product2(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off,             \
+                           uint32_t* prod, uint32_t m, hipStream_t s) {                                                                   \
+    hipLaunchKernelGGL((k_miller_product_slots<LP, 2>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64),                               \
+                       Slots<LP>::product_lds_bytes(2), s, g1, i1, g2, i2, off, prod, m);                                    \
+  }                                                                                                                                       \
+  void LL::gt_product(const uint32_t* f, const uint32_t* off, uint32_t* prod, uint32_t m, hipStream_t s) {                               \
+    hipLaunchKernelGGL((k_gt_product_lanes<LP>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64), 0, s, f, off, prod, m);               \
+  }                                                                                                                                       \
+  void LL::gt_tree(const uint32_t* in, uint32_t* out, uint32_t n_in, hipStream_t s) {                                                     \
+    const uint32_t n_out = (n_in + 1) / 2;                                                                                                \
+    hipLaunchKernelGGL((k_gt_tree_lanes<LP>), dim3((n_out + LP::GROUPS - 1) / LP::GROUPS), dim3(64), 0, s, in, out, n_in);                \
+  }
+#define CELO_DEFINE_SLOT_FE_LAUNCHER(LL, LP)                                                                                              \
+  void LL::final_exp(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint32_t m, int do_fe, hipStream_t s) {                         \
+    hipLaunchKernelGGL((k_final_exp_slots<LP>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64), Slots<LP>::LDS_BYTES, s, prod, is_one, gt, m, do_fe); \
   }
 #define CELO_DEFINE_LANE_FE_LAUNCHER(LL, LP)                                                                                              \
   void LL::final_exp(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint32_t m, int do_fe, hipStream_t s) {                         \

@@ -200,6 +200,7 @@ HD WireStatus wire_decode_g1(const uint8_t* in, const WireConsts& k, bool check_
   for (int i = 0; i < 48; i++) buf[i] = in[i];
   const uint8_t flags = buf[47] & 0xC0;
   buf[47] &= 0x3F;
+  if (flags == 0xC0) return WIRE_INVALID;       // ark-serialize SWFlags::from_u8: (sign, infinity) both set is no encoding at all
   if (flags & 0x40) return WIRE_INFINITY;
   Fq x, y;
   if (!wire_fq_from_bytes(buf, x)) return WIRE_INVALID;
@@ -216,6 +217,7 @@ HD WireStatus wire_decode_g2(const uint8_t* in, const WireConsts& k, bool check_
   for (int i = 0; i < 96; i++) buf[i] = in[i];
   const uint8_t flags = buf[95] & 0xC0;
   buf[95] &= 0x3F;
+  if (flags == 0xC0) return WIRE_INVALID;
   if (flags & 0x40) return WIRE_INFINITY;
   Fq2 x, y;
   if (!wire_fq_from_bytes(buf, x.c0) || !wire_fq_from_bytes(buf + 48, x.c1)) return WIRE_INVALID;

@@ -269,6 +269,7 @@ uint8_t decode_one(int g2, const uint8_t* in, int check, u64* out) {
   const uint8_t flags = buf[nb - 1] & 0xC0;
   buf[nb - 1] &= 0x3F;
   memset(out, 0, (g2 ? 24 : 12) * 8);
+  if (flags == 0xC0) return 2;      // ark-serialize SWFlags::from_u8 -> None
   if (flags & 0x40) return 1;
   if (g2) {
     Fq2_377 x;

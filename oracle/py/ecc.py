@@ -349,6 +349,7 @@ def deser_point(curve, data, compressed=True, check_subgroup=False):
     data = bytearray(data)
     flags = data[-1] & 0xC0
     data[-1] &= 0x3F
+    assert flags != 0xC0, "sign and infinity flags both set: SWFlags::from_u8 returns None (one encoding of the identity only)"
     if flags & 0x40:
         return None
     if curve.f2:

@@ -238,3 +238,25 @@ def test_bw6_761_vs_oracle(gpu, golden, n):
         s = H.scalars_np(sc, 6)
         exp = co.jac_to_affine(co.msm(grp, xy, inf, s, threads=8), "761")
         assert _affine(gpu.msm(grp, xy, inf, s), "761") == exp
+
+
+def test_gpu_reproduces_the_frozen_msm_fixtures(gpu):
+    """tests/golden/msm_fixtures.json: results frozen from the big-int definition (tests/golden/make_msm_fixtures.py) - the GPU
+    path against committed data, not only against a checker computed in the same run."""
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msm_fixtures.json")) as f:
+        fx = json.load(f)
+    for n, want in fx["g1"].items():
+        n = int(n)
+        pts = H.seeded_points(ecc.E1_377, ecc.G1_377, n, 100 + n)
+        sc = H.seeded_scalars(n, 200 + n, ecc.R377)
+        xy, inf = co.pack_g1_377(pts)
+        got = _affine(gpu.msm("bls12_377_g1", xy, inf, H.scalars_np(sc, 4)), "g1_377")
+        assert got == (int(want[0], 16), int(want[1], 16)), n
+    for n, want in fx["g2"].items():
+        n = int(n)
+        pts = H.seeded_points(ecc.E2_377, ecc.G2_377, n, 100 + n)
+        sc = H.seeded_scalars(n, 200 + n, ecc.R377)
+        xy, inf = co.pack_g2_377(pts)
+        got = _affine(gpu.msm("bls12_377_g2", xy, inf, H.scalars_np(sc, 4)), "g2_377")
+        assert got == ((int(want[0][0], 16), int(want[0][1], 16)), (int(want[1][0], 16), int(want[1][1], 16))), n

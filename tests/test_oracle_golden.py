@@ -291,3 +291,38 @@ def test_oracle_c_decompress_matches_python_and_reference_points(golden):
     assert st.tolist() == [1, 2, 2, 3, 0] and not xy[:4].any()
     xy, st = co.decompress("g1", b"".join(enc), check_subgroup=False)
     assert st.tolist() == [1, 2, 2, 0, 0] and co.from_mont(xy[3].reshape(2, 6), q) == [xo, yo]
+
+
+# ---------------------------------------------------------------- frozen MSM results (tests/golden/msm_fixtures.json)
+def _msm_fixture():
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msm_fixtures.json")) as f:
+        return json.load(f)
+
+
+def _unhex(P, f2=False):
+    if P is None:
+        return None
+    if f2:
+        return ((int(P[0][0], 16), int(P[0][1], 16)), (int(P[1][0], 16), int(P[1][1], 16)))
+    return (int(P[0], 16), int(P[1], 16))
+
+
+def test_oracle_pippenger_reproduces_the_frozen_msm_fixtures():
+    """the C++ restatement of arkworks' Pippenger (the full-size checker) against results frozen from the big-int definition
+    (tests/golden/make_msm_fixtures.py): the reference itself holds no MSM vector."""
+    from tests import helpers as H
+    from oracle import cpu_oracle as co
+    fx = _msm_fixture()
+    for n, want in fx["g1"].items():
+        n = int(n)
+        pts = H.seeded_points(ecc.E1_377, ecc.G1_377, n, 100 + n)
+        sc = H.seeded_scalars(n, 200 + n, ecc.R377)
+        xy, inf = co.pack_g1_377(pts)
+        assert co.jac_to_affine(co.msm("bls12_377_g1", xy, inf, H.scalars_np(sc, 4), threads=2), "g1_377") == _unhex(want), n
+    for n, want in fx["g2"].items():
+        n = int(n)
+        pts = H.seeded_points(ecc.E2_377, ecc.G2_377, n, 100 + n)
+        sc = H.seeded_scalars(n, 200 + n, ecc.R377)
+        xy, inf = co.pack_g2_377(pts)
+        assert co.jac_to_affine(co.msm("bls12_377_g2", xy, inf, H.scalars_np(sc, 4), threads=2), "g2_377") == _unhex(want, True), n

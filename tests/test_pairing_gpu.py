@@ -170,3 +170,23 @@ def test_shared_accumulator_mode_at_scale(gpu):
     gt = gpu.pairing_gt(g1, i1, g2, i2, off_all)
     assert np.array_equal(gt[6], co.pairing_product_377(g1u[offs[6]:offs[7]], None, g2u[offs[6]:offs[7]], None)[0])
     assert np.array_equal(gt[8 * 1234 + 7], co.pairing_product_377(g1u[offs[7]:offs[8]], None, g2u[offs[7]:offs[8]], None)[0])
+
+
+def test_bilinearity_on_reference_held_points(gpu, golden):
+    """A check that shares nothing with the Miller-loop / final-exponentiation restatements: for points the REFERENCE holds (a G1
+    hash-to-curve vector, crates/bls-crypto/src/hash_to_curve/mod.rs:412-455, and a validator key of its Groth16 FFI test,
+    crates/bls-snark-sys/src/snark/mod.rs:56) and known scalars a, b: e(aP, bQ) * e(-abP, Q) == 1 and e(aP, bQ) * e(-(ab+1)P, Q) != 1,
+    on the GPU and on the oracle.  Scalar multiplication is pinned separately (cofactor clearing of the hash-to-curve vectors)."""
+    P = ecc.deser_point(ecc.E1_377, bytes.fromhex(golden["hash_to_curve"]["g1_compat"]["points"][3]))
+    Q = ecc.deser_point(ecc.E2_377, bytes.fromhex(golden["groth16_bw6_761"]["first_pubkeys"])[:96])
+    assert ecc.E1_377.in_subgroup(P) and ecc.E2_377.in_subgroup(Q)
+    rng = ecc.SplitMix64(777)
+    for _ in range(3):
+        a, b = ecc.random_scalar(rng, ecc.R377), ecc.random_scalar(rng, ecc.R377)
+        aP, bQ = ecc.E1_377.mul(P, a), ecc.E2_377.mul(Q, b)
+        for delta, want in ((0, True), (1, False)):
+            m = ecc.E1_377.neg(ecc.E1_377.mul(P, (a * b + delta) % ecc.R377))
+            g1, i1 = co.pack_g1_377([aP, m])
+            g2, i2 = co.pack_g2_377([bQ, Q])
+            assert gpu.pairing_product_is_one(g1, i1, g2, i2) == want
+            assert bool(co.pairing_product_377(g1, i1, g2, i2)[1]) == want

@@ -104,6 +104,16 @@ def test_rejects_bad_encodings(sys_lib, golden):
     inf = ecc.ser_point(ecc.E1_377, None)
     h = _deser(sys_lib, "deserialize_signature", inf)
     assert h is not None and _ser(sys_lib, "serialize_signature", h) == inf
+    # sign AND infinity flags set: not an encoding (ark-serialize SWFlags::from_u8 returns None: the identity has one encoding)
+    both = bytearray(inf)
+    both[-1] |= 0x80
+    assert _deser(sys_lib, "deserialize_signature", bytes(both)) is None
+    both2 = bytearray(ecc.ser_point(ecc.E2_377, None))
+    both2[-1] |= 0x80
+    assert _deser(sys_lib, "deserialize_public_key", bytes(both2)) is None
+    import numpy as np
+    from oracle import cpu_oracle as co
+    assert co.decompress("g1", bytes(both))[1].tolist() == [2] and co.decompress("g2", bytes(both2))[1].tolist() == [2]
 
 
 def test_keys_and_aggregation(sys_lib):

@@ -44,18 +44,25 @@ class Ctx:
     pass
 
 
-def committed_traffic(kernel, log_n):
-    """HBM bytes per launch of `kernel` from the newest committed PMC profile of the same launch shape, or (None, why)."""
+# launch shapes the committed PMC profiles were taken at (tools/profile_bench.sh: the default bench command; tools/bench_groups.py 20)
+PROFILED_SHAPE = {"k_accumulate<G1_377>": 20, "k_accumulate<G2_377>": 20, "k_accumulate<G_761>": 20,
+                  "k_miller_product_slots<LPH377, 2>": 81920, "k_final_exp_slots<LPH377>": 81920}
+
+
+def committed_traffic(kernels, shape):
+    """HBM bytes per launch (summed over `kernels`) from the newest committed PMC profile that holds them at this launch shape
+    (profiles/r*_traffic.json, written by tools/summarise_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes), or (None, why)."""
+    kernels = [kernels] if isinstance(kernels, str) else list(kernels)
+    if any(PROFILED_SHAPE.get(k) != shape for k in kernels):
+        return None, "no committed PMC profile of this launch shape"
     try:
-        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-        for path in reversed(cand):
-            tj = json.load(open(path))
-            k = tj.get("kernels", {}).get(kernel)
-            if k and k.get("log_n", 20) == log_n:
-                return k["hbm_bytes_per_launch"], os.path.basename(path)
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            tj = json.load(open(path)).get("kernels", {})
+            if all(k in tj for k in kernels):
+                return sum(tj[k]["hbm_bytes_per_launch"] for k in kernels), os.path.basename(path)
     except Exception:
         pass
-    return None, "no committed PMC profile of this launch shape"
+    return None, "no committed PMC profile holds these kernels"
 
 
 # ===================================================================================================== MSM configurations (2 and 4)
@@ -465,10 +472,10 @@ def pairing_leg(ffi, check_oracle=True):
         raise SystemExit("PARITY FAILURE: GPU pairing accept vector != expected / oracle")
     secs = best["total_ms"] * 1e-3
     gbps = 2 * m * 288 / secs / 1e9
-    traffic, src = committed_traffic("k_miller_product_lanes<LP377>", 0)
+    traffic, src = committed_traffic(["k_miller_product_slots<LPH377, 2>", "k_final_exp_slots<LPH377>"], m)
     return {"metric": "BLS12-377 Miller loops/s (2-pair products, 1 final exponentiation per product)", "value": 2 * m / secs,
             "products": m, "device_ms": best["total_ms"], "wall_ms_incl_pcie": best["wall_ms"], "miller_ms": best["miller_ms"], "final_exp_ms": best["final_exp_ms"],
-            "roofline": {"bound": "hbm", "kernel": "k_miller_product_lanes<LP377> + k_final_exp_lanes<LP377>", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_miller_product_slots<LPH377, 2> + k_final_exp_slots<LPH377>", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src, "note": "algorithmic bytes = 288 B per Miller loop (SURVEY.md section 8d); integer-VALU bound"},
             "cpu_port_miller_loops_per_s_1core": cpu_rate, "accept_vector_matches_oracle": ok if check_oracle else None}
 

@@ -1,8 +1,10 @@
 """Host-side mirror of bls-crypto's hot-path API over the C ABI (same names, argument meaning and error behaviour as
 crates/bls-crypto/src/bls/{public,signature,batch}.rs) — thin orchestration; all group arithmetic runs on the GPU.
 
-Points are affine tuples of Python ints (G1: (x, y); G2: ((x0, x1), (y0, y1))), None = identity.  Hashing to G1 is NOT
-on this path: callers pass the message hash point H(m) explicitly.
+Points are affine tuples of Python ints (G1: (x, y); G2: ((x0, x1), (y0, y1))), None = identity.  This mirror takes the
+message hash point H(m) explicitly (the batched hashers are `ffi.hash_to_g1_direct` / `ffi.hash_to_g1_composite`, and the
+reference-named FFI symbols of include/celo_bls_snark_sys.h hash from message bytes); `batch_verify_strict` below is the
+list-of-tuples form of `ffi.batch_verify` (one chained device call on flat arrays).
 """
 import os
 import numpy as np

@@ -8,7 +8,16 @@
  * verify / batch-verify with BOTH hashers (DIRECT: Blake2s CRH + Blake2Xs XOF; COMPOSITE: Bowe-Hopwood-Pedersen CRH over
  * ed-on-BW6-761 + Blake2Xs XOF), plain and CIP22 try-and-increment with the deployed `compat` bit logic, Groth16 `verify`
  * and the two epoch encoders.  `(composite = false, cip22 = true)` is an error exactly as in the reference
- * (signatures.rs:61,265,321,387).  Hashing, decompression and bit-packing run on the host; every MSM and pairing on the GPU.
+ * (signatures.rs:61,265,321,387).  Single-key decoding, single hashes and bit-packing run on the host; every MSM and pairing, the
+ * message hashing of the batch entry points (every hasher, from 256 messages up) and the whole of batch_verify_strict's
+ * Batch::verify chain run on the GPU.  Re-entrant: callable from any number of host threads (no global lock).
+ *
+ * Differences from the reference, all deliberate:
+ *   - hash_composite / hash_composite_cip22 return ToBytes of the projective representative (x, y, 1) of the hash point (144 B);
+ *     arkworks' own Jacobian bit pattern depends on its scalar-multiplication schedule.  Same point, compare after into_affine().
+ *   - an epoch block that lists the point at infinity as a validator key is refused by encode_epoch_block_to_bytes* and verify
+ *     (the reference's read_pubkeys accepts it).
+ *   - a compressed point whose last byte has BOTH flag bits set (0xC0) is rejected, like ark-serialize's SWFlags::from_u8.
  */
 #ifndef CELO_BLS_SNARK_SYS_H
 #define CELO_BLS_SNARK_SYS_H

@@ -54,3 +54,21 @@ def test_no_device_fails_loudly():
         ffi.composite_crh([b"m"])
     with pytest.raises(RuntimeError):
         ffi.ntt(np.zeros((2, 6), dtype=np.uint64), 1, np.zeros(6, dtype=np.uint64))
+    # round 2 entry points: multi-device MSM, chained Batch::verify, the prover row, device binding
+    with pytest.raises(RuntimeError):
+        ffi.msm_multi("bls12_377_g1", [0, 0], xy, None, sc)
+    with pytest.raises(RuntimeError):
+        ffi.batch_verify(np.zeros((1, 24), dtype=np.uint64), np.zeros((1, 12), dtype=np.uint64), np.ones((1, 4), dtype=np.uint64),
+                         np.array([0, 1], dtype=np.uint32), np.zeros((1, 12), dtype=np.uint64), np.zeros(24, dtype=np.uint64))
+    z6 = np.zeros(6, dtype=np.uint64)
+    with pytest.raises(RuntimeError):
+        ffi.witness_map(np.zeros((2, 6), dtype=np.uint64), np.zeros((2, 6), dtype=np.uint64), np.zeros((2, 6), dtype=np.uint64), 1,
+                        {k: z6 for k in ("omega", "omega_inv", "coset", "coset_inv", "size_inv", "vanishing_inv")})
+    with pytest.raises(RuntimeError):
+        ffi.groth16_prove(np.zeros((2, 24), dtype=np.uint64), np.zeros((2, 24), dtype=np.uint64), np.zeros((1, 24), dtype=np.uint64),
+                          np.zeros((1, 24), dtype=np.uint64), np.zeros(24, dtype=np.uint64), np.zeros(24, dtype=np.uint64),
+                          np.ones((1, 6), dtype=np.uint64), 1, np.ones((1, 6), dtype=np.uint64))
+    with pytest.raises(RuntimeError):
+        ffi.use_device(0)
+    with pytest.raises(RuntimeError):
+        ffi.device_count()

@@ -203,7 +203,10 @@ template <class LP> struct Slots {
     fence();
     const V e = Tow::mul6_by_01(QB::add(ldv(sf, 0), ldv(sf, 1)), QB::add(s0, s3), s4);
     const V nb = QB::wred(QB::template sub<4>(QB::template sub<4>(e, A), b)), na = QB::wred(QB::add(A, Tow::mul_by_gen(b)));
-    if (commit) { stv(sf, 1, nb); stv(sf, 0, na); }
+    // branch-free: an uncommitted lane writes back what the slot holds (a divergent `if` around the stores made the register
+    // allocator spill ~140 dwords per step in the surrounding 442 KB loop body; the select costs 56 instructions)
+    stv(sf, 1, QB::choose(commit, nb, ldv(sf, 1)));
+    stv(sf, 0, QB::choose(commit, na, ldv(sf, 0)));
     fence();
   }
   // The routines of the inner loops are INLINED into them: an out-of-line call on gfx950 saves and restores the callee-saved

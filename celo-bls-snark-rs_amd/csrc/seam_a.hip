@@ -1093,9 +1093,9 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
       if (!batches[b].public_keys[i] || !batches[b].signatures[i]) return false;
   ph.mark("validate + allocate");
   // the message hashes depend on nothing computed here: they run on the host cores while the GPU does the two MSMs
-  std::vector<uint64_t> g1(2 * m * 12), g2(2 * m * 24);
+  std::vector<uint64_t> hxy(m * 12);
   std::vector<HashJob> jobs(m);
-  for (size_t b = 0; b < m; b++) jobs[b] = {batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, &g1[(2 * b + 1) * 12]};
+  for (size_t b = 0; b < m; b++) jobs[b] = {batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, &hxy[b * 12]};
   bool hash_ok = false;
   std::vector<uint8_t> hash_failed;
   std::thread hasher([&]() { hash_ok = hash_many(composite, cip22, SIG_DOMAIN, jobs, &hash_failed); });
@@ -1111,8 +1111,8 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   uint64_t one2[12], one1[6];
   Fq2_::one().to_ark(one2);
   Fq_::one().to_ark(one1);
-  auto work = [&](unsigned t) {
-    const size_t b_lo = m * t / nt, b_hi = m * (t + 1) / nt;
+  auto work = [&](unsigned t, size_t c_lo, size_t c_hi) {           // thread t's share of the batches [c_lo, c_hi)
+    const size_t b_lo = c_lo + (c_hi - c_lo) * t / nt, b_hi = c_lo + (c_hi - c_lo) * (t + 1) / nt;
     ChaCha20Rng& rng = rngs[t];
     std::vector<uint32_t> pk_todo, sg_todo;
     for (size_t b = b_lo; b < b_hi; b++) {
@@ -1153,28 +1153,47 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     fix(pk_todo, true);
     fix(sg_todo, false);
   };
-  if (nt == 1) work(0);
-  else {
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
-    for (auto& x : th) x.join();
-  }
-  ph.mark("gather handles -> affine, exponents");
-  // everything between the gathered handles and the verdicts is ONE chained device call (batch_verify_bls12_377): both batch MSMs
-  // in flight together on two engines, their sums normalised on the device into the pairing engine's input slots, m two-pair
-  // products.  The message hashes (started above, GPU or host cores) are joined just before it.
-  hasher.join();
-  if (!hash_ok) return false;
-  ph.mark("wait for the hashes");
-  std::vector<uint64_t> hxy(m * 12);
+  // Everything between the gathered handles and the verdicts is ONE chained device call per chunk (batch_verify_bls12_377: both
+  // batch MSMs in flight together on two engines, their sums normalised on the device into the pairing engine's input slots,
+  // two-pair products); the message hashes (started above, GPU or host cores) are joined before the first one.  The loop can
+  // pipeline chunks (GPU on chunk c while the host cores gather chunk c + 1; the engines are pooled, so the calls need no
+  // coordination) - MEASURED at 4096 x 256 with 4 chunks: 57-64 ms per call against 45.6 ms with one (four 1024-batch chains in
+  // flight are less efficient than one 4096-batch chain and their launch threads slow the gather): one chunk it is.
+  const size_t nchunks = 1;
   std::vector<uint8_t> hinf(m, 0), ok(m, 0);
-  for (size_t b = 0; b < m; b++) {
-    if (hash_failed[b]) hinf[b] = 1;                       // no H(m): that pair is left out, the verdict is forced below
-    else memcpy(&hxy[b * 12], &g1[(2 * b + 1) * 12], 96);
-  }
+  std::vector<int> chunk_rc(nchunks, 0);
+  std::vector<std::thread> gpu_calls;
+  struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } gpu_guard{gpu_calls};
   uint64_t ng2[24];
   neg_g2_generator(ng2);
-  if (batch_verify_bls12_377(pk_xy, pk_inf, sg_xy, sg_inf, sc, offs.data(), hxy.data(), hinf.data(), ng2, m, ok.data()) != 0) return false;
+  const int dev = api_device();
+  bool hashes_joined = false;
+  for (size_t c = 0; c < nchunks; c++) {
+    const size_t c_lo = m * c / nchunks, c_hi = m * (c + 1) / nchunks;
+    if (nt == 1) work(0, c_lo, c_hi);
+    else {
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t, c_lo, c_hi);
+      for (auto& x : th) x.join();
+    }
+    if (!hashes_joined) {
+      hasher.join();
+      hashes_joined = true;
+      if (!hash_ok) return false;
+      for (size_t b = 0; b < m; b++) if (hash_failed[b]) hinf[b] = 1;   // no H(m): that pair is left out, the verdict is forced below
+    }
+    gpu_calls.emplace_back([&, c, c_lo, c_hi]() {
+      if (api_bind_thread(dev) != 0) { chunk_rc[c] = 101; return; }
+      std::vector<uint32_t> co(c_hi - c_lo + 1);
+      for (size_t b = c_lo; b <= c_hi; b++) co[b - c_lo] = offs[b] - offs[c_lo];
+      const size_t at = offs[c_lo];
+      chunk_rc[c] = batch_verify_bls12_377(pk_xy + at * 24, pk_inf + at, sg_xy + at * 12, sg_inf + at, sc + at * 4, co.data(), &hxy[c_lo * 12],
+                                           &hinf[c_lo], ng2, c_hi - c_lo, &ok[c_lo]);
+    });
+  }
+  ph.mark("gather handles -> affine, exponents (chunks, GPU calls in flight)");
+  for (auto& t : gpu_calls) t.join();
+  for (int rc : chunk_rc) if (rc != 0) return false;
   ph.mark("G2 + G1 batch MSMs -> pairs -> pairing checks (GPU, chained)");
   bool all = true;
   for (size_t b = 0; b < m; b++) { out_results[b] = ok[b] != 0 && !hash_failed[b]; all = all && out_results[b]; }

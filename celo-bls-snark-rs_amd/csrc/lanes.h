@@ -101,18 +101,25 @@ template <class BP> struct QTriT {
     return r;
   }
   template <int K> QDEV static V bcast(const V& x) { return perm<QP(K, K, K)>(x); }
+  // selections by mask arithmetic: as `c ? a : b` the compiler sinks the operands' computations into exec-masked regions (hundreds
+  // per Miller step: scalar bookkeeping for no saved work on a SIMD, and divergent regions cost registers) - see QHex377::choose
+  QDEV static uint32_t lane_mask(bool c) { return 0u - (uint32_t)c; }
   template <int K> QDEV static V sel(const V& onk, const V& other) {
-    const bool c = lane() == K;
+    const uint32_t m = lane_mask(lane() == K);
     V r;
 #pragma unroll
-    for (int i = 0; i < NWORDS; i++) word(r, i) = c ? word(onk, i) : word(other, i);
+    for (int i = 0; i < NWORDS; i++) word(r, i) = (word(onk, i) & m) | (word(other, i) & ~m);
     return r;
   }
   QDEV static V pick(const V& a0, const V& a1, const V& a2) {
     const int q = lane();
+    const uint32_t m0 = lane_mask(q == 0), m1 = lane_mask(q == 1);
     V r;
 #pragma unroll
-    for (int i = 0; i < NWORDS; i++) word(r, i) = q == 0 ? word(a0, i) : q == 1 ? word(a1, i) : word(a2, i);
+    for (int i = 0; i < NWORDS; i++) {
+      const uint32_t t = (word(a1, i) & m1) | (word(a2, i) & ~m1);
+      word(r, i) = (word(a0, i) & m0) | (t & ~m0);
+    }
     return r;
   }
   QDEV static V zero() { return BP::zero(); }

@@ -60,9 +60,13 @@ struct QTri377 : QTriT<Base377> {
   QDEV static V twist_mul(const V& a) { return twist_b_times(a); }
   QDEV static F pickf(const F& a0, const F& a1, const F& a2) {
     const int q = lane();
+    const uint32_t m0 = lane_mask(q == 0), m1 = lane_mask(q == 1);
     F r;
 #pragma unroll
-    for (int i = 0; i < 14; i++) r.l[i] = q == 0 ? a0.l[i] : q == 1 ? a1.l[i] : a2.l[i];
+    for (int i = 0; i < 14; i++) {
+      const uint32_t t = (a1.l[i] & m1) | (a2.l[i] & ~m1);
+      r.l[i] = (a0.l[i] & m0) | (t & ~m0);
+    }
     return r;
   }
   QDEV static V constant(const uint32_t* c0, const uint32_t* c1) { return f2_from(c0, c1); }
@@ -197,10 +201,16 @@ struct QHex377 {
     return r;
   }
   QDEV static V swap(const V& x) { return from_addr(x, (wave_lane() ^ 1) << 2); }
+  // Per-lane selection by MASK ARITHMETIC, one v_bfi_b32 per word.  Written as `c ? a : b` the compiler turns selections between
+  // expensive operands into exec-masked branches (it sinks each operand's computation into "its" lanes' region: 466
+  // s_and_saveexec regions in the Miller loop body) - no work is saved on a SIMD, the scalar bookkeeping is pure overhead, and
+  // divergent regions push the register allocator into spills (pairing_lanes_kernels.h, ell_slot).
+  QDEV static uint32_t lane_mask(bool c) { return 0u - (uint32_t)c; }
   QDEV static V choose(bool c, const V& a, const V& b) {
+    const uint32_t m = lane_mask(c);
     V r;
 #pragma unroll
-    for (int i = 0; i < NWORDS; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    for (int i = 0; i < NWORDS; i++) r.l[i] = (a.l[i] & m) | (b.l[i] & ~m);
     return r;
   }
   QDEV static V mul(const V& a, const V& b) { return hex::mul(a, b, swap(a), swap(b), hsel()); }
@@ -236,9 +246,13 @@ struct QHex377 {
   template <int K> QDEV static V sel(const V& onk, const V& other) { return choose(lane() == K, onk, other); }
   QDEV static V pick(const V& a0, const V& a1, const V& a2) {
     const int q = lane();
+    const uint32_t m0 = lane_mask(q == 0), m1 = lane_mask(q == 1);
     V r;
 #pragma unroll
-    for (int i = 0; i < NWORDS; i++) r.l[i] = q == 0 ? a0.l[i] : q == 1 ? a1.l[i] : a2.l[i];
+    for (int i = 0; i < NWORDS; i++) {
+      const uint32_t t = (a1.l[i] & m1) | (a2.l[i] & ~m1);
+      r.l[i] = (a0.l[i] & m0) | (t & ~m0);
+    }
     return r;
   }
   QDEV static F pickf(const F& a0, const F& a1, const F& a2) { return pick(a0, a1, a2); }

@@ -136,8 +136,39 @@ class MsmConfig:
         line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": ACC_KERNEL[self.group], "achieved": fq_ops / (acc * 1e-3) / 1e9,
                                  "peak": valu_peak, "unit": "G field-mul-or-sqr/s", "frac": fq_ops / (acc * 1e-3) / 1e9 / valu_peak,
                                  "note": "peak from tools/ubench_fp.hip (register-resident multiply loops, 8 waves/SIMD); achieved = n*windows mixed adds * (8M+2S) / accumulate time"}
+        if cx.world == 1:
+            line["two_callers"] = self.two_callers()
         if not cx.args.no_cpu_baseline:
             line["cpu_baseline"] = self.cpu_baseline(result)
+
+    def two_callers(self):
+        """Secondary number (not `value`): the same MSM issued from TWO host threads at once (the library has no global lock: each call
+        leases its own engine and stream), so one call's latency-bound sort / bucket-reduction / host epilogue overlaps the other's
+        bucket accumulation.  Both results are checked against the sequential one."""
+        from celo_bls_snark_rs_amd import ffi
+        reps = max(4, self.cx.args.steps)
+        ref = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n)
+        outs = [None, None]
+
+        def run(i):
+            for _ in range(reps):
+                outs[i] = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n)
+        for i in range(2):
+            run(i)                                            # warm both engines' arenas
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        dt = time.perf_counter() - t0
+        from celo_bls_snark_rs_amd import codec
+        p = codec.Q377 if self.group.startswith("bls12_377") else codec.Q761
+        ext = 2 if self.group == "bls12_377_g2" else 1
+        aff = [codec.jacobian_to_affine(o, p, ext) for o in (ref, outs[0], outs[1])]   # the Jacobian representative depends on the schedule
+        if not (aff[0] == aff[1] == aff[2]):
+            raise SystemExit("PARITY FAILURE: concurrent MSM calls returned a different point")
+        return {"value": 2 * reps * self.n / dt, "unit": "scalar-muls/s", "ms_per_msm": dt * 1e3 / (2 * reps),
+                "note": "two host threads, %d MSMs each, engines and streams from the pool; results identical to the sequential call" % reps}
 
     def cpu_baseline(self, gpu_result):
         """Full-size parity of the timed result (every rank's inputs gathered on rank 0), then bounded timings of the port."""

@@ -9,6 +9,10 @@
 #include <cstdio>
 
 #include "runtime.h"
+// two waves per SIMD (scratch instead of AGPRs for what does not fit 256 VGPRs) unless overridden: -DFROW_OCC= for the A/B
+#ifndef FROW_OCC
+#define FROW_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 namespace celo {
 static std::mutex hash_mu;                 // bulk calls, serialised per process (each fills the GPU; buffers are per call)
 int wire_consts_device(WireConsts& out);   // unit_wire.hip
@@ -22,7 +26,7 @@ struct HashIn { const uint8_t* msgs; const uint64_t* msg_off; const uint8_t* ext
 // so a round finds a point with probability 1 - 0.58^16 and the call is two launches deep instead of eight).  The lowest
 // successful counter of the group wins (ballot), its lane stores the curve point BEFORE the cofactor; a group without success
 // appends its message to the next round's list.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) FROW_OCC
 k_hash_candidates(HashDom dom, HashIn in, const uint32_t* __restrict__ list, uint32_t count, uint32_t cand_log, uint32_t base, int mode, const EdPoint* __restrict__ gens,
                   uint64_t* __restrict__ cand_xy, uint8_t* __restrict__ attempts, uint32_t* __restrict__ next_list, uint32_t* __restrict__ next_count,
                   WireConsts k) {
@@ -59,7 +63,7 @@ k_hash_candidates(HashDom dom, HashIn in, const uint32_t* __restrict__ list, uin
 }
 // scale_by_cofactor + normalisation of the winning candidates, one message per lane (uniform: a 124-step ladder and one
 // inversion).  A multiple that is the identity (probability ~2^-125 per message) is flagged for the host's serial loop.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) FROW_OCC
 k_hash_finish(const uint64_t* __restrict__ cand_xy, const uint8_t* __restrict__ attempts, uint64_t* __restrict__ out, uint8_t* __restrict__ redo, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -183,7 +187,7 @@ done:
   return rc;
 }
 // ---- bulk Pedersen CRH (pedersen.h): one message per lane; the 52080-generator table (11.7 MB) is uploaded on first use
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) FROW_OCC
 k_pedersen_crh(const EdPoint* __restrict__ gens, const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off, uint8_t* __restrict__ out, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -4,6 +4,10 @@
 #include <mutex>
 #include "runtime.h"
 
+// two waves per SIMD (scratch instead of AGPRs for what does not fit 256 VGPRs) unless overridden: -DFROW_OCC= for the A/B
+#ifndef FROW_OCC
+#define FROW_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 namespace celo {
 // decode / normalise calls allocate their buffers per call and run on the caller's stream (or the null stream); calls from
 // several host threads are serialised per process by this lock (they are bulk calls: one fills the GPU)
@@ -12,7 +16,7 @@ static std::mutex wire_mu;
 // in: n x 48 (G1) / n x 96 (G2) wire bytes.  out: n x 12 / n x 24 u64, affine (x, y) in arkworks Montgomery limbs (the layout
 // the MSM and pairing entry points take), zeros unless status == WIRE_OK.  Control flow is uniform apart from the table scans of the square
 // root; the 253-step subgroup ladder that dominates uses the same scalar r in every lane.
-template <bool G2> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_decompress(const uint8_t* __restrict__ in, uint64_t* __restrict__ out,
+template <bool G2> __global__ void __launch_bounds__(64) FROW_OCC k_decompress(const uint8_t* __restrict__ in, uint64_t* __restrict__ out,
                                                                       uint8_t* __restrict__ status, uint32_t n, int check, WireConsts k) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -38,7 +42,7 @@ template <bool G2> __global__ void __launch_bounds__(64) __attribute__((amdgpu_w
 // inversion per K points, 3 products per point for the prefix / suffix products, then x = X z^-2, y = Y z^-3.  in: n x 3
 // coordinates (arkworks Montgomery limbs, identity = Z == 0); out: n x (x, y), zero rows + inf[i] = 1 for the identity.
 // Points that are already affine (Z == 1: everything that came off the wire) take part with z = 1; their x, y come out unchanged.
-template <class F, int K> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <class F, int K> __global__ void __launch_bounds__(64) FROW_OCC
 k_normalize(const uint64_t* __restrict__ jac, uint64_t* __restrict__ out, uint8_t* __restrict__ inf, uint32_t n) {
   constexpr int A = F::ARK64;
   const uint32_t lo = (blockIdx.x * blockDim.x + threadIdx.x) * K;

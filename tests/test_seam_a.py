@@ -324,6 +324,16 @@ def test_sign_verify_flow_on_gpu(sys_lib, gpu, composite, cip22):
     good = (_BatchMessageFFI * 2)(batches[0], batches[2])
     res2 = (C.c_bool * 2)()
     assert sys_lib.batch_verify_strict(good, C.c_size_t(2), CF, C22, res2) and list(res2) == [True, True]
+    # Batch::verify zips keys with signatures (crates/bls-crypto/src/bls/batch.rs:60-64): a batch that lists 4 keys and only their
+    # first 3 signatures is checked on those 3 pairs; the other batch of the call is unaffected
+    pks0, sgs0, m0 = holders[0]
+    short = _BatchMessageFFI(_Buffer(m0, len(m0)), _Buffer(b"", 0), pks0, 4, sgs0, 3)
+    mixed = (_BatchMessageFFI * 2)(short, batches[2])
+    res3 = (C.c_bool * 2)(False, False)
+    assert sys_lib.batch_verify_strict(mixed, C.c_size_t(2), CF, C22, res3) and list(res3) == [True, True]
+    # out_results is written on every path: a call that fails as a whole leaves "not verified" everywhere
+    res4 = (C.c_bool * 2)(True, True)
+    assert not sys_lib.batch_verify_strict(mixed, C.c_size_t(2), C.c_bool(False), C.c_bool(True), res4) and list(res4) == [False, False]
     assert not sys_lib.batch_verify_strict(good, C.c_size_t(2), C.c_bool(False), C.c_bool(True), res2) and list(res2) == [False, False]
 
 

@@ -639,6 +639,10 @@ void neg_g2_generator(uint64_t out_xy[24]) {
 }  // namespace
 
 namespace celo {
+struct BvJob { BatchRun keys, sigs; };      // unit_batchverify.hip: the chained Batch::verify in three steps
+int bv_begin_keys(BvJob*, const void*, const void*, const void*, int, const uint32_t*, size_t);
+int bv_begin_sigs(BvJob*, const void*, const void*, const void*, int, const uint32_t*, size_t);
+int bv_finish(BvJob*, int, const void*, const void*, int, const uint64_t*, size_t, uint8_t*);
 // the composite hasher's generator table for the bulk GPU kernel (unit_hash.hip: k_pedersen_crh)
 const EdPoint* celo_composite_gens(size_t* count) {
   const CompositeParams& cp = composite_params();
@@ -1086,6 +1090,34 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   uint64_t* sc = sg_xy + tot * 12;
   uint8_t* pk_inf = (uint8_t*)(sc + tot * 4);
   uint8_t* sg_inf = pk_inf + tot;
+  // device mirror of the staging buffer (same layout, grow-only) + m hash points and flags behind it, and one copy stream: the
+  // gather runs in PHASES over the batch range (all threads share each phase), and the calling thread sends a finished phase on its
+  // way (hipMemcpyAsync from pinned memory) while the workers gather the next: the 320 bytes per signer cross PCIe WHILE the host
+  // cores are still gathering (6 ms of copies at 4096 x 256 that used to follow the gather).  (Copies issued by the 64 workers
+  // themselves - 1280 small hipMemcpyAsync calls - cost more in the driver than they hid: gather 8 -> 21 ms.)
+  static uint8_t* d_stage = nullptr;
+  static size_t d_stage_cap = 0;
+  static hipStream_t copy_stream = nullptr;
+  const size_t d_need = need + m * 97 + 4096;
+  if (api_enter() != 0) return false;
+  if (d_need > d_stage_cap) {
+    if (d_stage) (void)hipFree(d_stage);
+    d_stage = nullptr; d_stage_cap = 0;
+    if (hipMalloc((void**)&d_stage, d_need + d_need / 4) != hipSuccess) { log_err("batch_verify_strict: device staging allocation failed"); return false; }
+    d_stage_cap = d_need + d_need / 4;
+  }
+  if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { copy_stream = nullptr; return false; }
+  uint64_t* d_pk_xy = (uint64_t*)d_stage;
+  uint64_t* d_sg_xy = d_pk_xy + tot * 24;
+  uint64_t* d_sc = d_sg_xy + tot * 12;
+  uint8_t* d_pk_inf = (uint8_t*)(d_sc + tot * 4);
+  uint8_t* d_sg_inf = d_pk_inf + tot;
+  uint64_t* d_hxy = (uint64_t*)(d_stage + ((need + 255) & ~size_t(255)));
+  uint8_t* d_hinf = (uint8_t*)(d_hxy + m * 12);
+  const int dev = api_device();
+  std::atomic<bool> copy_failed(false);
+  constexpr size_t PHASES = 4;
+  std::atomic<unsigned> phase_done[2 * PHASES];
   ChaCha20Rng master;
   if (!os_seeded_rng(master)) { log_err("batch_verify_strict: no OS randomness"); return false; }
   for (size_t b = 0; b < m; b++)
@@ -1097,7 +1129,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   std::vector<HashJob> jobs(m);
   for (size_t b = 0; b < m; b++) jobs[b] = {batches[b].data.ptr, batches[b].data.len, batches[b].extra.ptr, batches[b].extra.len, &hxy[b * 12]};
   bool hash_ok = false;
-  std::vector<uint8_t> hash_failed;
+  std::vector<uint8_t> hash_failed(m, 0);
   std::thread hasher([&]() { hash_ok = hash_many(composite, cip22, SIG_DOMAIN, jobs, &hash_failed); });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } hasher_guard{hasher};   // early returns must not leave it running
   // gather: ranges of batches across host threads; every thread draws its exponents from its own ChaCha20 stream (keys taken
@@ -1111,10 +1143,17 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   uint64_t one2[12], one1[6];
   Fq2_::one().to_ark(one2);
   Fq_::one().to_ark(one1);
-  auto work = [&](unsigned t, size_t c_lo, size_t c_hi) {           // thread t's share of the batches [c_lo, c_hi)
-    const size_t b_lo = c_lo + (c_hi - c_lo) * t / nt, b_hi = c_lo + (c_hi - c_lo) * (t + 1) / nt;
+  // The gather runs in two passes - the key handles with the exponents, then the signature handles - each in PHASES phases over
+  // the batch range that all worker threads share; the calling thread copies a finished phase to the device while the workers
+  // gather the next one, starts the G2 batch MSM (the longest leg of the chain) as soon as the keys are across, and the G1 batch MSM
+  // when the signatures are.  Handles with Z = 1 (everything that came from the wire) are copied straight into the affine arrays;
+  // the others are normalised with one shared inversion per thread and phase.
+  auto work = [&](unsigned t, int pass) {
+   for (size_t q = 0; q < PHASES; q++) {
+    const size_t p_lo = m * q / PHASES, p_hi = m * (q + 1) / PHASES;                                             // phase q
+    const size_t b_lo = p_lo + (p_hi - p_lo) * t / nt, b_hi = p_lo + (p_hi - p_lo) * (t + 1) / nt;              // thread t's share of it
     ChaCha20Rng& rng = rngs[t];
-    std::vector<uint32_t> pk_todo, sg_todo;
+    std::vector<uint32_t> todo;
     for (size_t b = b_lo; b < b_hi; b++) {
       const size_t n = blen[b];
       size_t lg = 0;
@@ -1123,19 +1162,21 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
       if (nbytes > 31) nbytes = 31;
       for (size_t i = 0; i < n; i++) {
         const size_t at = offs[b] + i;
-        const uint64_t* pk = batches[b].public_keys[i]->xyz;
-        const uint64_t* sg = batches[b].signatures[i]->xyz;
-        if (memcmp(pk + 24, one2, 96) == 0) { memcpy(pk_xy + at * 24, pk, 192); pk_inf[at] = 0; } else pk_todo.push_back((uint32_t)at);
-        if (memcmp(sg + 12, one1, 48) == 0) { memcpy(sg_xy + at * 12, sg, 96); sg_inf[at] = 0; } else sg_todo.push_back((uint32_t)at);
-        uint8_t rb[32];
-        memset(rb, 0, 32);
-        for (size_t k = 0; k < nbytes; k += 4) { uint32_t r = rng.next_u32(); memcpy(rb + k, &r, (nbytes - k) < 4 ? (nbytes - k) : 4); }
-        memcpy(sc + at * 4, rb, 32);
+        if (pass == 0) {
+          const uint64_t* pk = batches[b].public_keys[i]->xyz;
+          if (memcmp(pk + 24, one2, 96) == 0) { memcpy(pk_xy + at * 24, pk, 192); pk_inf[at] = 0; } else todo.push_back((uint32_t)at);
+          uint8_t rb[32];
+          memset(rb, 0, 32);
+          for (size_t k = 0; k < nbytes; k += 4) { uint32_t r = rng.next_u32(); memcpy(rb + k, &r, (nbytes - k) < 4 ? (nbytes - k) : 4); }
+          memcpy(sc + at * 4, rb, 32);
+        } else {
+          const uint64_t* sg = batches[b].signatures[i]->xyz;
+          if (memcmp(sg + 12, one1, 48) == 0) { memcpy(sg_xy + at * 12, sg, 96); sg_inf[at] = 0; } else todo.push_back((uint32_t)at);
+        }
       }
     }
-    // the handles that are not affine yet (aggregates, fresh signatures): gather, normalise, scatter
-    auto fix = [&](const std::vector<uint32_t>& todo, bool is_pk) {
-      if (todo.empty()) return;
+    if (!todo.empty()) {                       // the handles that are not affine yet (aggregates, fresh signatures): gather, normalise, scatter
+      const bool is_pk = pass == 0;
       const int A3 = is_pk ? 36 : 18, A2 = is_pk ? 24 : 12;
       std::vector<uint64_t> jac(todo.size() * A3), xy(todo.size() * A2);
       std::vector<uint8_t> inf(todo.size());
@@ -1149,52 +1190,50 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
         memcpy((is_pk ? pk_xy : sg_xy) + (size_t)todo[k] * A2, &xy[k * A2], A2 * 8);
         (is_pk ? pk_inf : sg_inf)[todo[k]] = inf[k];
       }
-    };
-    fix(pk_todo, true);
-    fix(sg_todo, false);
+    }
+    phase_done[pass * PHASES + q].fetch_add(1);
+   }
   };
-  // Everything between the gathered handles and the verdicts is ONE chained device call per chunk (batch_verify_bls12_377: both
-  // batch MSMs in flight together on two engines, their sums normalised on the device into the pairing engine's input slots,
-  // two-pair products); the message hashes (started above, GPU or host cores) are joined before the first one.  The loop can
-  // pipeline chunks (GPU on chunk c while the host cores gather chunk c + 1; the engines are pooled, so the calls need no
-  // coordination) - MEASURED at 4096 x 256 with 4 chunks: 57-64 ms per call against 45.6 ms with one (four 1024-batch chains in
-  // flight are less efficient than one 4096-batch chain and their launch threads slow the gather): one chunk it is.
-  const size_t nchunks = 1;
+  auto send_phase = [&](int pass, size_t q) {                          // calling thread: a gathered phase goes to the device
+    const size_t p_lo = m * q / PHASES, p_hi = m * (q + 1) / PHASES;
+    const size_t e_lo = offs[p_lo], e_n = offs[p_hi] - offs[p_lo];
+    if (!e_n) return;
+    bool bad;
+    if (pass == 0) bad = hipMemcpyAsync(d_pk_xy + e_lo * 24, pk_xy + e_lo * 24, e_n * 192, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+                         hipMemcpyAsync(d_sc + e_lo * 4, sc + e_lo * 4, e_n * 32, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+                         hipMemcpyAsync(d_pk_inf + e_lo, pk_inf + e_lo, e_n, hipMemcpyHostToDevice, copy_stream) != hipSuccess;
+    else bad = hipMemcpyAsync(d_sg_xy + e_lo * 12, sg_xy + e_lo * 12, e_n * 96, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+               hipMemcpyAsync(d_sg_inf + e_lo, sg_inf + e_lo, e_n, hipMemcpyHostToDevice, copy_stream) != hipSuccess;
+    if (bad) copy_failed = true;
+  };
+  for (size_t q = 0; q < 2 * PHASES; q++) phase_done[q].store(0);
+  BvJob job;
+  int rc_keys = 0, rc_sigs = 0;
+  {
+    std::vector<std::thread> th;
+    struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } guard{th};
+    for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() { work(t, 0); work(t, 1); });
+    for (int pass = 0; pass < 2; pass++) {
+      for (size_t q = 0; q < PHASES; q++) {
+        while (phase_done[pass * PHASES + q].load() < nt) std::this_thread::yield();
+        send_phase(pass, q);
+      }
+      if (copy_failed || hipStreamSynchronize(copy_stream) != hipSuccess) { copy_failed = true; break; }
+      if (pass == 0) { rc_keys = bv_begin_keys(&job, d_pk_xy, d_pk_inf, d_sc, 1, offs.data(), m); ph.mark("keys + exponents gathered and copied, G2 batch MSM started"); }
+      else { rc_sigs = bv_begin_sigs(&job, d_sg_xy, d_sg_inf, d_sc, 1, offs.data(), m); ph.mark("signatures gathered and copied, G1 batch MSM started"); }
+    }
+  }
+  hasher.join();
   std::vector<uint8_t> hinf(m, 0), ok(m, 0);
-  std::vector<int> chunk_rc(nchunks, 0);
-  std::vector<std::thread> gpu_calls;
-  struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } gpu_guard{gpu_calls};
+  if (hash_ok) for (size_t b = 0; b < m; b++) if (hash_failed[b]) hinf[b] = 1;   // no H(m): that pair is left out, the verdict is forced below
   uint64_t ng2[24];
   neg_g2_generator(ng2);
-  const int dev = api_device();
-  bool hashes_joined = false;
-  for (size_t c = 0; c < nchunks; c++) {
-    const size_t c_lo = m * c / nchunks, c_hi = m * (c + 1) / nchunks;
-    if (nt == 1) work(0, c_lo, c_hi);
-    else {
-      std::vector<std::thread> th;
-      for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t, c_lo, c_hi);
-      for (auto& x : th) x.join();
-    }
-    if (!hashes_joined) {
-      hasher.join();
-      hashes_joined = true;
-      if (!hash_ok) return false;
-      for (size_t b = 0; b < m; b++) if (hash_failed[b]) hinf[b] = 1;   // no H(m): that pair is left out, the verdict is forced below
-    }
-    gpu_calls.emplace_back([&, c, c_lo, c_hi]() {
-      if (api_bind_thread(dev) != 0) { chunk_rc[c] = 101; return; }
-      std::vector<uint32_t> co(c_hi - c_lo + 1);
-      for (size_t b = c_lo; b <= c_hi; b++) co[b - c_lo] = offs[b] - offs[c_lo];
-      const size_t at = offs[c_lo];
-      chunk_rc[c] = batch_verify_bls12_377(pk_xy + at * 24, pk_inf + at, sg_xy + at * 12, sg_inf + at, sc + at * 4, co.data(), &hxy[c_lo * 12],
-                                           &hinf[c_lo], ng2, c_hi - c_lo, &ok[c_lo]);
-    });
-  }
-  ph.mark("gather handles -> affine, exponents (chunks, GPU calls in flight)");
-  for (auto& t : gpu_calls) t.join();
-  for (int rc : chunk_rc) if (rc != 0) return false;
-  ph.mark("G2 + G1 batch MSMs -> pairs -> pairing checks (GPU, chained)");
+  const bool staged = hash_ok && !copy_failed && rc_keys == 0 && rc_sigs == 0 &&
+                      hipMemcpyAsync(d_hxy, hxy.data(), m * 96, hipMemcpyHostToDevice, copy_stream) == hipSuccess &&
+                      hipMemcpyAsync(d_hinf, hinf.data(), m, hipMemcpyHostToDevice, copy_stream) == hipSuccess &&
+                      hipStreamSynchronize(copy_stream) == hipSuccess;
+  if (bv_finish(&job, staged ? 1 : 0, d_hxy, d_hinf, 1, ng2, m, ok.data()) != 0 || !staged) return false;   // (bv_finish releases the engines either way)
+  ph.mark("pairs -> pairing checks (GPU, chained)");
   bool all = true;
   for (size_t b = 0; b < m; b++) { out_results[b] = ok[b] != 0 && !hash_failed[b]; all = all && out_results[b]; }
   ph.mark("results");

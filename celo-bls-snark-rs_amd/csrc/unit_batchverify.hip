@@ -65,23 +65,25 @@ k_pack_verify_pairs(const uint64_t* __restrict__ sig_sum /* m x 18 */, const uin
   }
 }
 
-// resident = 1: d_* are DEVICE pointers; 0: host pointers (staged by the engines).  offsets, out_ok: host.
-// pk_inf / sig_inf / hash_inf: optional byte-per-point "is the identity" arrays (host or device like the points).
-int batch_verify_377_run(const void* pk_xy, const void* pk_inf, const void* sig_xy, const void* sig_inf, const void* exponents, int resident,
-                         const uint32_t* offsets, const void* hash_xy, const void* hash_inf, const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
+// The chain in three steps, so that a caller whose inputs arrive in stages (Seam A gathers 10^6 key handles, then 10^6 signature
+// handles) can start the longest leg - the G2 MSM - as soon as ITS inputs are there:
+//   bv_begin_keys   enqueue the G2 batch MSM        bv_begin_sigs   enqueue the G1 batch MSM        bv_finish   pairs + products
+// resident = 1: DEVICE pointers; 0: host pointers (staged by the engines).  offsets, out_ok: host.  *_inf: optional byte-per-point
+// "is the identity" arrays (host or device like the points).  bv_finish releases everything, also after a failed begin.
+struct BvJob { BatchRun keys, sigs; };
+int bv_begin_keys(BvJob* j, const void* pk_xy, const void* pk_inf, const void* exponents, int resident, const uint32_t* offsets, size_t m) {
   if (int rc = api_enter()) return rc;
-  if (m == 0) return 0;
-  if (!pk_xy || !sig_xy || !exponents || !offsets || !hash_xy || !neg_g2_xy || !out_ok || m > 0x3fffffffu) return 2;
-  BatchRun r1, r2;
+  return msm_batch_begin_g2_377(pk_xy, pk_inf, exponents, resident, offsets, m, &j->keys);
+}
+int bv_begin_sigs(BvJob* j, const void* sig_xy, const void* sig_inf, const void* exponents, int resident, const uint32_t* offsets, size_t m) {
+  if (int rc = api_enter()) return rc;
+  return msm_batch_begin_g1_377(sig_xy, sig_inf, exponents, resident, offsets, m, &j->sigs);
+}
+int bv_finish(BvJob* j, int begun_ok, const void* hash_xy, const void* hash_inf, int resident, const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
+  BatchRun& r1 = j->sigs;
+  BatchRun& r2 = j->keys;
   PairingStage ps;
-  int rc1 = 0, rc2 = 0, rc = 0;
-  const int dev = api_device();
-  {
-    // each begin has one host round trip (the exponents' bit length sizes the window count): two threads keep both in flight
-    std::thread t1([&] { rc1 = api_bind_thread(dev); if (!rc1) rc1 = msm_batch_begin_g1_377(sig_xy, sig_inf, exponents, resident, offsets, m, &r1); });
-    rc2 = msm_batch_begin_g2_377(pk_xy, pk_inf, exponents, resident, offsets, m, &r2);
-    t1.join();
-  }
+  int rc = begun_ok ? 0 : 1;
   uint64_t* d_hash = nullptr;
   uint8_t* d_hinf = nullptr;
   hipEvent_t e1 = nullptr, e2 = nullptr;
@@ -90,7 +92,7 @@ int batch_verify_377_run(const void* pk_xy, const void* pk_inf, const void* sig_
   NegG2 ng2;
   for (int q = 0; q < 24; q++) ng2.xy[q] = neg_g2_xy[q];
   const uint32_t m_pad = ((uint32_t)m + 63u) & ~63u;
-  if (rc1 || rc2) { rc = rc1 ? rc1 : rc2; goto done; }
+  if (rc || !r1.lease || !r2.lease) { rc = rc ? rc : 1; goto done; }
   if ((rc = pairing_stage_377((uint32_t)(2 * m), m, &ps))) goto done;
   if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) { rc = 1; goto done; }
   if (!resident) {   // the message hashes: a small upload of our own
@@ -122,5 +124,22 @@ done:
   if (d_hash) (void)hipFree(d_hash);
   if (d_hinf) (void)hipFree(d_hinf);
   return rc;
+}
+int batch_verify_377_run(const void* pk_xy, const void* pk_inf, const void* sig_xy, const void* sig_inf, const void* exponents, int resident,
+                         const uint32_t* offsets, const void* hash_xy, const void* hash_inf, const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
+  if (int rc = api_enter()) return rc;
+  if (m == 0) return 0;
+  if (!pk_xy || !sig_xy || !exponents || !offsets || !hash_xy || !neg_g2_xy || !out_ok || m > 0x3fffffffu) return 2;
+  BvJob job;
+  int rc1 = 0, rc2 = 0;
+  const int dev = api_device();
+  {
+    // each begin has one host round trip (the exponents' bit length sizes the window count): two threads keep both in flight
+    std::thread t1([&] { rc1 = api_bind_thread(dev); if (!rc1) rc1 = bv_begin_sigs(&job, sig_xy, sig_inf, exponents, resident, offsets, m); });
+    rc2 = bv_begin_keys(&job, pk_xy, pk_inf, exponents, resident, offsets, m);
+    t1.join();
+  }
+  const int rc = bv_finish(&job, !rc1 && !rc2, hash_xy, hash_inf, resident, neg_g2_xy, m, out_ok);
+  return rc1 ? rc1 : rc2 ? rc2 : rc;
 }
 }  // namespace celo

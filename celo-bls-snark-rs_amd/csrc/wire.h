@@ -188,7 +188,7 @@ WIRE_FN bool wire_fq2_sqrt(const Fq2& a, const WireConsts& k, Fq2& out) {
 template <class F> WIRE_FN bool wire_in_subgroup(const Affine<F>& p, const WireConsts& k) {
   Xyzz<F> acc = Xyzz<F>::from_affine(p);
   for (int i = 251; i >= 0; i--) {
-    xyzz_dbl_fn(acc);
+    acc = xyzz_dbl(acc);      // inlined: the out-of-line variant saves / restores ~100 callee-saved VGPRs per call on gfx950 (252 calls per point)
     if ((k.r_order[i >> 6] >> (i & 63)) & 1) xyzz_madd(acc, p);
   }
   return acc.is_identity() || acc.ZZ.is_zero_mod_p();

@@ -491,7 +491,10 @@ template <class P> struct Fp {
     }
     return r;
   }
-  HD static Fp inv(const Fp& a) {  // a^(p-2); a must have lb<=1... (normalise first)
+  // a^-1 (0 for 0): safegcd division steps on the canonical integer (modinv.h) - uniform control flow, ~6x (377 bits) to ~16x
+  // (761 bits) fewer instructions than Fermat's a^(p-2), which stays as the cross-check
+  HD static Fp inv(const Fp& a);
+  HD static Fp inv_fermat(const Fp& a) {
     uint64_t e[P::N64];
 #pragma unroll
     for (int i = 0; i < P::N64; i++) e[i] = P::P64[i];
@@ -503,4 +506,13 @@ template <class P> struct Fp {
 typedef Fp<P377> Fq377d;
 typedef Fp<P761> Fq761d;
 
+}  // namespace celo
+#include "modinv.h"
+namespace celo {
+template <class P> HD Fp<P> Fp<P>::inv(const Fp& a) {
+  uint64_t x[P::N64], y[P::N64];
+  norm(a).to_canonical(x);
+  SafeGcd<P>::inv(x, y);
+  return from_canonical(y);
+}
 }  // namespace celo

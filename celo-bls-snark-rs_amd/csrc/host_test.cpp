@@ -278,6 +278,18 @@ void ht_pairing_377(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, 
                     uint64_t* out72, int* is_one) { pairing_op(mode, g1, g2, k, in72, in72b, out72, is_one); }
 void ht_pairing_377_lanes(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
                          uint64_t* out72, int* is_one) { pairing_op_lanes(mode, g1, g2, k, in72, in72b, out72, is_one); }
+// modular inversion: the safegcd routine on plain integers (field 0: BLS12-377 Fq, 1: BW6-761 Fq), and Fp::inv against Fermat
+void ht_modinv(int field, const uint64_t* x, uint64_t* out) {
+  if (field == 0) SafeGcd<P377>::inv(x, out); else SafeGcd<P761>::inv(x, out);
+}
+int ht_inv_matches_fermat(int field, const uint64_t* ark) {
+  if (field == 0) {
+    const Fq a = Fq::from_ark(ark);
+    return Fq::eq_mod_p(Fq::norm(Fq::inv(a)), Fq::norm(Fq::inv_fermat(a))) ? 1 : 0;
+  }
+  const Fw a = Fw::from_ark(ark);
+  return Fw::eq_mod_p(Fw::norm(Fw::inv(a)), Fw::norm(Fw::inv_fermat(a))) ? 1 : 0;
+}
 void ht_pairing_377_hex(int mode, const uint64_t* g1, const uint64_t* g2, size_t k, const uint64_t* in72, const uint64_t* in72b,
                        uint64_t* out72, int* is_one) { pairing_op_hex(mode, g1, g2, k, in72, in72b, out72, is_one); }
 void ht_fq377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp<P377>>(op, a, b, out); }

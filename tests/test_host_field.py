@@ -269,3 +269,25 @@ def test_table_driven_square_root_agrees_with_tonelli_shanks(ht):
             r = co.from_mont(out, p)[0]
             assert r * r % p == a
     assert 20 < n_res < len(cases)
+
+
+def test_safegcd_inversion_matches_the_definition():
+    """csrc/modinv.h (Bernstein-Yang division steps, what Fp::inv runs on the device and the host) against pow(x, -1, p) for both base
+    fields: edge values (0 -> 0, 1, 2, p - 1, p - 2, powers of two around the 62-bit limb boundary) and 300 random ones; and Fp::inv
+    through its Montgomery wrappers against Fermat's a^(p-2)."""
+    lib = C.CDLL(LIB) if os.path.exists(LIB) else None
+    if lib is None or not hasattr(lib, "ht_modinv"):
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB, os.path.join(CSRC, "host_test.cpp")])
+        lib = C.CDLL(LIB)
+    lib.ht_inv_matches_fermat.restype = C.c_int
+    rnd = random.Random(5)
+    for field, p, n in ((0, ecc.Q377, 6), (1, ecc.Q761, 12)):
+        vals = [0, 1, 2, p - 1, p - 2, (p + 1) // 2, 3, 1 << 64, (1 << 62) - 1, 1 << 62, 1 << 61] + [rnd.randrange(p) for _ in range(300)]
+        for x in vals:
+            xi = np.frombuffer(x.to_bytes(8 * n, "little"), dtype=np.uint64).copy()
+            out = np.zeros(n, dtype=np.uint64)
+            lib.ht_modinv(C.c_int(field), xi.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+            assert int.from_bytes(out.tobytes(), "little") == (0 if x == 0 else pow(x, -1, p)), (field, hex(x))
+        m = co.to_mont([rnd.randrange(1, p) for _ in range(10)] + [1, p - 1], p)
+        assert all(lib.ht_inv_matches_fermat(C.c_int(field), m[i].ctypes.data_as(C.c_void_p)) for i in range(m.shape[0]))

@@ -298,6 +298,11 @@ struct PP761 {
                                uint32_t* prod, uint32_t m, hipStream_t s);                                                         \
     static void miller_product2(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off, \
                                 uint32_t* prod, uint32_t m, hipStream_t s);   /* every product has <= 2 pairs */                   \
+    static bool has_prepared();     /* products of <= 2 pairs whose first pair shares one G2 point: prepared lines */              \
+    static void first_q_same(const uint64_t* g2, const uint32_t* off, uint32_t m, uint32_t* flag, hipStream_t s);                  \
+    static void prepare_lines(const uint64_t* q0, uint32_t* lines, hipStream_t s);                                                 \
+    static void miller_prepared(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off, \
+                                const uint32_t* lines, uint32_t* prod, uint32_t m, hipStream_t s);                                 \
     static void gt_product(const uint32_t* f, const uint32_t* off, uint32_t* prod, uint32_t m, hipStream_t s);                     \
     static void gt_tree(const uint32_t* in, uint32_t* out, uint32_t n_in, hipStream_t s);                                          \
     static void final_exp(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint32_t m, int do_fe, hipStream_t s);              \
@@ -367,6 +372,7 @@ template <class PP> class PairingEngine {
     lay.o_g1 = take((size_t)k * PP::G1_ARK64 * 8 + 8); lay.o_g2 = take((size_t)k * PP::G2_ARK64 * 8 + 8); lay.o_i1 = take(k + 8); lay.o_i2 = take(k + 8);
     lay.o_off = take((m + 1) * 4); lay.o_f = take((2 * (size_t)k + 8) * W * 4); lay.o_f2 = take(((size_t)k / 2 + 2) * W * 4);
     lay.o_prod = take((size_t)m * W * 4); lay.o_one = take(m + 8); lay.o_gt = take((size_t)m * 72 * 8);
+    lay.o_lines = take((size_t)69 * 96 * 4 + 256); lay.o_flag = take(256);
     if (ensure(off)) return 1;
     char* A = arena;
     *st = {(uint64_t*)(A + lay.o_g1), (uint64_t*)(A + lay.o_g2), (uint8_t*)(A + lay.o_i1), (uint8_t*)(A + lay.o_i2)};
@@ -401,7 +407,24 @@ template <class PP> class PairingEngine {
     uint32_t most = 0;
     for (size_t p = 0; p < m && shared; p++) { const uint32_t c = offsets[p + 1] - offsets[p]; shared = c <= 4; most = c > most ? c : most; }
     typedef typename PP::LL LL;
-    if (shared && most <= 2) LL::miller_product2(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
+    bool prepared = false;
+    if (shared && most <= 2 && LL::has_prepared() && k) {
+      // verify shapes: every product's first pair on the same G2 point (-g2)?  Then its line coefficients are computed once.
+      uint32_t* d_flag = (uint32_t*)(A + lay.o_flag);
+      uint32_t* d_lines = (uint32_t*)(A + lay.o_lines);
+      uint32_t h_flag = 1;
+      PAIR_HIP_OK(hipMemcpyAsync(d_flag, &h_flag, 4, hipMemcpyHostToDevice, stream));
+      LL::first_q_same(d_g2, d_off, (uint32_t)m, d_flag, stream);
+      PAIR_HIP_OK(hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, stream));
+      PAIR_HIP_OK(hipStreamSynchronize(stream));
+      if (h_flag) {
+        LL::prepare_lines(d_g2 + (size_t)offsets[0] * PP::G2_ARK64, d_lines, stream);
+        LL::miller_prepared(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_lines, d_prod, (uint32_t)m, stream);
+        prepared = true;
+      }
+    }
+    if (prepared) {
+    } else if (shared && most <= 2) LL::miller_product2(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
     else if (shared) LL::miller_product(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
     else if (k) LL::miller(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_f, k, stream);
     PAIR_HIP_OK(hipEventRecord(ev[1], stream));
@@ -436,7 +459,7 @@ template <class PP> class PairingEngine {
   static constexpr uint32_t WIDE_MAX_PAIRS = 21;
 
  private:
-  struct Layout { uint32_t k = 0; size_t m = 0, o_g1 = 0, o_g2 = 0, o_i1 = 0, o_i2 = 0, o_off = 0, o_f = 0, o_f2 = 0, o_prod = 0, o_one = 0, o_gt = 0; } lay;
+  struct Layout { uint32_t k = 0; size_t m = 0, o_g1 = 0, o_g2 = 0, o_i1 = 0, o_i2 = 0, o_off = 0, o_f = 0, o_f2 = 0, o_prod = 0, o_one = 0, o_gt = 0, o_lines = 0, o_flag = 0; } lay;
   char* arena = nullptr;
   size_t arena_bytes = 0;
   OwnedStream stream_;

@@ -382,6 +382,104 @@ __global__ void __launch_bounds__(64) LANES_OCC k_miller_product_slots(const uin
   }
   if (live) LP::store12(prod + (size_t)gi * lanes_gt_words<LP>(), S::ld12(0));
 }
+// ---- products whose FIRST pair has the same G2 point everywhere: e(S_b, -g2) * e(H_b, P_b) of every verify / Batch::verify
+// (crates/bls-crypto/src/bls/public.rs:102, batch.rs:83).  The point steps of that pair do not depend on the product: its 69
+// line-coefficient triples are computed ONCE (k_prepare_lines: what ark-ec keeps in a G2Prepared) and every product only
+// evaluates them at its own S_b - a Miller step without the doubling / addition of R (about 40 % of a step).
+constexpr int PREPARED_STEPS = 69;                      // 63 doubling + 6 addition steps of x = 0x8508c00000000001
+constexpr int PREPARED_LINE_WORDS = 3 * 32;             // c0, c1, c2: an Fq2 each, device form (2 x 16 words)
+template <class LP>
+__global__ void __launch_bounds__(64) LANES_OCC k_prepare_lines(const uint64_t* __restrict__ q0_xy, uint32_t* __restrict__ lines) {
+  typedef typename LP::QB QB;
+  typedef typename LP::Pair Pair;
+  if (QB::group() != 0) return;
+  const typename QB::V Qc = LP::load_q(q0_xy);
+  typename QB::V Rc = QB::template sel<2>(QB::one(), Qc);
+  const int h = QB::hsel();
+  const bool writer = QB::lane() == 0;                  // the coefficients are group-uniform: tower lane 0's two halves write them
+  int step = 0;
+  auto put = [&](const typename Pair::Line& l) {
+    if (writer) {
+      uint32_t* o = lines + (size_t)step * PREPARED_LINE_WORDS + h * 16;
+      l.c0.store(o); l.c1.store(o + 32); l.c2.store(o + 64);
+    }
+    step++;
+  };
+#pragma unroll 1
+  for (int b = 62; b >= 0; b--) {
+    typename Pair::Line l;
+    Pair::double_step(Rc, l);
+    put(l);
+    if ((T377::X >> b) & 1) { Pair::add_step(Rc, Qc, l); put(l); }
+  }
+}
+// flag[0] stays 1 iff every non-empty product's first pair carries the G2 point of product 0's
+template <class LP>     // (a template only so that the kernel may live in this header: it is included by several translation units)
+__global__ void __launch_bounds__(256) k_first_q_same(const uint64_t* __restrict__ g2, const uint32_t* __restrict__ offsets, uint32_t m, uint32_t g2w,
+                                                      uint32_t* __restrict__ flag) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m || offsets[p] == offsets[p + 1]) return;
+  const uint64_t* a = g2 + (size_t)offsets[p] * g2w;
+  const uint64_t* b = g2 + (size_t)offsets[0] * g2w;
+  uint64_t diff = 0;
+  for (uint32_t i = 0; i < g2w; i++) diff |= a[i] ^ b[i];
+  if (diff || offsets[0] == offsets[1]) atomicAnd(flag, 0u);
+}
+// one group per product of <= 2 pairs; pair 0 on the prepared lines, pair 1 as in k_miller_product_slots
+template <class LP>
+__global__ void __launch_bounds__(64) LANES_OCC k_miller_prepared_slots(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1,
+                                                                        const uint64_t* __restrict__ g2, const uint8_t* __restrict__ inf2,
+                                                                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ lines,
+                                                                        uint32_t* __restrict__ prod, uint32_t m) {
+  typedef Slots<LP> S;
+  typedef typename LP::Tow Tow;
+  typedef typename LP::QB QB;
+  typedef typename LP::Pair Pair;
+  typedef typename QB::V V;
+  constexpr int NS = S::product_slots(2);
+  const int gi = lanes_group_index<LP>();
+  const bool live = gi >= 0 && (uint32_t)gi < m;
+  const uint32_t lo = live ? offsets[gi] : 0, hi = live ? offsets[gi + 1] : 0;
+  const bool live_a = lo < hi && !((inf1 && inf1[lo]) || (inf2 && inf2[lo]));
+  const bool live_b = lo + 1 < hi && !((inf1 && inf1[lo + 1]) || (inf2 && inf2[lo + 1]));
+  const uint32_t ia = lo < hi ? lo : 0, ib = lo + 1 < hi ? lo + 1 : ia;      // dead slots walk a valid pair uncommitted
+  S::template st_p<NS>(0, 0, LP::load_p(g1 + (size_t)ia * LP::G1W, 0));
+  S::template st_p<NS>(0, 1, LP::load_p(g1 + (size_t)ia * LP::G1W, 1));
+  S::template st_p<NS>(1, 0, LP::load_p(g1 + (size_t)ib * LP::G1W, 0));
+  S::template st_p<NS>(1, 1, LP::load_p(g1 + (size_t)ib * LP::G1W, 1));
+  S::stv(1, 0, QB::template sel<2>(QB::one(), LP::load_q(g2 + (size_t)ib * LP::G2W)));
+  S::st12(0, Tow::one12());
+  const int h = QB::hsel();
+  int step = 0;
+  auto line_at = [&](int st) {
+    const uint32_t* o = lines + (size_t)st * PREPARED_LINE_WORDS + h * 16;
+    typename Pair::Line l;
+    l.c0 = V::load(o); l.c1 = V::load(o + 32); l.c2 = V::load(o + 64);
+    return l;
+  };
+  auto ldp_a = [](int c) { return S::template ld_p<NS>(0, c); };
+  auto ldp_b = [](int c) { return S::template ld_p<NS>(1, c); };
+#pragma unroll 1
+  for (int b = 62; b >= 0; b--) {
+    S::sqr12(0);
+    S::ell_slot(0, ldp_a, line_at(step), live_a);
+    step++;
+    {
+      const V r = S::step_double(S::ldv(1, 0), 0, ldp_b, live_b);
+      S::stv(1, 0, r);
+      S::fence();
+    }
+    if ((T377::X >> b) & 1) {
+      S::ell_slot(0, ldp_a, line_at(step), live_a);
+      step++;
+      const V Qc = LP::load_q(g2 + (size_t)ib * LP::G2W);
+      const V r = S::step_add(S::ldv(1, 0), Qc, 0, ldp_b, live_b);
+      S::stv(1, 0, r);
+      S::fence();
+    }
+  }
+  if (live) LP::store12(prod + (size_t)gi * lanes_gt_words<LP>(), S::ld12(0));
+}
 template <class LP>
 __global__ void __launch_bounds__(64) LANES_OCC k_final_exp_slots(const uint32_t* __restrict__ prod, uint8_t* __restrict__ is_one,
                                                                   uint64_t* __restrict__ gt_ark, uint32_t m, int do_final_exp) {
@@ -410,6 +508,11 @@ __global__ void __launch_bounds__(64) LANES_OCC k_final_exp_slots(const uint32_t
   }                                                                                                                                       \
   void LL::miller_product2(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off,             \
                            uint32_t* prod, uint32_t m, hipStream_t s) { miller_product(g1, i1, g2, i2, off, prod, m, s); }                \
+  bool LL::has_prepared() { return false; }                                                                                               \
+  void LL::first_q_same(const uint64_t*, const uint32_t*, uint32_t, uint32_t*, hipStream_t) {}                                            \
+  void LL::prepare_lines(const uint64_t*, uint32_t*, hipStream_t) {}                                                                      \
+  void LL::miller_prepared(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, const uint32_t*, uint32_t*, \
+                           uint32_t, hipStream_t) {}                                                                                      \
   void LL::gt_product(const uint32_t* f, const uint32_t* off, uint32_t* prod, uint32_t m, hipStream_t s) {                               \
     hipLaunchKernelGGL((k_gt_product_lanes<LP>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64), 0, s, f, off, prod, m);           \
   }                                                                                                                                       \
@@ -431,6 +534,18 @@ __global__ void __launch_bounds__(64) LANES_OCC k_final_exp_slots(const uint32_t
                            uint32_t* prod, uint32_t m, hipStream_t s) {                                                                   \
     hipLaunchKernelGGL((k_miller_product_slots<LP, 2>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64),                               \
                        Slots<LP>::product_lds_bytes(2), s, g1, i1, g2, i2, off, prod, m);                                    \
+  }                                                                                                                                       \
+  bool LL::has_prepared() { return true; }                                                                                                \
+  void LL::first_q_same(const uint64_t* g2, const uint32_t* off, uint32_t m, uint32_t* flag, hipStream_t s) {                             \
+    hipLaunchKernelGGL((k_first_q_same<LP>), dim3((m + 255) / 256), dim3(256), 0, s, g2, off, m, (uint32_t)LP::G2W, flag);                      \
+  }                                                                                                                                       \
+  void LL::prepare_lines(const uint64_t* q0, uint32_t* lines, hipStream_t s) {                                                            \
+    hipLaunchKernelGGL((k_prepare_lines<LP>), dim3(1), dim3(64), 0, s, q0, lines);                                                        \
+  }                                                                                                                                       \
+  void LL::miller_prepared(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off,             \
+                           const uint32_t* lines, uint32_t* prod, uint32_t m, hipStream_t s) {                                            \
+    hipLaunchKernelGGL((k_miller_prepared_slots<LP>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64),                                  \
+                       Slots<LP>::product_lds_bytes(2), s, g1, i1, g2, i2, off, lines, prod, m);                                          \
   }                                                                                                                                       \
   void LL::gt_product(const uint32_t* f, const uint32_t* off, uint32_t* prod, uint32_t m, hipStream_t s) {                               \
     hipLaunchKernelGGL((k_gt_product_lanes<LP>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64), 0, s, f, off, prod, m);               \

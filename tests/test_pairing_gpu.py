@@ -190,3 +190,51 @@ def test_bilinearity_on_reference_held_points(gpu, golden):
             g2, i2 = co.pack_g2_377([bQ, Q])
             assert gpu.pairing_product_is_one(g1, i1, g2, i2) == want
             assert bool(co.pairing_product_377(g1, i1, g2, i2)[1]) == want
+
+
+def test_prepared_first_pair_path_at_scale(gpu):
+    """>= 16384 two-pair products whose first pair shares one G2 point (the verify / Batch::verify shape e(S, -g2) * e(H, P)) take the
+    prepared-lines kernel (the shared point's 69 line triples computed once).  20480 products tiled from 8 signed messages (two with a
+    foreign key), plus: a product whose S is the identity (pair skipped), a one-pair product, an empty product.  Verdicts equal the
+    oracle's on the distinct products; the same call with ONE product's first point changed falls back to the generic kernel and
+    returns the same verdicts for all the others."""
+    rng = ecc.SplitMix64(2468)
+    ng2 = ecc.E2_377.neg(ecc.G2_377)
+    trip = []
+    for i in range(8):
+        sk = ecc.random_scalar(rng, ecc.R377)
+        Hm = ecc.E1_377.mul(ecc.G1_377, rng.next() | 1)
+        good = i not in (2, 5)
+        trip.append((ecc.E1_377.mul(Hm, sk), Hm, ecc.E2_377.mul(ecc.G2_377, sk if good else sk + 7), good))
+    m = 20480
+    g1l, g2l, offs, expect = [], [], [0], []
+    for i in range(8):
+        S, Hm, P, good = trip[i]
+        g1l += [S, Hm]; g2l += [ng2, P]
+    g1b, i1b = co.pack_g1_377(g1l); g2b, i2b = co.pack_g2_377(g2l)
+    g1 = np.tile(g1b, (m // 8, 1)); g2 = np.tile(g2b, (m // 8, 1))
+    i1 = np.zeros(2 * m, dtype=np.uint8); i2 = np.zeros(2 * m, dtype=np.uint8)
+    expect = [int(trip[i % 8][3]) for i in range(m)]
+    offs = np.arange(0, 2 * m + 1, 2, dtype=np.uint32)
+    # product 11: S = identity -> only e(H, P) remains: not 1.  Product 12: both pairs skipped -> 1.
+    i1[22] = 1; expect[11] = 0
+    i1[24] = 1; i1[25] = 1; expect[12] = 1
+    got = gpu.pairing_product_is_one_batch(g1, i1, g2, i2, offs)
+    assert got.tolist() == expect
+    for p in list(range(8)) + [11, 12]:
+        lo = 2 * p
+        assert bool(co.pairing_product_377(g1[lo:lo + 2], i1[lo:lo + 2], g2[lo:lo + 2], i2[lo:lo + 2])[1]) == bool(expect[p])
+    # ragged: a one-pair product and an empty product in the middle (offsets no longer uniform)
+    offs2 = offs.copy().astype(np.int64)
+    offs2[101:] -= 1                         # product 100 keeps only its first pair e(S, -g2): not 1
+    offs2[201:] -= 2                         # product 200 is empty: 1
+    keep = np.ones(2 * m, dtype=bool); keep[201] = False; keep[400] = False; keep[401] = False
+    got2 = gpu.pairing_product_is_one_batch(g1[keep], i1[keep], g2[keep], i2[keep], offs2.astype(np.uint32))
+    exp2 = list(expect); exp2[100] = 0; exp2[200] = 1
+    assert got2.tolist() == exp2
+    # one product with another first point: the generic shared-accumulator kernel runs instead; every verdict is unchanged
+    g2c = g2.copy()
+    g2c[2 * 300] = g2c[2 * 300 + 1]
+    got3 = gpu.pairing_product_is_one_batch(g1, i1, g2c, i2, offs)
+    exp3 = list(expect); exp3[300] = int(co.pairing_product_377(g1[600:602], None, g2c[600:602], None)[1])
+    assert got3.tolist() == exp3

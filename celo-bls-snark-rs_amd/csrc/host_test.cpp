@@ -242,6 +242,18 @@ void ht_wire_decode(int g2, const uint8_t* in, size_t n, int check, uint64_t* ou
     }
   }
 }
+// the two forms of the subgroup test on one affine on-curve point (ark limbs): bit 0 = endomorphism form (what the decoders run),
+// bit 1 = the r * P ladder (the reference's definition)
+int ht_wire_subgroup_both(int g2, const uint64_t* xy) {
+  const WireConsts& k = wire_consts();
+  if (g2) {
+    const Affine<Fq2> p = {{Fq::from_ark(xy), Fq::from_ark(xy + 6)}, {Fq::from_ark(xy + 12), Fq::from_ark(xy + 18)}};
+    const Affine<Fq2> q = {Fq2::norm(p.x), Fq2::norm(p.y)};
+    return (wire_in_subgroup(q, k) ? 1 : 0) | (wire_in_subgroup_ladder(q, k) ? 2 : 0);
+  }
+  const Affine<Fq> q = {Fq::norm(Fq::from_ark(xy)), Fq::norm(Fq::from_ark(xy + 6))};
+  return (wire_in_subgroup(q, k) ? 1 : 0) | (wire_in_subgroup_ladder(q, k) ? 2 : 0);
+}
 // hash_direct.h under bounds tracking: one try-and-increment hash; returns the attempt counter, -1 when none succeeds
 int ht_hash_to_g1_direct(const uint8_t* dom, const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen, uint64_t* out_xy) {
   Affine<Fq> p = {Fq::zero(), Fq::zero()};

@@ -26,12 +26,16 @@ struct WireTables {         // for the discrete logarithm in the 2^46-th roots o
   Fq t8[256];               // reduce(h^j), h = z^(2^38): the 256-th roots of unity by exponent (the 64-th ones are every 4th entry)
   Fq bt[12][16];            // z^(-j 2^(4m)): removes nibble m of the logarithm from b
   Fq ht[12][16];            // z^(-j 2^(4m) / 2): the matching correction of the root (m = 0: even j only)
+  uint16_t slot[1024];      // open-addressed index of t8 by the low limb of the reduced value (linear probing, 0xffff = empty)
 };
 struct WireConsts {         // built once on the host (wire_consts()), handed to the kernels by value
   uint64_t tm1_half[6];     // (t - 1) / 2 where q - 1 = 2^46 t, t odd
   uint64_t r_order[4];      // r, the prime subgroup order
   Fq z;                     // c^t for the smallest quadratic non-residue c: a generator of the 2^46-th roots of unity
   Fq inv2, inv5;
+  Fq m5_x, m5_b;            // (-5)^((t+1)/2), (-5)^t: the root parts of the fixed non-residue -5 (wire_fq2_sqrt)
+  Fq beta;                  // the cube root of unity with (beta x, y) = -[x^2](x, y) on G1 (wire_in_subgroup)
+  Fq psi_x, psi_y;          // (-5)^((q-1)/6), (-5)^((q-1)/4): the twisted Frobenius of G2, psi(x, y) = (psi_x conj(x), psi_y conj(y))
   const WireTables* tab;    // in the memory space of whoever runs the functions below (unit_wire.hip: wire_consts_device())
 };
 
@@ -87,12 +91,6 @@ WIRE_FN Fq wire_pow_w4(const Fq& a_, const uint64_t* e, int nlimbs) {
   }
   return r;
 }
-WIRE_FN Fq wire_inv(const Fq& a) {   // a^(q - 2)
-  uint64_t e[6];
-  for (int i = 0; i < 6; i++) e[i] = P377::P64[i];
-  e[0] -= 2;
-  return wire_pow_w4(a, e, 6);
-}
 
 // Square root in Fq (q - 1 = 2^46 t).  One exponentiation w = a^((t-1)/2) gives x = a w = a^((t+1)/2) and b = x w = a^t, a
 // 2^46-th root of unity: b = z^e, and a is a square exactly when e is even, with root x z^(-e/2).  e is found digit by
@@ -101,26 +99,29 @@ WIRE_FN Fq wire_inv(const Fq& a) {   // a^(q - 2)
 // while x collects the half power.  110 squarings and <= 24 products after the exponentiation, the same for every input:
 // the classic Tonelli-Shanks order search it replaces takes ~550 squarings on average and ~1000 for the slowest lane of a
 // wave.  An odd first digit means a non-residue.
-WIRE_FN bool wire_fq_sqrt(const Fq& a_, const WireConsts& k, Fq& out) {
-  const Fq a = Fq::norm(a_);
-  if (a.is_zero_mod_p()) { out = Fq::zero(); return true; }
-  const Fq w = wire_pow_w4(a, k.tm1_half, 6);
-  Fq x = Fq::mul(a, w);
-  Fq b = Fq::mul(x, w);
+HD Fq wire_inv(const Fq& a) { return Fq::inv(a); }                 // division steps (modinv.h), not a^(q - 2)
+
+struct WireRootParts { Fq x, b; };                                  // x = a^((t+1)/2), b = a^t for the a last tried
+// the digit-by-digit part: x^2 = a b with b = z^e a 2^46-th root of unity -> x z^(-e/2) (false: e odd, a non-residue)
+WIRE_FN bool wire_root_finish(Fq x, Fq b, const WireConsts& k, Fq& out) {
   const WireTables& T = *k.tab;
   for (int i = 0; i < 6; i++) {
-    const int s = 8 * i, wd = i == 5 ? 6 : 8, stride = i == 5 ? 4 : 1;
+    const int s = 8 * i, wd = i == 5 ? 6 : 8;
     Fq u = b;
     for (int q = 0; q < 46 - s - wd; q++) u = Fq::sqr(u);
     u = Fq::reduce(u);
     int e = -1;
-    for (int j = 0; j < (1 << wd); j++) {
-      const Fq& c = T.t8[j * stride];
-      if (c.l[0] != u.l[0] || c.l[1] != u.l[1]) continue;
+    uint32_t sl = u.l[0] & 1023u;                                   // two dependent loads per digit instead of a scan of the table
+    for (int probe = 0; probe < 1024; probe++) {
+      const uint32_t j = T.slot[sl];
+      if (j == 0xffffu) break;
+      const Fq& c = T.t8[j];
       bool same = true;
-      for (int q = 2; q < P377::L; q++) same = same && c.l[q] == u.l[q];
-      if (same) { e = j; break; }
+      for (int q = 0; q < P377::L; q++) same = same && c.l[q] == u.l[q];
+      if (same) { e = (int)j; break; }
+      sl = (sl + 1) & 1023u;
     }
+    if (i == 5 && e >= 0) e = (e & 3) ? -1 : e >> 2;               // the last digit has 6 bits: a 64-th root of unity
     if (e < 0) return false;                 // cannot happen: b is a 2^46-th root of unity
     if (i == 0 && (e & 1)) return false;     // odd logarithm: a is a non-residue
     const int lo = e & 15, hi = e >> 4;
@@ -129,6 +130,18 @@ WIRE_FN bool wire_fq_sqrt(const Fq& a_, const WireConsts& k, Fq& out) {
   }
   out = x;
   return true;
+}
+WIRE_FN bool wire_fq_sqrt_keep(const Fq& a_, const WireConsts& k, Fq& out, WireRootParts& parts) {
+  const Fq a = Fq::norm(a_);
+  if (a.is_zero_mod_p()) { out = Fq::zero(); parts.x = Fq::zero(); parts.b = Fq::one(); return true; }
+  const Fq w = wire_pow_w4(a, k.tm1_half, 6);
+  parts.x = Fq::mul(a, w);
+  parts.b = Fq::mul(parts.x, w);
+  return wire_root_finish(parts.x, parts.b, k, out);
+}
+HD bool wire_fq_sqrt(const Fq& a, const WireConsts& k, Fq& out) {
+  WireRootParts parts;
+  return wire_fq_sqrt_keep(a, k, out, parts);
 }
 // The textbook Tonelli-Shanks loop (order search): kept as the cross-check of the table-driven root (tests/test_host_field.py)
 WIRE_FN bool wire_fq_sqrt_ts(const Fq& a_, const WireConsts& k, Fq& out) {
@@ -173,25 +186,84 @@ WIRE_FN bool wire_fq2_sqrt(const Fq2& a, const WireConsts& k, Fq2& out) {
   const Fq n = Fq::norm(Fq::add(Fq::sqr(a0), Fq::norm(Fq::add(Fq::dbl(Fq::dbl(s1)), s1))));
   Fq al, x0;
   if (!wire_fq_sqrt(n, k, al)) return false;
-  Fq d = Fq::mul(Fq::norm(Fq::add(a0, al)), k.inv2);
-  if (!wire_fq_sqrt(d, k, x0)) {
-    d = Fq::mul(Fq::norm(Fq::sub<4, 1>(a0, Fq::norm(al))), k.inv2);
-    if (!wire_fq_sqrt(d, k, x0)) return false;
+  const Fq d = Fq::norm(Fq::mul(Fq::norm(Fq::add(a0, al)), k.inv2));
+  WireRootParts pd;
+  Fq x1;
+  if (wire_fq_sqrt_keep(d, k, x0, pd)) x1 = Fq::mul(a1, Fq::inv(Fq::norm(Fq::dbl(x0))));
+  else {
+    // d is a non-residue and so is -5, so -5 d is a square whose (t+1)/2-th and t-th powers are products of what the failed
+    // attempt already computed and two constants: only the digit part is run again.  The other candidate is
+    // d' = (a0 - alpha) / 2 = -5 a1^2 / (4 d) = (-5 d) (a1 / (2 d))^2, so with s = sqrt(-5 d): x0 = s a1 / (2 d), x1 = a1 / (2 x0) = d / s.
+    Fq sr;
+    if (!wire_root_finish(Fq::mul(k.m5_x, pd.x), Fq::mul(k.m5_b, pd.b), k, sr)) return false;
+    const Fq isd = Fq::norm(Fq::inv(Fq::norm(Fq::mul(sr, d))));      // (s d)^-1: one inversion for 1/s and 1/d
+    const Fq si = Fq::mul(isd, d), di = Fq::mul(isd, sr);
+    x1 = Fq::mul(d, si);
+    x0 = Fq::mul(Fq::mul(sr, a1), Fq::mul(di, k.inv2));
   }
-  const Fq x1 = Fq::mul(a1, wire_inv(Fq::norm(Fq::dbl(x0))));
   out = {x0, x1};
   const Fq2 chk = Fq2::sqr(out);
   return wire_eq(chk.c0, a0) && wire_eq(chk.c1, a1);
 }
 
-// r * P == O, MSB-first double-and-add over the 253 bits of r (the reference's is_in_correct_subgroup_assuming_on_curve)
-template <class F> WIRE_FN bool wire_in_subgroup(const Affine<F>& p, const WireConsts& k) {
+// r * P == O, MSB-first double-and-add over the 253 bits of r: the reference's is_in_correct_subgroup_assuming_on_curve
+// (ark-ec 0.1 GroupAffine) as written.  Kept as the definition the two tests below are checked against
+// (tests/test_host_field.py, tests/test_wire_gpu.py); the decoders use the endomorphism forms.
+template <class F> WIRE_FN bool wire_in_subgroup_ladder(const Affine<F>& p, const WireConsts& k) {
   Xyzz<F> acc = Xyzz<F>::from_affine(p);
   for (int i = 251; i >= 0; i--) {
     acc = xyzz_dbl(acc);      // inlined: the out-of-line variant saves / restores ~100 callee-saved VGPRs per call on gfx950 (252 calls per point)
     if ((k.r_order[i >> 6] >> (i & 63)) & 1) xyzz_madd(acc, p);
   }
   return acc.is_identity() || acc.ZZ.is_zero_mod_p();
+}
+
+// The same predicate through the curves' efficient endomorphisms (x = 0x8508c00000000001 is the BLS12 parameter,
+// r = x^4 - x^2 + 1, q + 1 - t = h1 r with t = x + 1): a 64-bit ladder (or two) instead of a 253-bit one.
+//
+// G1.  phi(x, y) = (beta x, y) satisfies phi^2 + phi + 1 = 0 on all of E(Fq).  If phi(P) = -[x^2]P then
+//      0 = (phi^2 + phi + 1)P = [x^4 - x^2 + 1]P = [r]P; conversely phi acts on the order-r points as one of the two roots
+//      of l^2 + l + 1 mod r, which are -x^2 and x^2 - 1, and beta is the cube root of unity that gives -x^2.  So
+//      "phi(P) == -[x^2]P" holds exactly when r P = O: no cofactor condition is involved.
+// G2.  psi = twist^-1 o Frobenius o twist satisfies psi^2 - t psi + q = 0 on all of E'(Fq2).  If psi(P) = [x]P then
+//      0 = [x^2 - (x + 1) x + q]P = [q - x]P = [h1 r]P, and P also has order dividing #E'(Fq2) = h2 r; gcd(h1, h2) = 1 for
+//      BLS12-377 (checked numerically in tests/test_oracle_golden.py), so r P = O.  Conversely psi acts on G2 as
+//      multiplication by q = t - 1 = x mod r.  So "psi(P) == [x]P" holds exactly when r P = O.
+// (The tests of Scott, eprint 2021/1130, with the cofactor condition of El Housni-Guillevic-Piellard, eprint 2022/352;
+// later arkworks and gnark releases use them for this curve.)  Identical verdicts, 2.5x / 5x fewer field products.
+static constexpr uint64_t WIRE_X = 0x8508c00000000001ULL;
+template <class F> HD Xyzz<F> wire_mul_x(const Affine<F>& p) {     // [x]P, p finite
+  Xyzz<F> acc = Xyzz<F>::from_affine(p);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int i = 62; i >= 0; i--) {
+    acc = xyzz_dbl(acc);
+    if ((WIRE_X >> i) & 1) xyzz_madd(acc, p);
+  }
+  return acc;
+}
+WIRE_FN bool wire_in_subgroup(const Affine<Fq>& p, const WireConsts& k) {
+  const Xyzz<Fq> a = wire_mul_x(p);                                  // [x]P
+  Xyzz<Fq> acc = a;                                                  // [x]([x]P): the same ladder with full additions
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int i = 62; i >= 0; i--) {
+    acc = xyzz_dbl(acc);
+    if ((WIRE_X >> i) & 1) xyzz_add(acc, a);
+  }
+  if (acc.is_identity() || acc.ZZ.is_zero_mod_p()) return false;     // phi(P) is a finite point
+  // -[x^2]P == (beta x, y):  X == beta x ZZ  and  -Y == y ZZZ
+  return wire_eq(acc.X, Fq::mul(Fq::mul(k.beta, p.x), acc.ZZ)) && wire_eq(wire_neg(acc.Y), Fq::mul(p.y, acc.ZZZ));
+}
+WIRE_FN bool wire_in_subgroup(const Affine<Fq2>& p, const WireConsts& k) {
+  const Xyzz<Fq2> a = wire_mul_x(p);                                 // [x]P
+  if (a.is_identity() || a.ZZ.is_zero_mod_p()) return false;
+  const Fq2 px = {Fq::mul(p.x.c0, k.psi_x), Fq::mul(wire_neg(p.x.c1), k.psi_x)};
+  const Fq2 py = {Fq::mul(p.y.c0, k.psi_y), Fq::mul(wire_neg(p.y.c1), k.psi_y)};
+  const Fq2 lx = Fq2::mul(Fq2::norm(px), a.ZZ), ly = Fq2::mul(Fq2::norm(py), a.ZZZ);
+  return wire_eq(a.X.c0, lx.c0) && wire_eq(a.X.c1, lx.c1) && wire_eq(a.Y.c0, ly.c0) && wire_eq(a.Y.c1, ly.c1);
 }
 
 // 48 bytes -> affine G1 point (y^2 = x^3 + 1)
@@ -251,12 +323,42 @@ inline WireConsts wire_consts_build() {
   const uint64_t two[6] = {2, 0, 0, 0, 0, 0}, five[6] = {5, 0, 0, 0, 0, 0};
   k.inv2 = Fq::inv(Fq::from_canonical(two));
   k.inv5 = Fq::inv(Fq::from_canonical(five));
+  {
+    const Fq m5 = wire_neg(Fq::from_canonical(five));
+    const Fq w5 = Fq::pow64(m5, k.tm1_half, 6);
+    const Fq x5 = Fq::mul(m5, w5);
+    k.m5_x = Fq::wred(Fq::norm(x5));
+    k.m5_b = Fq::wred(Fq::norm(Fq::mul(x5, w5)));
+  }
+  {  // the endomorphism constants of wire_in_subgroup: (-5)^((q-1)/6), (-5)^((q-1)/4) and beta = psi_x^4
+    auto div_small = [&](uint64_t d, uint64_t* o) {
+      unsigned __int128 rem = 0;
+      for (int i = 5; i >= 0; i--) {
+        const unsigned __int128 cur = (rem << 64) | pm1[i];
+        o[i] = (uint64_t)(cur / d);
+        rem = cur % d;
+      }
+    };
+    uint64_t e6[6], e4[6];
+    div_small(6, e6);
+    div_small(4, e4);
+    const Fq m5 = wire_neg(Fq::from_canonical(five));
+    k.psi_x = Fq::wred(Fq::norm(Fq::pow64(m5, e6, 6)));
+    k.psi_y = Fq::wred(Fq::norm(Fq::pow64(m5, e4, 6)));
+    k.beta = Fq::wred(Fq::norm(Fq::sqr(Fq::sqr(k.psi_x))));
+  }
   // the discrete-log tables of wire_fq_sqrt
   static WireTables T;
   Fq h = k.z;
   for (int i = 0; i < 38; i++) h = Fq::sqr(h);                       // z^(2^38): a primitive 256-th root of unity
   Fq p = Fq::one();
   for (int j = 0; j < 256; j++) { T.t8[j] = Fq::reduce(p); p = Fq::mul(p, h); }
+  for (int j = 0; j < 1024; j++) T.slot[j] = 0xffff;
+  for (int j = 0; j < 256; j++) {
+    uint32_t sl = T.t8[j].l[0] & 1023u;
+    while (T.slot[sl] != 0xffff) sl = (sl + 1) & 1023u;
+    T.slot[sl] = (uint16_t)j;
+  }
   const Fq zi = Fq::inv(k.z);
   Fq base = zi;                                                       // z^-(2^(4m)) for m = 0, 1, ...
   Fq half = zi;                                                       // z^-(2^(4m - 1)) for m >= 1 (m = 0 handled below)

@@ -291,3 +291,74 @@ def test_safegcd_inversion_matches_the_definition():
             assert int.from_bytes(out.tobytes(), "little") == (0 if x == 0 else pow(x, -1, p)), (field, hex(x))
         m = co.to_mont([rnd.randrange(1, p) for _ in range(10)] + [1, p - 1], p)
         assert all(lib.ht_inv_matches_fermat(C.c_int(field), m[i].ctypes.data_as(C.c_void_p)) for i in range(m.shape[0]))
+
+
+def _small_factors(n, bound=1 << 16):
+    out = []
+    d = 2
+    while d < bound:
+        if n % d == 0:
+            k = 0
+            while n % d == 0:
+                n //= d
+                k += 1
+            out.append((d, k))
+        d += 1 if d == 2 else 2
+    return out, n
+
+
+def test_subgroup_test_by_endomorphism_equals_the_ladder(ht):
+    """wire_in_subgroup (phi(P) == -[x^2]P on G1, psi(P) == [x]P on G2: what the decoders run) against the reference's
+    definition r * P == O (ark-ec GroupAffine::is_in_correct_subgroup_assuming_on_curve, used by PublicKey / Signature
+    deserialisation, crates/bls-crypto/src/bls/public.rs:123-149, signature.rs:31-57) on the host with bounds tracking:
+    subgroup points, random curve points, points of every small prime order the cofactors contain, and sums of both kinds.
+    Also the arithmetic fact the G2 argument needs: gcd(h1, h2) = 1."""
+    from math import gcd, isqrt
+    q, r, x = ecc.Q377, ecc.R377, ecc.X
+    t = x + 1
+    h1 = (q + 1 - t) // r
+    assert h1 * r == q + 1 - t and h1 == (x - 1) ** 2 // 3 and r == x ** 4 - x ** 2 + 1
+    f = isqrt((4 * q - t * t) // 3)
+    assert 3 * f * f == 4 * q - t * t
+    t2 = t * t - 2 * q
+    rng = random.Random(41)
+    f2 = ecc.F2_377
+
+    def rand_point(curve, is2):
+        while True:
+            X = (rng.randrange(q), rng.randrange(q)) if is2 else rng.randrange(q)
+            if is2:
+                y = f2.sqrt(f2.add(f2.mul(f2.sqr(X), X), curve.b))
+            else:
+                y = ecc.sqrt_fp((X * X * X + curve.b) % q, q)
+            if y is not None:
+                return (X, y)
+
+    probe = rand_point(ecc.E2_377, True)
+    n2 = [n for n in (q * q + 1 - (t2 + 3 * t * f) // 2, q * q + 1 - (t2 - 3 * t * f) // 2, q * q + 1 + (t2 + 3 * t * f) // 2, q * q + 1 + (t2 - 3 * t * f) // 2)
+          if n % r == 0 and ecc.E2_377.mul(probe, n) is None]
+    assert len(n2) == 1
+    h2 = n2[0] // r
+    assert gcd(h1, h2) == 1
+
+    def both(curve, is2, P):
+        xy = (co.pack_g2_377 if is2 else co.pack_g1_377)([P])[0].reshape(-1)
+        return ht.ht_wire_subgroup_both(C.c_int(is2), _p(np.ascontiguousarray(xy)))
+
+    for curve, is2, gen, h in ((ecc.E1_377, False, ecc.G1_377, h1), (ecc.E2_377, True, ecc.G2_377, h2)):
+        inside = [curve.mul(gen, rng.randrange(1, r)) for _ in range(3)]
+        for P in inside:
+            assert both(curve, is2, P) == 3
+        outside = [rand_point(curve, is2) for _ in range(3)]
+        small, _ = _small_factors(h)                                    # h1 = 2^92 3 7^2 13^2 499^2; h2 has no factor below 2^16
+        assert small or is2
+        outside.append(curve.add(outside[0], inside[1]))
+        for (l, k) in small[:6]:
+            P = curve.mul(rand_point(curve, is2), h * r // l ** k)       # l-power order
+            while P is not None and curve.mul(P, l) is not None:
+                P = curve.mul(P, l)
+            if P is not None:                                            # order exactly l
+                outside += [P, curve.add(P, inside[0])]
+        for P in outside:
+            assert curve.on_curve(P) and not curve.in_subgroup(P)
+            assert both(curve, is2, P) == 0

@@ -45,6 +45,13 @@ template <class BP> struct QHostT {
   template <int K> static V neg(const V& a) { return map1(a, [](const T& x) { return BP::template neg<K>(x); }); }
   static V wred(const V& a) { return map1(a, [](const T& x) { return BP::wred(x); }); }
   static V mul_nr(const V& a) { return map1(a, [](const T& x) { return BP::mul_nr(x); }); }
+  // the "lazy" forms (result only ever handed to sub / wred, which carry-propagate themselves; mul_nr_k: operand vb <= K):
+  // these backends keep every value normalised, the six-lane ones (pairing_lanes.h) skip the carry passes
+  static constexpr bool LAZY = false;
+  static V add_l(const V& a, const V& b) { return add(a, b); }
+  static V dbl_l(const V& a) { return dbl(a); }
+  template <int K> static V sub_l(const V& a, const V& b) { return sub<K>(a, b); }
+  template <int K> static V mul_nr_k(const V& a) { return mul_nr(a); }
   static V half(const V& a) { return map1(a, [](const T& x) { return BP::half(x); }); }
   static V inv(const V& a) { return map1(a, [](const T& x) { return BP::inv_inl(x); }); }
   template <int CTRL> static V perm(const V& x) { V r; for (int i = 0; i < NL; i++) r.v[i] = x.v[(CTRL >> (2 * i)) & 3]; return r; }
@@ -80,6 +87,11 @@ template <class BP> struct QTriT {
   template <int K> QDEV static V neg(const V& a) { return BP::template neg<K>(a); }
   QDEV static V wred(const V& a) { return BP::wred(a); }
   QDEV static V mul_nr(const V& a) { return BP::mul_nr(a); }
+  static constexpr bool LAZY = false;
+  QDEV static V add_l(const V& a, const V& b) { return BP::add(a, b); }      // lazy forms: see QHostT
+  QDEV static V dbl_l(const V& a) { return BP::dbl(a); }
+  template <int K> QDEV static V sub_l(const V& a, const V& b) { return BP::template sub<K>(a, b); }
+  template <int K> QDEV static V mul_nr_k(const V& a) { return BP::mul_nr(a); }
   QDEV static V half(const V& a) { return BP::half(a); }
   QDEV static V inv(const V& a) { return BP::inv_inl(a); }
   template <int CTRL> QDEV static int src_addr() {

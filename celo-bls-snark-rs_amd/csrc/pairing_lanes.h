@@ -110,6 +110,12 @@ HD Fq mul_nr(const Fq& xo, int h) {
   const Fq t5 = Fq::norm(Fq::add(Fq::dbl(Fq::dbl(xo)), xo));
   return Fq::norm(Fq::neg<64, 1>(t5));
 }
+// the same with one carry pass: -5 x = 5 (K p - x), for vb(partner) <= K (K = 4: products and weak-reduced values; 16: sums of a few)
+template <int K> HD Fq mul_nr_k(const Fq& xo, int h) {
+  if (h) return xo;
+  const Fq n = Fq::neg<K, 1>(xo);
+  return Fq::norm(Fq::add(Fq::dbl(Fq::dbl(n)), n));
+}
 HD Fq conj(const Fq& x, int h) { return h ? Fq::wred(Fq::norm(Fq::neg<4, 1>(x))) : x; }
 // B' x for the twist constant B' = (0, b1): (-5 b1 x1, b1 x0); p = b1 * (own half), po = the partner's p
 HD Fq twist_own(const Fq& x) { return Fq::mul(x, Fq::from_limbs(T377::TWIST_B_C1)); }
@@ -133,6 +139,16 @@ HD Fq dbl(const Fq& a) { return Fq::norm(Fq::add(a, a)); }
 HD Fq tpl(const Fq& a) { return Fq::norm(Fq::add(Fq::add(a, a), a)); }
 template <int K> HD Fq sub(const Fq& a, const Fq& b) { return Fq::norm(Fq::sub<K, 1>(a, b)); }
 template <int K> HD Fq neg(const Fq& a) { return Fq::norm(Fq::neg<K, 1>(a)); }
+// lazy forms: no carry pass - the result goes to sub (as the minuend), wred or another lazy form only (limb bound asserted on the host)
+#if defined(CELO_HEX_EAGER)   // A/B switch: every form carries
+HD Fq add_l(const Fq& a, const Fq& b) { return Fq::norm(Fq::add(a, b)); }
+HD Fq dbl_l(const Fq& a) { return Fq::norm(Fq::add(a, a)); }
+template <int K> HD Fq sub_l(const Fq& a, const Fq& b) { return Fq::norm(Fq::sub<K, 1>(a, b)); }
+#else
+HD Fq add_l(const Fq& a, const Fq& b) { return Fq::add(a, b); }
+HD Fq dbl_l(const Fq& a) { return Fq::add(a, a); }
+template <int K> HD Fq sub_l(const Fq& a, const Fq& b) { return Fq::sub<K, 1>(a, b); }
+#endif
 }  // namespace hex
 
 // host backend: six explicit lanes, index 2 j + h
@@ -153,6 +169,11 @@ struct QHostHex377 {
   static V wred(const V& a) { return map1(a, [](const Fq& x, int) { return Fq::wred(x); }); }
   static V half(const V& a) { return map1(a, [](const Fq& x, int) { return Fq::half(x); }); }
   static V mul_nr(const V& a) { V r; for (int i = 0; i < 6; i++) r.v[i] = hex::mul_nr(a.v[i ^ 1], i & 1); return r; }
+  static constexpr bool LAZY = true;
+  template <int K> static V mul_nr_k(const V& a) { V r; for (int i = 0; i < 6; i++) r.v[i] = hex::mul_nr_k<K>(a.v[i ^ 1], i & 1); return r; }
+  static V add_l(const V& a, const V& b) { return map2(a, b, [](const Fq& x, const Fq& y) { return hex::add_l(x, y); }); }
+  static V dbl_l(const V& a) { return map1(a, [](const Fq& x, int) { return hex::dbl_l(x); }); }
+  template <int K> static V sub_l(const V& a, const V& b) { return map2(a, b, [](const Fq& x, const Fq& y) { return hex::sub_l<K>(x, y); }); }
   static V conj(const V& a) { return map1(a, [](const Fq& x, int h) { return hex::conj(x, h); }); }
   static V mul_fp(const V& a, const F& k) { return map2(a, k, [](const Fq& x, const Fq& y) { return Fq::mul(x, y); }); }
   static V twist_mul(const V& a) {
@@ -213,6 +234,8 @@ struct QHex377 {
     for (int i = 0; i < NWORDS; i++) r.l[i] = (a.l[i] & m) | (b.l[i] & ~m);
     return r;
   }
+  // (fetching Y = b's half 0 and D = b's half 1 by two pair-broadcasts instead of one exchange + 28 selects was measured: faster for a
+  // lone wave, 4 % slower with the chip full - the LDS crossbar is shared by the CU's four SIMDs)
   QDEV static V mul(const V& a, const V& b) { return hex::mul(a, b, swap(a), swap(b), hsel()); }
   QDEV static V add(const V& a, const V& b) { return hex::add(a, b); }
   QDEV static V dbl(const V& a) { return hex::dbl(a); }
@@ -225,6 +248,14 @@ struct QHex377 {
     const V o = swap(a);
     return choose(hsel() != 0, o, hex::mul_nr(o, 0));
   }
+  static constexpr bool LAZY = true;
+  template <int K> QDEV static V mul_nr_k(const V& a) {
+    const V o = swap(a);
+    return choose(hsel() != 0, o, hex::mul_nr_k<K>(o, 0));
+  }
+  QDEV static V add_l(const V& a, const V& b) { return hex::add_l(a, b); }
+  QDEV static V dbl_l(const V& a) { return hex::dbl_l(a); }
+  template <int K> QDEV static V sub_l(const V& a, const V& b) { return hex::sub_l<K>(a, b); }
   QDEV static V conj(const V& a) { return choose(hsel() != 0, hex::conj(a, 1), a); }
   QDEV static V mul_fp(const V& a, const F& k) { return Fq::mul(a, k); }
   QDEV static V twist_mul(const V& a) {
@@ -286,6 +317,10 @@ template <class QB> struct QTower {
     V r = QB::template perm<QP(2, 0, 1)>(x);
     return QB::template sel<0>(QB::mul_nr(r), r);
   }
+  template <int K> QFN static V mul_by_gen_k(const V& x) {      // for vb(x) <= K; result vb <= 5 K
+    V r = QB::template perm<QP(2, 0, 1)>(x);
+    return QB::template sel<0>(QB::template mul_nr_k<K>(r), r);
+  }
   // Fq6 product, Karatsuba across lanes: lane j computes v_j = x_j y_j and the cross product it needs.  Inputs vb <= 40,
   // output weak-reduced.
   QFN static V mul6(const V& x, const V& y) {
@@ -294,14 +329,14 @@ template <class QB> struct QTower {
     V xs = QB::add(QB::template perm<QP(1, 0, 0)>(x), QB::template perm<QP(2, 1, 2)>(x));
     V ys = QB::add(QB::template perm<QP(1, 0, 0)>(y), QB::template perm<QP(2, 1, 2)>(y));
     V c = QB::mul(xs, ys);
-    V t = QB::template sub<4>(QB::template sub<4>(c, QB::template perm<QP(1, 0, 0)>(v)), QB::template perm<QP(2, 1, 2)>(v));  // vb <= 11
+    V t = QB::template sub<4>(QB::template sub_l<4>(c, QB::template perm<QP(1, 0, 0)>(v)), QB::template perm<QP(2, 1, 2)>(v));  // vb <= 11
     V vr = QB::template perm<QP(0, 2, 1)>(v);   // lane 0: v0, lane 1: v2, lane 2: v1
     V w = QB::template sel<0>(t, vr);              // what xi multiplies on lanes 0 and 1
-    V xw = QB::mul_nr(w);
+    V xw = QB::template mul_nr_k<16>(w);
     // z0 = v0 + xi (c12 - v1 - v2);  z1 = (c01 - v0 - v1) + xi v2;  z2 = (c02 - v0 - v2) + v1
     V lhs = QB::template sel<0>(vr, t);
     V rhs = QB::template sel<2>(vr, xw);
-    return QB::wred(QB::add(lhs, rhs));
+    return QB::wred(QB::add_l(lhs, rhs));
   }
   QNI static E12 mul12(const E12& x, const E12& y) { return mul12_inl(x, y); }
   QFN static E12 mul12_inl(const E12& x, const E12& y) {
@@ -309,31 +344,31 @@ template <class QB> struct QTower {
     V v1 = mul6(x.b, y.b);
     V t = mul6(QB::add(x.a, x.b), QB::add(y.a, y.b));
     E12 r;
-    r.b = QB::wred(QB::template sub<4>(QB::template sub<4>(t, v0), v1));
-    r.a = QB::wred(QB::add(v0, mul_by_gen(v1)));
+    r.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(t, v0), v1));
+    r.a = QB::wred(QB::add_l(v0, mul_by_gen_k<4>(v1)));
     return r;
   }
   QFN static E12 sqr12(const E12& x) {  // complex squaring: 2 Fq6 products
     V ab = mul6(x.a, x.b);
-    V s2 = QB::wred(QB::add(x.a, mul_by_gen(x.b)));
+    V s2 = QB::wred(QB::add_l(x.a, mul_by_gen_k<4>(x.b)));
     V t = mul6(QB::add(x.a, x.b), s2);
-    V c0 = QB::template sub<64>(QB::template sub<4>(t, ab), mul_by_gen(ab));
-    return {QB::wred(c0), QB::wred(QB::dbl(ab))};
+    V c0 = QB::template sub_l<64>(QB::template sub_l<4>(t, ab), mul_by_gen_k<4>(ab));
+    return {QB::wred(c0), QB::wred(QB::dbl_l(ab))};
   }
   QFN static E12 conj12(const E12& x) { return {x.a, QB::wred(QB::template neg<4>(x.b))}; }
   // x * (d0 + d1 v) for group-uniform d0, d1: lane j: x_j d0 + x_{j-1} d1 (xi on the wrapped term of lane 0)
   QFN static V mul6_by_01(const V& x, const V& d0, const V& d1) {
     V p = QB::mul(x, d0);
     V qv = QB::mul(QB::template perm<QP(2, 0, 1)>(x), d1);
-    return QB::wred(QB::add(p, QB::template sel<0>(QB::mul_nr(qv), qv)));
+    return QB::wred(QB::add_l(p, QB::template sel<0>(QB::template mul_nr_k<4>(qv), qv)));
   }
   // f *= s0 + (s3 + s4 v) w   (ark-ff Fp12::mul_by_034), s* group-uniform
   QFN static void mul_by_034(E12& f, const V& s0, const V& s3, const V& s4) {
     V A = QB::mul(f.a, s0);
     V b = mul6_by_01(f.b, s3, s4);
     V e = mul6_by_01(QB::add(f.a, f.b), QB::add(s0, s3), s4);
-    f.b = QB::wred(QB::template sub<4>(QB::template sub<4>(e, A), b));
-    f.a = QB::wred(QB::add(A, mul_by_gen(b)));
+    f.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(e, A), b));
+    f.a = QB::wred(QB::add_l(A, mul_by_gen_k<4>(b)));
   }
   // Granger-Scott cyclotomic squaring: lane k squares the Fq4 pair k: (a0, b1), (b0, a2), (a1, b2)
   QNI static E12 cyclotomic_sqr(const E12& f) { return cyclotomic_sqr_inl(f); }
@@ -341,15 +376,20 @@ template <class QB> struct QTower {
     V x = QB::template sel<1>(QB::template perm<QP(0, 0, 1)>(f.b), QB::template perm<QP(0, 0, 1)>(f.a));
     V y = QB::template sel<1>(QB::template perm<QP(1, 2, 2)>(f.a), QB::template perm<QP(1, 1, 2)>(f.b));
     V tmp = QB::mul(x, y);
-    V m = QB::mul(QB::add(x, y), QB::add(QB::mul_nr(y), x));
-    V o0 = QB::wred(QB::template sub<64>(QB::template sub<4>(m, tmp), QB::mul_nr(tmp)));
-    V o1 = QB::dbl(tmp);
-    // a_j' = 3 o0 - 2 a_j on every lane;  b_j' = 3 u + 2 b_j with u = o1 of the previous lane (xi on the wrap to lane 0)
-    V u = QB::template perm<QP(2, 0, 1)>(o1);
-    u = QB::template sel<0>(QB::wred(QB::mul_nr(u)), u);
+    V m = QB::mul(QB::add(x, y), QB::add(QB::template mul_nr_k<4>(y), x));
+    V o0 = QB::wred(QB::template sub_l<64>(QB::template sub_l<4>(m, tmp), QB::template mul_nr_k<4>(tmp)));
+    // a_j' = 3 o0 - 2 a_j on every lane;  b_j' = 3 u + 2 b_j with u = o1 = 2 tmp of the previous lane (xi on the wrap to lane 0)
+    V u;
+    if constexpr (QB::LAZY) {
+      V ut = QB::template perm<QP(2, 0, 1)>(tmp);
+      u = QB::dbl_l(QB::template sel<0>(QB::template mul_nr_k<4>(ut), ut));
+    } else {
+      u = QB::template perm<QP(2, 0, 1)>(QB::dbl(tmp));
+      u = QB::template sel<0>(QB::wred(QB::mul_nr(u)), u);
+    }
     E12 z;
-    z.a = QB::wred(QB::add(QB::dbl(QB::template sub<4>(o0, f.a)), o0));
-    z.b = QB::wred(QB::add(QB::dbl(QB::add(u, f.b)), u));
+    z.a = QB::wred(QB::add_l(QB::dbl_l(QB::template sub_l<4>(o0, f.a)), o0));
+    z.b = QB::wred(QB::add_l(QB::dbl_l(QB::add_l(u, f.b)), u));
     return z;
   }
   // Fq6 inverse, coefficients one per lane (ark-ff Fp6::inverse)

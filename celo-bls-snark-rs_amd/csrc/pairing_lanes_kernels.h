@@ -202,7 +202,7 @@ template <class LP> struct Slots {
     const V b = Tow::mul6_by_01(ldv(sf, 1), s3, s4);
     fence();
     const V e = Tow::mul6_by_01(QB::add(ldv(sf, 0), ldv(sf, 1)), QB::add(s0, s3), s4);
-    const V nb = QB::wred(QB::template sub<4>(QB::template sub<4>(e, A), b)), na = QB::wred(QB::add(A, Tow::mul_by_gen(b)));
+    const V nb = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(e, A), b)), na = QB::wred(QB::add_l(A, Tow::template mul_by_gen_k<4>(b)));
     // branch-free: an uncommitted lane writes back what the slot holds (a divergent `if` around the stores made the register
     // allocator spill ~140 dwords per step in the surrounding 442 KB loop body; the select costs 56 instructions)
     stv(sf, 1, QB::choose(commit, nb, ldv(sf, 1)));
@@ -251,8 +251,8 @@ template <class LP> struct Slots {
     fence();
     const V t = Tow::mul6(QB::add(ldv(a, 0), ldv(a, 1)), QB::add(ldv(b, 0), ldv(b, 1)));
     fence();
-    stv(dst, 1, QB::wred(QB::template sub<4>(QB::template sub<4>(t, v0), v1)));
-    stv(dst, 0, QB::wred(QB::add(v0, Tow::mul_by_gen(v1))));
+    stv(dst, 1, QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(t, v0), v1)));
+    stv(dst, 0, QB::wred(QB::add_l(v0, Tow::template mul_by_gen_k<4>(v1))));
   }
   __device__ __forceinline__ static void cyclo(int s) {        // Tow::cyclotomic_sqr_inl with f re-read for the last step
     typedef typename LP::QB QB;
@@ -264,14 +264,14 @@ template <class LP> struct Slots {
     }
     fence();
     const V tmp = QB::mul(x, y);
-    const V m = QB::mul(QB::add(x, y), QB::add(QB::mul_nr(y), x));
-    const V o0 = QB::wred(QB::template sub<64>(QB::template sub<4>(m, tmp), QB::mul_nr(tmp)));
-    const V o1 = QB::dbl(tmp);
-    V u = QB::template perm<QP(2, 0, 1)>(o1);
-    u = QB::template sel<0>(QB::wred(QB::mul_nr(u)), u);
+    const V m = QB::mul(QB::add(x, y), QB::add(QB::template mul_nr_k<4>(y), x));
+    const V o0 = QB::wred(QB::template sub_l<64>(QB::template sub_l<4>(m, tmp), QB::template mul_nr_k<4>(tmp)));
+    static_assert(QB::LAZY, "the slot kernels run on the six-lane backend");
+    const V ut = QB::template perm<QP(2, 0, 1)>(tmp);
+    const V u = QB::dbl_l(QB::template sel<0>(QB::template mul_nr_k<4>(ut), ut));
     fence();
-    const V za = QB::wred(QB::add(QB::dbl(QB::template sub<4>(o0, ldv(s, 0))), o0));
-    const V zb = QB::wred(QB::add(QB::dbl(QB::add(u, ldv(s, 1))), u));
+    const V za = QB::wred(QB::add_l(QB::dbl_l(QB::template sub_l<4>(o0, ldv(s, 0))), o0));
+    const V zb = QB::wred(QB::add_l(QB::dbl_l(QB::add_l(u, ldv(s, 1))), u));
     stv(s, 0, za); stv(s, 1, zb);
   }
   __device__ __attribute__((noinline)) static void exp_loop() {        // slot 0 <- slot 1 ^ x

@@ -46,7 +46,8 @@ class Ctx:
 
 # launch shapes the committed PMC profiles were taken at (tools/profile_bench.sh: the default bench command; tools/bench_groups.py 20)
 PROFILED_SHAPE = {"k_accumulate<G1_377>": 20, "k_accumulate<G2_377>": 20, "k_accumulate<G_761>": 20,
-                  "k_miller_product_slots<LPH377, 2>": 81920, "k_final_exp_slots<LPH377>": 81920}
+                  "k_miller_product_slots<LPH377, 2>": 81920, "k_miller_prepared_slots<LPH377>": 81920, "k_prepare_lines<LPH377>": 81920,
+                  "k_final_exp_slots<LPH377>": 81920}
 
 
 def committed_traffic(kernels, shape):
@@ -503,10 +504,12 @@ def pairing_leg(ffi, check_oracle=True):
         raise SystemExit("PARITY FAILURE: GPU pairing accept vector != expected / oracle")
     secs = best["total_ms"] * 1e-3
     gbps = 2 * m * 288 / secs / 1e9
-    traffic, src = committed_traffic(["k_miller_product_slots<LPH377, 2>", "k_final_exp_slots<LPH377>"], m)
+    # every product's first pair is (sig, -g2): the engine evaluates prepared line coefficients for it (pairing.h run_staged)
+    kernels = ["k_prepare_lines<LPH377>", "k_miller_prepared_slots<LPH377>", "k_final_exp_slots<LPH377>"]
+    traffic, src = committed_traffic(kernels, m)
     return {"metric": "BLS12-377 Miller loops/s (2-pair products, 1 final exponentiation per product)", "value": 2 * m / secs,
             "products": m, "device_ms": best["total_ms"], "wall_ms_incl_pcie": best["wall_ms"], "miller_ms": best["miller_ms"], "final_exp_ms": best["final_exp_ms"],
-            "roofline": {"bound": "hbm", "kernel": "k_miller_product_slots<LPH377, 2> + k_final_exp_slots<LPH377>", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": " + ".join(kernels), "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src, "note": "algorithmic bytes = 288 B per Miller loop (SURVEY.md section 8d); integer-VALU bound"},
             "cpu_port_miller_loops_per_s_1core": cpu_rate, "accept_vector_matches_oracle": ok if check_oracle else None}
 

@@ -76,6 +76,33 @@ template <class F> static void lane_point_op(int op, const uint64_t* p1, const u
   xyzz_to_jac(r, out);
 }
 
+// the same ops for G2 of BLS12-377 on the SIX-lane host backend (halves of an Fq2 in adjacent lanes: msm.h k_batch_horner_hex)
+static void lane_point_op_hex(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) {
+  typedef Fp2<P377> F;
+  typedef QHostHex377 QB;
+  typedef LanePoint<QB> LP;
+  Affine<F> a = load_aff<F>(p1), b = load_aff<F>(p2);
+  auto lift = [](const Affine<F>& p) { LP::P r = {QB::uni2(p.x.c0, p.x.c1), QB::uni2(p.y.c0, p.y.c1), QB::uni2(Fq::one(), Fq::zero()), QB::uni2(Fq::one(), Fq::zero())}; return r; };
+  LP::Pt acc = {lift(a), false};
+  switch (op) {
+    case 0: LP::add(acc, lift(b), false); break;
+    case 1: LP::dbl(acc); break;
+    case 2: { LP::Pt t = {lift(b), false}; LP::dbl(t); LP::add(t, lift(a), false); LP::add(acc, t.p, t.inf); } break;
+    case 4: LP::add(acc, lift(affine_neg(a)), false); break;
+    case 6: { for (uint32_t i = 0; i < k; i++) LP::add(acc, lift(b), false); } break;
+    case 7: { LP::P t = acc.p; LP::add(acc, t, false); } break;
+    case 8: { for (uint32_t i = 0; i < k; i++) LP::dbl(acc); LP::add(acc, lift(b), false); } break;
+    default: break;
+  }
+  auto f2 = [](const QB::V& v, int j) { return F{v.v[2 * j], v.v[2 * j + 1]}; };
+  Xyzz<F> r = acc.inf ? Xyzz<F>::identity() : Xyzz<F>{f2(acc.p.X, 0), f2(acc.p.Y, 0), f2(acc.p.ZZ, 0), f2(acc.p.ZZZ, 0)};
+  for (int l = 1; l < 3 && !acc.inf; l++) {   // the tower lanes must agree
+    if (!F::norm(F::template sub<64, 1>(F::norm(f2(acc.p.X, l)), F::norm(r.X))).is_zero_mod_p() ||
+        !F::norm(F::template sub<64, 1>(F::norm(f2(acc.p.ZZZ, l)), F::norm(r.ZZZ))).is_zero_mod_p()) r = Xyzz<F>::identity();
+  }
+  xyzz_to_jac(r, out);
+}
+
 // pairing tower on the host with bounds tracking.  mode 0: product of pairings (GT), 1: Miller-loop product only,
 // 2: final exponentiation of the given GT (in72), 3: Fq12 mul (in72 * in72b), 4: Fq12 inverse, 5: cyclotomic square,
 // 6: frobenius 1, 7: frobenius 2, 8: frobenius 3, 9: Fq12 square
@@ -311,6 +338,7 @@ void ht_g1_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint6
 void ht_g2_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { point_op<Fp2<P377>>(op, p1, p2, k, out); }
 void ht_lane_g1_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { lane_point_op<Fp<P377>>(op, p1, p2, k, out); }
 void ht_lane_g2_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { lane_point_op<Fp2<P377>>(op, p1, p2, k, out); }
+void ht_lane_g2_377_hex(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { lane_point_op_hex(op, p1, p2, k, out); }
 void ht_lane_g_761(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { lane_point_op<Fp<P761>>(op, p1, p2, k, out); }
 void ht_g_761(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { point_op<Fp<P761>>(op, p1, p2, k, out); }
 void ht_fq377_canon(const uint64_t* canon, uint64_t* out_ark, uint64_t* out_canon) {

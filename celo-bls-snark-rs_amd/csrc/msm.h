@@ -28,6 +28,7 @@
 #include "curve.h"
 #include "host64.h"
 #include "curve_lanes.h"
+#include "pairing_lanes.h"
 #include "fp2.h"
 #include "runtime.h"
 
@@ -633,6 +634,52 @@ __global__ void __launch_bounds__(64) k_batch_horner_lanes(const uint32_t* __res
   }
 }
 
+// G2 of BLS12-377: SIX lanes per instance - the two halves of every Fq2 coordinate in adjacent lanes (QHex377, pairing_lanes.h:
+// one signed two-product Montgomery pass per lane and product instead of a three-product Karatsuba), so a lane executes half
+// the instructions per doubling: the Horner chain of Batch::verify's key sums is latency and nothing else.  10 instances per
+// 64-lane block.  LanePoint runs unchanged on the backend (same formulas, same decisions per group).
+template <class G>   // G2_377 only (a template so that every translation unit including this header may hold a copy)
+__global__ void __launch_bounds__(64) k_batch_horner_hex(const uint32_t* __restrict__ wsum, uint64_t* __restrict__ out, uint32_t nw, uint32_t c, uint32_t m) {
+  typedef PointIO<Fq2> IO;
+  typedef QHex377 QB;
+  typedef LanePoint<QB> LP;
+  constexpr int HW = Fq::WORDS;                      // device words per Fq half (a coordinate is c0 then c1)
+  const int g = QB::group(), h = QB::hsel();
+  const uint32_t inst = blockIdx.x * 10u + (uint32_t)g;
+  if (g >= 10 || inst >= m) return;
+  LP::Pt acc;
+  acc.inf = true;
+  for (int w = (int)nw - 1; w >= 0; w--) {
+    for (uint32_t k = 0; k < c; k++) LP::dbl(acc);
+    const uint32_t* src = wsum + ((size_t)inst * nw + w) * IO::XYZZ_WORDS + h * HW;   // every lane loads its half of the window sum
+    const LP::P b = {Fq::load(src), Fq::load(src + 2 * HW), Fq::load(src + 4 * HW), Fq::load(src + 6 * HW)};
+    const int z = b.ZZ.limbs_all_zero() ? 1 : 0;                                       // the identity is stored as exact zeros
+    const bool b_inf = (z & __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ 1) << 2, z)) != 0;
+    LP::add(acc, b, b_inf);
+  }
+  if (QB::lane() != 0) return;
+  uint64_t* o = out + (size_t)inst * 3 * IO::ARK64 + h * Fq::ARK64;
+  if (acc.inf || QB::is_zero_u(acc.p.ZZ)) {
+    Fq::zero().to_ark(o);
+    (h ? Fq::zero() : Fq::one()).to_ark(o + IO::ARK64);
+    Fq::zero().to_ark(o + 2 * IO::ARK64);
+  } else {
+    QB::mul(acc.p.X, acc.p.ZZ).to_ark(o);
+    QB::mul(acc.p.Y, acc.p.ZZZ).to_ark(o + IO::ARK64);
+    acc.p.ZZ.to_ark(o + 2 * IO::ARK64);
+  }
+}
+template <class G> struct BatchHornerLanes {
+  static void launch(const uint32_t* d_wsum, uint64_t* d_out, uint32_t nw, uint32_t c, uint32_t m, hipStream_t stream) {
+    hipLaunchKernelGGL((k_batch_horner_lanes<G>), dim3((m + 20) / 21), dim3(64), 0, stream, d_wsum, d_out, nw, c, m);
+  }
+};
+template <> struct BatchHornerLanes<G2_377> {
+  static void launch(const uint32_t* d_wsum, uint64_t* d_out, uint32_t nw, uint32_t c, uint32_t m, hipStream_t stream) {
+    hipLaunchKernelGGL((k_batch_horner_hex<G2_377>), dim3((m + 9) / 10), dim3(64), 0, stream, d_wsum, d_out, nw, c, m);
+  }
+};
+
 // ---------------------------------------------------------------- host driver
 struct MsmTimings {  // milliseconds, HIP events on the MSM's stream (last call)
   float convert = 0, sort = 0, accumulate = 0, reduce = 0, total = 0;
@@ -970,7 +1017,7 @@ template <class G> class MsmEngine {
                        d_nwork, d_partials);
     HIP_OK(hipEventRecord(ev[3], stream));
     hipLaunchKernelGGL((k_batch_reduce<G>), dim3(((uint32_t)nvw + 127) / 128), dim3(128), 0, stream, d_partials, d_plen, d_wsum, B, (uint32_t)nvw);
-    if (lane_horner) hipLaunchKernelGGL((k_batch_horner_lanes<G>), dim3(((uint32_t)m + 20) / 21), dim3(64), 0, stream, d_wsum, d_out, (uint32_t)nw, (uint32_t)c, (uint32_t)m);
+    if (lane_horner) BatchHornerLanes<G>::launch(d_wsum, d_out, (uint32_t)nw, (uint32_t)c, (uint32_t)m, stream);
     else hipLaunchKernelGGL((k_batch_horner<G>), dim3(((uint32_t)m + 127) / 128), dim3(128), 0, stream, d_wsum, d_out, (uint32_t)nw, (uint32_t)c, (uint32_t)m);
     HIP_OK(hipEventRecord(ev[4], stream));
     if (out) HIP_OK(hipMemcpyAsync(out, d_out, m * 3 * IO::ARK64 * 8, hipMemcpyDeviceToHost, stream));

@@ -609,7 +609,7 @@ bool epoch_from_ffi(const EpochBlockFFI& src, EpochBlockHost& e) {  // snark/epo
   e.maximum_non_signers = src.maximum_non_signers; e.maximum_validators = src.maximum_validators;
   e.pubkeys.resize(src.pubkeys_num);
   e.pubkeys_jac.resize(src.pubkeys_num * 36);
-  // one square root in Fq2 + one subgroup check per key (~1 ms each): spread over the host cores for real validator sets
+  // one square root in Fq2 + one subgroup check per key (~0.5 ms each): spread over the host cores for real validator sets
   std::atomic<bool> ok(true);
   auto decode = [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi && ok; i++) {
@@ -722,7 +722,7 @@ bool deserialize_public_key(const uint8_t* in_bytes, int in_len, PublicKey** out
 }
 // The reference memoises decompression in a 512-entry LRU keyed by the serialized bytes (serialization.rs:44-61,
 // crates/bls-crypto/src/bls/cache.rs:36,49-65): validator keys recur epoch after epoch, and a hit replaces a square root and a
-// subgroup check (~1 ms) by a 288-byte copy.  Decoding is a pure function, so the cache is not observable through the ABI.
+// subgroup check (~0.5 ms) by a 288-byte copy.  Decoding is a pure function, so the cache is not observable through the ABI.
 bool deserialize_public_key_cached(const uint8_t* in_bytes, int in_len, PublicKey** out) {
   if (!in_bytes || in_len != 96 || !out) return deserialize_public_key(in_bytes, in_len, out);
   static std::mutex mu;

@@ -15,7 +15,7 @@ static std::mutex wire_mu;
 
 // in: n x 48 (G1) / n x 96 (G2) wire bytes.  out: n x 12 / n x 24 u64, affine (x, y) in arkworks Montgomery limbs (the layout
 // the MSM and pairing entry points take), zeros unless status == WIRE_OK.  Control flow is uniform apart from the table scans of the square
-// root; the 253-step subgroup ladder that dominates uses the same scalar r in every lane.
+// root; the subgroup test (64-bit ladders by the curve parameter x, wire.h) uses the same scalar in every lane.
 template <bool G2> __global__ void __launch_bounds__(64) FROW_OCC k_decompress(const uint8_t* __restrict__ in, uint64_t* __restrict__ out,
                                                                       uint8_t* __restrict__ status, uint32_t n, int check, WireConsts k) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -123,7 +123,7 @@ def test_point_ops_bw6(ht, golden):
     assert op(6, A, B, 9) == cur.add(A, cur.mul(B, 9))
 
 
-@pytest.mark.parametrize("kind", ["g1_377", "g2_377"])
+@pytest.mark.parametrize("kind", ["g1_377", "g2_377", "g2_377_hex"])
 def test_lane_parallel_point_ops(ht, kind):
     """curve_lanes.h (XYZZ doubling / addition spread over three lanes: the batched MSM's Horner kernel) on the three-explicit-
     lanes host backend with bounds tracking, against the oracle's group law: addition, doubling, chains, P + P through add,
@@ -131,7 +131,9 @@ def test_lane_parallel_point_ops(ht, kind):
     cur, gen, fn, pack, nw = {
         "g1_377": (ecc.E1_377, ecc.G1_377, ht.ht_lane_g1_377, co.pack_g1_377, 18),
         "g2_377": (ecc.E2_377, ecc.G2_377, ht.ht_lane_g2_377, co.pack_g2_377, 36),
+        "g2_377_hex": (ecc.E2_377, ecc.G2_377, ht.ht_lane_g2_377_hex, co.pack_g2_377, 36),    # six lanes: k_batch_horner_hex's backend
     }[kind]
+    kind = kind.replace("_hex", "")
 
     def op(o, P1, P2, k=0):
         a, _ = pack([P1])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Bulk decoding of compressed BLS12-377 points (decompress_bls12_377_g1/_g2_dev), wire bytes resident in HBM: kernel time
 from HIP events, points/s, algorithmic GB/s (48 B in + 96 B out per G1 point, 96 B + 192 B per G2 point) against the 8 TB/s
-HBM roofline - this is integer-VALU work (one square root + a 253-step ladder per point), the HBM fraction is reported
+HBM roofline - this is integer-VALU work (one square root + the endomorphism subgroup test, 64-bit ladders, per point), the HBM fraction is reported
 because it is the roofline the brief names.  Beside it: the oracle's C restatement on the host cores (bounded sample)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

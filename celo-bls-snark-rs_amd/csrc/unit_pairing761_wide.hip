@@ -5,9 +5,10 @@
 // Miller iterations per pair, then a 449-bit and a 575-bit exponentiation back to back - 65 ms of a 70 ms `verify` (round 2
 // profile).  The pieces are independent, so here they run side by side in different WAVES (different loops must not share a
 // wave: divergent lanes would run them one after the other):
-//   k_wide_miller   block 0: the f_{x+1} loops of all pairs, block 1: the f_{x^3-x^2-x} loops (one lane group per pair and loop)
+//   k_wide_miller   block 0: the f_{x+1} loops of all pairs (one lane group per pair); block 1: the f_{x^3-x^2-x} loops, four waves:
+//                   the point steps | three iteration ranges of the accumulator updates (see the kernel)
 //   k_wide_easy     one group: f = prod f1_i * frob(prod f2_i), the easy part m = f^((q^3-1)(q+1)), and m^q
-//   k_wide_pow      block 0: m^R0, block 1: (m^q)^R1, signed-digit (NAF) ladders: a third fewer multiplications than binary
+//   k_wide_pow      block 0: m^R0, block 1: (m^q)^R1, signed-digit (NAF) ladders, each split over two waves: squarings | multiplications
 //   k_wide_final    one group: the product of the two powers, == 1, export
 // Same field elements as the throughput path at every stage (tests: the reference's Groth16 vector, GT values vs the oracle).
 #include "pairing_lanes_kernels.h"
@@ -19,49 +20,234 @@ namespace {
 typedef LP761 LP;
 typedef LP::Tow Tow;
 typedef LP::Pair Pair;
+typedef LP::QB QB;
+typedef QB::V V;
+typedef Tow::E12 E12;
 
-__global__ void __launch_bounds__(64) LANES_OCC k_wide_miller(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1, const uint64_t* __restrict__ g2,
-                                                              const uint8_t* __restrict__ inf2, uint32_t* __restrict__ f_out, uint32_t k, uint32_t blocks_per_loop) {
-  const int g = LP::QB::group();
-  const uint32_t which = blockIdx.x / blocks_per_loop;                       // 0: f1 loops, 1: f2 loops (wave-uniform)
-  const uint32_t i = (blockIdx.x % blocks_per_loop) * LP::GROUPS + (uint32_t)g;
-  if (g >= LP::GROUPS || i >= k) return;
-  const LP::F px = LP::load_p(g1 + (size_t)i * LP::G1W, 0), py = LP::load_p(g1 + (size_t)i * LP::G1W, 1);
-  const LP::QB::V Qc = LP::load_q(g2 + (size_t)i * LP::G2W);
-  Tow::E12 f = which == 0 ? Pair::miller_f1(px, py, Qc) : Pair::miller_f2(px, py, Qc);
-  if ((inf1 && inf1[i]) || (inf2 && inf2[i])) f = Tow::one12();
-  LP::store12(f_out + (size_t)(which * k + i) * lanes_gt_words<LP>(), f);
+// ---- three lane groups per value ("super-group" of nine lanes): the quadratic level's Karatsuba products side by side.
+// An Fq6 product is three independent Fq3 products (a a', b b', (a + b)(a' + b')), a squaring two, the sparse line product
+// three: every lane group of a super-group holds the WHOLE Fq6 element, group r computes product r (one instruction stream: the
+// operands are selected per group, never the code), the results travel by ds_bpermute and every group finishes the same
+// combination.  An Fq6 product then costs the latency of ONE Fq3 product (2 dependent multiplication rounds instead of 6), a
+// squaring 2 instead of 4, a line product 2 instead of 5: this path exists for the latency of a lone product, lanes are free.
+__device__ __forceinline__ int sub3() { return QB::group() % 3; }                 // which product this lane group computes
+template <int R> __device__ __forceinline__ V from_sub(const V& x) {               // the value the same lane of sub-group R holds
+  const int addr = ((int)__lane_id() + 3 * (R - sub3())) << 2;
+  V r;
+#pragma unroll
+  for (int i = 0; i < QB::NWORDS; i++) r.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)x.l[i]);
+  return r;
 }
-// f_in: k f1 values then k f2 values.  out: [0] = m (or the Miller value f itself when !do_fe), [1] = m^q
-__global__ void __launch_bounds__(64) LANES_OCC k_wide_easy(const uint32_t* __restrict__ f_in, uint32_t k, uint32_t* __restrict__ out, int do_fe) {
-  if (LP::QB::group() != 0) return;
-  constexpr int W = lanes_gt_words<LP>();
-  Tow::E12 a = LP::load12(f_in), b = LP::load12(f_in + (size_t)k * W);
-  for (uint32_t i = 1; i < k; i++) {
-    a = Tow::mul12(a, LP::load12(f_in + (size_t)i * W));
-    b = Tow::mul12(b, LP::load12(f_in + (size_t)(k + i) * W));
+__device__ __forceinline__ V pick3(const V& a0, const V& a1, const V& a2) {        // by sub-group, mask arithmetic (no exec regions)
+  const int q = sub3();
+  const uint32_t m0 = QB::lane_mask(q == 0), m1 = QB::lane_mask(q == 1);
+  V r;
+#pragma unroll
+  for (int i = 0; i < QB::NWORDS; i++) {
+    const uint32_t t = (a1.l[i] & m1) | (a2.l[i] & ~m1);
+    r.l[i] = (a0.l[i] & m0) | (t & ~m0);
   }
-  Tow::E12 f = Tow::mul12(a, Pair::frob1(b));
+  return r;
+}
+__device__ __forceinline__ E12 mul12_w3(const E12& x, const E12& y) {              // Tow::mul12_inl
+  const V p = Tow::mul6(pick3(x.a, x.b, QB::add(x.a, x.b)), pick3(y.a, y.b, QB::add(y.a, y.b)));
+  const V v0 = from_sub<0>(p), v1 = from_sub<1>(p), t = from_sub<2>(p);
+  E12 r;
+  r.b = QB::wred(QB::template sub<4>(QB::template sub<4>(t, v0), v1));
+  r.a = QB::wred(QB::add(v0, Tow::mul_by_gen(v1)));
+  return r;
+}
+__device__ __forceinline__ E12 sqr12_w3(const E12& x) {                            // Tow::sqr12 (sub-group 2 repeats product 0)
+  const V s2 = QB::wred(QB::add(x.a, Tow::mul_by_gen(x.b)));
+  const V p = Tow::mul6(pick3(x.a, QB::add(x.a, x.b), x.a), pick3(x.b, s2, x.b));
+  const V ab = from_sub<0>(p), t = from_sub<1>(p);
+  const V c0 = QB::template sub<64>(QB::template sub<4>(t, ab), Tow::mul_by_gen(ab));
+  return {QB::wred(c0), QB::wred(QB::dbl(ab))};
+}
+// f *= line at P (Pair::ell = one scaling round + mul_by_014): v0 = f.a (s0 + s1 u), v1 = f.b (s4 u), t = (f.a + f.b)(s0 + (s1 + s4) u) as
+// ONE mul6_by_01 with per-group operands (v1's d0 is zero: a wasted product, but no divergence)
+__device__ __forceinline__ void ell_w3(E12& f, const Pair::Line& l, const V& px, const V& py) {
+  const V sc = QB::mul(QB::template sel<0>(l.c1, l.c2), QB::pick(px, py, py));
+  const V s0 = l.c0, s1 = QB::template bcast<0>(sc), s4 = QB::template bcast<1>(sc);
+  const V p = Tow::mul6_by_01(pick3(f.a, f.b, QB::add(f.a, f.b)), pick3(s0, QB::zero(), s0), pick3(s1, s4, QB::add(s1, s4)));
+  const V v0 = from_sub<0>(p), v1 = from_sub<1>(p), t = from_sub<2>(p);
+  f.b = QB::wred(QB::template sub<4>(QB::template sub<4>(t, v0), v1));
+  f.a = QB::wred(QB::add(v0, Tow::mul_by_gen(v1)));
+}
+// value-per-super-group storage: sub-group 0 writes, every sub-group reads
+__device__ __forceinline__ void store12_w3(uint32_t* p, const E12& f) { if (sub3() == 0) LP::store12(p, f); }
+constexpr int WIDE_SUPER = 7;                    // super-groups per wave (63 lanes): pairs per product on this path
+
+// The f_{x^3-x^2-x} loop (189 iterations, the longest chain of the whole check) is cut further.  The point arithmetic does not
+// depend on f: wave 0 of its block walks R <- 2R (+- Q) for all pairs and writes every step's line coefficients to a buffer in
+// global memory (233 steps of 1 KB per pair), bumping a counter in LDS.  The accumulator updates f <- f^2 * line are split by
+// ITERATION RANGE over three more waves: with F_h the value after h iterations, F_n = F_h^(2^(n-h)) * G where G runs the same
+// recurrence over iterations h .. n-1 starting from 1.  Wave c takes iterations [CUT[c], CUT[c+1]) from 1 and then squares
+// n - CUT[c+1] times; the product of the three results is the loop's value (k_wide_easy multiplies everything anyway).  The cuts
+// balance the three chains given where the loop's 30 additions sit (all but one in the first half): 1211 product rounds
+// instead of 2783, with the f_{x+1} loop (~900, block 0, one wave as before) beside them.  Exact arithmetic: the same field element.
+constexpr int WIDE_LINE_WORDS = 3 * 3 * 28;      // per step and pair: c0, c1, c2, each as the group's three lanes hold it
+constexpr int WIDE_CONSUMERS = 3;
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void line_store(uint32_t* p, const Pair::Line& l) {
+  const int j = LP::QB::lane();
+  l.c0.store(p + j * 28); l.c1.store(p + (3 + j) * 28); l.c2.store(p + (6 + j) * 28);
+}
+__device__ __forceinline__ Pair::Line line_load(const uint32_t* p) {
+  const int j = LP::QB::lane();
+  return {Fw::load(p + j * 28), Fw::load(p + (3 + j) * 28), Fw::load(p + (6 + j) * 28)};
+}
+__device__ __forceinline__ int loop2_digit(int it) { return T761::LOOP2_NAF[T761::LOOP2_LEN - 2 - it]; }   // iteration it = 0 .. LOOP2_LEN - 2
+// f_out: k values of the f_{x+1} loops, then WIDE_CONSUMERS * k partial values of the f_{x^3-x^2-x} loops.  k <= WIDE_SUPER pairs.
+// Waves that update an accumulator give every pair a super-group (pair = group / 3); the point wave of block 1 one group (pair = group).
+__global__ void __launch_bounds__(64 * (1 + WIDE_CONSUMERS)) LANES_OCC
+k_wide_miller(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1, const uint64_t* __restrict__ g2, const uint8_t* __restrict__ inf2,
+              uint32_t* __restrict__ f_out, uint32_t k, uint32_t* __restrict__ lines) {
+  constexpr int N = T761::LOOP2_LEN - 1;                                      // iterations of the second loop
+  constexpr int CUT[WIDE_CONSUMERS + 1] = {0, 59, 118, N};
+  constexpr int W = lanes_gt_words<LP>();
+  __shared__ uint32_t produced;                                              // line steps written so far
+  if (threadIdx.x == 0) produced = 0;
+  __syncthreads();
+  const int wave = (int)(threadIdx.x >> 6), g = QB::group();
+  if (g >= LP::GROUPS) return;
+  if (blockIdx.x == 1 && wave == 0) {                                         // the points of the second loop: one group per pair
+    const uint32_t i = (uint32_t)g;
+    if (i >= k) return;
+    const V Qc = LP::load_q(g2 + (size_t)i * LP::G2W);
+    const V Qn = QB::template sel<1>(QB::wred(QB::template neg<4>(Qc)), Qc);  // (Q.x, -Q.y)
+    V Rc = QB::template sel<2>(QB::one(), Qc);
+    uint32_t s = 0;
+#pragma unroll 1
+    for (int it = 0; it < N; it++) {
+      Pair::Line l;
+      Pair::double_step(Rc, l);
+      line_store(lines + ((size_t)s * k + i) * WIDE_LINE_WORDS, l);
+      lds_st(&produced, ++s);
+      const int d = loop2_digit(it);
+      if (d != 0) {
+        Pair::add_step(Rc, d > 0 ? Qc : Qn, l);
+        line_store(lines + ((size_t)s * k + i) * WIDE_LINE_WORDS, l);
+        lds_st(&produced, ++s);
+      }
+    }
+    return;
+  }
+  const uint32_t i = (uint32_t)(g / 3);                                       // this super-group's pair
+  if (i >= k) return;
+  const bool dead = (inf1 && inf1[i]) || (inf2 && inf2[i]);
+  const V px = LP::load_p(g1 + (size_t)i * LP::G1W, 0), py = LP::load_p(g1 + (size_t)i * LP::G1W, 1);
+  if (blockIdx.x == 0) {                                                      // the f_{x+1} loop: one wave, points and accumulator together
+    if (wave != 0) return;
+    const V Qc = LP::load_q(g2 + (size_t)i * LP::G2W);
+    V Rc = QB::template sel<2>(QB::one(), Qc);
+    E12 f = Tow::one12();
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+      f = sqr12_w3(f);
+      Pair::Line l;
+      Pair::double_step(Rc, l);
+      ell_w3(f, l, px, py);
+      if ((T761::LOOP1 >> b) & 1) {
+        Pair::add_step(Rc, Qc, l);
+        ell_w3(f, l, px, py);
+      }
+    }
+    if (dead) f = Tow::one12();
+    store12_w3(f_out + (size_t)i * W, f);
+    return;
+  }
+  const int c = wave - 1, lo = CUT[c], hi = CUT[c + 1];
+  uint32_t s = 0;                                                             // the step that holds iteration lo's doubling line
+  for (int it = 0; it < lo; it++) s += 1 + (loop2_digit(it) != 0 ? 1 : 0);
+  E12 f = Tow::one12();
+#pragma unroll 1
+  for (int it = lo; it < hi; it++) {
+    if (it != lo) f = sqr12_w3(f);
+    const int steps = 1 + (loop2_digit(it) != 0 ? 1 : 0);
+    for (int q = 0; q < steps; q++) {
+      while (lds_ld(&produced) <= s) __builtin_amdgcn_s_sleep(4);
+      const Pair::Line l = line_load(lines + ((size_t)s * k + i) * WIDE_LINE_WORDS);
+      ell_w3(f, l, px, py);
+      s++;
+    }
+  }
+#pragma unroll 1
+  for (int q = hi; q < N; q++) f = sqr12_w3(f);
+  if (dead) f = Tow::one12();
+  store12_w3(f_out + (size_t)((1 + c) * k + i) * W, f);
+}
+// f_in: k f1 values then nb f2 values (partial products of the second loops).  out: [0] = m (or the Miller value f itself when !do_fe), [1] = m^q
+__global__ void __launch_bounds__(64) LANES_OCC k_wide_easy(const uint32_t* __restrict__ f_in, uint32_t k, uint32_t nb, uint32_t* __restrict__ out, int do_fe) {
+  if (QB::group() >= 3) return;                                              // one super-group
+  constexpr int W = lanes_gt_words<LP>();
+  E12 a = LP::load12(f_in), b = LP::load12(f_in + (size_t)k * W);
+  for (uint32_t i = 1; i < k; i++) a = mul12_w3(a, LP::load12(f_in + (size_t)i * W));
+  for (uint32_t i = 1; i < nb; i++) b = mul12_w3(b, LP::load12(f_in + (size_t)(k + i) * W));
+  E12 f = mul12_w3(a, Pair::frob1(b));
   if (do_fe) {
-    f = Pair::easy_part(f);
-    LP::store12(out + W, Pair::frob1(f));
+    f = mul12_w3(Tow::conj12(f), Tow::inv12(f));                             // f^(q^3 - 1)   (Pair::easy_part)
+    f = mul12_w3(Pair::frob1(f), f);                                         // ^(q + 1)
+    store12_w3(out + W, Pair::frob1(f));
   }
-  LP::store12(out, f);
+  store12_w3(out, f);
 }
-__global__ void __launch_bounds__(64) LANES_OCC k_wide_pow(const uint32_t* __restrict__ m_in, const int8_t* __restrict__ naf0, int len0, int neg0,
-                                                           const int8_t* __restrict__ naf1, int len1, int neg1, uint32_t* __restrict__ out) {
-  if (LP::QB::group() != 0) return;
+// One ladder per block, TWO waves per ladder.  Right-to-left: wave 0 walks the squaring chain m^(2^i) (len - 1 dependent
+// squarings: the floor of this stage) and hands the powers that carry a non-zero digit to wave 1 through a ring in LDS; wave 1
+// multiplies them (or their conjugates: m is unitary) into the result.  A multiplication costs 1.5 squarings and every third
+// digit is non-zero, so wave 1 keeps up and the ladder takes the time of its squarings: the same group element as the
+// left-to-right ladder, a third less latency.
+constexpr int POW_RING = 8;
+__global__ void __launch_bounds__(128) LANES_OCC k_wide_pow(const uint32_t* __restrict__ m_in, const int8_t* __restrict__ naf0, int len0, int neg0,
+                                                            const int8_t* __restrict__ naf1, int len1, int neg1, uint32_t* __restrict__ out) {
   constexpr int W = lanes_gt_words<LP>();
+  __shared__ uint32_t ring[POW_RING * W];
+  __shared__ uint32_t produced, consumed;                                    // counts of ring entries written / read so far
   const bool second = blockIdx.x != 0;                                       // wave-uniform
-  const Tow::E12 f = LP::load12(m_in + (second ? W : 0));
-  LP::store12(out + (second ? W : 0), Pair::pow_naf(f, second ? naf1 : naf0, second ? len1 : len0, second ? neg1 != 0 : neg0 != 0));
+  const int8_t* d = second ? naf1 : naf0;
+  const int len = second ? len1 : len0;
+  if (threadIdx.x == 0) { produced = 0; consumed = 0; }
+  __syncthreads();
+  if (QB::group() >= 3) return;                                              // one super-group per wave works
+  if (threadIdx.x < 64) {
+    Tow::E12 cur = LP::load12(m_in + (second ? W : 0));
+    uint32_t np = 0;
+#pragma unroll 1
+    for (int i = 0; i < len; i++) {
+      if (d[i] != 0) {
+        while (np - lds_ld(&consumed) >= (uint32_t)POW_RING) __builtin_amdgcn_s_sleep(4);
+        store12_w3(ring + (np % POW_RING) * W, cur);
+        lds_st(&produced, ++np);
+      }
+      if (i + 1 < len) cur = sqr12_w3(cur);
+    }
+  } else {
+    Tow::E12 acc = Tow::one12();
+    bool first = true;
+    uint32_t nc = 0;
+#pragma unroll 1
+    for (int i = 0; i < len; i++) {
+      const int di = d[i];
+      if (di == 0) continue;
+      while (lds_ld(&produced) <= nc) __builtin_amdgcn_s_sleep(4);
+      Tow::E12 e = LP::load12(ring + (nc % POW_RING) * W);
+      lds_st(&consumed, ++nc);
+      if (di < 0) e = Tow::conj12(e);
+      acc = first ? e : mul12_w3(acc, e);
+      first = false;
+    }
+    const bool neg = second ? neg1 != 0 : neg0 != 0;
+    store12_w3(out + (second ? W : 0), neg ? Tow::conj12(acc) : acc);
+  }
 }
 __global__ void __launch_bounds__(64) LANES_OCC k_wide_final(const uint32_t* __restrict__ p, int do_fe, uint8_t* __restrict__ is_one, uint64_t* __restrict__ gt_ark) {
-  if (LP::QB::group() != 0) return;
+  if (QB::group() >= 3) return;
   constexpr int W = lanes_gt_words<LP>();
-  Tow::E12 r = LP::load12(p);
-  if (do_fe) r = Tow::mul12(r, LP::load12(p + W));
+  E12 r = LP::load12(p);
+  if (do_fe) r = mul12_w3(r, LP::load12(p + W));
   const bool one = Tow::is_one12(r);
+  if (sub3() != 0) return;
   if (is_one && LP::writer()) is_one[0] = one ? 1 : 0;
   if (gt_ark) LP::to_ark12(r, gt_ark);
 }
@@ -104,18 +290,18 @@ int naf_tables(NafTables& out) {                                             // 
 }
 }  // namespace
 
-// One product of k pairs, everything enqueued on `s`.  d_f: room for 2k + 4 GT values.  Returns non-zero if the tables cannot be set up.
-int wide_product_761(const uint64_t* d_g1, const uint8_t* d_i1, const uint64_t* d_g2, const uint8_t* d_i2, uint32_t k, uint32_t* d_f, uint8_t* d_one,
+// One product of k <= WIDE_SUPER (7) pairs, everything enqueued on `s`.  d_f: room for (1 + WIDE_CONSUMERS) k + 4 GT values; d_lines: wide_lines_words(k) words.
+size_t wide_lines_words_761(uint32_t k) { return (size_t)256 * k * WIDE_LINE_WORDS; }    // 189 doublings + 30 additions of the second loop, rounded up
+int wide_product_761(const uint64_t* d_g1, const uint8_t* d_i1, const uint64_t* d_g2, const uint8_t* d_i2, uint32_t k, uint32_t* d_f, uint32_t* d_lines, uint8_t* d_one,
                      uint64_t* d_gt, int do_fe, hipStream_t s) {
   NafTables t;
   if (naf_tables(t)) return 1;
   constexpr int W = lanes_gt_words<LP>();
-  const uint32_t bpl = (k + LP::GROUPS - 1) / LP::GROUPS;
-  uint32_t* d_m = d_f + (size_t)2 * k * W;      // m, m^q
-  uint32_t* d_p = d_m + 2 * W;                  // m^R0, (m^q)^R1
-  hipLaunchKernelGGL(k_wide_miller, dim3(2 * bpl), dim3(64), 0, s, d_g1, d_i1, d_g2, d_i2, d_f, k, bpl);
-  hipLaunchKernelGGL(k_wide_easy, dim3(1), dim3(64), 0, s, d_f, k, d_m, do_fe);
-  if (do_fe) hipLaunchKernelGGL(k_wide_pow, dim3(2), dim3(64), 0, s, d_m, t.d0, t.len0, T761::R0_NEG ? 1 : 0, t.d1, t.len1, T761::R1_NEG ? 1 : 0, d_p);
+  uint32_t* d_m = d_f + (size_t)(1 + WIDE_CONSUMERS) * k * W;      // m, m^q
+  uint32_t* d_p = d_m + 2 * W;                                     // m^R0, (m^q)^R1
+  hipLaunchKernelGGL(k_wide_miller, dim3(2), dim3(64 * (1 + WIDE_CONSUMERS)), 0, s, d_g1, d_i1, d_g2, d_i2, d_f, k, d_lines);
+  hipLaunchKernelGGL(k_wide_easy, dim3(1), dim3(64), 0, s, d_f, k, (uint32_t)WIDE_CONSUMERS * k, d_m, do_fe);
+  if (do_fe) hipLaunchKernelGGL(k_wide_pow, dim3(2), dim3(128), 0, s, d_m, t.d0, t.len0, T761::R0_NEG ? 1 : 0, t.d1, t.len1, T761::R1_NEG ? 1 : 0, d_p);
   hipLaunchKernelGGL(k_wide_final, dim3(1), dim3(64), 0, s, do_fe ? d_p : d_m, do_fe, d_one, d_gt);
   return 0;
 }

@@ -74,6 +74,52 @@ __device__ __forceinline__ void ell_w3(E12& f, const Pair::Line& l, const V& px,
   f.b = QB::wred(QB::template sub<4>(QB::template sub<4>(t, v0), v1));
   f.a = QB::wred(QB::add(v0, Tow::mul_by_gen(v1)));
 }
+// ---- one level further for a lone value (the ladders of the hard part): the two multiplication rounds of an Fq3 product are
+// independent as well (the own products x_j y_j and the Karatsuba cross products (x_i + x_j)(y_i + y_j)), so a value takes
+// EIGHTEEN lanes - half hh = group / 3 of a super-group computes round hh - and an Fq6 product costs the latency of ONE base
+// field multiplication.  Lane = 9 hh + 3 r + j.
+__device__ __forceinline__ int half2() { return QB::group() / 3; }                 // 0 or 1 inside the 18-lane super-group at lanes 0 .. 17
+template <int H> __device__ __forceinline__ V from_half(const V& x) {
+  const int addr = ((int)__lane_id() + 9 * (H - half2())) << 2;
+  V r;
+#pragma unroll
+  for (int i = 0; i < QB::NWORDS; i++) r.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)x.l[i]);
+  return r;
+}
+__device__ __forceinline__ V pickh(const V& a0, const V& a1) {
+  const uint32_t m = QB::lane_mask(half2() == 0);
+  V r;
+#pragma unroll
+  for (int i = 0; i < QB::NWORDS; i++) r.l[i] = (a0.l[i] & m) | (a1.l[i] & ~m);
+  return r;
+}
+__device__ __forceinline__ V mul6_h(const V& x, const V& y) {                      // Tow::mul6 with its two rounds side by side
+  const V xs = QB::add(QB::template perm<QP(1, 0, 0)>(x), QB::template perm<QP(2, 1, 2)>(x));
+  const V ys = QB::add(QB::template perm<QP(1, 0, 0)>(y), QB::template perm<QP(2, 1, 2)>(y));
+  const V p = QB::mul(pickh(x, xs), pickh(y, ys));
+  const V v = from_half<0>(p), c = from_half<1>(p);
+  const V t = QB::template sub<4>(QB::template sub<4>(c, QB::template perm<QP(1, 0, 0)>(v)), QB::template perm<QP(2, 1, 2)>(v));
+  const V vr = QB::template perm<QP(0, 2, 1)>(v);
+  const V xw = QB::mul_nr(QB::template sel<0>(t, vr));
+  return QB::wred(QB::add(QB::template sel<0>(vr, t), QB::template sel<2>(vr, xw)));
+}
+__device__ __forceinline__ int sub3h() { return QB::group() % 3; }
+__device__ __forceinline__ E12 mul12_h(const E12& x, const E12& y) {
+  const V p = mul6_h(pick3(x.a, x.b, QB::add(x.a, x.b)), pick3(y.a, y.b, QB::add(y.a, y.b)));
+  const V v0 = from_sub<0>(p), v1 = from_sub<1>(p), t = from_sub<2>(p);
+  E12 r;
+  r.b = QB::wred(QB::template sub<4>(QB::template sub<4>(t, v0), v1));
+  r.a = QB::wred(QB::add(v0, Tow::mul_by_gen(v1)));
+  return r;
+}
+__device__ __forceinline__ E12 sqr12_h(const E12& x) {
+  const V s2 = QB::wred(QB::add(x.a, Tow::mul_by_gen(x.b)));
+  const V p = mul6_h(pick3(x.a, QB::add(x.a, x.b), x.a), pick3(x.b, s2, x.b));
+  const V ab = from_sub<0>(p), t = from_sub<1>(p);
+  const V c0 = QB::template sub<64>(QB::template sub<4>(t, ab), Tow::mul_by_gen(ab));
+  return {QB::wred(c0), QB::wred(QB::dbl(ab))};
+}
+__device__ __forceinline__ void store12_h(uint32_t* p, const E12& f) { if (QB::group() == 0) LP::store12(p, f); }
 // value-per-super-group storage: sub-group 0 writes, every sub-group reads
 __device__ __forceinline__ void store12_w3(uint32_t* p, const E12& f) { if (sub3() == 0) LP::store12(p, f); }
 constexpr int WIDE_SUPER = 7;                    // super-groups per wave (63 lanes): pairs per product on this path
@@ -209,7 +255,7 @@ __global__ void __launch_bounds__(128) LANES_OCC k_wide_pow(const uint32_t* __re
   const int len = second ? len1 : len0;
   if (threadIdx.x == 0) { produced = 0; consumed = 0; }
   __syncthreads();
-  if (QB::group() >= 3) return;                                              // one super-group per wave works
+  if (QB::group() >= 6) return;                                              // one 18-lane super-group per wave works
   if (threadIdx.x < 64) {
     Tow::E12 cur = LP::load12(m_in + (second ? W : 0));
     uint32_t np = 0;
@@ -217,10 +263,10 @@ __global__ void __launch_bounds__(128) LANES_OCC k_wide_pow(const uint32_t* __re
     for (int i = 0; i < len; i++) {
       if (d[i] != 0) {
         while (np - lds_ld(&consumed) >= (uint32_t)POW_RING) __builtin_amdgcn_s_sleep(4);
-        store12_w3(ring + (np % POW_RING) * W, cur);
+        store12_h(ring + (np % POW_RING) * W, cur);
         lds_st(&produced, ++np);
       }
-      if (i + 1 < len) cur = sqr12_w3(cur);
+      if (i + 1 < len) cur = sqr12_h(cur);
     }
   } else {
     Tow::E12 acc = Tow::one12();
@@ -234,11 +280,11 @@ __global__ void __launch_bounds__(128) LANES_OCC k_wide_pow(const uint32_t* __re
       Tow::E12 e = LP::load12(ring + (nc % POW_RING) * W);
       lds_st(&consumed, ++nc);
       if (di < 0) e = Tow::conj12(e);
-      acc = first ? e : mul12_w3(acc, e);
+      acc = first ? e : mul12_h(acc, e);
       first = false;
     }
     const bool neg = second ? neg1 != 0 : neg0 != 0;
-    store12_w3(out + (second ? W : 0), neg ? Tow::conj12(acc) : acc);
+    store12_h(out + (second ? W : 0), neg ? Tow::conj12(acc) : acc);
   }
 }
 __global__ void __launch_bounds__(64) LANES_OCC k_wide_final(const uint32_t* __restrict__ p, int do_fe, uint8_t* __restrict__ is_one, uint64_t* __restrict__ gt_ark) {

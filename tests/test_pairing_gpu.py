@@ -44,6 +44,28 @@ def test_gt_values_bit_exact(gpu):
     assert np.array_equal(gt3[0], co.pairing_product_377(g1, None, g2, None)[0])
 
 
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_single_product_latency_path_bit_exact(gpu, k):
+    """ONE product of k <= 3 pairs takes the latency path (csrc/unit_pairing377_wide.hip: operations side by side in three lane
+    groups, the Miller loop cut into a point-step wave and three iteration ranges): the Miller value - a product of partial values
+    there - and the GT value must be the field elements the oracle's shared-squaring loop and final exponentiation produce
+    (what verify / verify_pop compute, crates/bls-crypto/src/bls/public.rs:71-120), also with a pair at infinity."""
+    rng = ecc.SplitMix64(4100 + k)
+    P = [ecc.E1_377.mul(ecc.G1_377, rng.next()) for _ in range(k)]
+    Q = [ecc.E2_377.mul(ecc.G2_377, rng.next()) for _ in range(k)]
+    offs = np.array([0, k], dtype=np.uint32)
+    for drop in (None, k - 1):
+        Pd = [None if j == drop else p for j, p in enumerate(P)]
+        g1, i1 = co.pack_g1_377(Pd)
+        g2, i2 = co.pack_g2_377(Q)
+        ml = gpu.pairing_gt(g1, i1, g2, i2, offs, miller_only=True)
+        gt = gpu.pairing_gt(g1, i1, g2, i2, offs)
+        assert np.array_equal(ml[0], co.miller_loop_377(g1, i1, g2, i2))
+        want, one = co.pairing_product_377(g1, i1, g2, i2)
+        assert np.array_equal(gt[0], want)
+        assert bool(gpu.pairing_product_is_one(g1, i1, g2, i2)) == bool(one)
+
+
 def test_bilinearity(gpu):
     a, b = 0x1234567890ABCDEF, 0xFEDCBA0987654321
     P, Q = ecc.G1_377, ecc.G2_377

@@ -130,8 +130,8 @@ constexpr int WIDE_SUPER = 7;                    // super-groups per wave (63 la
 // ITERATION RANGE over three more waves: with F_h the value after h iterations, F_n = F_h^(2^(n-h)) * G where G runs the same
 // recurrence over iterations h .. n-1 starting from 1.  Wave c takes iterations [CUT[c], CUT[c+1]) from 1 and then squares
 // n - CUT[c+1] times; the product of the three results is the loop's value (k_wide_easy multiplies everything anyway).  The cuts
-// balance the three chains given where the loop's 30 additions sit (all but one in the first half): 1211 product rounds
-// instead of 2783, with the f_{x+1} loop (~900, block 0, one wave as before) beside them.  Exact arithmetic: the same field element.
+// balance the three chains given where the loop's 30 additions sit (all but one in the first half) and what the point wave
+// can deliver, with the f_{x+1} loop (block 0, one wave) beside them.  Exact arithmetic: the same field element.
 constexpr int WIDE_LINE_WORDS = 3 * 3 * 28;      // per step and pair: c0, c1, c2, each as the group's three lanes hold it
 constexpr int WIDE_CONSUMERS = 3;
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -145,22 +145,85 @@ __device__ __forceinline__ Pair::Line line_load(const uint32_t* p) {
   return {Fw::load(p + j * 28), Fw::load(p + (3 + j) * 28), Fw::load(p + (6 + j) * 28)};
 }
 __device__ __forceinline__ int loop2_digit(int it) { return T761::LOOP2_NAF[T761::LOOP2_LEN - 2 - it]; }   // iteration it = 0 .. LOOP2_LEN - 2
+// ---- the point wave's steps on TWO lane groups per pair (six lanes: half hp = group % 2 of them), products that do not depend
+// on each other in the same round: a doubling is 2 dependent rounds instead of 3 (Y Z and X Y next to the three squares; the
+// products of the new point next to (2e)^2), an addition 4 instead of 5 (lambda q.y next to theta^2, lambda^2, theta q.x; the
+// two last rounds merged).  Same formulas and values as Pair::double_step / add_step (pairing_lanes.h).
+__device__ __forceinline__ int halfp() { return QB::group() & 1; }
+template <int H> __device__ __forceinline__ V from_halfp(const V& x) {
+  const int addr = ((int)__lane_id() + 3 * (H - halfp())) << 2;
+  V r;
+#pragma unroll
+  for (int i = 0; i < QB::NWORDS; i++) r.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)x.l[i]);
+  return r;
+}
+__device__ __forceinline__ V pickp(const V& a0, const V& a1) {
+  const uint32_t m = QB::lane_mask(halfp() == 0);
+  V r;
+#pragma unroll
+  for (int i = 0; i < QB::NWORDS; i++) r.l[i] = (a0.l[i] & m) | (a1.l[i] & ~m);
+  return r;
+}
+__device__ __forceinline__ void double_step_p(V& Rc, Pair::Line& l) {
+  const V X = QB::template bcast<0>(Rc), Y = QB::template bcast<1>(Rc), Z = QB::template bcast<2>(Rc);
+  // round 1: half 0: X^2, Y^2, Z^2; half 1: Y Z, X Y, (unused)
+  const V p1 = QB::mul(pickp(Rc, QB::pick(Y, X, Z)), pickp(Rc, QB::pick(Z, Y, Z)));
+  const V r1 = from_halfp<0>(p1), q1 = from_halfp<1>(p1);
+  const V b = QB::template bcast<1>(r1), c = QB::template bcast<2>(r1);
+  const V e = QB::wred(QB::dbl(QB::dbl(QB::tpl(c))));                // B' * 3c = 12 c
+  const V e_2 = QB::dbl(e);
+  const V h = QB::dbl(QB::template bcast<0>(q1));                    // 2YZ
+  const V f3 = QB::tpl(e);
+  const V g = QB::add(b, f3);
+  const V a2 = QB::dbl(QB::template bcast<1>(q1));                   // 2XY
+  const V i = QB::template sub<4>(e, b);
+  // round 2: half 0: 2a (b - f3) = X', g^2, 4b h = Z'; half 1: (2e)^2 in every lane
+  const V p2 = QB::mul(pickp(QB::pick(a2, g, QB::dbl(QB::dbl(b))), e_2), pickp(QB::pick(QB::template sub<16>(b, f3), g, h), e_2));
+  const V r3 = from_halfp<0>(p2), e2s = from_halfp<1>(p2);
+  const V y3 = QB::wred(QB::template sub<8>(r3, QB::tpl(e2s)));      // lane 1: g^2 - 3 (2e)^2
+  Rc = QB::template sel<1>(y3, r3);
+  l.c0 = QB::wred(i);
+  l.c1 = QB::wred(QB::tpl(QB::template bcast<0>(r1)));
+  l.c2 = QB::wred(QB::template neg<16>(h));
+}
+__device__ __forceinline__ void add_step_p(V& Rc, const V& Qc, Pair::Line& l) {   // Qc: lane 0 = Q.x, lane 1 = +-Q.y
+  const V X = QB::template bcast<0>(Rc), Y = QB::template bcast<1>(Rc), Z = QB::template bcast<2>(Rc);
+  const V qx = QB::template bcast<0>(Qc), qy = QB::template bcast<1>(Qc);
+  const V r1 = QB::mul(QB::template sel<0>(qy, qx), Z);               // round 1 (both halves alike)
+  const V theta = QB::template sub<4>(Y, QB::template bcast<0>(r1)), lambda = QB::template sub<4>(X, QB::template bcast<1>(r1));
+  // round 2: half 0: theta^2, lambda^2, theta q.x; half 1: lambda q.y in every lane
+  const V p2 = QB::mul(pickp(QB::pick(theta, lambda, theta), lambda), pickp(QB::pick(theta, lambda, qx), qy));
+  const V r2 = from_halfp<0>(p2), lq = from_halfp<1>(p2);
+  const V c = QB::template bcast<0>(r2), d = QB::template bcast<1>(r2);
+  const V r3 = QB::mul(QB::pick(lambda, Z, X), QB::pick(d, c, d));    // round 3: e, f, g (both halves alike)
+  const V e = QB::template bcast<0>(r3), g = QB::template bcast<2>(r3);
+  const V h = QB::template sub<8>(QB::add(e, QB::template bcast<1>(r3)), QB::dbl(g));
+  // round 4: half 0: (e Y), e Y, Z e = Z'; half 1: lambda h = X', theta (g - h)
+  const V p4 = QB::mul(pickp(QB::pick(e, e, Z), QB::template sel<0>(lambda, theta)), pickp(QB::pick(Y, Y, e), QB::template sel<0>(h, QB::template sub<16>(g, h))));
+  const V r4 = from_halfp<0>(p4), r5 = from_halfp<1>(p4);
+  l.c0 = QB::wred(QB::template sub<4>(QB::template bcast<2>(r2), lq));
+  const V y3 = QB::wred(QB::template sub<4>(r5, r4));                 // lane 1: theta (g - h) - e Y
+  Rc = QB::pick(r5, y3, r4);
+  l.c1 = QB::wred(QB::template neg<8>(theta));
+  l.c2 = QB::wred(lambda);
+}
 // f_out: k values of the f_{x+1} loops, then WIDE_CONSUMERS * k partial values of the f_{x^3-x^2-x} loops.  k <= WIDE_SUPER pairs.
 // Waves that update an accumulator give every pair a super-group (pair = group / 3); the point wave of block 1 one group (pair = group).
 __global__ void __launch_bounds__(64 * (1 + WIDE_CONSUMERS)) LANES_OCC
 k_wide_miller(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1, const uint64_t* __restrict__ g2, const uint8_t* __restrict__ inf2,
               uint32_t* __restrict__ f_out, uint32_t k, uint32_t* __restrict__ lines) {
   constexpr int N = T761::LOOP2_LEN - 1;                                      // iterations of the second loop
-  constexpr int CUT[WIDE_CONSUMERS + 1] = {0, 59, 118, N};
+  constexpr int CUT[WIDE_CONSUMERS + 1] = {0, 73, 133, N};   // balanced for: squaring 2 rounds, line product 3, doubling 2, addition 4
   constexpr int W = lanes_gt_words<LP>();
   __shared__ uint32_t produced;                                              // line steps written so far
   if (threadIdx.x == 0) produced = 0;
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6), g = QB::group();
   if (g >= LP::GROUPS) return;
-  if (blockIdx.x == 1 && wave == 0) {                                         // the points of the second loop: one group per pair
-    const uint32_t i = (uint32_t)g;
+  if (blockIdx.x == 1 && wave == 0) {                                         // the points of the second loop: two groups per pair
+    const uint32_t i = (uint32_t)(g / 2);
     if (i >= k) return;
+    const bool writer = halfp() == 0;
     const V Qc = LP::load_q(g2 + (size_t)i * LP::G2W);
     const V Qn = QB::template sel<1>(QB::wred(QB::template neg<4>(Qc)), Qc);  // (Q.x, -Q.y)
     V Rc = QB::template sel<2>(QB::one(), Qc);
@@ -168,13 +231,13 @@ k_wide_miller(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1,
 #pragma unroll 1
     for (int it = 0; it < N; it++) {
       Pair::Line l;
-      Pair::double_step(Rc, l);
-      line_store(lines + ((size_t)s * k + i) * WIDE_LINE_WORDS, l);
+      double_step_p(Rc, l);
+      if (writer) line_store(lines + ((size_t)s * k + i) * WIDE_LINE_WORDS, l);
       lds_st(&produced, ++s);
       const int d = loop2_digit(it);
       if (d != 0) {
-        Pair::add_step(Rc, d > 0 ? Qc : Qn, l);
-        line_store(lines + ((size_t)s * k + i) * WIDE_LINE_WORDS, l);
+        add_step_p(Rc, d > 0 ? Qc : Qn, l);
+        if (writer) line_store(lines + ((size_t)s * k + i) * WIDE_LINE_WORDS, l);
         lds_st(&produced, ++s);
       }
     }

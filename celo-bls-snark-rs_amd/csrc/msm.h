@@ -441,6 +441,47 @@ __global__ void __launch_bounds__(128) k_bitsum(const uint32_t* __restrict__ par
   if (mode != 4) xyzz_add(a, b);     // inlined for every field: each launch is one addition deep, its latency is the cost
   IO::store_xyzz(work + ((size_t)jobs.dst[j] + i) * IO::XYZZ_WORDS, a);
 }
+// The same launch with THREE LANES PER ADDITION (curve_lanes.h): the late levels of the reduction hold fewer additions than the
+// chip has SIMDs, each launch costs the latency of one addition on a lone wave (~20 us for G1: 14 dependent-ish products), and
+// spreading an addition's independent products over a lane group cuts that chain to 5 product rounds.  Used once a launch has
+// few enough outputs that the tripled lane count still leaves every wave a SIMD of its own.
+template <class G>
+__global__ void __launch_bounds__(64) k_bitsum_lanes(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
+                                                     const uint32_t* __restrict__ pfirst, const uint32_t* __restrict__ pieces_of, uint32_t SEG,
+                                                     uint32_t* __restrict__ work, BitsumJobs jobs) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  typedef QTriT<FieldBase<F>> QB;
+  typedef LanePoint<QB> LP;
+  const int g = QB::group();
+  const uint32_t t = blockIdx.x * 21u + (uint32_t)g;
+  if (g >= 21 || t >= jobs.end[jobs.njobs - 1]) return;
+  uint32_t j = 0;
+  while (t >= jobs.end[j]) j++;
+  const uint32_t i = t - (j ? jobs.end[j - 1] : 0u);
+  const uint32_t mode = jobs.mode[j];
+  Xyzz<F> a, b = Xyzz<F>::identity();
+  if (mode == 2) {
+    a = load_bucket<G>(partials, counts, pfirst, pieces_of, 2 * i, SEG);
+    b = load_bucket<G>(partials, counts, pfirst, pieces_of, 2 * i + 1, SEG);
+  } else if (mode == 3) {
+    a = load_bucket<G>(partials, counts, pfirst, pieces_of, 4 * i + 1, SEG);
+    b = load_bucket<G>(partials, counts, pfirst, pieces_of, 4 * i + 3, SEG);
+  } else {
+    const uint32_t* in = work + (size_t)jobs.src[j] * IO::XYZZ_WORDS;
+    const size_t ia = mode == 0 ? 2 * (size_t)i : mode == 1 ? 4 * (size_t)i + 1 : 2 * (size_t)i + 1;
+    a = IO::load_xyzz(in + ia * IO::XYZZ_WORDS);
+    if (mode != 4) b = IO::load_xyzz(in + (ia + (mode == 0 ? 1 : 2)) * IO::XYZZ_WORDS);
+  }
+  typename LP::Pt acc = {{a.X, a.Y, a.ZZ, a.ZZZ}, a.is_identity()};
+  if (mode != 4) {
+    const typename LP::P pb = {b.X, b.Y, b.ZZ, b.ZZZ};
+    LP::add(acc, pb, b.is_identity());
+  }
+  if (QB::lane() != 0) return;
+  const Xyzz<F> r = acc.inf ? Xyzz<F>::identity() : Xyzz<F>{acc.p.X, acc.p.Y, acc.p.ZZ, acc.p.ZZZ};
+  IO::store_xyzz(work + ((size_t)jobs.dst[j] + i) * IO::XYZZ_WORDS, r);
+}
 // the final results (node(0,0) and the O_l of every window), in place: device form -> arkworks limbs for the host's 64-bit
 // Horner pass (host64.h).  Its own tiny launch: inside k_bitsum the conversion doubled the register count of every level.
 template <class G>
@@ -717,6 +758,8 @@ template <class G> class MsmEngine {
   int force_c = 0;  // test hook / tuning: 0 = auto
   hipStream_t own_stream() { return stream_.get(); }   // this engine's non-blocking stream (host-pointer entry points)
   bool lane_horner = true;  // batched path: three lanes per instance in the Horner pass (tuning hook)
+  bool lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;   // big path: three lanes per addition in the late levels of the bucket reduction (A/B hook)
+  uint32_t BITSUM_LANES_MAX = getenv("CELO_LANE_BITSUM_MAX") ? (uint32_t)atoi(getenv("CELO_LANE_BITSUM_MAX")) : 21 * 1024;   // outputs of a launch: one wave of 21 additions per SIMD
 
   // bases/scalars/inf are DEVICE pointers (ark layout); result: Jacobian in ark Montgomery form (3*ARK64 u64) on host.
   int run_device(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, uint64_t* out_jac,
@@ -853,8 +896,11 @@ template <class G> class MsmEngine {
           tree = {dst, outs, true, tree.level - 1};
         }
         lists.swap(next_lists);
-        hipLaunchKernelGGL((k_bitsum<G>), dim3((total_out + 127) / 128), dim3(128), 0, stream, d_partials, d_counts, d_pfirst, d_piecesof, SEG,
-                           d_work, jobs);
+        if (lane_bitsum && total_out <= BITSUM_LANES_MAX)
+          hipLaunchKernelGGL((k_bitsum_lanes<G>), dim3((total_out + 20) / 21), dim3(64), 0, stream, d_partials, d_counts, d_pfirst, d_piecesof, SEG, d_work, jobs);
+        else
+          hipLaunchKernelGGL((k_bitsum<G>), dim3((total_out + 127) / 128), dim3(128), 0, stream, d_partials, d_counts, d_pfirst, d_piecesof, SEG,
+                             d_work, jobs);
       }
       hipLaunchKernelGGL((k_results_to_ark<G>), dim3((res_pts + 63) / 64), dim3(64), 0, stream, d_work, res_pts);
     }

@@ -353,6 +353,35 @@ __global__ void __launch_bounds__(128) k_combine_mid(const uint32_t* __restrict_
     pieces_of[t] = 1;
   }
 }
+// the same fold with three lanes per bucket (curve_lanes.h): the folds are a handful of dependent additions on lone waves (the
+// 4096 buckets of a short top window, four pieces each), i.e. latency - see k_bitsum_lanes
+template <class G>
+__global__ void __launch_bounds__(64) k_combine_mid_lanes(const uint32_t* __restrict__ mid, const uint32_t* __restrict__ nmid,
+                                                          const uint32_t* __restrict__ counts, const uint32_t* __restrict__ pfirst,
+                                                          uint32_t* __restrict__ partials, uint32_t* __restrict__ pieces_of, uint32_t SEG) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  typedef QTriT<FieldBase<F>> QB;
+  typedef LanePoint<QB> LP;
+  const int g = QB::group();
+  if (g >= 21) return;
+  for (uint32_t q = blockIdx.x * 21u + (uint32_t)g; q < *nmid; q += gridDim.x * 21u) {
+    const uint32_t t = mid[q];
+    const uint32_t pc = (counts[t] + SEG - 1) / SEG, pf = pfirst[t];
+    const Xyzz<F> a = IO::load_xyzz(partials + (size_t)pf * IO::XYZZ_WORDS);
+    typename LP::Pt acc = {{a.X, a.Y, a.ZZ, a.ZZZ}, a.is_identity()};
+    for (uint32_t k = 1; k < pc; k++) {
+      const Xyzz<F> v = IO::load_xyzz(partials + (size_t)(pf + k) * IO::XYZZ_WORDS);
+      const typename LP::P pb = {v.X, v.Y, v.ZZ, v.ZZZ};
+      LP::add(acc, pb, v.is_identity());
+    }
+    if (QB::lane() == 0) {
+      const Xyzz<F> r = acc.inf ? Xyzz<F>::identity() : Xyzz<F>{acc.p.X, acc.p.Y, acc.p.ZZ, acc.p.ZZZ};
+      IO::store_xyzz(partials + (size_t)pf * IO::XYZZ_WORDS, r);
+      pieces_of[t] = 1;
+    }
+  }
+}
 
 // ---- 5b. buckets cut into many pieces (skewed inputs): one workgroup per such bucket folds its pieces into the first
 template <class G>
@@ -854,7 +883,8 @@ template <class G> class MsmEngine {
                        d_nwork, d_partials);
     HIP_OK(hipEventRecord(ev[3], stream));
     // ---- bucket reduction
-    hipLaunchKernelGGL((k_combine_mid<G>), dim3(256), dim3(128), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
+    if (lane_bitsum) hipLaunchKernelGGL((k_combine_mid_lanes<G>), dim3(1024), dim3(64), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
+    else hipLaunchKernelGGL((k_combine_mid<G>), dim3(256), dim3(128), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
     hipLaunchKernelGGL((k_combine_big<G>), dim3(256), dim3(256), 0, stream, d_big, d_nbig, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
     {
       // work area (in points): [0, res_pts) results, then two launch-alternating halves of half_pts

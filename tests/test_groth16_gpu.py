@@ -48,3 +48,22 @@ def test_bw6_gt_bit_exact(gpu, golden):
         assert np.array_equal(gt[i], co.pairing_product_761(g1[i:i + 1], None, g2[i:i + 1], None)[0])
     gt2 = gpu.pairing_gt_bw6(g1, None, g2, None, np.array([0, 2], dtype=np.uint32))
     assert np.array_equal(gt2[0], co.pairing_product_761(g1, None, g2, None)[0])
+
+
+@pytest.mark.parametrize("k", [1, 3, 4, 7, 8])
+def test_bw6_single_product_paths_bit_exact(gpu, golden, k):
+    """ONE product of k pairs: k <= 7 takes the latency path (csrc/unit_pairing761_wide.hip: products of an Fq6 operation side by
+    side in lane groups, the long Miller loop cut into a point wave and three iteration ranges, two-wave ladders), k = 8 the
+    throughput kernels.  Miller value and GT value against the oracle's restatement of ark-ec's BW6 engine (what
+    ark_groth16::verify_proof computes at crates/epoch-snark/src/api/verifier.rs:35), also with a pair at infinity."""
+    vk, pr, _ = _groth16_setup(golden)
+    P = [ecc.E1_761.mul(vk["alpha_g1"], 3 + 2 * j) if j % 2 else ecc.E1_761.mul(pr["a"], 5 + j) for j in range(k)]
+    Q = [ecc.E2_761.mul(vk["beta_g2"], 7 + j) if j % 3 else ecc.E2_761.mul(pr["b"], 2 + j) for j in range(k)]
+    offs = np.array([0, k], dtype=np.uint32)
+    for drop in ((None, k // 2) if k > 1 else (None,)):
+        g1, i1 = co.pack_761([None if j == drop else p for j, p in enumerate(P)])
+        g2, i2 = co.pack_761(Q)
+        want, one = co.pairing_product_761(g1, i1, g2, i2)
+        gt = gpu.pairing_gt_bw6(g1, i1, g2, i2, offs)
+        assert np.array_equal(gt[0], want)
+        assert bool(gpu.pairing_product_is_one_bw6(g1, i1, g2, i2)) == bool(one)

@@ -324,28 +324,30 @@ struct PairingTimings { float miller = 0, product = 0, final_exp = 0, total = 0;
 int wide_product_761(const uint64_t* d_g1, const uint8_t* d_i1, const uint64_t* d_g2, const uint8_t* d_i2, uint32_t k, uint32_t* d_f, uint32_t* d_lines, uint8_t* d_one,
                      uint64_t* d_gt, int do_fe, hipStream_t s);
 size_t wide_lines_words_761(uint32_t k);
-int wide_product_377(const uint64_t* d_g1, const uint8_t* d_i1, const uint64_t* d_g2, const uint8_t* d_i2, uint32_t k, uint32_t* d_f, uint32_t* d_lines, uint8_t* d_one,
-                     uint64_t* d_gt, int do_fe, hipStream_t s);
+int wide_products_377(const uint64_t* d_g1, const uint8_t* d_i1, const uint64_t* d_g2, const uint8_t* d_i2, const uint32_t* d_off, uint32_t m, uint32_t kt, uint32_t* d_f,
+                      uint32_t* d_lines, uint8_t* d_one, uint64_t* d_gt, int do_fe, hipStream_t s);
 size_t wide_lines_words_377(uint32_t k);
 template <class PP> struct WideProduct {   // curves without such a path
   static constexpr bool available = false;
-  static constexpr uint32_t MAX_PAIRS = 0;
+  static constexpr uint32_t MAX_PAIRS = 0, MAX_PRODUCTS = 0;
   static size_t lines_words(uint32_t) { return 0; }
-  static int run(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, uint32_t, uint32_t*, uint32_t*, uint8_t*, uint64_t*, int, hipStream_t) { return 1; }
+  static int run(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint8_t*, uint64_t*, int, hipStream_t) { return 1; }
 };
 template <> struct WideProduct<PP377> {
   static constexpr bool available = true;
-  static constexpr uint32_t MAX_PAIRS = 3;    // one super-group of 18 lanes per pair (unit_pairing377_wide.hip)
+  static constexpr uint32_t MAX_PAIRS = 3;    // per product: one super-group of 18 lanes per pair (unit_pairing377_wide.hip)
+  static constexpr uint32_t MAX_PRODUCTS = 768;   // a block of four waves each (measured: 512 products 2.9 ms, 768: 3.5, 1024: 5.1 against 4.7 ms on the throughput kernels)
   static size_t lines_words(uint32_t k) { return wide_lines_words_377(k); }
-  static int run(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, uint32_t k, uint32_t* f, uint32_t* lines, uint8_t* one, uint64_t* gt, int do_fe,
-                 hipStream_t s) { return wide_product_377(g1, i1, g2, i2, k, f, lines, one, gt, do_fe, s); }
+  static int run(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off, uint32_t m, uint32_t k, uint32_t* f, uint32_t* lines,
+                 uint8_t* one, uint64_t* gt, int do_fe, hipStream_t s) { return wide_products_377(g1, i1, g2, i2, off, m, k, f, lines, one, gt, do_fe, s); }
 };
 template <> struct WideProduct<PP761> {
   static constexpr bool available = true;
   static constexpr uint32_t MAX_PAIRS = 7;    // one super-group of nine lanes per pair (unit_pairing761_wide.hip)
+  static constexpr uint32_t MAX_PRODUCTS = 1;
   static size_t lines_words(uint32_t k) { return wide_lines_words_761(k); }
-  static int run(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, uint32_t k, uint32_t* f, uint32_t* lines, uint8_t* one, uint64_t* gt, int do_fe,
-                 hipStream_t s) { return wide_product_761(g1, i1, g2, i2, k, f, lines, one, gt, do_fe, s); }
+  static int run(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t*, uint32_t, uint32_t k, uint32_t* f, uint32_t* lines,
+                 uint8_t* one, uint64_t* gt, int do_fe, hipStream_t s) { return wide_product_761(g1, i1, g2, i2, k, f, lines, one, gt, do_fe, s); }
 };
 
 template <class PP> class PairingEngine {
@@ -388,7 +390,7 @@ template <class PP> class PairingEngine {
     lay.o_off = take((m + 1) * 4); lay.o_f = take((4 * (size_t)k + 8) * W * 4); lay.o_f2 = take(((size_t)k / 2 + 2) * W * 4);
     lay.o_prod = take((size_t)m * W * 4); lay.o_one = take(m + 8); lay.o_gt = take((size_t)m * 72 * 8);
     lay.o_lines = take((size_t)69 * 96 * 4 + 256); lay.o_flag = take(256);
-    lay.o_wide = take(WideProduct<PP>::available && m == 1 && k <= WideProduct<PP>::MAX_PAIRS ? WideProduct<PP>::lines_words(k) * 4 : 0);
+    lay.o_wide = take(WideProduct<PP>::available && m <= WideProduct<PP>::MAX_PRODUCTS && k <= m * WideProduct<PP>::MAX_PAIRS ? WideProduct<PP>::lines_words(k) * 4 : 0);
     if (ensure(off)) return 1;
     char* A = arena;
     *st = {(uint64_t*)(A + lay.o_g1), (uint64_t*)(A + lay.o_g2), (uint8_t*)(A + lay.o_i1), (uint8_t*)(A + lay.o_i2)};
@@ -406,9 +408,11 @@ template <class PP> class PairingEngine {
     uint32_t* d_prod = (uint32_t*)(A + lay.o_prod); uint8_t* d_one = (uint8_t*)(A + lay.o_one); uint64_t* d_gt = (uint64_t*)(A + lay.o_gt);
     PAIR_HIP_OK(hipMemcpyAsync(d_off, offsets, (m + 1) * 4, hipMemcpyHostToDevice, stream));
     PAIR_HIP_OK(hipEventRecord(ev[0], stream));
-    if (WideProduct<PP>::available && m == 1 && k >= 1 && k <= WideProduct<PP>::MAX_PAIRS) {   // ONE product: the latency path (pieces side by side in several waves)
-      if (WideProduct<PP>::run(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, k, d_f, (uint32_t*)(A + lay.o_wide), out_is_one ? d_one : nullptr, out_gt ? d_gt : nullptr,
-                               mode == 0 ? 1 : 0, stream)) return 1;
+    bool wide = WideProduct<PP>::available && m <= WideProduct<PP>::MAX_PRODUCTS && k >= 1;
+    for (size_t p = 0; p < m && wide; p++) wide = offsets[p + 1] - offsets[p] <= WideProduct<PP>::MAX_PAIRS;
+    if (wide) {   // few products of few pairs: the latency path (the pieces of a product side by side in several lane groups and waves)
+      if (WideProduct<PP>::run(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, (uint32_t)m, k, d_f, (uint32_t*)(A + lay.o_wide),
+                               out_is_one ? d_one : nullptr, out_gt ? d_gt : nullptr, mode == 0 ? 1 : 0, stream)) return 1;
       PAIR_HIP_OK(hipEventRecord(ev[3], stream));
       if (out_is_one) PAIR_HIP_OK(hipMemcpyAsync(out_is_one, d_one, m, hipMemcpyDeviceToHost, stream));
       if (out_gt) PAIR_HIP_OK(hipMemcpyAsync(out_gt, d_gt, (size_t)m * 72 * 8, hipMemcpyDeviceToHost, stream));

@@ -1,6 +1,6 @@
-// Translation unit: the single-product LATENCY path of the BLS12-377 pairing check - verify / verify_pop / verify_sig of ONE
-// signature (crates/bls-crypto/src/bls/public.rs:71-120, reached from verify_signature / verify_pop of bls-snark-sys), two or three
-// pairs.  The throughput kernels give a pair (or a product) to one six-lane group from start to finish; a lone product then costs
+// Translation unit: the LATENCY path of the BLS12-377 pairing check - verify / verify_pop / verify_sig of ONE signature
+// (crates/bls-crypto/src/bls/public.rs:71-120, reached from verify_signature / verify_pop of bls-snark-sys), two or three pairs,
+// or of the few that concurrent callers bring at once (capi.hip's combined launch): up to 768 products of <= 3 pairs, a block each.  The throughput kernels give a pair (or a product) to one six-lane group from start to finish; a lone product then costs
 // one wave walking 63 Miller iterations and a 5-ladder final exponentiation with every multiplication of an Fq12 operation in
 // sequence (4.8 ms through the FFI, twice one host core).  Same treatment as unit_pairing761_wide.hip, on the six-lane backend:
 //   * a super-group of three six-lane groups (18 lanes) holds every Fq12 value three times; group r computes the r-th of the
@@ -92,20 +92,22 @@ __device__ __forceinline__ Pair::Line line_load(const uint32_t* p) {
 }
 __device__ __forceinline__ int x_bit(int it) { return (int)((T377::X >> (62 - it)) & 1); }           // iteration it = 0 .. 62
 
-// f_out: CONSUMERS * k partial Miller values.  k <= SUPER pairs.
+// One block per product (its pairs: offsets[p] .. offsets[p + 1], at most SUPER of them).  kt = pairs of the whole call;
+// f_out: CONSUMERS * kt partial Miller values ((c, pair) at c * kt + pair); lines: step-major, (step, pair) at step * kt + pair.
 __global__ void __launch_bounds__(64 * (1 + CONSUMERS)) LANES_OCC
 k377_wide_miller(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1, const uint64_t* __restrict__ g2, const uint8_t* __restrict__ inf2,
-                 uint32_t* __restrict__ f_out, uint32_t k, uint32_t* __restrict__ lines) {
+                 const uint32_t* __restrict__ offsets, uint32_t* __restrict__ f_out, uint32_t kt, uint32_t* __restrict__ lines) {
   constexpr int N = 63;
   constexpr int CUT[CONSUMERS + 1] = {0, 28, 48, N};
   __shared__ uint32_t produced;
   if (threadIdx.x == 0) produced = 0;
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6), g = QB::group();
+  const uint32_t first = offsets[blockIdx.x], k = offsets[blockIdx.x + 1] - first;     // this product's pairs
   if (g >= LP::GROUPS) return;
   if (wave == 0) {                                                            // the point steps: one six-lane group per pair
-    const uint32_t i = (uint32_t)g;
-    if (i >= k) return;
+    if ((uint32_t)g >= k) return;
+    const uint32_t i = first + (uint32_t)g;
     const V Qc = LP::load_q(g2 + (size_t)i * LP::G2W);
     V Rc = QB::template sel<2>(QB::one(), Qc);
     uint32_t s = 0;
@@ -113,18 +115,18 @@ k377_wide_miller(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ in
     for (int it = 0; it < N; it++) {
       Pair::Line l;
       Pair::double_step(Rc, l);
-      line_store(lines + ((size_t)s * k + i) * LINE_WORDS, l);
+      line_store(lines + ((size_t)s * kt + i) * LINE_WORDS, l);
       lds_st(&produced, ++s);
       if (x_bit(it)) {
         Pair::add_step(Rc, Qc, l);
-        line_store(lines + ((size_t)s * k + i) * LINE_WORDS, l);
+        line_store(lines + ((size_t)s * kt + i) * LINE_WORDS, l);
         lds_st(&produced, ++s);
       }
     }
     return;
   }
-  const uint32_t i = (uint32_t)(g / 3);                                       // this super-group's pair
-  if (g >= 3 * SUPER || i >= k) return;
+  if (g >= 3 * SUPER || (uint32_t)(g / 3) >= k) return;
+  const uint32_t i = first + (uint32_t)(g / 3);                               // this super-group's pair
   const bool dead = (inf1 && inf1[i]) || (inf2 && inf2[i]);
   const LP::F px = LP::load_p(g1 + (size_t)i * LP::G1W, 0), py = LP::load_p(g1 + (size_t)i * LP::G1W, 1);
   const int c = wave - 1, lo = CUT[c], hi = CUT[c + 1];
@@ -137,7 +139,7 @@ k377_wide_miller(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ in
     const int steps = 1 + x_bit(it);
     for (int q = 0; q < steps; q++) {
       while (lds_ld(&produced) <= s) __builtin_amdgcn_s_sleep(4);
-      const Pair::Line l = line_load(lines + ((size_t)s * k + i) * LINE_WORDS);
+      const Pair::Line l = line_load(lines + ((size_t)s * kt + i) * LINE_WORDS);
       ell_w3(f, l, px, py);
       s++;
     }
@@ -145,7 +147,7 @@ k377_wide_miller(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ in
 #pragma unroll 1
   for (int q = hi; q < N; q++) f = sqr12_w3(f);
   if (dead) f = Tow::one12();
-  store12_w3(f_out + (size_t)(c * k + i) * W377, f);
+  store12_w3(f_out + (size_t)(c * kt + i) * W377, f);
 }
 
 __device__ __attribute__((noinline)) E12 exp_by_x_w3(const E12& f) {
@@ -157,12 +159,20 @@ __device__ __attribute__((noinline)) E12 exp_by_x_w3(const E12& f) {
   }
   return acc;
 }
-// f_in: n partial Miller values; their product, then (do_fe) ark-ec's bls12 final exponentiation (pairing_lanes.h final_exponentiation_t)
-__global__ void __launch_bounds__(64) LANES_OCC k377_wide_final(const uint32_t* __restrict__ f_in, uint32_t n, int do_fe, uint8_t* __restrict__ is_one,
-                                                                uint64_t* __restrict__ gt_ark) {
+// one block per product: the product of its pairs' partial Miller values, then (do_fe) ark-ec's bls12 final exponentiation
+// (pairing_lanes.h final_exponentiation_t) on the side-by-side operations
+__global__ void __launch_bounds__(64) LANES_OCC k377_wide_final(const uint32_t* __restrict__ f_in, const uint32_t* __restrict__ offsets, uint32_t kt, int do_fe,
+                                                                uint8_t* __restrict__ is_one, uint64_t* __restrict__ gt_ark) {
   if (QB::group() >= 3) return;                                              // one super-group
-  E12 f = LP::load12(f_in);
-  for (uint32_t i = 1; i < n; i++) f = mul12_w3(f, LP::load12(f_in + (size_t)i * W377));
+  const uint32_t p = blockIdx.x, lo = offsets[p], hi = offsets[p + 1];
+  E12 f = Tow::one12();
+  bool first = true;
+  for (uint32_t i = lo; i < hi; i++)
+    for (int c = 0; c < CONSUMERS; c++) {
+      const E12 v = LP::load12(f_in + (size_t)(c * kt + i) * W377);
+      f = first ? v : mul12_w3(f, v);
+      first = false;
+    }
   if (do_fe) {
     E12 f2 = Tow::inv12(f);
     E12 r = mul12_w3(Tow::conj12(f), f2);
@@ -187,17 +197,18 @@ __global__ void __launch_bounds__(64) LANES_OCC k377_wide_final(const uint32_t* 
   }
   const bool one = Tow::is_one12(f);
   if (sub3() != 0) return;
-  if (is_one && LP::writer()) is_one[0] = one ? 1 : 0;
-  if (gt_ark) LP::to_ark12(f, gt_ark);
+  if (is_one && LP::writer()) is_one[p] = one ? 1 : 0;
+  if (gt_ark) LP::to_ark12(f, gt_ark + (size_t)p * 72);
 }
 }  // namespace
 
-size_t wide_lines_words_377(uint32_t k) { return (size_t)LINE_STEPS * k * LINE_WORDS; }
-// One product of k <= 3 pairs, everything enqueued on `s`.  d_f: room for CONSUMERS * k GT values; d_lines: wide_lines_words_377(k) words.
-int wide_product_377(const uint64_t* d_g1, const uint8_t* d_i1, const uint64_t* d_g2, const uint8_t* d_i2, uint32_t k, uint32_t* d_f, uint32_t* d_lines, uint8_t* d_one,
-                     uint64_t* d_gt, int do_fe, hipStream_t s) {
-  hipLaunchKernelGGL(k377_wide_miller, dim3(1), dim3(64 * (1 + CONSUMERS)), 0, s, d_g1, d_i1, d_g2, d_i2, d_f, k, d_lines);
-  hipLaunchKernelGGL(k377_wide_final, dim3(1), dim3(64), 0, s, d_f, (uint32_t)CONSUMERS * k, do_fe, d_one, d_gt);
+size_t wide_lines_words_377(uint32_t kt) { return (size_t)LINE_STEPS * kt * LINE_WORDS; }
+// m products of <= 3 pairs each (kt pairs in all, d_off: their offsets on the device), everything enqueued on `s`.
+// d_f: room for CONSUMERS * kt GT values; d_lines: wide_lines_words_377(kt) words.
+int wide_products_377(const uint64_t* d_g1, const uint8_t* d_i1, const uint64_t* d_g2, const uint8_t* d_i2, const uint32_t* d_off, uint32_t m, uint32_t kt, uint32_t* d_f,
+                      uint32_t* d_lines, uint8_t* d_one, uint64_t* d_gt, int do_fe, hipStream_t s) {
+  hipLaunchKernelGGL(k377_wide_miller, dim3(m), dim3(64 * (1 + CONSUMERS)), 0, s, d_g1, d_i1, d_g2, d_i2, d_off, d_f, kt, d_lines);
+  hipLaunchKernelGGL(k377_wide_final, dim3(m), dim3(64), 0, s, d_f, d_off, kt, do_fe, d_one, d_gt);
   return 0;
 }
 }  // namespace celo

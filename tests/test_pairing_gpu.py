@@ -260,3 +260,29 @@ def test_prepared_first_pair_path_at_scale(gpu):
     got3 = gpu.pairing_product_is_one_batch(g1, i1, g2c, i2, offs)
     exp3 = list(expect); exp3[300] = int(co.pairing_product_377(g1[600:602], None, g2c[600:602], None)[1])
     assert got3.tolist() == exp3
+
+
+def test_small_batches_on_the_latency_path(gpu):
+    """Up to 768 products of <= 3 pairs take the latency path a block each (what concurrent verify callers, combined into one
+    launch, or a small batch_verify bring): mixed pair counts, an empty product, a corrupted one; verdicts as constructed and GT
+    values against the oracle on a sample."""
+    rng = ecc.SplitMix64(977)
+    g1l, g2l, offs, want = [], [], [0], []
+    for p in range(40):
+        npairs = (p % 3) + 2 if p != 7 else 0                       # 2, 3 (rejects: a 4-pair product would leave the path), one empty
+        if npairs == 0:
+            offs.append(offs[-1]); want.append(True); continue
+        if npairs == 4:
+            npairs = 3
+        a, b = _signed_pairs(rng, min(npairs, 3), bad=(0 if p % 5 == 4 else None))
+        g1l += a; g2l += b
+        offs.append(offs[-1] + len(a)); want.append(p % 5 != 4)
+    g1, i1 = co.pack_g1_377(g1l)
+    g2, i2 = co.pack_g2_377(g2l)
+    offs = np.array(offs, dtype=np.uint32)
+    got = gpu.pairing_product_is_one_batch(g1, i1, g2, i2, offs)
+    assert [bool(x) for x in got.tolist()] == want
+    gt = gpu.pairing_gt(g1, i1, g2, i2, offs)
+    for p in (0, 4, 8, 39):
+        lo, hi = int(offs[p]), int(offs[p + 1])
+        assert np.array_equal(gt[p], co.pairing_product_377(g1[lo:hi], i1[lo:hi], g2[lo:hi], i2[lo:hi])[0])

@@ -10,12 +10,13 @@
 //   1 k_convert_bases   ark Montgomery (2^384 / 2^768 radix, 64-bit limbs) -> 28-bit-limb device form,
 //                       128 B (G1-377) / 256 B per affine point, coalesced in, 16-B vector stores out
 //   2 k_digits          signed c-bit digits per scalar, stored once as u16 per (window, scalar)
-//     k_count           LDS-staged counting sort, pass 1: one workgroup per (chunk, window) histograms its digits in LDS
-//     k_bucket_totals   (up to 2^15 counters = 128 KB of the CU's 160 KB LDS), no global atomics
-//     k_scan            exclusive prefix sums per window (wave shuffles + LDS)
-//     k_scatter         pass 2: LDS cursors, (point index | sign) written into per-bucket runs
-//   3 k_make_pieces     runs are cut into pieces of <= SEG points; counting sort of the pieces by length -> longest-first
-//     k_size_*          schedule, lanes of a wave get equal-length pieces
+//     k_part_hist       two-level counting sort, level 1: a window's entries are partitioned into <= 128 bins by the low bits
+//     k_part_scan       of the bucket index (per-block LDS histograms, one scan per window, LDS-staged scatter: every global
+//     k_part_scatter    store is a run of consecutive addresses)
+//     k_tile_count      level 2: a bin's region (tens of KB, L2-resident) is sorted by the remaining <= 8 bits in tiles, one
+//     k_tile_sort       workgroup each, LDS counters and staging; the region's first tile also cuts its buckets' runs into
+//   3                   pieces of <= SEG points (piece ids need no scan over the window)
+//     k_size_*          counting sort of the pieces by length -> longest-first schedule, lanes of a wave get equal-length pieces
 //   4 k_accumulate      one lane per piece: gathers its points (128 B each), XYZZ mixed adds      <- dominant kernel
 //   5 k_combine_big     (skewed inputs only) folds buckets that were cut into many pieces
 //     k_bitsum          bit-sliced bucket reduction: binary tree over the bucket index + the odd-node sums of every level
@@ -124,122 +125,301 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   }
 }
 
-// ---- 2b. per-workgroup LDS histogram: block (j, w) counts chunk j of window w; no global atomics.
+// ---- 2b. TWO-LEVEL counting sort of the (window, bucket) keys.  The first design sorted in one level - LDS histograms of all
+// 2^15 buckets per block, then a scatter of 4-byte entries into 2^15 runs per window: a block's 65536 entries land two per run,
+// every store dirties a line of its own (523 MB written for 67 MB of payload, 0.21 of that sort's 0.41 ms at 2^20; the new one
+// takes 0.18 ms, and 0.25 instead of 0.49 ms for the 24 windows of BW6-761).  Here a window's entries are first PARTITIONED into
+// NBIN <= 128 bins by the LOW bits of the bucket index (uniform even in a short top window, whose high bits are all zero): a
+// block's entries of one bin form a contiguous run of hundreds of bytes that the L2 merges into whole lines.  A bin's region is
+// then sorted by the remaining <= 8 high bits in tiles of TILE entries - one workgroup per tile, LDS counters, the region is
+// tens of KB and stays in the L2; a heavy region (skewed scalars: unit scalars put every entry into one bucket) simply has
+// more tiles, which meet through one global atomic per (tile, bucket).  The first tile of a region, knowing the final count of
+// each of its buckets, also cuts them into pieces of <= SEG points (section 3 below) with piece ids that need no scan over the window:
+//   pfirst(bucket) = w PW + bin NLO + floor(region_start / SEG) + (pieces of the earlier buckets of the region),   NLO = B / NBIN,
+// disjoint between regions because sum ceil(c_i / SEG) <= NLO + floor(sum c_i / SEG), and < (w + 1) PW with PW = B + n / SEG + 1.
+// Bucket of (bin, key): b = key << HIB | bin, HIB = log2(NBIN); runs of a window are laid out region by region, not by bucket
+// index - nothing downstream assumes an order (pieces carry their own start).
 template <class G>
-__global__ void __launch_bounds__(1024) k_count(const uint16_t* __restrict__ digits, uint32_t* __restrict__ blockcnt, uint32_t n,
-                                                uint32_t B, uint32_t chunk) {
-  extern __shared__ uint32_t lds[];
+__global__ void __launch_bounds__(1024) k_part_hist(const uint16_t* __restrict__ digits, uint32_t* __restrict__ blockcnt, uint32_t n,
+                                                    uint32_t chunk, uint32_t NBIN) {
+  __shared__ uint32_t h[128];
   const uint32_t j = blockIdx.x, w = blockIdx.y, KB = gridDim.x;
-  for (uint32_t b = threadIdx.x; b < B; b += 1024) lds[b] = 0;
+  if (threadIdx.x < 128) h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lo = j * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
   const uint16_t* dg = digits + (size_t)w * n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
-    uint32_t d = dg[i];
-    if (d != 0xFFFFu) atomicAdd(&lds[d & 0x7FFFu], 1u);
+  for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += 8 * 1024) {
+    uint32_t d[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) { const uint32_t i = i0 + k * 1024; d[k] = i < hi ? dg[i] : 0xFFFFu; }
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++)
+      if (d[k] != 0xFFFFu) atomicAdd(&h[d[k] & (NBIN - 1)], 1u);
   }
   __syncthreads();
-  uint32_t* out = blockcnt + ((size_t)w * KB + j) * B;
-  for (uint32_t b = threadIdx.x; b < B; b += 1024) out[b] = lds[b];
+  if (threadIdx.x < NBIN) blockcnt[((size_t)w * NBIN + threadIdx.x) * KB + j] = h[threadIdx.x];   // bin-major, block-minor
 }
-
-// ---- 2c. per bucket: exclusive prefix of the per-block counts over the blocks (in place) and the bucket total
+// exclusive scan of a window's NBIN x KB (<= 8192) block counts in place (-> each block's first position in each bin,
+// window-relative), the NBIN + 1 region boundaries and the prefix of the regions' tile counts; one workgroup per window
 template <class G>
-__global__ void __launch_bounds__(256) k_bucket_totals(uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ counts, uint32_t B,
-                                                       uint32_t KB, uint32_t total) {
-  uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  uint32_t w = t / B, b = t - w * B;
-  uint32_t run = 0;
-  for (uint32_t j = 0; j < KB; j++) {
-    size_t idx = ((size_t)w * KB + j) * B + b;
-    uint32_t v = blockcnt[idx];
-    blockcnt[idx] = run;
-    run += v;
-  }
-  counts[t] = run;
-}
-
-// ---- 2d. exclusive scan per window (one 1024-thread workgroup per window, wave scans + LDS) of the bucket counts
-// (-> starts) and of the piece counts ceil(count/SEG) (-> pfirst, offset by the window's static piece region w*PW).
-template <class G>
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
-                                               uint32_t* __restrict__ pfirst, uint32_t B, uint32_t SEG, uint32_t PW) {
-  __shared__ uint32_t wave_tot[16], wave_tot2[16];
-  __shared__ uint32_t running, running2;
-  const uint32_t* c = counts + (size_t)blockIdx.x * B;
-  uint32_t* st = starts + (size_t)blockIdx.x * B;
-  uint32_t* pf = pfirst + (size_t)blockIdx.x * B;
-  if (threadIdx.x == 0) { running = 0; running2 = blockIdx.x * PW; }
-  __syncthreads();
+__global__ void __launch_bounds__(1024) k_part_scan(uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ binstart,
+                                                    uint32_t* __restrict__ tileprefix, uint32_t NBIN, uint32_t KB, uint32_t TILE) {
+  __shared__ uint32_t wave_tot[16], bs[129], tw[2];
+  const uint32_t E = NBIN * KB, w = blockIdx.x;
+  uint32_t* c = blockcnt + (size_t)w * E;
+  const uint32_t PER = (E + 1023) / 1024;   // <= 8
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (uint32_t base = 0; base < B; base += 1024) {
-    uint32_t idx = base + threadIdx.x;
-    uint32_t v = idx < B ? c[idx] : 0;
-    uint32_t p = idx < B ? (v + SEG - 1) / SEG : 0;
-    uint32_t x = v, y = p;
+  uint32_t v[8], sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 8; k++) {
+    const uint32_t e = threadIdx.x * PER + k;
+    v[k] = (k < PER && e < E) ? c[e] : 0;
+    sum += v[k];
+  }
+  uint32_t x = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wave_tot[wv] = x;
+  __syncthreads();
+  uint32_t pre = 0;
+  for (int k = 0; k < wv; k++) pre += wave_tot[k];
+  uint32_t run = pre + x - sum;
+#pragma unroll
+  for (uint32_t k = 0; k < 8; k++) {
+    const uint32_t e = threadIdx.x * PER + k;
+    if (k < PER && e < E) {
+      c[e] = run;
+      if (e % KB == 0) bs[e / KB] = run;
+      run += v[k];
+    }
+  }
+  if (threadIdx.x == 1023) bs[NBIN] = pre + x;
+  __syncthreads();
+  if (threadIdx.x <= NBIN) binstart[w * (NBIN + 1) + threadIdx.x] = bs[threadIdx.x];
+  uint32_t tiles = 0, ty = 0;
+  if (threadIdx.x < 128) {   // two whole waves: exclusive scan of the regions' tile counts
+    tiles = threadIdx.x < NBIN ? (bs[threadIdx.x + 1] - bs[threadIdx.x] + TILE - 1) / TILE : 0;
+    ty = tiles;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      uint32_t x2 = __shfl_up(x, o, 64), y2 = __shfl_up(y, o, 64);
-      if (lane >= o) { x += x2; y += y2; }
+      uint32_t y2 = __shfl_up(ty, o, 64);
+      if (lane >= o) ty += y2;
     }
-    if (lane == 63) { wave_tot[wv] = x; wave_tot2[wv] = y; }
-    __syncthreads();
-    uint32_t pre = running, pre2 = running2;
-    for (int k = 0; k < wv; k++) { pre += wave_tot[k]; pre2 += wave_tot2[k]; }
-    if (idx < B) { st[idx] = pre + x - v; pf[idx] = pre2 + y - p; }
-    __syncthreads();
-    if (threadIdx.x == 1023) { running = pre + x; running2 = pre2 + y; }
-    __syncthreads();
+    if (lane == 63) tw[wv] = ty;
+  }
+  __syncthreads();
+  if (threadIdx.x < NBIN) {
+    const uint32_t excl = ty - tiles + (wv == 1 ? tw[0] : 0u);
+    tileprefix[w * (NBIN + 1) + threadIdx.x] = excl;
+    if (threadIdx.x == NBIN - 1) tileprefix[w * (NBIN + 1) + NBIN] = excl + tiles;
   }
 }
-
-// ---- 2e. scatter: block (j, w) owns LDS cursors = bucket start + this block's prefix; positions by LDS atomics
+// Scattered 4-byte stores are bound by the L2's request rate (~128 per clock chip-wide: 2^24 entries = 0.1 ms however local
+// the addresses), so both scatters stage a batch in LDS in output order and store it with consecutive lanes on consecutive
+// addresses: a wave's store covers two or three runs instead of 64 lines.
 template <class G>
-__global__ void __launch_bounds__(1024) k_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ blockcnt,
-                                                  const uint32_t* __restrict__ starts, uint32_t* __restrict__ sorted, uint32_t n,
-                                                  uint32_t B, uint32_t chunk) {
-  extern __shared__ uint32_t lds[];
-  const uint32_t j = blockIdx.x, w = blockIdx.y, KB = gridDim.x;
-  const uint32_t* bc = blockcnt + ((size_t)w * KB + j) * B;
-  const uint32_t* st = starts + (size_t)w * B;
-  for (uint32_t b = threadIdx.x; b < B; b += 1024) lds[b] = st[b] + bc[b];
-  __syncthreads();
+__global__ void __launch_bounds__(1024) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ blockoff,
+                                                       uint32_t* __restrict__ rec_idx, uint8_t* __restrict__ rec_key, uint32_t n,
+                                                       uint32_t chunk, uint32_t HIB, uint32_t NBIN) {
+  constexpr uint32_t SB = 8 * 1024;   // entries per batch
+  __shared__ uint32_t cur[128], lcnt[128], loff[128], wt[2];
+  __shared__ uint32_t st_idx[SB];
+  __shared__ uint8_t st_key[SB], st_bin[SB];
+  const uint32_t j = blockIdx.x, w = blockIdx.y, KB = gridDim.x, t = threadIdx.x;
+  if (t < 128) cur[t] = t < NBIN ? blockoff[((size_t)w * NBIN + t) * KB + j] : 0u;
   const uint32_t lo = j * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
   const uint16_t* dg = digits + (size_t)w * n;
-  uint32_t* out = sorted + (size_t)w * n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
-    uint32_t d = dg[i];
-    if (d != 0xFFFFu) {
-      uint32_t pos = atomicAdd(&lds[d & 0x7FFFu], 1u);
-      out[pos] = i | ((d >> 15) << 31);
+  uint32_t* oi = rec_idx + (size_t)w * n;
+  uint8_t* ok = rec_key + (size_t)w * n;
+  const int lane = t & 63, wv = t >> 6;
+  for (uint32_t i0 = lo; i0 < hi; i0 += SB) {
+    uint32_t d[8], r[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) { const uint32_t i = i0 + k * 1024 + t; d[k] = i < hi ? dg[i] : 0xFFFFu; }
+    if (t < 128) lcnt[t] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++)
+      if (d[k] != 0xFFFFu) r[k] = atomicAdd(&lcnt[d[k] & (NBIN - 1)], 1u);
+    __syncthreads();
+    uint32_t c = 0, x = 0;
+    if (t < 128) {   // two whole waves: exclusive scan of the batch's bin counts
+      c = lcnt[t]; x = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        uint32_t x2 = __shfl_up(x, o, 64);
+        if (lane >= o) x += x2;
+      }
+      if (lane == 63) wt[wv] = x;
     }
+    __syncthreads();
+    if (t < 128) loff[t] = x - c + (wv == 1 ? wt[0] : 0u);
+    const uint32_t valid = wt[0] + wt[1];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++)
+      if (d[k] != 0xFFFFu) {
+        const uint32_t b = d[k] & 0x7FFFu, bin = b & (NBIN - 1);
+        const uint32_t s_ = loff[bin] + r[k];
+        st_idx[s_] = (i0 + k * 1024 + t) | ((d[k] >> 15) << 31);
+        st_key[s_] = (uint8_t)(b >> HIB);
+        st_bin[s_] = (uint8_t)bin;
+      }
+    __syncthreads();
+    for (uint32_t s_ = t; s_ < valid; s_ += 1024) {
+      const uint32_t bin = st_bin[s_];
+      const uint32_t dest = cur[bin] + (s_ - loff[bin]);
+      oi[dest] = st_idx[s_];
+      ok[dest] = st_key[s_];
+    }
+    __syncthreads();
+    if (t < 128) cur[t] += c;
+  }
+}
+// level 2.  Workgroup (x, w) is tile x of window w: region `bin` by binary search over the tile prefix, its z-th part (all of a
+// lane's loads in flight at once).
+constexpr uint32_t TILE_EPT = 10;   // entries per lane of a tile workgroup (registers); a tile holds up to TILE_EPT * blockDim entries
+__device__ __forceinline__ bool tile_locate(const uint32_t* __restrict__ tp, uint32_t NBIN, uint32_t x, uint32_t& bin, uint32_t& z,
+                                            uint32_t& tiles) {
+  if (x >= tp[NBIN]) return false;
+  uint32_t lo = 0, hi = NBIN;          // the bin with tp[bin] <= x < tp[bin + 1] (tp non-decreasing; empty regions repeat a value)
+  while (hi - lo > 1) {
+    const uint32_t m = (lo + hi) >> 1;
+    if (tp[m] <= x) lo = m; else hi = m;
+  }
+  bin = lo; z = x - tp[lo]; tiles = tp[lo + 1] - tp[lo];
+  return true;
+}
+// a region of rc entries is cut into `tiles` equal parts (the tile capacity leaves slack over the mean region, so that the usual
+// region is ONE tile and not a full tile plus a sliver)
+__device__ __forceinline__ void tile_range(uint32_t rs, uint32_t re, uint32_t z, uint32_t tiles, uint32_t& tile_lo, uint32_t& tile_n) {
+  const uint32_t rc = re - rs, per = (rc + tiles - 1) / tiles;
+  tile_lo = rs + z * per;
+  tile_n = tile_lo >= re ? 0u : (re - tile_lo < per ? re - tile_lo : per);
+}
+template <class G>
+__global__ void __launch_bounds__(1024) k_tile_count(const uint8_t* __restrict__ rec_key, const uint32_t* __restrict__ binstart,
+                                                     const uint32_t* __restrict__ tileprefix, uint32_t* __restrict__ counts, uint32_t n,
+                                                     uint32_t B, uint32_t HIB, uint32_t NBIN) {
+  __shared__ uint32_t cnt[256];
+  const uint32_t w = blockIdx.y, t = threadIdx.x, bd = blockDim.x;
+  uint32_t bin, z, tiles, tile_lo, tile_n;
+  if (!tile_locate(tileprefix + w * (NBIN + 1), NBIN, blockIdx.x, bin, z, tiles)) return;
+  tile_range(binstart[w * (NBIN + 1) + bin], binstart[w * (NBIN + 1) + bin + 1], z, tiles, tile_lo, tile_n);
+  if (t < 256) cnt[t] = 0;
+  __syncthreads();
+  const uint8_t* kp = rec_key + (size_t)w * n + tile_lo;
+  uint32_t key[TILE_EPT];
+#pragma unroll
+  for (uint32_t k = 0; k < TILE_EPT; k++) { const uint32_t e = k * bd + t; key[k] = e < tile_n ? kp[e] : 0xFFFFFFFFu; }
+#pragma unroll
+  for (uint32_t k = 0; k < TILE_EPT; k++)
+    if (key[k] != 0xFFFFFFFFu) atomicAdd(&cnt[key[k]], 1u);
+  __syncthreads();
+  if (t < 256 && cnt[t]) atomicAdd(&counts[w * B + ((t << HIB) | bin)], cnt[t]);
+}
+// `cursor` (zeroed) hands every tile its offset inside each bucket's run: one global atomic per (tile, non-empty bucket)
+template <class G>
+__global__ void __launch_bounds__(1024) k_tile_sort(const uint32_t* __restrict__ rec_idx, const uint8_t* __restrict__ rec_key,
+                                                    const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ tileprefix,
+                                                    const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursor,
+                                                    uint32_t* __restrict__ sorted, uint32_t* __restrict__ pfirst,
+                                                    uint32_t* __restrict__ pstart, uint32_t* __restrict__ plen, uint32_t* __restrict__ big,
+                                                    uint32_t* __restrict__ nbig, uint32_t* __restrict__ mid, uint32_t* __restrict__ nmid,
+                                                    uint32_t n, uint32_t B, uint32_t HIB, uint32_t NBIN, uint32_t SEG, uint32_t PW) {
+  __shared__ uint32_t cnt[256], cur[256], loff[256], wt[4], wt2[4], wt3[4], lists[4];
+  __shared__ uint32_t st_idx[TILE_EPT * 1024];
+  __shared__ uint8_t st_key[TILE_EPT * 1024];
+  const uint32_t w = blockIdx.y, t = threadIdx.x, bd = blockDim.x, NLO = B >> HIB;
+  uint32_t bin, z, tiles, tile_lo, tile_n;
+  if (!tile_locate(tileprefix + w * (NBIN + 1), NBIN, blockIdx.x, bin, z, tiles)) return;
+  const uint32_t rs = binstart[w * (NBIN + 1) + bin];
+  tile_range(rs, binstart[w * (NBIN + 1) + bin + 1], z, tiles, tile_lo, tile_n);
+  if (t < 256) cnt[t] = 0;
+  if (t < 4) lists[t] = 0;
+  uint32_t lrank = 0;
+  __syncthreads();
+  const uint8_t* kp = rec_key + (size_t)w * n + tile_lo;
+  const uint32_t* ip = rec_idx + (size_t)w * n + tile_lo;
+  uint32_t key[TILE_EPT], idx[TILE_EPT], r[TILE_EPT];
+#pragma unroll
+  for (uint32_t k = 0; k < TILE_EPT; k++) {
+    const uint32_t e = k * bd + t;
+    key[k] = e < tile_n ? kp[e] : 0xFFFFFFFFu;
+    idx[k] = e < tile_n ? ip[e] : 0u;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < TILE_EPT; k++)
+    if (key[k] != 0xFFFFFFFFu) r[k] = atomicAdd(&cnt[key[k]], 1u);
+  __syncthreads();
+  uint32_t v = 0, p = 0, mine = 0, x = 0, y = 0, q = 0;
+  const uint32_t g = w * B + ((t << HIB) | bin);      // bucket of thread t < NLO
+  const int lane = t & 63, wv = t >> 6;
+  if (t < 256) {   // four whole waves: exclusive scans of the region's bucket counts and piece counts and of the tile's own counts
+    v = t < NLO ? counts[g] : 0;
+    p = (v + SEG - 1) / SEG;
+    mine = cnt[t];
+    x = v; y = p; q = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t x2 = __shfl_up(x, o, 64), y2 = __shfl_up(y, o, 64), q2 = __shfl_up(q, o, 64);
+      if (lane >= o) { x += x2; y += y2; q += q2; }
+    }
+    if (lane == 63) { wt[wv] = x; wt2[wv] = y; wt3[wv] = q; }
+  }
+  __syncthreads();
+  if (t < 256) {
+    uint32_t pre = 0, pre2 = 0, pre3 = 0;
+    for (int k = 0; k < wv; k++) { pre += wt[k]; pre2 += wt2[k]; pre3 += wt3[k]; }
+    loff[t] = pre3 + q - mine;
+    if (t < NLO) {
+      const uint32_t st = rs + pre + x - v;                                    // window-relative start of the bucket's run
+      cur[t] = st + (mine ? atomicAdd(&cursor[g], mine) : 0u);
+      if (z == 0) {
+        const uint32_t pf = w * PW + bin * NLO + rs / SEG + pre2 + y - p;
+        pfirst[g] = pf;
+        if (v) {
+          const uint32_t s_ = w * n + st;
+          for (uint32_t k = 0; k < p; k++) {
+            pstart[pf + k] = s_ + k * SEG;
+            plen[pf + k] = (v - k * SEG < SEG) ? v - k * SEG : SEG;
+          }
+          // multi-piece buckets go on the fold lists: ranks from LDS, ONE global atomic per workgroup and list (every bucket of
+          // a short top window is on the mid list - 4096 atomics on one address took 40 us)
+          if (p > 16) lrank = atomicAdd(&lists[0], 1u) | 0x80000000u;
+          else if (p > 1) lrank = atomicAdd(&lists[1], 1u) | 0x40000000u;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (z == 0) {
+    if (t < 2 && lists[t]) lists[2 + t] = atomicAdd(t == 0 ? nbig : nmid, lists[t]);
+    __syncthreads();
+    if (lrank & 0x80000000u) big[lists[2] + (lrank & 0x3FFFFFFFu)] = g;
+    else if (lrank & 0x40000000u) mid[lists[3] + (lrank & 0x3FFFFFFFu)] = g;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < TILE_EPT; k++)
+    if (key[k] != 0xFFFFFFFFu) {
+      const uint32_t s_ = loff[key[k]] + r[k];
+      st_idx[s_] = idx[k];
+      st_key[s_] = (uint8_t)key[k];
+    }
+  __syncthreads();
+  uint32_t* out = sorted + (size_t)w * n;
+  for (uint32_t s_ = t; s_ < tile_n; s_ += bd) {
+    const uint32_t kk = st_key[s_];
+    out[cur[kk] + (s_ - loff[kk])] = st_idx[s_];
   }
 }
 
 // ---- 3. work items.  A bucket's run is cut into pieces of at most SEG points so that no lane works much longer than
 // the average (the top window of a 253-bit scalar has ~12 significant bits -> 16x fewer, 16x longer buckets; skewed
 // inputs are worse).  Piece ids of bucket t: pfirst[t] .. pfirst[t] + ceil(count/SEG) - 1 (a static region per window).
-template <class G>
-__global__ void __launch_bounds__(256) k_make_pieces(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
-                                                     const uint32_t* __restrict__ pfirst, uint32_t* __restrict__ pstart,
-                                                     uint32_t* __restrict__ plen, uint32_t* __restrict__ big, uint32_t* __restrict__ nbig,
-                                                     uint32_t* __restrict__ mid, uint32_t* __restrict__ nmid,
-                                                     uint32_t B, uint32_t SEG, uint32_t n, uint32_t total) {
-  uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  uint32_t c = counts[t];
-  if (c == 0) return;
-  uint32_t w = t / B;
-  uint32_t pc = (c + SEG - 1) / SEG, pf = pfirst[t], s = w * n + starts[t];
-  for (uint32_t k = 0; k < pc; k++) {
-    pstart[pf + k] = s + k * SEG;
-    plen[pf + k] = (c - k * SEG < SEG) ? c - k * SEG : SEG;
-  }
-  if (pc > 16) big[atomicAdd(nbig, 1u)] = t;
-  else if (pc > 1) mid[atomicAdd(nmid, 1u)] = t;
-}
-
 // longest-first schedule of the pieces: counting sort by length (descending); zero-length slots are dropped
 constexpr uint32_t SIZE_BINS = 2048;  // SEG < SIZE_BINS
 template <class G>
@@ -801,12 +981,6 @@ template <class G> class MsmEngine {
     if ((uint64_t)n * (uint64_t)nw >= (uint64_t(1) << 32)) return 2;  // run offsets are 32-bit (n*windows < 2^32: n <= 2^27 at c = 16)
     const uint32_t B = 1u << (c - 1);
     const uint32_t total = (uint32_t)nw * B;
-    // blocks per window for the LDS counting sort: fill the chip, at least ~4096 digits per block
-    uint32_t KB = 256 / (uint32_t)nw;
-    if (KB < 1) KB = 1;
-    while (KB > 1 && (n + KB - 1) / KB < 4096) KB >>= 1;
-    if (KB > 64) KB = 64;
-    const uint32_t chunk = (n + KB - 1) / KB;
     // piece length: twice the average bucket, within [32, SIZE_BINS-1]
     uint32_t SEG = 2 * (n / B + 1);
     if (SEG < 32) SEG = 32;
@@ -823,17 +997,30 @@ template <class G> class MsmEngine {
     const size_t o_bases = take((size_t)n * IO::AFF_WORDS * 4);
     const size_t o_digits = take((size_t)n * nw * 2);
     const size_t o_sorted = take((size_t)n * nw * 4);
-    const size_t o_blockcnt = take((size_t)nw * KB * B * 4);
+    // two-level sort: NBIN bins per window by the low HIB bucket bits, KB2 blocks per window in the partition pass
+    const uint32_t HIB = LB < 8 ? 0u : (uint32_t)LB - 8u, NBIN = 1u << HIB;     // bins by the low HIB bucket bits, <= 8 key bits above
+    uint32_t KB2 = n / (64 * NBIN > 4096 ? 64 * NBIN : 4096);
+    if (KB2 < 1) KB2 = 1;
+    if (KB2 > 64) KB2 = 64;
+    const uint32_t chunk2 = (n + KB2 - 1) / KB2;
+    const size_t o_blockcnt = take((size_t)nw * NBIN * KB2 * 4);
+    const size_t o_binstart = take((size_t)nw * (NBIN + 1) * 4);
+    const size_t o_tileprefix = take((size_t)nw * (NBIN + 1) * 4);
+    const size_t o_recidx = take((size_t)n * nw * 4);
+    const size_t o_reckey = take((size_t)n * nw);
+    // zeroed per call, adjacent so that ONE fill covers them: bucket counts, the tiles' run cursors (`starts`), the folded-bucket
+    // flags, the piece lengths (unused slots stay 0) and the size bins with their counters
     const size_t o_counts = take((size_t)total * 4);
     const size_t o_starts = take((size_t)total * 4);
-    const size_t o_pfirst = take((size_t)total * 4);
     const size_t o_piecesof = take((size_t)total * 4);
+    const size_t o_plen = take((size_t)slots * 4);
+    const size_t o_bins = take((size_t)SIZE_BINS * 4 + 256);  // + nwork, nbig, nmid
+    const size_t o_zero_end = off;
+    const size_t o_pfirst = take((size_t)total * 4);
     const size_t o_big = take((size_t)total * 4);
     const size_t o_mid = take((size_t)total * 4);
     const size_t o_pstart = take((size_t)slots * 4);
-    const size_t o_plen = take((size_t)slots * 4);
     const size_t o_order = take((size_t)slots * 4);
-    const size_t o_bins = take((size_t)SIZE_BINS * 4 + 256);  // + nwork, nbig
     const size_t o_partials = take((size_t)slots * IO::XYZZ_WORDS * 4);
     const size_t o_work = take(((size_t)res_pts + 2 * (size_t)half_pts + 64) * IO::XYZZ_WORDS * 4);
     if (ensure(off)) return 1;
@@ -843,6 +1030,10 @@ template <class G> class MsmEngine {
     uint16_t* d_digits = (uint16_t*)(A + o_digits);
     uint32_t* d_sorted = (uint32_t*)(A + o_sorted);
     uint32_t* d_blockcnt = (uint32_t*)(A + o_blockcnt);
+    uint32_t* d_binstart = (uint32_t*)(A + o_binstart);
+    uint32_t* d_recidx = (uint32_t*)(A + o_recidx);
+    uint8_t* d_reckey = (uint8_t*)(A + o_reckey);
+    uint32_t* d_tileprefix = (uint32_t*)(A + o_tileprefix);
     uint32_t* d_counts = (uint32_t*)(A + o_counts);
     uint32_t* d_starts = (uint32_t*)(A + o_starts);
     uint32_t* d_pfirst = (uint32_t*)(A + o_pfirst);
@@ -864,16 +1055,18 @@ template <class G> class MsmEngine {
     HIP_OK(hipEventRecord(ev[1], stream));
     // ---- sort
     if (launch_digits(c, d_scalars, d_inf, d_digits, n, stream)) return 3;
-    hipLaunchKernelGGL((k_count<G>), dim3(KB, nw), dim3(1024), B * 4, stream, d_digits, d_blockcnt, n, B, chunk);
-    hipLaunchKernelGGL((k_bucket_totals<G>), dim3((total + 255) / 256), dim3(256), 0, stream, d_blockcnt, d_counts, B, KB, total);
-    hipLaunchKernelGGL((k_scan<G>), dim3(nw), dim3(1024), 0, stream, d_counts, d_starts, d_pfirst, B, SEG, PW);
-    hipLaunchKernelGGL((k_scatter<G>), dim3(KB, nw), dim3(1024), B * 4, stream, d_digits, d_blockcnt, d_starts, d_sorted, n, B, chunk);
+    HIP_OK(hipMemsetAsync(d_counts, 0, o_zero_end - o_counts, stream));
+    // mean region n / NBIN: the smallest workgroup whose tile capacity (TILE_EPT entries per lane) holds it with 20 % to spare
+    const uint32_t region = n / NBIN;
+    const uint32_t ts_threads = region <= 2048 ? 256u : region <= 4096 ? 512u : 1024u;
+    const uint32_t TILE = TILE_EPT * ts_threads, max_tiles = NBIN + n / TILE + 1;
+    hipLaunchKernelGGL((k_part_hist<G>), dim3(KB2, nw), dim3(1024), 0, stream, d_digits, d_blockcnt, n, chunk2, NBIN);
+    hipLaunchKernelGGL((k_part_scan<G>), dim3(nw), dim3(1024), 0, stream, d_blockcnt, d_binstart, d_tileprefix, NBIN, KB2, TILE);
+    hipLaunchKernelGGL((k_part_scatter<G>), dim3(KB2, nw), dim3(1024), 0, stream, d_digits, d_blockcnt, d_recidx, d_reckey, n, chunk2, HIB, NBIN);
+    hipLaunchKernelGGL((k_tile_count<G>), dim3(max_tiles, nw), dim3(ts_threads), 0, stream, d_reckey, d_binstart, d_tileprefix, d_counts, n, B, HIB, NBIN);
+    hipLaunchKernelGGL((k_tile_sort<G>), dim3(max_tiles, nw), dim3(ts_threads), 0, stream, d_recidx, d_reckey, d_binstart, d_tileprefix, d_counts,
+                       d_starts, d_sorted, d_pfirst, d_pstart, d_plen, d_big, d_nbig, d_mid, d_nmid, n, B, HIB, NBIN, SEG, PW);
     // ---- work items, longest first
-    HIP_OK(hipMemsetAsync(d_plen, 0, (size_t)slots * 4, stream));
-    HIP_OK(hipMemsetAsync(d_bins, 0, (size_t)SIZE_BINS * 4 + 256, stream));
-    HIP_OK(hipMemsetAsync(d_piecesof, 0, (size_t)total * 4, stream));
-    hipLaunchKernelGGL((k_make_pieces<G>), dim3((total + 255) / 256), dim3(256), 0, stream, d_counts, d_starts, d_pfirst, d_pstart,
-                       d_plen, d_big, d_nbig, d_mid, d_nmid, B, SEG, n, total);
     hipLaunchKernelGGL((k_size_hist<G>), dim3(slots / 256 < 512 ? (slots + 255) / 256 : 512), dim3(256), 0, stream, d_plen, d_bins, slots);
     hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
     hipLaunchKernelGGL((k_size_scatter<G>), dim3((slots + 4095) / 4096), dim3(1024), 0, stream, d_plen, d_bins, d_order, slots);
@@ -1154,9 +1347,6 @@ template <class G> class MsmEngine {
       for (int i = 0; i < 6; i++) HIP_OK(hipEventCreate(&ev[i]));
     if (!h_out) {
       HIP_OK(hipHostMalloc(&h_out, H_OUT_POINTS * IO::XYZZ_WORDS * 4));
-      // the LDS histograms use up to 128 KB of dynamic LDS (2^15 counters)
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_count<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     if (bytes > arena_bytes) {
       if (arena) (void)hipFree(arena);

@@ -77,10 +77,12 @@ def test_g1_skewed_scalars(gpu):
     assert _affine(gpu.msm("bls12_377_g1", xy, inf, s), "g1_377") == exp
 
 
-def test_g1_heavy_skew_large(gpu):
-    """Skew at a size where runs are cut into many pieces (k_combine_mid / k_combine_big): 2^16 points, (a) every scalar
-    equal -> one bucket per window holds all points, (b) witness-like: 40% zero, 30% one, rest uniform."""
-    n = 1 << 16
+@pytest.mark.parametrize("logn", [16, 20])
+def test_g1_heavy_skew_large(gpu, logn):
+    """Skew at sizes where runs are cut into many pieces (k_combine_mid / k_combine_big) and one region of the two-level sort
+    spans many tiles (k_tile_count / k_tile_sort; 2^20 is the 16-bit-window, 128-bin configuration of the headline): (a) every
+    scalar equal -> one bucket per window holds all points, (b) witness-like: 40% zero, 30% one, rest uniform."""
+    n = 1 << logn
     gen, _ = co.pack_g1_377([ecc.G1_377])
     bases = _gen_points_gpu(gpu, "bls12_377_g1", n, 0xABCD, gen.reshape(-1), 12)
     h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 12)

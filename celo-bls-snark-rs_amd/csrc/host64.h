@@ -141,4 +141,18 @@ template <class H> inline void hxyzz_add(HXyzz<H>& a, const HXyzz<H>& b) {
   a = {X3, R * (Q - X3) - S1 * PPP, a.ZZ * b.ZZ * PP, a.ZZZ * b.ZZZ * PPP};
 }
 
+// The Horner recombination of the big MSM's per-window results as a list of steps over point slots (msm.h builds the list):
+// step k doubles the accumulator (unless bit 30 of order[k] is set), then adds slot order[k] & 0x3fffffff (order[k] = -1: no
+// addend).  A slot is `stride` u64: X, Y, ZZ, ZZZ at multiples of `cs` words, arkworks form, ZZ = 0: identity.  host_ifma.cpp
+// runs the same list eight products at a time where the CPU has AVX-512 IFMA.
+constexpr int32_t HORNER_NODBL = 0x40000000;
+template <class H> inline HXyzz<H> host64_horner(const uint64_t* pts, size_t stride, int cs, const int32_t* order, int steps) {
+  HXyzz<H> acc = HXyzz<H>::identity();
+  for (int k = 0; k < steps; k++) {
+    if (order[k] < 0 || !(order[k] & HORNER_NODBL)) acc = hxyzz_dbl(acc);
+    if (order[k] >= 0) hxyzz_add(acc, HXyzz<H>::load(pts + (size_t)(order[k] & 0x3fffffff) * stride, cs));
+  }
+  return acc;
+}
+
 }  // namespace celo

@@ -7,6 +7,7 @@
 #include "curve_lanes.h"
 #include "wire.h"
 #include "hash_direct.h"
+#include "host64.h"
 #include <cstring>
 using namespace celo;
 
@@ -251,6 +252,9 @@ static void pairing_op_761(int mode, const uint64_t* g1, const uint64_t* g2, siz
   if (is_one) *is_one = quad_is_one(r) ? 1 : 0;
 }
 
+extern "C" int celo_ifma_available();
+extern "C" int celo_ifma_horner_377(const uint64_t* pts, size_t stride, const int32_t* order, int steps, uint64_t* out, int* inf);
+extern "C" int celo_ifma_horner_761(const uint64_t* pts, size_t stride, const int32_t* order, int steps, uint64_t* out, int* inf);
 extern "C" {
 // wire.h under bounds tracking: n compressed points -> affine ark limbs + status (the GPU kernels run the same functions)
 void ht_wire_decode(int g2, const uint8_t* in, size_t n, int check, uint64_t* out, uint8_t* status) {
@@ -341,6 +345,17 @@ void ht_lane_g2_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, 
 void ht_lane_g2_377_hex(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { lane_point_op_hex(op, p1, p2, k, out); }
 void ht_lane_g_761(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { lane_point_op<Fp<P761>>(op, p1, p2, k, out); }
 void ht_g_761(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { point_op<Fp<P761>>(op, p1, p2, k, out); }
+// Horner step lists (host64.h) on the 64-bit-limb path and on the IFMA path (host_ifma.cpp), field 0: BLS12-377 Fq, 1: BW6-761 Fq.
+// out: X, Y, ZZ, ZZZ (arkworks form; all zero = identity).  ht_horner_ifma returns -1 without AVX-512 IFMA, 1 on a special case.
+void ht_horner64(int field, const uint64_t* pts, size_t stride, const int32_t* order, int steps, uint64_t* out) {
+  if (field == 0) { auto r = host64_horner<HFp<P377>>(pts, stride, 6, order, steps); r.X.store(out); r.Y.store(out + 6); r.ZZ.store(out + 12); r.ZZZ.store(out + 18); }
+  else { auto r = host64_horner<HFp<P761>>(pts, stride, 12, order, steps); r.X.store(out); r.Y.store(out + 12); r.ZZ.store(out + 24); r.ZZZ.store(out + 36); }
+}
+int ht_horner_ifma(int field, const uint64_t* pts, size_t stride, const int32_t* order, int steps, uint64_t* out) {
+  if (!celo_ifma_available()) return -1;
+  int inf = 0;
+  return field == 0 ? celo_ifma_horner_377(pts, stride, order, steps, out, &inf) : celo_ifma_horner_761(pts, stride, order, steps, out, &inf);
+}
 void ht_fq377_canon(const uint64_t* canon, uint64_t* out_ark, uint64_t* out_canon) {
   Fp<P377> x = Fp<P377>::from_canonical(canon);
   x.to_ark(out_ark);

@@ -931,6 +931,15 @@ template <> struct BatchHornerLanes<G2_377> {
 };
 
 // ---------------------------------------------------------------- host driver
+// the IFMA Horner epilogue (host_ifma.cpp, host_cpu.cpp) exists for the two prime fields
+extern "C" int celo_ifma_available();
+extern "C" int celo_ifma_horner_377(const uint64_t* pts, size_t stride, const int32_t* order, int steps, uint64_t* out, int* inf);
+extern "C" int celo_ifma_horner_761(const uint64_t* pts, size_t stride, const int32_t* order, int steps, uint64_t* out, int* inf);
+typedef int (*ifma_horner_fn)(const uint64_t*, size_t, const int32_t*, int, uint64_t*, int*);
+template <class F> struct IfmaHorner { static constexpr ifma_horner_fn fn = nullptr; };
+template <> struct IfmaHorner<Fp<P377>> { static constexpr ifma_horner_fn fn = &celo_ifma_horner_377; };
+template <> struct IfmaHorner<Fp<P761>> { static constexpr ifma_horner_fn fn = &celo_ifma_horner_761; };
+
 struct MsmTimings {  // milliseconds, HIP events on the MSM's stream (last call)
   float convert = 0, sort = 0, accumulate = 0, reduce = 0, total = 0;
 };
@@ -1139,19 +1148,29 @@ template <class G> class MsmEngine {
     (void)hipEventElapsedTime(&tm.total, ev[0], ev[5]);
     last_c = c; last_nw = nw; last_buckets = total;
     // ---- host epilogue: total = sum_w 2^(c w) (node_w + sum_l 2^(LB-l) O_{w,l}): one Horner pass, c doublings and c additions per
-    // window, on 64-bit limbs (host64.h; the results arrive as arkworks limbs)
+    // window (the results arrive as arkworks limbs), as a list of steps: on AVX-512 IFMA where the CPU has it (host_ifma.cpp: the
+    // products of one point operation eight at a time, 0.24 -> ~0.1 ms for 253-bit scalars), else - or if that path meets equal or
+    // opposite operands, which it does not handle - on 64-bit limbs (host64.h)
     typedef typename HostField<F>::type HF;
     const uint64_t* h64 = reinterpret_cast<const uint64_t*>(h_out);
     constexpr size_t PT64 = (size_t)IO::XYZZ_WORDS / 2;
-    HXyzz<HF> total_pt = HXyzz<HF>::identity();
+    horner_steps.clear();
     for (int w = nw - 1; w >= 0; w--) {
-      total_pt = hxyzz_dbl(total_pt);
-      for (int l = 1; l <= LB; l++) {
-        total_pt = hxyzz_dbl(total_pt);
-        hxyzz_add(total_pt, HXyzz<HF>::load(h64 + ((size_t)l * nw + w) * PT64, IO::ARK64));
-      }
-      hxyzz_add(total_pt, HXyzz<HF>::load(h64 + (size_t)w * PT64, IO::ARK64));
+      horner_steps.push_back(-1);
+      for (int l = 1; l <= LB; l++) horner_steps.push_back(l * nw + w);
+      horner_steps.push_back(w | HORNER_NODBL);
     }
+    HXyzz<HF> total_pt;
+    bool done = false;
+    if (IfmaHorner<F>::fn && celo_ifma_available()) {
+      uint64_t r[4 * IO::ARK64];
+      int inf = 0;
+      if (IfmaHorner<F>::fn(h64, PT64, horner_steps.data(), (int)horner_steps.size(), r, &inf) == 0) {
+        total_pt = inf ? HXyzz<HF>::identity() : HXyzz<HF>::load(r, IO::ARK64);
+        done = true;
+      }
+    }
+    if (!done) total_pt = host64_horner<HF>(h64, PT64, IO::ARK64, horner_steps.data(), (int)horner_steps.size());
     if (total_pt.is_identity()) { write_identity(out_jac); return 0; }
     (total_pt.X * total_pt.ZZ).store(out_jac);                 // (X ZZ, Y ZZZ, ZZ) is a Jacobian representative with Z = ZZ
     (total_pt.Y * total_pt.ZZZ).store(out_jac + IO::ARK64);
@@ -1339,6 +1358,7 @@ template <class G> class MsmEngine {
   uint32_t* h_out = nullptr;
   static constexpr size_t H_OUT_POINTS = 17 * 64;   // pinned result buffer: (LB + 1) * windows points; checked per call
   OwnedStream stream_;
+  std::vector<int32_t> horner_steps;   // the host epilogue's step list (host64.h), rebuilt per call
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap_in = 0;
 

@@ -32,3 +32,13 @@ def splitmix64_at(seed, i):
     z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
     z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
     return z ^ (z >> 31)
+
+
+def build_hosttest():
+    """Builds (make decides whether anything is stale) and returns the path of the host-only bounds-tracking library: host_test.cpp
+    with -DCELO_FP_TRACK plus the host units it exercises (the IFMA Horner epilogue and the CPU probe)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "celo-bls-snark-rs_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, "../build/libcelo_hosttest.so"])
+    return os.path.join(root, "celo-bls-snark-rs_amd", "build", "libcelo_hosttest.so")

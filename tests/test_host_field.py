@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 from oracle.py import ecc
 from oracle import cpu_oracle as co
+from tests import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "celo-bls-snark-rs_amd", "csrc")
@@ -17,11 +18,7 @@ LIB = os.path.join(ROOT, "celo-bls-snark-rs_amd", "build", "libcelo_hosttest.so"
 
 @pytest.fixture(scope="module")
 def ht():
-    if not os.path.exists(LIB):
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB,
-                               os.path.join(CSRC, "host_test.cpp")])
-    return C.CDLL(LIB)
+    return C.CDLL(H.build_hosttest())
 
 
 def _p(a):
@@ -277,11 +274,7 @@ def test_safegcd_inversion_matches_the_definition():
     """csrc/modinv.h (Bernstein-Yang division steps, what Fp::inv runs on the device and the host) against pow(x, -1, p) for both base
     fields: edge values (0 -> 0, 1, 2, p - 1, p - 2, powers of two around the 62-bit limb boundary) and 300 random ones; and Fp::inv
     through its Montgomery wrappers against Fermat's a^(p-2)."""
-    lib = C.CDLL(LIB) if os.path.exists(LIB) else None
-    if lib is None or not hasattr(lib, "ht_modinv"):
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB, os.path.join(CSRC, "host_test.cpp")])
-        lib = C.CDLL(LIB)
+    lib = C.CDLL(H.build_hosttest())
     lib.ht_inv_matches_fermat.restype = C.c_int
     rnd = random.Random(5)
     for field, p, n in ((0, ecc.Q377, 6), (1, ecc.Q761, 12)):
@@ -364,3 +357,51 @@ def test_subgroup_test_by_endomorphism_equals_the_ladder(ht):
         for P in outside:
             assert curve.on_curve(P) and not curve.in_subgroup(P)
             assert both(curve, is2, P) == 0
+
+
+@pytest.mark.parametrize("field,prime,n64,stride", [(0, ecc.Q377, 6, 32), (1, ecc.Q761, 12, 64)])
+def test_ifma_horner_matches_the_64_bit_epilogue(ht, field, prime, n64, stride):
+    """csrc/host_ifma.cpp (the big MSM's Horner epilogue on AVX-512 IFMA, eight field products side by side) against csrc/host64.h
+    (the same step list on 64-bit limbs, what runs without IFMA) on random coordinates: the formulas are polynomial identities, so
+    arbitrary field elements exercise them; window shapes of the 16-, 11- and 13-bit configurations, identity slots, and a list
+    that adds a point to itself (the special case the IFMA path must refuse with 1 so that the caller falls back)."""
+    ht.ht_horner_ifma.restype = C.c_int
+    rnd = random.Random(11 + field)
+
+    def slots(npts, ident_rate):
+        pts = np.zeros((npts, stride), dtype=np.uint64)
+        for s in range(npts):
+            if rnd.random() < ident_rate:
+                continue
+            for e in range(4):
+                v = rnd.randrange(1, prime)
+                pts[s, e * n64:(e + 1) * n64] = np.frombuffer(v.to_bytes(8 * n64, "little"), dtype=np.uint64)
+        return pts
+
+    def both(pts, order):
+        order = np.array(order, dtype=np.int32)
+        o1 = np.zeros(4 * n64, dtype=np.uint64)
+        o2 = np.zeros(4 * n64, dtype=np.uint64)
+        ht.ht_horner64(C.c_int(field), _p(pts), C.c_size_t(stride), _p(order), C.c_int(len(order)), _p(o1))
+        rc = ht.ht_horner_ifma(C.c_int(field), _p(pts), C.c_size_t(stride), _p(order), C.c_int(len(order)), _p(o2))
+        return rc, o1, o2
+
+    rc, _, _ = both(slots(2, 0.0), [0, 1])
+    if rc == -1:
+        pytest.skip("no AVX-512 IFMA on this CPU: the library uses host64.h")
+    for nw, LB, ident in [(16, 15, 0.0), (23, 10, 0.0), (29, 12, 0.1), (3, 4, 0.3), (1, 3, 0.0)]:
+        pts = slots((LB + 1) * nw, ident)
+        order = []
+        for w in range(nw - 1, -1, -1):
+            order.append(-1)
+            order += [l * nw + w for l in range(1, LB + 1)]
+            order.append(w | 0x40000000)
+        rc, o1, o2 = both(pts, order)
+        assert rc == 0 and (o1 == o2).all()
+    # all slots the identity -> identity (all-zero output on both paths)
+    rc, o1, o2 = both(np.zeros((4, stride), dtype=np.uint64), [0, 1, 2, 3])
+    assert rc == 0 and not o1.any() and not o2.any()
+    # P + P without a doubling in between (equal operands): refused, the caller's fallback handles it
+    pts = slots(1, 0.0)
+    rc, _, _ = both(pts, [0, 0 | 0x40000000])
+    assert rc == 1

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 from oracle.py import ecc
 from oracle import cpu_oracle as co
+from tests import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "celo-bls-snark-rs_amd", "csrc")
@@ -17,15 +18,7 @@ LIB = os.path.join(ROOT, "celo-bls-snark-rs_amd", "build", "libcelo_hosttest.so"
 
 @pytest.fixture(scope="module")
 def ht():
-    srcs = [os.path.join(CSRC, f) for f in ("host_test.cpp", "fp.h", "fp2.h", "curve.h", "curve_lanes.h", "lanes.h", "tower.h", "pairing.h", "pairing_lanes.h", "fp_consts.h")]
-    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB, srcs[0]])
-    lib = C.CDLL(LIB)
-    if not hasattr(lib, "ht_pairing_377_hex"):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DCELO_FP_TRACK", "-o", LIB, srcs[0]])
-        lib = C.CDLL(LIB)
-    return lib
+    return C.CDLL(H.build_hosttest())
 
 
 def _p(a):

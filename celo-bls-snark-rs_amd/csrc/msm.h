@@ -92,7 +92,14 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint64_t* __restric
 }
 
 // ---- 2a. signed-digit recoding, once per MSM: digits[w*n + i] (u16): 0xFFFF = zero digit, else (|d|-1) | (d<0)<<15.
-template <int SW, int CB, int NW>
+// Windows of MIXED width: NW windows of CB bits cover more than the scalar needs, and a plain split leaves a ragged top window of
+// few, heavy buckets (253 = 15 * 16 + 13: 4096 buckets of 256 points at 2^20; 377 = 23 * 16 + 9: 256 buckets of 4096 - pieces to
+// fold, 0.68 ms of a BW6-761 MSM).  With KN = NW * CB - (SCALAR_BITS + 1) > 0 the top KN windows are CB - 1 bits wide instead:
+// NW - KN windows of CB bits + KN of CB - 1 = SCALAR_BITS + 1 bits exactly (14 * 16 + 2 * 15 = 254, 18 * 16 + 6 * 15 = 378), every
+// window full.  A narrow window uses the lower half of its bucket table; its top tree level is empty, so the host's Horner pass
+// leaves that level and its doubling out.  The extra bit is the headroom of the signed recoding: bits from SCALAR_BITS up are
+// ignored (as ark-ec's VariableBaseMSM ignores them), so the top digit plus its carry never exceeds 2^(width - 1).
+template <int SW, int CB, int NW, int KN>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
                                                 uint16_t* __restrict__ digits, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,20 +113,23 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   }
   s[SW] = 0;
   const bool skip = inf && inf[i];
-  constexpr uint32_t B = 1u << (CB - 1);
+  constexpr int WIDE = NW - KN;
   uint32_t carry = 0;
 #pragma unroll
   for (int w = 0; w < NW; w++) {
-    const int bit = w * CB;
+    const int width = w < WIDE ? CB : CB - 1;
+    const int bit = w < WIDE ? w * CB : WIDE * CB + (w - WIDE) * (CB - 1);
+    const uint32_t B = 1u << (width - 1);
     const int wi = bit >> 5, off = bit & 31;
     uint32_t raw = 0;
     if (wi < SW) {
       uint64_t two = ((uint64_t)s[wi + 1] << 32) | s[wi];
-      raw = (uint32_t)(two >> off) & ((1u << CB) - 1);
+      raw = (uint32_t)(two >> off) & ((1u << width) - 1);
     }
+    if (KN > 0 && w == NW - 1) raw &= B - 1;     // the window's top bit is bit SCALAR_BITS: not part of the scalar
     uint32_t d = raw + carry;
     uint32_t neg = d > B ? 1u : 0u;
-    uint32_t mag = neg ? ((1u << CB) - d) : d;
+    uint32_t mag = neg ? ((1u << width) - d) : d;
     carry = neg;
     digits[(size_t)w * n + i] = (mag == 0 || skip) ? (uint16_t)0xFFFF : (uint16_t)((mag - 1) | (neg << 15));
   }
@@ -975,6 +985,12 @@ template <class G> class MsmEngine {
   }
   int force_c = 0;  // test hook / tuning: 0 = auto
   hipStream_t own_stream() { return stream_.get(); }   // this engine's non-blocking stream (host-pointer entry points)
+  // big path: mixed window widths (k_digits) for the 16-bit configuration only - the large inputs, where the work is throughput
+  // and a ragged top window costs folds and balance (2^20 terms: G1 3.32 -> 3.31, G2 10.85 -> 10.75, BW6-761 19.5 -> 19.0 ms).
+  // Small inputs are bound by their longest bucket run, and narrower windows mean longer runs: BW6-761 at 2^14 with 18 x 13 + 12 x 12
+  // bits instead of 29 x 13 (+ a carry window) 1.39 -> 1.88 ms, at 2^17 3.58 -> 3.79 ms.  CELO_NO_NARROW=1 is the A/B switch.
+  bool narrow_windows = getenv("CELO_NO_NARROW") == nullptr;
+  bool narrow_top(int c) const { return narrow_windows && c == 16; }
   bool lane_horner = true;  // batched path: three lanes per instance in the Horner pass (tuning hook)
   bool lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;   // big path: three lanes per addition in the late levels of the bucket reduction (A/B hook)
   uint32_t BITSUM_LANES_MAX = getenv("CELO_LANE_BITSUM_MAX") ? (uint32_t)atoi(getenv("CELO_LANE_BITSUM_MAX")) : 21 * 1024;   // outputs of a launch: one wave of 21 additions per SIMD
@@ -1155,9 +1171,10 @@ template <class G> class MsmEngine {
     const uint64_t* h64 = reinterpret_cast<const uint64_t*>(h_out);
     constexpr size_t PT64 = (size_t)IO::XYZZ_WORDS / 2;
     horner_steps.clear();
+    const int kn = narrow_top(c) ? nw * c - (G::SCALAR_BITS + 1) : 0;    // the top kn windows are c - 1 bits wide (k_digits)
     for (int w = nw - 1; w >= 0; w--) {
       horner_steps.push_back(-1);
-      for (int l = 1; l <= LB; l++) horner_steps.push_back(l * nw + w);
+      for (int l = (w >= nw - kn ? 2 : 1); l <= LB; l++) horner_steps.push_back(l * nw + w);
       horner_steps.push_back(w | HORNER_NODBL);
     }
     HXyzz<HF> total_pt;
@@ -1401,7 +1418,9 @@ template <class G> class MsmEngine {
   }
   template <int CB> int launch_digits_c(const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {
     constexpr int NW = (G::SCALAR_BITS + CB) / CB;
-    hipLaunchKernelGGL((k_digits<SW, CB, NW>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);
+    constexpr int KN = NW * CB - (G::SCALAR_BITS + 1);     // 0 <= KN < CB <= NW for every window size in use
+    if (narrow_top(CB) && KN > 0) hipLaunchKernelGGL((k_digits<SW, CB, NW, KN>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);
+    else hipLaunchKernelGGL((k_digits<SW, CB, NW, 0>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);
     return 0;
   }
   int launch_digits(int c, const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {

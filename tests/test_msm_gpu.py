@@ -154,6 +154,46 @@ def test_g1_large_device_resident(gpu, logn):
         assert b == ecc.E1_377.add(a, a)
 
 
+def test_g1_16_bit_windows_edge_scalars_and_odd_size(gpu):
+    """The 16-bit configuration runs windows of mixed width (14 x 16 + 2 x 15 bits, csrc/msm.h k_digits): (a) scalars at the edges of
+    the recoding - r - 1, r - 2, 2^252, the window boundaries 2^224, 2^239, 2^240 and their neighbours, runs of ones that carry
+    through every window - against the big-integer definition; (b) an odd size above 2^19 (the size from which the configuration is
+    chosen: ragged last blocks and tiles of the two-level sort), with r - 1 - i among uniform scalars, against the C++ oracle."""
+    r = ecc.R377
+    edge = [r - 1, r - 2, 1, 2, 1 << 252, (1 << 252) - 1, (1 << 252) + 1, 1 << 224, (1 << 224) - 1, 1 << 239, (1 << 239) - 1,
+            1 << 240, (1 << 240) - 1, (1 << 16) - 1, 1 << 15, (1 << 15) + 1, (1 << 252) - (1 << 15), r >> 1, (r >> 1) + 1,
+            int("8000" * 15, 16) >> 3, int("7fff" * 15, 16), int("8001" * 15, 16) >> 3]
+    edge = [k % r for k in edge]
+    n = len(edge)
+    pts = H.seeded_points(ecc.E1_377, ecc.G1_377, n, 1601)
+    xy, inf = co.pack_g1_377(pts)
+    exp = None
+    for P, k in zip(pts, edge):
+        exp = ecc.E1_377.add(exp, ecc.E1_377.mul(P, k))
+    gpu.set_window_bits("bls12_377_g1", 16)
+    try:
+        assert _affine(gpu.msm("bls12_377_g1", xy, inf, H.scalars_np(edge, 4)), "g1_377") == exp
+        for k, P in zip(edge, pts):      # one term at a time: a wrong digit cannot cancel against another term
+            pxy, pinf = co.pack_g1_377([P])
+            assert _affine(gpu.msm("bls12_377_g1", pxy, pinf, H.scalars_np([k], 4)), "g1_377") == ecc.E1_377.mul(P, k), hex(k)
+    finally:
+        gpu.set_window_bits("bls12_377_g1", 0)
+    n = (1 << 19) + 12345
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    bases = _gen_points_gpu(gpu, "bls12_377_g1", n, 0x5EED0019, gen.reshape(-1), 12)
+    rng = np.random.default_rng(1919)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    sc ^= rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)
+    sc[:2000] = co.ints_to_limbs([r - 1 - i for i in range(2000)], 4)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = gpu.msm_dev("bls12_377_g1", bases.data_ptr(), 0, d_sc.data_ptr(), n)
+    assert gpu.msm_timings("bls12_377_g1")["window_bits"] == 16
+    h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 12)
+    exp = co.msm("bls12_377_g1", h_bases, None, sc, threads=max(1, min(32, co.lib().orc_hardware_threads())))
+    assert _affine(out, "g1_377") == co.jac_to_affine(exp, "g1_377")
+
+
 def test_g1_two_to_22_device_resident(gpu):
     """Beyond the headline size (BASELINE config 5's G1 leg is 2^22): oracle comparison at 4M terms."""
     n = 1 << 22
@@ -240,6 +280,33 @@ def test_bw6_761_vs_oracle(gpu, golden, n):
         s = H.scalars_np(sc, 6)
         exp = co.jac_to_affine(co.msm(grp, xy, inf, s, threads=8), "761")
         assert _affine(gpu.msm(grp, xy, inf, s), "761") == exp
+
+
+def test_bw6_761_16_bit_windows_edge_scalars(gpu, golden):
+    """BW6-761's 16-bit configuration: 18 x 16 + 6 x 15 = 378 bits.  Edge scalars of the 377-bit scalar field (r - 1, powers of two at
+    the wide / narrow boundary 2^288 and at the narrow windows' edges, carries through every window), each alone and all together,
+    against the big-integer definition; both groups."""
+    from oracle.py import epoch as ep
+    vk = ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))
+    r = ecc.R761
+    edge = [r - 1, r - 2, 1, 1 << 376, (1 << 376) - 1, 1 << 288, (1 << 288) - 1, 1 << 303, (1 << 303) - 1, 1 << 363, (1 << 363) - 1,
+            (1 << 376) - (1 << 15), r >> 1, int("8000" * 23, 16), int("7fff" * 23, 16), int("8001" * 23, 16)]
+    edge = [k % r for k in edge]
+    for grp, G, cur in (("bw6_761_g1", vk["alpha_g1"], ecc.E1_761), ("bw6_761_g2", vk["beta_g2"], ecc.E2_761)):
+        rng = ecc.SplitMix64(761)
+        pts = [cur.mul(G, rng.next() | 1) for _ in edge]
+        xy, inf = co.pack_761(pts)
+        exp = None
+        for P, k in zip(pts, edge):
+            exp = cur.add(exp, cur.mul(P, k))
+        gpu.set_window_bits(grp, 16)
+        try:
+            assert _affine(gpu.msm(grp, xy, inf, H.scalars_np(edge, 6)), "761") == exp
+            for k, P in zip(edge[:8], pts):
+                pxy, pinf = co.pack_761([P])
+                assert _affine(gpu.msm(grp, pxy, pinf, H.scalars_np([k], 6)), "761") == cur.mul(P, k), hex(k)
+        finally:
+            gpu.set_window_bits(grp, 0)
 
 
 def test_gpu_reproduces_the_frozen_msm_fixtures(gpu):

@@ -439,6 +439,93 @@ template <class P> struct Fp {
     TRK(assert(a.lb <= 1 && b.lb <= 1 && c.lb <= 1 && d.lb <= 1);)
     return mul2k<SUB5 ? -5 : 1>(a, b, c, d);
   }
+  // ---- a^2 - 5 c^2 in one reduction pass with the symmetric limb products taken once (Fp2 squaring's real part, u^2 = -5): 2 x 105
+  // limb products instead of the 2 x 196 of mul2k<-5>(a, a, c, c).  Inputs normalised; column bound as mul2k<-5>.
+  HD static Fp sqr2m5(const Fp& a, const Fp& c) {
+    TRK(assert(a.lb <= 1 && c.lb <= 1); assert(L * 7 <= 255); assert(a.vb * a.vb + 5 * c.vb * c.vb <= 32768.0);)
+    Fp r;
+    uint32_t m[L], a2[L], c5[L], c10[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) { a2[i] = a.l[i] << 1; c5[i] = c.l[i] * 5u; c10[i] = c.l[i] * 10u; }
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+      for (int i = 0; 2 * i < k; i++) { acc += (uint64_t)a2[i] * a.l[k - i]; acc -= (uint64_t)c10[i] * c.l[k - i]; }
+      if ((k & 1) == 0) { acc += (uint64_t)a.l[k / 2] * a.l[k / 2]; acc -= (uint64_t)c5[k / 2] * c.l[k / 2]; }
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      uint32_t lo = (uint32_t)acc;
+      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      acc += (uint64_t)m[k] * P::P[0];
+      acc = (uint64_t)((int64_t)acc >> W);
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+      for (int i = k - L + 1; 2 * i < k; i++) { acc += (uint64_t)a2[i] * a.l[k - i]; acc -= (uint64_t)c10[i] * c.l[k - i]; }
+      if ((k & 1) == 0) { acc += (uint64_t)a.l[k / 2] * a.l[k / 2]; acc -= (uint64_t)c5[k / 2] * c.l[k / 2]; }
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      acc += P::P[k - L];  // + p after the division by R keeps the result positive
+      r.l[k - L] = (uint32_t)acc & MASK;
+      acc = (uint64_t)((int64_t)acc >> W);
+    }
+    acc += P::P[L - 1];
+    r.l[L - 1] = (uint32_t)acc;
+    TRK(r.lb = 1; r.vb = 3;)
+    return r;
+  }
+  // ---- four products in one reduction pass: (a b + KC c d - e f - KC g h)/R + p, KC in {-5, +1}: the two halves of an Fp2
+  // difference of products a b - c d (Y3 of the curve formulas over Fp2: 8 limb-product sweeps and 2 reductions instead of 4).
+  // Inputs normalised; columns: L (1 + |KC| + 1 + |KC| + 1) <= 255 needs L <= 19 (the 14-limb field).
+  template <int KC> HD static Fp mul4k(const Fp& a, const Fp& b, const Fp& c, const Fp& d, const Fp& e, const Fp& f, const Fp& g, const Fp& h) {
+    static_assert(KC == 1 || KC == -5, "unsupported multiplier");
+    constexpr uint32_t AK = KC < 0 ? (uint32_t)(-KC) : (uint32_t)KC;
+    static_assert(L * (2 * AK + 3) <= 255, "column bound");
+    TRK(assert(a.lb <= 1 && b.lb <= 1 && c.lb <= 1 && d.lb <= 1 && e.lb <= 1 && f.lb <= 1 && g.lb <= 1 && h.lb <= 1);
+        assert(a.vb * b.vb + AK * c.vb * d.vb + e.vb * f.vb + AK * g.vb * h.vb <= 32768.0);)
+    Fp r;
+    uint32_t m[L], cc[L], gg[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) { cc[i] = AK == 1 ? c.l[i] : c.l[i] * AK; gg[i] = AK == 1 ? g.l[i] : g.l[i] * AK; }
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc += (uint64_t)a.l[i] * b.l[k - i];
+        acc -= (uint64_t)e.l[i] * f.l[k - i];
+        if (KC < 0) { acc -= (uint64_t)cc[i] * d.l[k - i]; acc += (uint64_t)gg[i] * h.l[k - i]; }
+        else { acc += (uint64_t)cc[i] * d.l[k - i]; acc -= (uint64_t)gg[i] * h.l[k - i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      uint32_t lo = (uint32_t)acc;
+      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      acc += (uint64_t)m[k] * P::P[0];
+      acc = (uint64_t)((int64_t)acc >> W);
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) {
+        acc += (uint64_t)a.l[i] * b.l[k - i];
+        acc -= (uint64_t)e.l[i] * f.l[k - i];
+        if (KC < 0) { acc -= (uint64_t)cc[i] * d.l[k - i]; acc += (uint64_t)gg[i] * h.l[k - i]; }
+        else { acc += (uint64_t)cc[i] * d.l[k - i]; acc -= (uint64_t)gg[i] * h.l[k - i]; }
+      }
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::P[k - i];
+      acc += P::P[k - L];  // + p after the division by R keeps the result positive
+      r.l[k - L] = (uint32_t)acc & MASK;
+      acc = (uint64_t)((int64_t)acc >> W);
+    }
+    acc += P::P[L - 1];
+    r.l[L - 1] = (uint32_t)acc;
+    TRK(r.lb = 1; r.vb = 3;)
+    return r;
+  }
   // a*b - c*d in one pass where the column bound allows it (14-limb fields), two products and a subtraction otherwise
   HD static Fp mul_sub(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
     if constexpr (L * 12 <= 255) return mul2k<-1>(a, b, c, d);   // lb_a*lb_b <= 9, lb_c*lb_d <= 1

@@ -4,7 +4,8 @@
 // G2 paths: crates/bls-crypto/src/bls/public.rs:61 (G2 MSM) and the Miller loop's G2 arithmetic.
 //
 // Every product is two sum-of-products passes (Fp::mul2): c0 = a0 b0 - 5 a1 b1, c1 = a0 b1 + a1 b0,
-// i.e. 4 limb-product sweeps + 2 Montgomery reductions, no Karatsuba operand additions.
+// i.e. 4 limb-product sweeps + 2 Montgomery reductions, no Karatsuba operand additions; a difference of two products (the
+// curve formulas' Y3) is two passes over FOUR products each (Fp::mul4k), a squaring's real part one symmetric pass (Fp::sqr2m5).
 // mul2 needs normalised inputs, so mul/sqr normalise theirs (cheap next to 6 L^2 mads).
 // Outputs: lb = 1, vb <= 3.
 #pragma once
@@ -24,11 +25,16 @@ template <class P> struct Fp2 {
     B a0 = B::norm(a.c0), a1 = B::norm(a.c1), b0 = B::norm(b.c0), b1 = B::norm(b.c1);
     return {B::template mul2<true>(a0, b0, a1, b1), B::template mul2<false>(a0, b1, a1, b0)};
   }
-  HD static Fp2 sqr(const Fp2& a) {
+  HD static Fp2 sqr(const Fp2& a) {     // (a0^2 - 5 a1^2) + 2 a0 a1 u: the real part with the symmetric limb products taken once
     B a0 = B::norm(a.c0), a1 = B::norm(a.c1);
-    return {B::template mul2<true>(a0, a0, a1, a1), B::mul(B::dbl(a0), a1)};
+    return {B::sqr2m5(a0, a1), B::mul(B::dbl(a0), a1)};
   }
-  HD static Fp2 mul_sub(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { return norm(sub<4, 1>(mul(a, b), mul(c, d))); }
+  // a b - c d with ONE reduction per half: c0 = a0 b0 - 5 a1 b1 - c0 d0 + 5 c1 d1, c1 = a0 b1 + a1 b0 - c0 d1 - c1 d0
+  HD static Fp2 mul_sub(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) {
+    const B a0 = B::norm(a.c0), a1 = B::norm(a.c1), b0 = B::norm(b.c0), b1 = B::norm(b.c1);
+    const B c0 = B::norm(c.c0), c1 = B::norm(c.c1), d0 = B::norm(d.c0), d1 = B::norm(d.c1);
+    return {B::template mul4k<-5>(a0, b0, a1, b1, c0, d0, c1, d1), B::template mul4k<1>(a0, b1, a1, b0, c0, d1, c1, d0)};
+  }
   HD static Fp2 mul_fp(const Fp2& a, const B& k) {  // k normalised or lb*lb within Fp::mul's bound
     return {B::mul(a.c0, k), B::mul(a.c1, k)};
   }

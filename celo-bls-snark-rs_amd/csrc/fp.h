@@ -526,10 +526,15 @@ template <class P> struct Fp {
     TRK(r.lb = 1; r.vb = 3;)
     return r;
   }
-  // a*b - c*d in one pass where the column bound allows it (14-limb fields), two products and a subtraction otherwise
+  // a*b - c*d in ONE reduction pass.  The column bound L (lb_a lb_b + lb_c lb_d + 1) <= 255 holds for the 14-limb field with the
+  // loosely reduced operands the curve formulas hand over (lb_a lb_b <= 9, lb_c lb_d <= 1); the 28-limb field first carries its
+  // operands (two ~84-instruction passes for the 784 multiply-adds of the reduction saved: 5 % of a mixed addition)
   HD static Fp mul_sub(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
-    if constexpr (L * 12 <= 255) return mul2k<-1>(a, b, c, d);   // lb_a*lb_b <= 9, lb_c*lb_d <= 1
-    else return norm(sub<4, 1>(mul(a, b), mul(c, d)));
+    if constexpr (L * 12 <= 255) return mul2k<-1>(a, b, c, d);
+    else {
+      static_assert(L * 3 <= 255, "column bound with carried operands");
+      return mul2k<-1>(norm(a), norm(b), norm(c), norm(d));
+    }
   }
 
   // ---- arkworks Montgomery (R = 2^(64*N64), 64-bit limbs) <-> device form

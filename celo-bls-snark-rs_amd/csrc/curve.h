@@ -30,57 +30,57 @@ template <class F> struct Xyzz {
 // curves' r-torsion; handled anyway (result identity).
 template <class F> HD Xyzz<F> xyzz_dbl_affine(const Affine<F>& p) {
   if (p.y.is_zero_mod_p()) return Xyzz<F>::identity();
-  F U = F::dbl(p.y);                                  // [2, 4]
-  F V = F::sqr(U);                                    // [1, 2]
-  F W = F::mul(U, V);                                 // [1, 2]
-  F S = F::mul(p.x, V);                               // [1, 2]
-  F xx = F::sqr(p.x);
-  F M = F::add(F::add(xx, xx), xx);                   // [3, 6]
-  F M2 = F::sqr(M);                                   // 9 ok
+  F U = F::prep(F::dbl(p.y));                         // [2, 4]   (prep / _nn: operands carried once, see Fp::prep)
+  F V = F::sqr_nn(U);                                 // [1, 2]
+  F W = F::mul_nn(U, V);                              // [1, 2]
+  F S = F::mul_nn(p.x, V);                            // [1, 2]
+  F xx = F::sqr_nn(p.x);
+  F M = F::prep(F::add(F::add(xx, xx), xx));          // [3, 6]
+  F M2 = F::sqr_nn(M);                                // 9 ok
   F X3 = F::norm(F::template sub<16, 3>(M2, F::dbl(S)));   // [1, 10]
-  F t = F::template sub<32, 1>(S, X3);                // [3, 18]
-  F Y3 = F::mul_sub(M, t, W, p.y);                    // [1, <=7]
+  F t = F::prep(F::template sub<32, 1>(S, X3));       // [3, 18]
+  F Y3 = F::mul_sub_nn(M, t, W, p.y);                 // [1, <=7]
   return {X3, Y3, V, W};
 }
 
 template <class F> HD Xyzz<F> xyzz_dbl(const Xyzz<F>& a) {
   if (a.is_identity()) return a;
   if (a.Y.is_zero_mod_p()) return Xyzz<F>::identity();
-  F U = F::dbl(a.Y);                                  // [2, 12]
-  F V = F::sqr(U);
-  F W = F::mul(U, V);
-  F S = F::mul(a.X, V);
-  F xx = F::sqr(a.X);
-  F M = F::add(F::add(xx, xx), xx);                   // [3, 6]
-  F M2 = F::sqr(M);
+  F U = F::prep(F::dbl(a.Y));                         // [2, 12]
+  F V = F::sqr_nn(U);
+  F W = F::mul_nn(U, V);
+  F S = F::mul_nn(a.X, V);
+  F xx = F::sqr_nn(a.X);
+  F M = F::prep(F::add(F::add(xx, xx), xx));          // [3, 6]
+  F M2 = F::sqr_nn(M);
   F X3 = F::norm(F::template sub<16, 3>(M2, F::dbl(S)));
-  F t = F::template sub<32, 1>(S, X3);
-  F Y3 = F::mul_sub(M, t, W, a.Y);
-  return {X3, Y3, F::mul(V, a.ZZ), F::mul(W, a.ZZZ)};
+  F t = F::prep(F::template sub<32, 1>(S, X3));
+  F Y3 = F::mul_sub_nn(M, t, W, a.Y);
+  return {X3, Y3, F::mul_nn(V, a.ZZ), F::mul_nn(W, a.ZZZ)};
 }
 
 // acc += (x2, y2) affine (madd-2008-s).  acc may be the identity.
 template <class F> HD void xyzz_madd(Xyzz<F>& a, const Affine<F>& p) {
   if (a.is_identity()) { a = Xyzz<F>::from_affine(p); return; }
-  F U2 = F::mul(p.x, a.ZZ);                           // [1, 2]
-  F S2 = F::mul(p.y, a.ZZZ);
-  F Pd = F::template sub<32, 1>(U2, a.X);             // [3, 18]
-  F R = F::template sub<16, 1>(S2, a.Y);              // [3, 18]
+  F U2 = F::mul_nn(p.x, a.ZZ);                        // [1, 2]
+  F S2 = F::mul_nn(p.y, a.ZZZ);
+  F Pd = F::prep(F::template sub<32, 1>(U2, a.X));    // [3, 18]
+  F R = F::prep(F::template sub<16, 1>(S2, a.Y));     // [3, 18]
   if (Pd.is_zero_mod_p()) {
     if (R.is_zero_mod_p()) a = xyzz_dbl_affine(p);
     else a = Xyzz<F>::identity();
     return;
   }
-  F PP = F::sqr(Pd);                                  // 9 ok -> [1, 2]
-  F PPP = F::mul(Pd, PP);
-  F Q = F::mul(a.X, PP);
-  F R2 = F::sqr(R);
+  F PP = F::sqr_nn(Pd);                               // 9 ok -> [1, 2]
+  F PPP = F::mul_nn(Pd, PP);
+  F Q = F::mul_nn(a.X, PP);
+  F R2 = F::sqr_nn(R);
   F s = F::add(F::add(PPP, Q), Q);                    // [3, 6]
   F X3 = F::norm(F::template sub<16, 3>(R2, s));       // [1, 10]
-  F t = F::template sub<32, 1>(Q, X3);                // [3, 18]
-  F Y3 = F::mul_sub(R, t, a.Y, PPP);                  // R*t - Y1*PPP, one reduction pass on 14-limb fields: [1, <=7]
-  a.ZZ = F::mul(a.ZZ, PP);
-  a.ZZZ = F::mul(a.ZZZ, PPP);
+  F t = F::prep(F::template sub<32, 1>(Q, X3));       // [3, 18]
+  F Y3 = F::mul_sub_nn(R, t, a.Y, PPP);               // R*t - Y1*PPP, one reduction pass: [1, <=7]
+  a.ZZ = F::mul_nn(a.ZZ, PP);
+  a.ZZZ = F::mul_nn(a.ZZZ, PPP);
   a.X = X3;
   a.Y = Y3;
 }
@@ -89,27 +89,27 @@ template <class F> HD void xyzz_madd(Xyzz<F>& a, const Affine<F>& p) {
 template <class F> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& b) {
   if (b.is_identity()) return;
   if (a.is_identity()) { a = b; return; }
-  F U1 = F::mul(a.X, b.ZZ);
-  F U2 = F::mul(b.X, a.ZZ);
-  F S1 = F::mul(a.Y, b.ZZZ);
-  F S2 = F::mul(b.Y, a.ZZZ);
-  F Pd = F::template sub<4, 1>(U2, U1);               // [3, 6]
-  F R = F::template sub<4, 1>(S2, S1);
+  F U1 = F::mul_nn(a.X, b.ZZ);
+  F U2 = F::mul_nn(b.X, a.ZZ);
+  F S1 = F::mul_nn(a.Y, b.ZZZ);
+  F S2 = F::mul_nn(b.Y, a.ZZZ);
+  F Pd = F::prep(F::template sub<4, 1>(U2, U1));      // [3, 6]
+  F R = F::prep(F::template sub<4, 1>(S2, S1));
   if (Pd.is_zero_mod_p()) {
     if (R.is_zero_mod_p()) a = xyzz_dbl<F>(a);
     else a = Xyzz<F>::identity();
     return;
   }
-  F PP = F::sqr(Pd);
-  F PPP = F::mul(Pd, PP);
-  F Q = F::mul(U1, PP);
-  F R2 = F::sqr(R);
+  F PP = F::sqr_nn(Pd);
+  F PPP = F::mul_nn(Pd, PP);
+  F Q = F::mul_nn(U1, PP);
+  F R2 = F::sqr_nn(R);
   F s = F::add(F::add(PPP, Q), Q);
   F X3 = F::norm(F::template sub<16, 3>(R2, s));
-  F t = F::template sub<32, 1>(Q, X3);
-  F Y3 = F::mul_sub(R, t, S1, PPP);
-  a.ZZ = F::mul(F::mul(a.ZZ, b.ZZ), PP);
-  a.ZZZ = F::mul(F::mul(a.ZZZ, b.ZZZ), PPP);
+  F t = F::prep(F::template sub<32, 1>(Q, X3));
+  F Y3 = F::mul_sub_nn(R, t, S1, PPP);
+  a.ZZ = F::mul_nn(F::mul_nn(a.ZZ, b.ZZ), PP);
+  a.ZZZ = F::mul_nn(F::mul_nn(a.ZZZ, b.ZZZ), PPP);
   a.X = X3;
   a.Y = Y3;
 }

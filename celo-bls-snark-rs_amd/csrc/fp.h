@@ -78,8 +78,9 @@ template <class P> struct Fp {
   // For L > 25 (BW6-761: 28 limbs) a column of 2L products only fits 64 bits when lb_a*lb_b <= 8, so the
   // un-normalised subtraction results (lb 3) the curve formulas feed in are normalised on entry there.
   static constexpr bool NORM_IN = (L * 10 > 255);
-  HD static Fp mul(const Fp& a_, const Fp& b) {
-    const Fp a = NORM_IN ? norm(a_) : a_;
+  // NIN = false: the caller hands over a first operand whose limbs already meet the column bound (the _nn forms below)
+  template <bool NIN = NORM_IN> HD static Fp mul(const Fp& a_, const Fp& b) {
+    const Fp a = NIN ? norm(a_) : a_;
     TRK(assert(L * (a.lb * b.lb + 1) <= 255.5); assert(a.vb * b.vb <= 32768.0);)
     Fp r;
     uint32_t m[L];
@@ -108,8 +109,8 @@ template <class P> struct Fp {
     TRK(r.lb = 1; r.vb = 2;)
     return r;
   }
-  HD static Fp sqr(const Fp& a_) {
-    const Fp a = NORM_IN ? norm(a_) : a_;
+  template <bool NIN = NORM_IN> HD static Fp sqr(const Fp& a_) {
+    const Fp a = NIN ? norm(a_) : a_;
     TRK(assert(L * (a.lb * a.lb + 1) <= 255.5); assert(a.vb * a.vb <= 32768.0);)
     Fp r;
     uint32_t m[L], a2[L];
@@ -526,6 +527,14 @@ template <class P> struct Fp {
     TRK(r.lb = 1; r.vb = 3;)
     return r;
   }
+  // ---- the curve formulas' interface for operands they have prepared once (curve.h): prep() carries the limbs where this field's
+  // products need it (28 limbs) and is the identity where loosely reduced operands fit the column bound anyway (14 limbs); the _nn
+  // products then skip the per-call carry pass of mul / sqr / mul_sub - a mixed addition of the 28-limb field ran 13 of them for
+  // the 3 operands (the two differences and t) that need one.
+  HD static Fp prep(const Fp& a) { return NORM_IN ? norm(a) : a; }
+  HD static Fp mul_nn(const Fp& a, const Fp& b) { return mul<false>(a, b); }
+  HD static Fp sqr_nn(const Fp& a) { return sqr<false>(a); }
+  HD static Fp mul_sub_nn(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return mul2k<-1>(a, b, c, d); }
   // a*b - c*d in ONE reduction pass.  The column bound L (lb_a lb_b + lb_c lb_d + 1) <= 255 holds for the 14-limb field with the
   // loosely reduced operands the curve formulas hand over (lb_a lb_b <= 9, lb_c lb_d <= 1); the 28-limb field first carries its
   // operands (two ~84-instruction passes for the 784 multiply-adds of the reduction saved: 5 % of a mixed addition)

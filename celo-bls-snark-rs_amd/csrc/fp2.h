@@ -35,6 +35,15 @@ template <class P> struct Fp2 {
     const B c0 = B::norm(c.c0), c1 = B::norm(c.c1), d0 = B::norm(d.c0), d1 = B::norm(d.c1);
     return {B::template mul4k<-5>(a0, b0, a1, b1, c0, d0, c1, d1), B::template mul4k<1>(a0, b1, a1, b0, c0, d1, c1, d0)};
   }
+  // operands prepared once by the caller (curve.h): every half normalised - see Fp::prep
+  HD static Fp2 prep(const Fp2& a) { return norm(a); }
+  HD static Fp2 mul_nn(const Fp2& a, const Fp2& b) {
+    return {B::template mul2<true>(a.c0, b.c0, a.c1, b.c1), B::template mul2<false>(a.c0, b.c1, a.c1, b.c0)};
+  }
+  HD static Fp2 sqr_nn(const Fp2& a) { return {B::sqr2m5(a.c0, a.c1), B::mul(B::dbl(a.c0), a.c1)}; }
+  HD static Fp2 mul_sub_nn(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) {
+    return {B::template mul4k<-5>(a.c0, b.c0, a.c1, b.c1, c.c0, d.c0, c.c1, d.c1), B::template mul4k<1>(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0)};
+  }
   HD static Fp2 mul_fp(const Fp2& a, const B& k) {  // k normalised or lb*lb within Fp::mul's bound
     return {B::mul(a.c0, k), B::mul(a.c1, k)};
   }

@@ -9,7 +9,10 @@
 // inputs and cheaper general adds for the bucket reduction).  Group elements are unique, so the
 // affine-normalised result is bit-identical to the reference's.
 //
-// Every formula is annotated with the [lb, vb] bounds of fp.h's contract.
+// Every formula is annotated with the [lb, vb] bounds of fp.h's contract.  Operand contract of the products: stored coordinates,
+// loaded points and product outputs are normalised (lb 1); the few loosely reduced values a formula multiplies (the differences
+// Pd, R, the doubled Y, 3 X^2 and t) go through F::prep() once - a carry pass for the fields whose products need normalised
+// operands (Fp2, the 28-limb field), nothing for the 14-limb field - and the products are the _nn forms that do not carry again.
 #pragma once
 #include "fp.h"
 

@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(1024) k_tile_count(const uint8_t* __restrict__
   const uint32_t w = blockIdx.y, t = threadIdx.x, bd = blockDim.x;
   uint32_t bin, z, tiles, tile_lo, tile_n;
   if (!tile_locate(tileprefix + w * (NBIN + 1), NBIN, blockIdx.x, bin, z, tiles)) return;
+  if (tiles == 1) return;      // a one-tile region (the usual case) is counted by its k_tile_sort workgroup itself
   tile_range(binstart[w * (NBIN + 1) + bin], binstart[w * (NBIN + 1) + bin + 1], z, tiles, tile_lo, tile_n);
   if (t < 256) cnt[t] = 0;
   __syncthreads();
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(1024) k_tile_count(const uint8_t* __restrict__
 template <class G>
 __global__ void __launch_bounds__(1024) k_tile_sort(const uint32_t* __restrict__ rec_idx, const uint8_t* __restrict__ rec_key,
                                                     const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ tileprefix,
-                                                    const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursor,
+                                                    uint32_t* __restrict__ counts, uint32_t* __restrict__ cursor,
                                                     uint32_t* __restrict__ sorted, uint32_t* __restrict__ pfirst,
                                                     uint32_t* __restrict__ pstart, uint32_t* __restrict__ plen, uint32_t* __restrict__ big,
                                                     uint32_t* __restrict__ nbig, uint32_t* __restrict__ mid, uint32_t* __restrict__ nmid,
@@ -369,9 +370,9 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint32_t* __restrict__
   const uint32_t g = w * B + ((t << HIB) | bin);      // bucket of thread t < NLO
   const int lane = t & 63, wv = t >> 6;
   if (t < 256) {   // four whole waves: exclusive scans of the region's bucket counts and piece counts and of the tile's own counts
-    v = t < NLO ? counts[g] : 0;
-    p = (v + SEG - 1) / SEG;
     mine = cnt[t];
+    v = t < NLO ? (tiles == 1 ? mine : counts[g]) : 0;     // the region's count: the tile's own if it is the only one
+    p = (v + SEG - 1) / SEG;
     x = v; y = p; q = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -387,7 +388,8 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint32_t* __restrict__
     loff[t] = pre3 + q - mine;
     if (t < NLO) {
       const uint32_t st = rs + pre + x - v;                                    // window-relative start of the bucket's run
-      cur[t] = st + (mine ? atomicAdd(&cursor[g], mine) : 0u);
+      cur[t] = st + ((tiles > 1 && mine) ? atomicAdd(&cursor[g], mine) : 0u);
+      if (tiles == 1) counts[g] = v;
       if (z == 0) {
         const uint32_t pf = w * PW + bin * NLO + rs / SEG + pre2 + y - p;
         pfirst[g] = pf;

@@ -707,16 +707,20 @@ __global__ void __launch_bounds__(64) k_bitsum_lanes(const uint32_t* __restrict_
 // Horner pass (host64.h).  Its own tiny launch: inside k_bitsum the conversion doubled the register count of every level.
 template <class G>
 __global__ void __launch_bounds__(64) k_results_to_ark(uint32_t* __restrict__ work, uint32_t res_pts) {
+  // one lane per COORDINATE (the launch is a single conversion deep); a point's four lanes sit in one workgroup, and every load of
+  // the workgroup precedes its stores: the arkworks form is shorter, so a coordinate's output overlaps its neighbour's input
   typedef typename G::F F;
   typedef PointIO<F> IO;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= res_pts) return;
-  uint32_t* slot = work + (size_t)t * IO::XYZZ_WORDS;
-  const Xyzz<F> a = IO::load_xyzz(slot);
-  uint64_t* o = reinterpret_cast<uint64_t*>(slot);
-  const bool id = a.is_identity();
-  a.X.to_ark(o); a.Y.to_ark(o + IO::ARK64); a.ZZ.to_ark(o + 2 * IO::ARK64); a.ZZZ.to_ark(o + 3 * IO::ARK64);
-  if (id) for (int q = 0; q < IO::ARK64; q++) o[2 * IO::ARK64 + q] = 0;   // ZZ == 0 exactly marks the identity
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, pt = t >> 2, q = t & 3;
+  const bool live = pt < res_pts;
+  uint64_t out[IO::ARK64];
+  if (live) F::load(work + (size_t)pt * IO::XYZZ_WORDS + q * IO::FW).to_ark(out);   // exact zeros (the identity's ZZ) stay exact zeros
+  __syncthreads();
+  if (live) {
+    uint64_t* o = reinterpret_cast<uint64_t*>(work + (size_t)pt * IO::XYZZ_WORDS) + q * IO::ARK64;
+#pragma unroll
+    for (int i = 0; i < IO::ARK64; i++) o[i] = out[i];
+  }
 }
 
 // =====================================================================================================================
@@ -1152,7 +1156,7 @@ template <class G> class MsmEngine {
           hipLaunchKernelGGL((k_bitsum<G>), dim3((total_out + 127) / 128), dim3(128), 0, stream, d_partials, d_counts, d_pfirst, d_piecesof, SEG,
                              d_work, jobs);
       }
-      hipLaunchKernelGGL((k_results_to_ark<G>), dim3((res_pts + 63) / 64), dim3(64), 0, stream, d_work, res_pts);
+      hipLaunchKernelGGL((k_results_to_ark<G>), dim3((4 * res_pts + 63) / 64), dim3(64), 0, stream, d_work, res_pts);
     }
     HIP_OK(hipEventRecord(ev[4], stream));
     HIP_OK(hipMemcpyAsync(h_out, d_work, (size_t)res_pts * IO::XYZZ_WORDS * 4, hipMemcpyDeviceToHost, stream));

@@ -8,6 +8,13 @@
   --scaling weak        per-GPU work fixed as N grows (default; cfg4 weak = its per-GPU shard 2^21)
   --scaling strong      total work fixed (2^20 / 4096 batches / 2^24 / 2^22+2^22+2^14 split over the N ranks)
 
+  --gpus N              N > 1 without a launcher around it: bench.py starts its own N ranks (torch.distributed.run, one process per GPU,
+                        RCCL); under the driver's torch.distributed.run the ranks are already there.  A line whose n_gpus differs from
+                        --gpus is never printed.
+  --in-process          configs 2 / 4 with N > 1: ONE process drives the N devices through msm_*_multi_dev (the shape of the reference's
+                        callers, crates/bls-snark-sys/src/signatures.rs:343, crates/epoch-snark/src/api/prover.rs:78): one host thread per
+                        device inside the library, partial sums folded on the host, no collective
+
 A "step" is one pass of the hot path over one batch of synthetic input that is resident in HBM before the timed region.
 With N > 1 ranks (one process per GPU, launched by torch.distributed.run) an MSM is ONE job sharded by index range
 (SURVEY.md section 8e): each rank computes the partial sum of its slice, the 144 / 288-byte Jacobian partials are exchanged with
@@ -73,7 +80,7 @@ class MsmConfig:
         a = cx.args
         log_n = a.log_n if a.log_n else log_n_total
         n_total = 1 << log_n
-        self.n = n_total // cx.world if a.scaling == "strong" else n_total
+        self.n = n_total // cx.nshards if a.scaling == "strong" else n_total
         if cx.cfg == 4 and a.scaling == "weak" and not a.log_n:
             self.n = 1 << 21                                   # cfg4's job is 2^24 over 8 GPUs: the per-GPU shard is the weak unit
         self.log_n = (self.n - 1).bit_length()
@@ -83,6 +90,8 @@ class MsmConfig:
         cx = self.cx
         if cx.args.window_bits:
             ffi.set_window_bits(self.group, cx.args.window_bits)
+        if cx.devices:
+            return self.setup_in_process()
         self.bases = syn.device_points(self.group, self.n, 0x5EED0002 + 0x1000 * cx.rank)
         sc = syn.witness_like_scalars(self.group, self.n, 0x5EED0001 + cx.rank) if cx.args.witness_like else syn.uniform_scalars(self.group, self.n, 0x5EED0001 + cx.rank)
         if cx.args.balanced and self.group == "bls12_377_g1":
@@ -98,8 +107,31 @@ class MsmConfig:
         self.acc_ms, self.tot_ms = [], []
         torch.cuda.synchronize()
 
+    def setup_in_process(self):
+        """Shard d of the job resident on device cx.devices[d] (a device may be listed more than once: that many engines on it)."""
+        from celo_bls_snark_rs_amd import ffi, synthetic as syn
+        cx = self.cx
+        self.sh_bases, self.sh_sc, self.sc_host = [], [], []
+        for r, d in enumerate(cx.devices):
+            torch.cuda.set_device(d)
+            ffi.use_device(d)
+            self.sh_bases.append(syn.device_points(self.group, self.n, 0x5EED0002 + 0x1000 * r, device="cuda:%d" % d))
+            sc = syn.witness_like_scalars(self.group, self.n, 0x5EED0001 + r) if cx.args.witness_like else syn.uniform_scalars(self.group, self.n, 0x5EED0001 + r)
+            self.sc_host.append(sc)
+            self.sh_sc.append(torch.from_numpy(sc.view(np.int64)).to("cuda:%d" % d))
+            torch.cuda.synchronize(d)
+        torch.cuda.set_device(cx.devices[0])
+        ffi.use_device(cx.devices[0])
+        self.bases, self.d_sc, self.sc = self.sh_bases[0], self.sh_sc[0], self.sc_host[0]
+        self.O = ffi.GROUP_SHAPE[self.group][2]
+        self.acc_ms, self.tot_ms = [], []
+
     def step(self):
         from celo_bls_snark_rs_amd import ffi
+        cx = self.cx
+        if cx.devices:
+            return ffi.msm_multi_dev(self.group, cx.devices, [b.data_ptr() for b in self.sh_bases], None, [s_.data_ptr() for s_ in self.sh_sc],
+                                     [self.n] * len(cx.devices))
         out = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n, self.cx.stream)
         return self.fold(out)
 
@@ -109,7 +141,7 @@ class MsmConfig:
         self.acc_ms.append(tm["accumulate_ms"]); self.tot_ms.append(tm["total_ms"])
 
     def units_per_step(self):
-        return self.cx.world * self.n
+        return self.cx.nshards * self.n
 
     def report(self, line, result):
         from celo_bls_snark_rs_amd import ffi, synthetic as syn
@@ -123,7 +155,9 @@ class MsmConfig:
         line["unit"] = "scalar-muls/s"
         line["config"] = {"workload": "%s, 2^%d random bases/scalars per GPU%s, inputs resident in HBM" % (self.name, self.log_n, " (witness-like scalar mix)" if cx.args.witness_like else ""),
                           "bases_per_gpu": self.n, "window_bits": tm["window_bits"], "windows": tm["windows"], "buckets": tm["buckets"],
-                          "sharding": "index-range shards + all_gather of %d-B partial sums" % (self.O * 8) if cx.world > 1 else "single GPU"}
+                          "sharding": ("index-range shards resident on %d devices of ONE process (msm_%s_multi_dev: a host thread per device, host fold of %d-B partial sums)"
+                                       % (len(cx.devices), self.group, self.O * 8)) if cx.devices else
+                                      "index-range shards + all_gather of %d-B partial sums" % (self.O * 8) if cx.world > 1 else "single GPU"}
         line["roofline"] = {"bound": "hbm", "kernel": ACC_KERNEL[self.group], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
                             "note": "integer-VALU bound, not HBM bound (SURVEY.md section 8d); algorithmic bytes = n*%d B per launch; kernel ms (median over the timed "
@@ -137,7 +171,7 @@ class MsmConfig:
         line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": ACC_KERNEL[self.group], "achieved": fq_ops / (acc * 1e-3) / 1e9,
                                  "peak": valu_peak, "unit": "G field-mul-or-sqr/s", "frac": fq_ops / (acc * 1e-3) / 1e9 / valu_peak,
                                  "note": "peak from tools/ubench_fp.hip (register-resident multiply loops, 8 waves/SIMD); achieved = n*windows mixed adds * (8M+2S) / accumulate time"}
-        if cx.world == 1:
+        if cx.world == 1 and not cx.devices:
             line["two_callers"] = self.two_callers()
         if not cx.args.no_cpu_baseline:
             line["cpu_baseline"] = self.cpu_baseline(result)
@@ -176,7 +210,11 @@ class MsmConfig:
         from oracle import cpu_oracle as co
         cx = self.cx
         A = self.bases.numel() // self.n
-        h_b, h_s = gather_to_rank0(cx, self.bases.view(self.n, A)), gather_to_rank0(cx, self.d_sc.view(self.n, -1))
+        if cx.devices:
+            h_b = np.concatenate([b.view(self.n, A).cpu().numpy().view(np.uint64) for b in self.sh_bases])
+            h_s = np.concatenate([s_.view(self.n, -1).cpu().numpy().view(np.uint64) for s_ in self.sh_sc])
+        else:
+            h_b, h_s = gather_to_rank0(cx, self.bases.view(self.n, A)), gather_to_rank0(cx, self.d_sc.view(self.n, -1))
         if cx.rank != 0:
             return None
         hw = co.lib().orc_hardware_threads()
@@ -196,7 +234,7 @@ class MsmConfig:
             if not ok:
                 raise SystemExit("PARITY FAILURE: GPU MSM result != CPU oracle result at full size")
             res = {"value": n_all / secs, "seconds": secs, "parity_with_gpu": True,
-                   "sample": "the full %d-term job once (all %d rank(s)), arkworks windowing c=%d (%d windows), one thread per window like rayon" % (n_all, cx.world, c, windows)}
+                   "sample": "the full %d-term job once (all %d shard(s)), arkworks windowing c=%d (%d windows), one thread per window like rayon" % (n_all, cx.nshards, c, windows)}
         else:                                                   # bounded: time a 2^18 sample; parity by linearity on the sample (a fresh GPU call)
             from celo_bls_snark_rs_amd import ffi
             k = 1 << 18
@@ -594,6 +632,23 @@ def wire_leg(ffi, check_oracle=True):
 
 
 # ===================================================================================================== driver
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: re-run this command line as N ranks (one process per GPU) under
+    torch.distributed.run on 127.0.0.1; rank 0's JSON line passes through on stdout.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["CELO_BENCH_LAUNCHER"] = "bench.py --gpus %d (self-launched torch.distributed.run)" % n
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -609,18 +664,43 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pairing", action="store_true", help="config 2, N = 1: skip the secondary pairing / NTT / wire legs")
     ap.add_argument("--balanced", action="store_true", help="diagnostic: scalars whose digits fill every bucket equally (not the headline workload)")
+    ap.add_argument("--in-process", action="store_true", help="configs 2 / 4, N > 1: one process drives the N devices through msm_*_multi_dev (no ranks, no collective)")
+    ap.add_argument("--devices", default="", help="--in-process: comma-separated device ordinals (default 0..N-1; repeats allowed, e.g. 0,0 on a 1-GPU box)")
     args = ap.parse_args()
+
+    world_env = int(os.environ.get("WORLD_SIZE", "0"))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.in_process and args.config not in (2, 4):
+        raise SystemExit("--in-process drives msm_*_multi_dev: configs 2 and 4 only")
+    if args.gpus > 1 and not args.in_process and world_env == 0:
+        sys.exit(launch_ranks(args.gpus))            # plain `python bench.py --gpus N`: start the N ranks ourselves
+    if world_env and (args.in_process or world_env != args.gpus):
+        raise SystemExit("bench.py: --gpus %d%s but the launcher started WORLD_SIZE=%d ranks: refusing to print a line for a different job"
+                         % (args.gpus, " --in-process" if args.in_process else "", world_env))
 
     cx = Ctx()
     cx.args, cx.cfg = args, args.config
-    cx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    cx.world = max(1, world_env)
     cx.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cx.devices = None
+    if args.in_process and args.gpus > 1:
+        cx.devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        if len(cx.devices) != args.gpus:
+            raise SystemExit("--devices must list --gpus ordinals")
+        if max(cx.devices) >= torch.cuda.device_count():
+            raise SystemExit("--in-process --gpus %d: only %d device(s) visible (list repeats with --devices to share one)" % (args.gpus, torch.cuda.device_count()))
+        local_rank = cx.devices[0]
+    cx.nshards = len(cx.devices) if cx.devices else cx.world
     # CELO_BENCH_BACKEND=gloo + CELO_BENCH_DEVICE=0 lets the N>1 code path be smoke-tested on a 1-GPU box (both ranks on
     # one device, host-staged exchange); the driver's multi-GPU runs use the defaults: RCCL, one GPU per rank.
     backend = os.environ.get("CELO_BENCH_BACKEND", "nccl")
     if "CELO_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["CELO_BENCH_DEVICE"])
+    elif cx.world > 1 and local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d device(s) visible (CELO_BENCH_BACKEND=gloo CELO_BENCH_DEVICE=0 shares one GPU for a smoke run)"
+                         % (cx.rank, local_rank, torch.cuda.device_count()))
     if cx.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -661,10 +741,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    line = {"metric": None, "value": job.units_per_step() * args.steps / elapsed, "unit": None, "n_gpus": cx.world, "steps": args.steps, "warmup": args.warmup,
+    line = {"metric": None, "value": job.units_per_step() * args.steps / elapsed, "unit": None, "n_gpus": cx.nshards, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": DTYPE, "data": "synthetic", "baseline_config": cx.cfg}
+    line["launch"] = ({"mode": "in-process", "devices": cx.devices, "ranks": 1, "rccl_world": None, "backend": None,
+                       "note": "one process, msm_*_multi_dev: a host thread and an engine per listed device, host fold; no collective"} if cx.devices else
+                      {"mode": "one process per GPU", "ranks": cx.world, "rccl_world": dist.get_world_size() if cx.world > 1 else 1,
+                       "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if cx.world > 1 else None,
+                       "launcher": os.environ.get("CELO_BENCH_LAUNCHER", "external (torch.distributed.run)" if cx.world > 1 else "none"),
+                       "device_of_rank0": local_rank})
     job.report(line, result)                                  # every rank takes part (gathers for the full-size parity check)
+    if line["n_gpus"] != args.gpus:
+        raise SystemExit("bench.py: the job ran on %d GPU(s) but --gpus %d was asked for: no line" % (line["n_gpus"], args.gpus))
     if cx.rank == 0:
         if cx.cfg == 2 and cx.world == 1 and not args.no_pairing:
             line["pairing"] = pairing_leg(ffi, check_oracle=not args.no_cpu_baseline)

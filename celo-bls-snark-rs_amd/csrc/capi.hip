@@ -16,7 +16,6 @@ namespace celo {
 static std::atomic<int> g_device_count{-1};
 static std::atomic<int> g_default_device{0};
 static thread_local int t_bound_device = -1;
-static thread_local int t_applied_device = -1;
 static int device_count() {
   int n = g_device_count.load();
   if (n >= 0) return n;
@@ -31,11 +30,10 @@ int api_enter() {
     fprintf(stderr, "[celo-amd] no HIP device: the MSM/pairing path has no CPU fallback\n");
     return 100;
   }
-  const int dev = api_device();
-  if (t_applied_device != dev) {
-    if (hipSetDevice(dev) != hipSuccess) return 102;
-    t_applied_device = dev;
-  }
+  // applied on every entry, not cached: HIP's current device is shared with whatever else runs on this thread (torch in the
+  // bench and the tests), which may have switched it between two calls into the library; hipSetDevice is a TLS store when
+  // nothing changes
+  if (hipSetDevice(api_device()) != hipSuccess) return 102;
   return 0;
 }
 int api_bind_thread(int device) {

@@ -973,6 +973,7 @@ template <class G> class MsmEngine {
       if (p) (void)hipFree(p);
     d_in_bases = nullptr; d_in_scalars = nullptr; d_in_inf = nullptr; cap_in = 0;
     if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; }
+    if (d_side_out) { (void)hipFree(d_side_out); d_side_out = nullptr; side_out_bytes = 0; }
     for (int i = 0; i < 6; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
   }
   // Measured on the MI355X (sweep over c at n = 2^8 .. 2^20, uniform scalars, all groups): with the log-depth bucket reduction
@@ -1242,16 +1243,39 @@ template <class G> class MsmEngine {
       uint32_t k = offsets[p + 1] - offsets[p];
       if (k > max_n) max_n = k;
     }
-    if (max_n > BATCH_MAX_N || total_pts == 0) {  // fall back to instance-at-a-time on the big pipeline (still the GPU)
-      if (resident || !out) return 2;             // the chained / resident form is for Batch::verify-sized instances
+    if (max_n > BATCH_MAX_N || total_pts == 0) {
+      // An instance beyond the per-workgroup sort (or a call whose instances are all empty): every instance goes through the big
+      // pipeline, one after the other (still the GPU; Batch::verify takes any number of signers and accepts an empty batch,
+      // crates/bls-crypto/src/bls/batch.rs:44-84).  The big pipeline carves this engine's arena, so in the chained form the m
+      // results are collected on the host and put into a buffer of their own; the call is then synchronous, which the chained
+      // contract allows (the consumer waits on the stream either way).
+      std::vector<uint64_t> hres;
+      uint64_t* dst = out;
+      if (!out) { hres.resize(m * 3 * IO::ARK64); dst = hres.data(); }
       for (size_t p = 0; p < m; p++) {
-        uint32_t lo = offsets[p], k = offsets[p + 1] - lo;
-        int rc = run_host(bases + (size_t)lo * 2 * IO::ARK64, inf ? inf + lo : nullptr, scalars + (size_t)lo * (SW / 2), k,
-                          out + p * 3 * IO::ARK64, stream);
+        const uint32_t lo = offsets[p], k = offsets[p + 1] - lo;
+        const uint8_t* pi = inf ? inf + lo : nullptr;
+        const int rc = resident ? run_device(bases + (size_t)lo * 2 * IO::ARK64, pi, (const uint32_t*)scalars + (size_t)lo * SW, k, dst + p * 3 * IO::ARK64, stream)
+                                : run_host(bases + (size_t)lo * 2 * IO::ARK64, pi, scalars + (size_t)lo * (SW / 2), k, dst + p * 3 * IO::ARK64, stream);
         if (rc) return rc;
+      }
+      tm_batch = tm;
+      if (!out) {
+        const size_t bytes = m * 3 * IO::ARK64 * 8;
+        if (bytes > side_out_bytes) {
+          if (d_side_out) (void)hipFree(d_side_out);
+          d_side_out = nullptr; side_out_bytes = 0;
+          HIP_OK(hipMalloc(&d_side_out, bytes));
+          side_out_bytes = bytes;
+        }
+        HIP_OK(hipMemcpyAsync(d_side_out, hres.data(), bytes, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        if (d_out_ret) *d_out_ret = d_side_out;
+        side_path = true;
       }
       return 0;
     }
+    side_path = false;
     // window size ~ log2(n) - 3 (measured on 4096 x 256, 136-bit exponents: c = 5 beats 6 and 7; the per-(instance,window)
     // running sums and the per-instance Horner are latency-bound, so fewer buckets per window win)
     int c = force_c ? force_c : 3;
@@ -1342,6 +1366,7 @@ template <class G> class MsmEngine {
     return 0;
   }
   void collect_batch_timings() {     // after the stream has drained
+    if (side_path) { tm = tm_batch; return; }
     (void)hipEventElapsedTime(&tm_batch.convert, ev[0], ev[1]);
     (void)hipEventElapsedTime(&tm_batch.sort, ev[1], ev[2]);
     (void)hipEventElapsedTime(&tm_batch.accumulate, ev[2], ev[3]);
@@ -1379,6 +1404,9 @@ template <class G> class MsmEngine {
   uint64_t* d_in_scalars = nullptr;
   uint8_t* d_in_inf = nullptr;
   uint32_t* h_out = nullptr;
+  uint64_t* d_side_out = nullptr;      // results of a chained batch call that went through the big pipeline (run_batch)
+  size_t side_out_bytes = 0;
+  bool side_path = false;
   static constexpr size_t H_OUT_POINTS = 17 * 64;   // pinned result buffer: (LB + 1) * windows points; checked per call
   OwnedStream stream_;
   std::vector<int32_t> horner_steps;   // the host epilogue's step list (host64.h), rebuilt per call

@@ -47,7 +47,17 @@ template <class E> class EnginePool {
     Slot& s = slots[dev];
     for (;;) {
       if (!s.free_list.empty()) { E* e = s.free_list.back(); s.free_list.pop_back(); return Lease(this, dev, e); }
-      if (s.created < MAX_PER_DEVICE) { s.created++; lk.unlock(); return Lease(this, dev, new E()); }   // engines live for the process
+      if (s.created < MAX_PER_DEVICE) {   // engines live for the process
+        s.created++;
+        lk.unlock();
+        E* e = nullptr;
+        try { e = new E(); } catch (...) {            // a failed construction must not cost the pool a slot for good
+          { std::lock_guard<std::mutex> g(mu); slots[dev].created--; }
+          cv.notify_one();
+          throw;
+        }
+        return Lease(this, dev, e);
+      }
       cv.wait(lk);
     }
   }

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <mutex>
 #include <vector>
+#include <unordered_set>
 #include <thread>
 #include <atomic>
 #include <memory>
@@ -820,32 +821,51 @@ bool compress_pubkey(const uint8_t* in, int in_len, uint8_t** out, int* out_len)
 bool destroy_private_key(PrivateKey* p) { if (!p) return false; delete p; return true; }
 bool destroy_public_key(PublicKey* p) { if (!p) return false; delete p; return true; }
 bool destroy_signature(Signature* p) { if (!p) return false; delete p; return true; }
-bool free_vec(uint8_t* bytes, int len) { (void)len; if (!bytes) return false; free(bytes); return true; }
+bool free_vec(uint8_t* bytes, int len) { if (!bytes || len < 0) return false; free(bytes); return true; }   // buffers are malloc blocks: the length is not needed to release one
 
 // ---------------------------------------------------------------- aggregation (signatures.rs:428-505)
+// aggregate_public_keys and aggregate_public_keys_subtract route their list through PublicKeyCache::aggregate
+// (crates/bls-crypto/src/bls/cache.rs:65-87), which collects the keys into a HashSet with BYTE-LEVEL equality of the Jacobian
+// (x, y, z) limbs (cache.rs:95-104): a handle listed twice - or two handles holding the same limbs - counts once, whereas two
+// different Jacobian representatives of one point count twice.  The cache's incremental update (subtract the keys that left,
+// add the new ones) is an optimisation of "sum of the set"; only the set semantics is observable.  aggregate_signatures is a
+// plain sum (Signature::aggregate, signature.rs:61-67).
+static bool unique_key_limbs(const PublicKey* const* in, int n, std::vector<uint64_t>& buf, size_t first) {
+  struct Ref { const uint64_t* p; };
+  struct H { size_t operator()(const Ref& r) const { uint64_t h = 0xcbf29ce484222325ull; for (int i = 12; i < 24; i++) h = (h ^ r.p[i]) * 0x100000001b3ull; return (size_t)h; } };
+  struct E { bool operator()(const Ref& a, const Ref& b) const { return memcmp(a.p, b.p, 288) == 0; } };
+  std::unordered_set<Ref, H, E> seen;
+  seen.reserve((size_t)n * 2 + 1);
+  buf.resize(first * 36);
+  for (int i = 0; i < n; i++) {
+    if (!in[i]) return false;
+    if (!seen.insert(Ref{in[i]->xyz}).second) continue;
+    buf.insert(buf.end(), in[i]->xyz, in[i]->xyz + 36);
+  }
+  return true;
+}
 bool aggregate_public_keys(const PublicKey* const* in, int n, PublicKey** out) {
   if (!out || n < 0 || (n > 0 && !in)) return false;
-  std::vector<uint64_t> buf((size_t)n * 36);
-  for (int i = 0; i < n; i++) { if (!in[i]) return false; memcpy(&buf[(size_t)i * 36], in[i]->xyz, 288); }
+  std::vector<uint64_t> buf;
+  if (!unique_key_limbs(in, n, buf, 0)) return false;
   PublicKey* pk = new PublicKey;
-  if (celo_amd_sum_jacobian_bls12_377_g2(buf.data(), (size_t)n, pk->xyz) != 0) { delete pk; return false; }
+  if (celo_amd_sum_jacobian_bls12_377_g2(buf.data(), buf.size() / 36, pk->xyz) != 0) { delete pk; return false; }
   *out = pk;
   return true;
 }
 bool aggregate_public_keys_subtract(const PublicKey* agg, const PublicKey* const* in, int n, PublicKey** out) {
   if (!agg || !out || n < 0 || (n > 0 && !in)) return false;
-  std::vector<uint64_t> buf((size_t)(n + 1) * 36);
+  std::vector<uint64_t> buf;
+  if (!unique_key_limbs(in, n, buf, 1)) return false;
   memcpy(buf.data(), agg->xyz, 288);
-  for (int i = 0; i < n; i++) {
-    if (!in[i]) return false;
-    uint64_t* d = &buf[(size_t)(i + 1) * 36];
-    memcpy(d, in[i]->xyz, 288);
+  for (size_t i = 1; i < buf.size() / 36; i++) {
+    uint64_t* d = &buf[i * 36];
     Fq2_ y = Fq2_::from_ark(d + 12);                       // negate: (X, -Y, Z)
     Fq2_ ny = {fq_neg(y.c0), fq_neg(y.c1)};
     ny.to_ark(d + 12);
   }
   PublicKey* pk = new PublicKey;
-  if (celo_amd_sum_jacobian_bls12_377_g2(buf.data(), (size_t)n + 1, pk->xyz) != 0) { delete pk; return false; }
+  if (celo_amd_sum_jacobian_bls12_377_g2(buf.data(), buf.size() / 36, pk->xyz) != 0) { delete pk; return false; }
   *out = pk;
   return true;
 }
@@ -1073,10 +1093,15 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   const size_t tot = offs[m];
   // staging: one grow-only PINNED host buffer kept by the library (allocating and releasing ~0.5 GB of pageable memory per call
   // cost 50-100 ms at config-3 scale, and pinned pages halve the host-to-device copies of the two MSMs)
-  static std::mutex stage_mu;
-  std::lock_guard<std::mutex> stage_lk(stage_mu);
-  static uint8_t* stage = nullptr;
-  static size_t stage_cap = 0;
+  // (kept PER DEVICE: a caller bound to another device with celo_amd_use_device must not run its engines against device-0 memory
+  // and a device-0 stream)
+  if (api_enter() != 0) return false;
+  struct DevStage { std::mutex mu; uint8_t* stage = nullptr; size_t stage_cap = 0; uint8_t* d_stage = nullptr; size_t d_stage_cap = 0; hipStream_t copy_stream = nullptr; };
+  static DevStage dev_stage[MAX_DEVICES];
+  DevStage& DS = dev_stage[api_device()];
+  std::lock_guard<std::mutex> stage_lk(DS.mu);
+  uint8_t*& stage = DS.stage;
+  size_t& stage_cap = DS.stage_cap;
   const size_t need = tot * (24 + 12 + 4) * 8 + 2 * tot + 4096;
   if (need > stage_cap) {
     if (api_enter() != 0) return false;
@@ -1095,9 +1120,9 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   // way (hipMemcpyAsync from pinned memory) while the workers gather the next: the 320 bytes per signer cross PCIe WHILE the host
   // cores are still gathering (6 ms of copies at 4096 x 256 that used to follow the gather).  (Copies issued by the 64 workers
   // themselves - 1280 small hipMemcpyAsync calls - cost more in the driver than they hid: gather 8 -> 21 ms.)
-  static uint8_t* d_stage = nullptr;
-  static size_t d_stage_cap = 0;
-  static hipStream_t copy_stream = nullptr;
+  uint8_t*& d_stage = DS.d_stage;
+  size_t& d_stage_cap = DS.d_stage_cap;
+  hipStream_t& copy_stream = DS.copy_stream;
   const size_t d_need = need + m * 97 + 4096;
   if (api_enter() != 0) return false;
   if (d_need > d_stage_cap) {

@@ -124,6 +124,33 @@ def test_batch_verify_ragged_and_degenerate(gpu):
     assert want == [True, False, True, True, True, True]
 
 
+def test_batch_verify_oversized_batches_on_the_chained_path(gpu):
+    """batch_verify_bls12_377[_dev] with a batch of more than 1024 signers (the batched MSM path's per-instance limit): the chained
+    call takes the big pipeline per instance and still returns the oracle's verdicts (it returned rc 2)."""
+    from celo_bls_snark_rs_amd import synthetic as syn
+    m, n = 3, 1300
+    w = syn.valid_batches(m, n, 0x5EED0311, [2])
+    ex = syn.batch_exponents(m * n, 0x5EED0312)
+    d_ex = torch.from_numpy(ex.view(np.int64)).cuda()
+    ng2 = syn.neg_g2_limbs()
+    got = gpu.batch_verify_dev(w["pk"].data_ptr(), w["sig"].data_ptr(), d_ex.data_ptr(), w["offsets"], w["hash"].data_ptr(), ng2)
+    assert got.tolist() == [1, 1, 0] == w["expect"].tolist()
+    pk = w["pk"].view(m * n, 24).cpu().numpy().view(np.uint64)
+    sg = w["sig"].view(m * n, 12).cpu().numpy().view(np.uint64)
+    hh = w["hash"].view(m, 12).cpu().numpy().view(np.uint64)
+    want = [_oracle_batch_verdict(pk[b * n:(b + 1) * n], sg[b * n:(b + 1) * n], ex[b * n:(b + 1) * n], hh[b], ng2) for b in range(m)]
+    assert [bool(x) for x in got] == want
+    # host-buffer form; ragged with an empty batch between two oversized ones, and a call whose batches are all empty
+    sizes = [1025, 0, 1300]
+    offs = np.array([0, 1025, 1025, 2325], dtype=np.uint32)
+    pk2 = np.concatenate([pk[:1025], pk[2 * n: 3 * n]]); sg2 = np.concatenate([sg[:1025], sg[2 * n: 3 * n]]); ex2 = np.concatenate([ex[:1025], ex[2 * n: 3 * n]])
+    got2 = gpu.batch_verify(pk2, sg2, ex2, offs, hh, ng2)
+    want2 = [_oracle_batch_verdict(pk2[:1025], sg2[:1025], ex2[:1025], hh[0], ng2), True, False]
+    assert [bool(x) for x in got2] == want2 and want2[0] is True
+    got3 = gpu.batch_verify(pk2[:0], sg2[:0], ex2[:0], np.zeros(3, dtype=np.uint32), hh[:2], ng2)
+    assert [bool(x) for x in got3] == [True, True]
+
+
 # ------------------------------------------------------------------------------------------------ cfg4
 def test_cfg4_bw6_761_g1_shard_size_vs_oracle(gpu):
     from celo_bls_snark_rs_amd import synthetic as syn

@@ -70,3 +70,30 @@ def test_two_rank_partial_sum_exchange():
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] and r[2] for r in res)
+
+
+def test_bench_gpus_flag_is_not_decorative(monkeypatch):
+    """bench.py --gpus N (the flag was parsed and ignored).  Without a launcher around it, N > 1 re-runs the command
+    line as N ranks under torch.distributed.run on 127.0.0.1; under a launcher whose WORLD_SIZE differs from --gpus it refuses to
+    run - so a line whose n_gpus differs from --gpus cannot be printed."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--scaling", "strong"])
+    assert bench.launch_ranks(2) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "3", "--scaling", "strong"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.undo()
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and not r.stdout.strip().startswith("{")

@@ -161,6 +161,57 @@ def test_keys_and_aggregation(sys_lib):
     assert int.from_bytes(_ser(sys_lib, "serialize_private_key", gen), "little") < ecc.R377
 
 
+def test_aggregate_public_keys_has_the_cache_set_semantics(sys_lib):
+    """aggregate_public_keys / aggregate_public_keys_subtract go through PublicKeyCache::aggregate in the reference
+    (crates/bls-snark-sys/src/signatures.rs:428-474 -> crates/bls-crypto/src/bls/cache.rs:65-87): the keys are collected into a
+    HashSet with byte equality of the Jacobian limbs (cache.rs:95-104), so a key listed twice counts ONCE and the order of the
+    list does not matter; aggregate_signatures is a plain sum (signatures.rs:485-505), where a repeat counts twice."""
+    rng = ecc.SplitMix64(4321)
+    pts = [ecc.E2_377.mul(ecc.G2_377, ecc.random_scalar(rng, ecc.R377)) for _ in range(4)]
+    hs = [_deser(sys_lib, "deserialize_public_key", ecc.ser_point(ecc.E2_377, P)) for P in pts]
+    assert all(h is not None for h in hs)
+
+    def agg(idx):
+        arr = (C.c_void_p * len(idx))(*[hs[i].value for i in idx])
+        out = C.c_void_p()
+        assert sys_lib.aggregate_public_keys(arr, C.c_int(len(idx)), C.byref(out))
+        return out
+
+    def total(idx):
+        t = None
+        for i in idx:
+            t = ecc.E2_377.add(t, pts[i])
+        return ecc.ser_point(ecc.E2_377, t)
+
+    assert _ser(sys_lib, "serialize_public_key", agg([0, 1, 2, 3])) == total([0, 1, 2, 3])
+    assert _ser(sys_lib, "serialize_public_key", agg([0, 1, 1, 2, 0, 0])) == total([0, 1, 2])          # repeats count once
+    assert _ser(sys_lib, "serialize_public_key", agg([2, 0, 1])) == total([0, 1, 2])                      # the same set in another order
+    assert _ser(sys_lib, "serialize_public_key", agg([3, 3])) == total([3])
+    # the same point behind two handles holding the same limbs (both came from the wire: Z = 1) is still one set element
+    twin = _deser(sys_lib, "deserialize_public_key", ecc.ser_point(ecc.E2_377, pts[1]))
+    arr = (C.c_void_p * 3)(hs[0].value, hs[1].value, twin.value)
+    out = C.c_void_p()
+    assert sys_lib.aggregate_public_keys(arr, C.c_int(3), C.byref(out))
+    assert _ser(sys_lib, "serialize_public_key", out) == total([0, 1])
+    # subtract: the list is aggregated as a set first, then subtracted once
+    full = agg([0, 1, 2, 3])
+    arr = (C.c_void_p * 4)(hs[1].value, hs[3].value, hs[1].value, hs[3].value)
+    sub = C.c_void_p()
+    assert sys_lib.aggregate_public_keys_subtract(full, arr, C.c_int(4), C.byref(sub))
+    assert _ser(sys_lib, "serialize_public_key", sub) == total([0, 2])
+    arr = (C.c_void_p * 2)(hs[3].value, hs[1].value)
+    sub2 = C.c_void_p()
+    assert sys_lib.aggregate_public_keys_subtract(full, arr, C.c_int(2), C.byref(sub2))
+    assert _ser(sys_lib, "serialize_public_key", sub2) == total([0, 2])
+    # signatures: a plain sum, a repeat counts twice
+    S = ecc.E1_377.mul(ecc.G1_377, 12345)
+    sh = _deser(sys_lib, "deserialize_signature", ecc.ser_point(ecc.E1_377, S))
+    arr = (C.c_void_p * 2)(sh.value, sh.value)
+    asig = C.c_void_p()
+    assert sys_lib.aggregate_signatures(arr, C.c_int(2), C.byref(asig))
+    assert _ser(sys_lib, "serialize_signature", asig) == ecc.ser_point(ecc.E1_377, ecc.E1_377.add(S, S))
+
+
 @pytest.mark.gpu
 def test_verify_hash_core_on_gpu(sys_lib, gpu):
     """verify_signature after hashing (crates/bls-snark-sys/src/signatures.rs:244 -> public.rs:94-120) on the GPU."""
@@ -696,3 +747,154 @@ def test_concurrent_verifications_are_combined(sys_lib, gpu):
     assert all(res)
     print("one call %.1f ms; 256 calls from 32 threads %.1f ms" % (t_one * 1e3, t_all * 1e3))
     assert t_all < 0.35 * 256 * t_one
+
+
+@pytest.mark.gpu
+def test_batch_verify_strict_oversized_and_empty_batches(sys_lib, gpu):
+    """Batch::verify takes any number of signers and accepts an empty batch (crates/bls-crypto/src/bls/batch.rs:44-84).  A batch
+    beyond the per-workgroup batched-MSM path (1024 signers) makes the whole call take the big MSM pipeline instance by instance;
+    a call of only empty batches does no MSM at all.  (both used to return false with every verdict false.)"""
+    for f in ("sign_message", "batch_verify_strict"):
+        getattr(sys_lib, f).restype = C.c_bool
+    CF, C22 = C.c_bool(False), C.c_bool(False)
+    rng = ecc.SplitMix64(909)
+    keys = []
+    for _ in range(5):
+        sk = ecc.random_scalar(rng, ecc.R377)
+        skh = _deser(sys_lib, "deserialize_private_key", sk.to_bytes(32, "little"))
+        pkh = C.c_void_p()
+        assert sys_lib.private_key_to_public_key(skh, C.byref(pkh))
+        keys.append((skh, pkh))
+
+    def sign(skh, m):
+        s = C.c_void_p()
+        assert sys_lib.sign_message(skh, m, C.c_int(len(m)), b"", C.c_int(0), CF, C22, C.byref(s))
+        return s
+
+    def batch(msg, n, spoil=None):
+        sig5 = [sign(sk, msg) for sk, _ in keys]
+        pks = (C.c_void_p * n)(*[keys[i % 5][1].value for i in range(n)])
+        sgl = [sig5[i % 5].value for i in range(n)]
+        if spoil is not None:
+            sgl[spoil] = sign(keys[spoil % 5][0], b"something else").value
+        sgs = (C.c_void_p * n)(*sgl)
+        return (pks, sgs, msg, sig5), _BatchMessageFFI(_Buffer(msg, len(msg)), _Buffer(b"", 0), pks, n, sgs, n)
+
+    h_big, big = batch(b"a batch of 1025 signers", 1025)
+    h_bad, bad = batch(b"another large batch", 1100, spoil=1033)
+    h_small, small = batch(b"a small batch beside them", 7)
+    empty = _BatchMessageFFI(_Buffer(b"nobody signed this", 18), _Buffer(b"", 0), None, 0, None, 0)
+    arr = (_BatchMessageFFI * 4)(big, empty, small, bad)
+    res = (C.c_bool * 4)()
+    assert not sys_lib.batch_verify_strict(arr, C.c_size_t(4), CF, C22, res)
+    assert list(res) == [True, True, True, False]
+    arr = (_BatchMessageFFI * 3)(big, empty, small)
+    res = (C.c_bool * 3)()
+    assert sys_lib.batch_verify_strict(arr, C.c_size_t(3), CF, C22, res) and list(res) == [True, True, True]
+    only_empty = (_BatchMessageFFI * 2)(empty, empty)
+    res = (C.c_bool * 2)()
+    assert sys_lib.batch_verify_strict(only_empty, C.c_size_t(2), CF, C22, res) and list(res) == [True, True]
+
+
+@pytest.mark.gpu
+def test_batch_verify_signature_4097_pair_product(sys_lib, gpu):
+    """BASELINE config 3, second shape (SURVEY.md section 8d): Signature::batch_verify over n = 4096 aggregates is ONE product of
+    4097 pairs, e(sum sig_i, -g2) * prod e(H(m_i), apk_i) == 1 (crates/bls-crypto/src/bls/signature.rs:101-155).  4096 epochs with
+    aggregate keys of 3 validators accept; one changed message, or one signature swapped for another epoch's, rejects."""
+    for f in ("sign_message", "batch_verify_signature", "aggregate_public_keys", "aggregate_signatures"):
+        getattr(sys_lib, f).restype = C.c_bool
+    CF, C22 = C.c_bool(False), C.c_bool(False)
+    rng = ecc.SplitMix64(4097)
+    n = 4096
+    vals = []
+    for _ in range(3):
+        sk = ecc.random_scalar(rng, ecc.R377)
+        skh = _deser(sys_lib, "deserialize_private_key", sk.to_bytes(32, "little"))
+        pkh = C.c_void_p()
+        assert sys_lib.private_key_to_public_key(skh, C.byref(pkh))
+        vals.append((sk, skh, pkh))
+    apk = C.c_void_p()
+    assert sys_lib.aggregate_public_keys((C.c_void_p * 3)(*[v[2].value for v in vals]), C.c_int(3), C.byref(apk))
+    # the aggregate signature of an epoch = (sk_1 + sk_2 + sk_3) H(m): signed once with the summed key (same group element)
+    sk_sum = sum(v[0] for v in vals) % ecc.R377
+    sum_h = _deser(sys_lib, "deserialize_private_key", sk_sum.to_bytes(32, "little"))
+    msgs = [b"epoch %d of 4096" % i for i in range(n)]
+    sigs = []
+    for m in msgs:
+        s = C.c_void_p()
+        assert sys_lib.sign_message(sum_h, m, C.c_int(len(m)), b"x", C.c_int(1), CF, C22, C.byref(s))
+        sigs.append(s)
+    # the first epoch's aggregate built the long way, as a check of the shortcut
+    parts = []
+    for _, skh, _ in vals:
+        s = C.c_void_p()
+        assert sys_lib.sign_message(skh, msgs[0], C.c_int(len(msgs[0])), b"x", C.c_int(1), CF, C22, C.byref(s))
+        parts.append(s)
+    a0 = C.c_void_p()
+    assert sys_lib.aggregate_signatures((C.c_void_p * 3)(*[p.value for p in parts]), C.c_int(3), C.byref(a0))
+    assert _ser(sys_lib, "serialize_signature", a0) == _ser(sys_lib, "serialize_signature", sigs[0])
+
+    def run(ms, sg):
+        arr = (_MessageFFI * n)(*[_MessageFFI(_Buffer(ms[i], len(ms[i])), _Buffer(b"x", 1), apk.value, sg[i].value) for i in range(n)])
+        ok = C.c_bool(False)
+        assert sys_lib.batch_verify_signature(arr, C.c_size_t(n), CF, C22, C.byref(ok))
+        return ok.value
+
+    assert run(msgs, sigs)
+    bad = list(msgs)
+    bad[4095] = b"epoch 4095 of 4097"
+    assert not run(bad, sigs)
+    # swapping two signatures leaves the SUM of the signatures unchanged, so the product still holds (the check is on the aggregate,
+    # as in the reference); replacing one by a foreign signature does not
+    swapped = list(sigs)
+    swapped[7], swapped[4000] = swapped[4000], swapped[7]
+    assert run(msgs, swapped)
+    foreign = list(sigs)
+    foreign[2048] = sigs[2049]
+    assert not run(msgs, foreign)
+
+
+@pytest.mark.gpu
+def test_batch_verify_strict_config3_scale_through_the_ffi(sys_lib, gpu):
+    """BASELINE config 3 through the reference-named C ABI: 4096 batches x 256 signers in ONE batch_verify_strict call
+    (crates/bls-snark-sys/src/signatures.rs:343-400), handles as they arrive from the wire, OS-RNG exponents; all batches accept,
+    and with two batches carrying a foreign signature exactly those two are rejected."""
+    for f in ("sign_message", "batch_verify_strict", "generate_private_key"):
+        getattr(sys_lib, f).restype = C.c_bool
+    CF, C22 = C.c_bool(False), C.c_bool(False)
+    NK, NS, m, nmsg = 16, 256, 4096, 8
+
+    def roundtrip(h, ser, deser):
+        return _deser(sys_lib, deser, _ser(sys_lib, ser, h))
+
+    keys = []
+    for _ in range(NK):
+        sk, pk = C.c_void_p(), C.c_void_p()
+        assert sys_lib.generate_private_key(C.byref(sk)) and sys_lib.private_key_to_public_key(sk, C.byref(pk))
+        keys.append((sk, roundtrip(pk, "serialize_public_key", "deserialize_public_key")))
+    per_msg = []
+    for b in range(nmsg):
+        msg = b"epoch-%06d" % b
+        sg = []
+        for sk, _ in keys:
+            s = C.c_void_p()
+            assert sys_lib.sign_message(sk, msg, C.c_int(len(msg)), b"", C.c_int(0), CF, C22, C.byref(s))
+            sg.append(roundtrip(s, "serialize_signature", "deserialize_signature"))
+        per_msg.append((msg, (C.c_void_p * NS)(*[keys[i % NK][1].value for i in range(NS)]), (C.c_void_p * NS)(*[sg[i % NK].value for i in range(NS)]), sg))
+    arr = (_BatchMessageFFI * m)()
+    for b in range(m):
+        msg, pk_arr, sg_arr, _ = per_msg[b % nmsg]
+        arr[b] = _BatchMessageFFI(_Buffer(msg, len(msg)), _Buffer(b"", 0), pk_arr, NS, sg_arr, NS)
+    out = (C.c_bool * m)()
+    assert sys_lib.batch_verify_strict(arr, C.c_size_t(m), CF, C22, out) and all(out)
+    # two spoiled batches: signer 100's signature replaced by the one it gave for another message
+    spoiled = {}
+    for b in (17, 4001):
+        msg, pk_arr, sg_arr, _ = per_msg[b % nmsg]
+        other = per_msg[(b + 1) % nmsg][3]
+        sl = [sg_arr[i] for i in range(NS)]
+        sl[100] = other[100 % NK].value
+        spoiled[b] = (C.c_void_p * NS)(*sl)
+        arr[b] = _BatchMessageFFI(_Buffer(msg, len(msg)), _Buffer(b"", 0), pk_arr, NS, spoiled[b], NS)
+    assert not sys_lib.batch_verify_strict(arr, C.c_size_t(m), CF, C22, out)
+    assert [b for b in range(m) if not out[b]] == [17, 4001]

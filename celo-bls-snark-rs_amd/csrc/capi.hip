@@ -56,7 +56,11 @@ DECL(g1_377) DECL(g2_377) DECL(761)
 int pairing_run_377(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
 int pairing_timings_377(float*);
 int ntt_run(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const uint64_t*, int, void*);
+int ntt_run_253(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const uint64_t*, int, void*);
 int ntt_timings(float*, int*);
+int witness_map_253_run(uint64_t*, uint64_t*, uint64_t*, unsigned, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, int, int, void*);
+int groth16_prove_377_run(const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, const uint64_t*,
+                          const uint64_t*, size_t, size_t, const uint64_t*, size_t, uint64_t*, uint64_t*, uint64_t*);
 int wire_decompress(int, const uint8_t*, size_t, int, uint64_t*, uint8_t*, int, void*);
 float wire_last_ms();
 int wire_normalize(int, const uint64_t*, size_t, uint64_t*, uint8_t*);
@@ -238,6 +242,29 @@ int groth16_prove_bw6_761(const uint64_t* a_query, size_t na, const uint64_t* b_
                           const uint64_t* h, size_t n_h, uint64_t out_a[36], uint64_t out_b[36], uint64_t out_c[36]) {
   msm_note_big_call_761();
   return groth16_prove_761_run(a_query, na, b_g2_query, nb, h_query, nh, l_query, nl, alpha_g1, beta_g2, assignment, n_assignment, n_aux, h, n_h, out_a, out_b, out_c);
+}
+int ntt_bls12_377_fr(uint64_t* data, unsigned log_n, const uint64_t omega[4], const uint64_t* coset, int coset_after, const uint64_t* scale) {
+  return ntt_run_253(data, log_n, omega, coset, coset_after, scale, 0, nullptr);
+}
+int ntt_bls12_377_fr_dev(uint64_t* d_data, unsigned log_n, const uint64_t omega[4], const uint64_t* coset, int coset_after, const uint64_t* scale,
+                         void* hip_stream) {
+  return ntt_run_253(d_data, log_n, omega, coset, coset_after, scale, 1, hip_stream);
+}
+int groth16_witness_map_bls12_377(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, const uint64_t omega[4], const uint64_t omega_inv[4], const uint64_t coset[4],
+                                  const uint64_t coset_inv[4], const uint64_t size_inv[4], const uint64_t vanishing_inv[4], int out_canonical) {
+  return witness_map_253_run(a, b, c, log_n, omega, omega_inv, coset, coset_inv, size_inv, vanishing_inv, out_canonical, 0, nullptr);
+}
+int groth16_witness_map_bls12_377_dev(uint64_t* d_a, uint64_t* d_b, uint64_t* d_c, unsigned log_n, const uint64_t omega[4], const uint64_t omega_inv[4],
+                                      const uint64_t coset[4], const uint64_t coset_inv[4], const uint64_t size_inv[4], const uint64_t vanishing_inv[4],
+                                      int out_canonical, void* hip_stream) {
+  return witness_map_253_run(d_a, d_b, d_c, log_n, omega, omega_inv, coset, coset_inv, size_inv, vanishing_inv, out_canonical, 1, hip_stream);
+}
+int groth16_prove_bls12_377(const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh, const uint64_t* l_query,
+                            size_t nl, const uint64_t alpha_g1[12], const uint64_t beta_g2[24], const uint64_t* assignment, size_t n_assignment, size_t n_aux,
+                            const uint64_t* h, size_t n_h, uint64_t out_a[18], uint64_t out_b[36], uint64_t out_c[18]) {
+  msm_note_big_call_g1_377();
+  msm_note_big_call_g2_377();
+  return groth16_prove_377_run(a_query, na, b_g2_query, nb, h_query, nh, l_query, nl, alpha_g1, beta_g2, assignment, n_assignment, n_aux, h, n_h, out_a, out_b, out_c);
 }
 int decompress_bls12_377_g1(const uint8_t* in, size_t n, int check_subgroup, uint64_t* out_xy, uint8_t* status) {
   return wire_decompress(0, in, n, check_subgroup, out_xy, status, 0, nullptr);

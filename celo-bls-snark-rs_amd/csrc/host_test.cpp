@@ -337,6 +337,14 @@ void ht_pairing_377_hex(int mode, const uint64_t* g1, const uint64_t* g2, size_t
                        uint64_t* out72, int* is_one) { pairing_op_hex(mode, g1, g2, k, in72, in72b, out72, is_one); }
 void ht_fq377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp<P377>>(op, a, b, out); }
 void ht_fq761(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp<P761>>(op, a, b, out); }
+// Fr(BLS12-377), the 10-limb field of the hash-helper proof's NTT (ntt.h); op 7 = weak reduction of a lazily grown sum (the butterfly's
+// x + y path), op 8 = canonical-integer round trip
+void ht_fr377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  typedef Fp<P253> F;
+  if (op == 7) { F x = F::from_ark(a), y = F::from_ark(b); F t = F::add(F::add(x, y), F::add(x, y)); t = F::add(t, t); F::wred(F::add(t, x)).to_ark(out); return; }   // 5x + 4y, value bound ~ 27p
+  if (op == 8) { F x = F::from_canonical(a); x.to_canonical(out); return; }
+  field_op<F>(op, a, b, out);
+}
 void ht_fq2_377(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) { field_op<Fp2<P377>>(op, a, b, out); }
 void ht_g1_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { point_op<Fp<P377>>(op, p1, p2, k, out); }
 void ht_g2_377(int op, const uint64_t* p1, const uint64_t* p2, uint32_t k, uint64_t* out) { point_op<Fp2<P377>>(op, p1, p2, k, out); }

@@ -1,8 +1,10 @@
-// Translation unit: the Groth16 prover's device work for BW6-761 - what
-// ark_groth16::create_proof_no_zk does after R1CS synthesis, as called at crates/epoch-snark/src/api/prover.rs:78,112:
+// Translation unit: the Groth16 prover's device work - what ark_groth16::create_proof_no_zk does after
+// R1CS synthesis, for BOTH proofs of an epoch: the epoch proof over BW6-761 (crates/epoch-snark/src/api/prover.rs:78 ->
+// generate_epoch_proof) and the hash-helper proof over BLS12-377 (prover.rs:83-118, create_proof_no_zk::<BLSCurve, _> at :112):
 //   1. witness map (ark-groth16 r1cs_to_qap.rs R1CStoQAP::witness_map): the QAP evaluations a, b, c over the domain
 //        ifft(a), ifft(b), ifft(c); coset_fft(a), coset_fft(b), coset_fft(c); ab = (a o b - c) / Z(coset); coset_ifft(ab) = h
-//      seven radix-2 transforms over Fr(BW6-761) (ntt.h) and one pointwise kernel; Z is constant on the coset: g^n - 1.
+//      seven radix-2 transforms over the curve's scalar field (ntt.h: Fr(BW6-761) = 377 bits, Fr(BLS12-377) = 253 bits) and one
+//      pointwise kernel; Z is constant on the coset: g^n - 1.
 //   2. the proof (create_proof with r = s = 0):
 //        A = a_query[0] + MSM(a_query[1..], assignment) + alpha_g1
 //        B = b_g2_query[0] + MSM(b_g2_query[1..], assignment) + beta_g2
@@ -19,25 +21,36 @@
 
 namespace celo {
 typedef Fp<P377> Fr761;          // the scalar field of BW6-761 is the base field of BLS12-377 (ntt.h)
-constexpr int NTT_WORDS = 16;    // device form: 14 limbs padded to 16 words
+typedef Fp<P253> Fr377;          // the scalar field of BLS12-377
 int ntt_run(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const uint64_t*, int, void*);
+int ntt_run_253(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const uint64_t*, int, void*);
 int msm_host_761(const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*);
 int sum_jac_761(const uint64_t*, size_t, uint64_t*);
+int msm_host_g1_377(const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*);
+int msm_host_g2_377(const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*);
+int sum_jac_g1_377(const uint64_t*, size_t, uint64_t*);
+int sum_jac_g2_377(const uint64_t*, size_t, uint64_t*);
+template <class FR> struct NttOf;
+template <> struct NttOf<Fr761> { static int run(uint64_t* d, unsigned l, const uint64_t* w, const uint64_t* g, int after, const uint64_t* sc, void* st) { return ntt_run(d, l, w, g, after, sc, 1, st); } };
+template <> struct NttOf<Fr377> { static int run(uint64_t* d, unsigned l, const uint64_t* w, const uint64_t* g, int after, const uint64_t* sc, void* st) { return ntt_run_253(d, l, w, g, after, sc, 1, st); } };
 
 // a[i] <- (a[i] b[i] - c[i]) z   (arkworks Montgomery limbs in and out; optionally the canonical integer: Fr::into_repr())
+template <class FR>
 __global__ void __launch_bounds__(256) k_qap_combine(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, const uint64_t* __restrict__ c, uint32_t n,
                                                      const uint32_t* __restrict__ z_dev) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Fr761 x = Fr761::from_ark(a + (size_t)i * 6), y = Fr761::from_ark(b + (size_t)i * 6), w = Fr761::from_ark(c + (size_t)i * 6);
-  const Fr761 z = Fr761::load(z_dev);
-  const Fr761 t = Fr761::norm(Fr761::sub<4, 1>(Fr761::mul(x, y), w));
-  Fr761::mul(t, z).to_ark(a + (size_t)i * 6);
+  constexpr int A = FR::ARK64;
+  const FR x = FR::from_ark(a + (size_t)i * A), y = FR::from_ark(b + (size_t)i * A), w = FR::from_ark(c + (size_t)i * A);
+  const FR z = FR::load(z_dev);
+  const FR t = FR::norm(FR::template sub<4, 1>(FR::mul(x, y), w));
+  FR::mul(t, z).to_ark(a + (size_t)i * A);
 }
+template <class FR>
 __global__ void __launch_bounds__(256) k_to_canonical(uint64_t* __restrict__ a, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fr761::from_ark(a + (size_t)i * 6).to_canonical(a + (size_t)i * 6);
+  FR::from_ark(a + (size_t)i * FR::ARK64).to_canonical(a + (size_t)i * FR::ARK64);
 }
 
 #define PRV_OK(x)                                                                                                  \
@@ -47,18 +60,19 @@ __global__ void __launch_bounds__(256) k_to_canonical(uint64_t* __restrict__ a, 
   } while (0)
 
 // dev = 1: a, b, c are DEVICE pointers (a is overwritten with h; b and c are overwritten with intermediate values).
-int witness_map_run(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, const uint64_t* omega, const uint64_t* omega_inv, const uint64_t* coset,
+template <class FR>
+static int witness_map_t(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, const uint64_t* omega, const uint64_t* omega_inv, const uint64_t* coset,
                     const uint64_t* coset_inv, const uint64_t* n_inv, const uint64_t* z_inv, int out_canonical, int dev, void* stream_) {
   if (int rc0 = api_enter()) return rc0;
   if (!a || !b || !c || !omega || !omega_inv || !coset || !coset_inv || !n_inv || !z_inv || log_n > 28) return 2;
-  const size_t n = size_t(1) << log_n, bytes = n * 48;
+  const size_t n = size_t(1) << log_n, bytes = n * FR::ARK64 * 8;
   hipStream_t stream = (hipStream_t)stream_;
   uint64_t *da = a, *db = b, *dc = c;
   uint32_t* d_z = nullptr;
   int rc = 0;
-  uint32_t zw[NTT_WORDS];
+  uint32_t zw[FR::WORDS];
   {
-    Fr761 v = Fr761::wred(Fr761::from_ark(z_inv));
+    FR v = FR::wred(FR::from_ark(z_inv));
     memset(zw, 0, sizeof zw);
     v.store(zw);
   }
@@ -73,11 +87,11 @@ int witness_map_run(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, const
   PRV_OK(hipMemcpyAsync(d_z, zw, sizeof zw, hipMemcpyHostToDevice, stream));
   // an NTT engine keeps the twiddle table of its last (omega, n) and the pool hands the same engine back to a serial caller: the
   // table is rebuilt three times per witness map (inverse, forward, inverse: ~20 us each at 2^20), not seven
-  for (uint64_t* p : {da, db, dc}) if ((rc = ntt_run(p, log_n, omega_inv, nullptr, 0, n_inv, 1, stream))) goto done;        // ifft
-  for (uint64_t* p : {da, db, dc}) if ((rc = ntt_run(p, log_n, omega, coset, 0, nullptr, 1, stream))) goto done;             // coset_fft
-  hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, da, db, dc, (uint32_t)n, d_z);
-  if ((rc = ntt_run(da, log_n, omega_inv, coset_inv, 1, n_inv, 1, stream))) goto done;                                          // coset_ifft
-  if (out_canonical) hipLaunchKernelGGL(k_to_canonical, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, da, (uint32_t)n);
+  for (uint64_t* p : {da, db, dc}) if ((rc = NttOf<FR>::run(p, log_n, omega_inv, nullptr, 0, n_inv, stream))) goto done;        // ifft
+  for (uint64_t* p : {da, db, dc}) if ((rc = NttOf<FR>::run(p, log_n, omega, coset, 0, nullptr, stream))) goto done;             // coset_fft
+  hipLaunchKernelGGL((k_qap_combine<FR>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, da, db, dc, (uint32_t)n, d_z);
+  if ((rc = NttOf<FR>::run(da, log_n, omega_inv, coset_inv, 1, n_inv, stream))) goto done;                                          // coset_ifft
+  if (out_canonical) hipLaunchKernelGGL((k_to_canonical<FR>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, da, (uint32_t)n);
   PRV_OK(hipGetLastError());
   if (!dev) PRV_OK(hipMemcpyAsync(a, da, bytes, hipMemcpyDeviceToHost, stream));
   PRV_OK(hipStreamSynchronize(stream));
@@ -85,6 +99,15 @@ done:
   if (!dev) { if (da) (void)hipFree(da); if (db) (void)hipFree(db); if (dc) (void)hipFree(dc); }
   if (d_z) (void)hipFree(d_z);
   return rc;
+}
+
+int witness_map_run(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, const uint64_t* omega, const uint64_t* omega_inv, const uint64_t* coset,
+                    const uint64_t* coset_inv, const uint64_t* n_inv, const uint64_t* z_inv, int out_canonical, int dev, void* stream_) {
+  return witness_map_t<Fr761>(a, b, c, log_n, omega, omega_inv, coset, coset_inv, n_inv, z_inv, out_canonical, dev, stream_);
+}
+int witness_map_253_run(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, const uint64_t* omega, const uint64_t* omega_inv, const uint64_t* coset,
+                        const uint64_t* coset_inv, const uint64_t* n_inv, const uint64_t* z_inv, int out_canonical, int dev, void* stream_) {
+  return witness_map_t<Fr377>(a, b, c, log_n, omega, omega_inv, coset, coset_inv, n_inv, z_inv, out_canonical, dev, stream_);
 }
 
 // all pointers HOST.  Queries: affine points, arkworks layout (24 u64 each).  assignment: n_assign = na - 1 canonical scalars (public
@@ -125,5 +148,47 @@ int groth16_prove_761_run(const uint64_t* a_query, size_t na, const uint64_t* b_
   if (int rc = sum_jac_761(&terms[0][0], 3, out_b)) return rc;
   memcpy(terms[0], acc[2], 288); memcpy(terms[1], acc[3], 288);
   return sum_jac_761(&terms[0][0], 2, out_c);
+}
+
+// The same composition over BLS12-377 (the hash-helper proof, prover.rs:112): A, C and the a / h / l queries live in G1 (affine 12 u64,
+// Jacobian 18), B and the b_g2 query in G2 (24 / 36), scalars are 4 u64.  (create_proof also accumulates B in G1 - g_b_g1 - for the
+// r B term of C; with r = s = 0 that term vanishes whatever B's G1 image is, so it is not computed.)
+int groth16_prove_377_run(const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh,
+                          const uint64_t* l_query, size_t nl, const uint64_t* alpha_g1, const uint64_t* beta_g2, const uint64_t* assignment,
+                          size_t n_assign, size_t n_aux, const uint64_t* h, size_t n_h, uint64_t* out_a, uint64_t* out_b, uint64_t* out_c) {
+  if (int rc0 = api_enter()) return rc0;
+  if (!a_query || !b_g2_query || !alpha_g1 || !beta_g2 || !out_a || !out_b || !out_c || na == 0 || nb == 0) return 2;
+  if ((n_assign && !assignment) || n_aux > n_assign || (n_h && !h) || (nh && !h_query) || (nl && !l_query)) return 2;
+  const size_t ka = (na - 1 < n_assign) ? na - 1 : n_assign, kb = (nb - 1 < n_assign) ? nb - 1 : n_assign;
+  const size_t kl = nl < n_aux ? nl : n_aux, kh = nh < n_h ? nh : n_h;
+  const uint64_t* aux = assignment + (n_assign - n_aux) * 4;
+  uint64_t acc1[3][18], acc2[36];
+  int rcs[4] = {0, 0, 0, 0};
+  const int dev = api_device();
+  auto run1 = [&](int i, uint64_t* out, const uint64_t* bases, const uint64_t* sc, size_t k) {
+    rcs[i] = api_bind_thread(dev);
+    if (!rcs[i]) rcs[i] = msm_host_g1_377(bases, nullptr, sc, k, out);
+  };
+  auto run2 = [&]() {
+    rcs[1] = api_bind_thread(dev);
+    if (!rcs[1]) rcs[1] = msm_host_g2_377(b_g2_query + 24, nullptr, assignment, kb, acc2);
+  };
+  {
+    std::thread t0(run1, 0, acc1[0], a_query + 12, assignment, ka), t1(run2), t2(run1, 2, acc1[1], l_query, aux, kl);
+    run1(3, acc1[2], h_query, h, kh);
+    t0.join(); t1.join(); t2.join();
+  }
+  for (int r : rcs) if (r) return r;
+  uint64_t t1[3][18], t2[3][36];
+  memcpy(t1[0], a_query, 96); Fq377d::one().to_ark(t1[0] + 12);
+  memcpy(t1[1], acc1[0], 144);
+  memcpy(t1[2], alpha_g1, 96); Fq377d::one().to_ark(t1[2] + 12);
+  if (int rc = sum_jac_g1_377(&t1[0][0], 3, out_a)) return rc;
+  memcpy(t2[0], b_g2_query, 192); Fq377d::one().to_ark(t2[0] + 24); Fq377d::zero().to_ark(t2[0] + 30);
+  memcpy(t2[1], acc2, 288);
+  memcpy(t2[2], beta_g2, 192); Fq377d::one().to_ark(t2[2] + 24); Fq377d::zero().to_ark(t2[2] + 30);
+  if (int rc = sum_jac_g2_377(&t2[0][0], 3, out_b)) return rc;
+  memcpy(t1[0], acc1[1], 144); memcpy(t1[1], acc1[2], 144);
+  return sum_jac_g1_377(&t1[0][0], 2, out_c);
 }
 }  // namespace celo

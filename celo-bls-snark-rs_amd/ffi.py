@@ -307,6 +307,66 @@ def groth16_prove(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, assi
     return out
 
 
+# ---- the hash-helper proof's field and curve: Fr(BLS12-377) elements are 4 u64, G1 points 12 u64 affine / 18 Jacobian, G2 24 / 36
+def ntt_fr377(data, log_n, omega4, coset4=None, coset_after=False, scale4=None):
+    """In-place NTT over Fr(BLS12-377) on HOST data (ntt_bls12_377_fr): (n, 4) uint64 arkworks Montgomery limbs.  Returns a copy."""
+    out = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    assert out.shape == (1 << log_n, 4)
+    w = np.ascontiguousarray(omega4, dtype=np.uint64)
+    g = None if coset4 is None else np.ascontiguousarray(coset4, dtype=np.uint64)
+    sc = None if scale4 is None else np.ascontiguousarray(scale4, dtype=np.uint64)
+    rc = lib().ntt_bls12_377_fr(_p(out), C.c_uint(log_n), _p(w), _p(g), C.c_int(1 if coset_after else 0), _p(sc))
+    if rc != 0:
+        raise RuntimeError("ntt_bls12_377_fr failed with code %d" % rc)
+    return out
+
+
+def ntt_fr377_dev(d_ptr, log_n, omega4, coset4=None, coset_after=False, scale4=None, stream=0):
+    w = np.ascontiguousarray(omega4, dtype=np.uint64)
+    g = None if coset4 is None else np.ascontiguousarray(coset4, dtype=np.uint64)
+    sc = None if scale4 is None else np.ascontiguousarray(scale4, dtype=np.uint64)
+    rc = lib().ntt_bls12_377_fr_dev(C.c_void_p(d_ptr), C.c_uint(log_n), _p(w), _p(g), C.c_int(1 if coset_after else 0), _p(sc), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError("ntt_bls12_377_fr_dev failed with code %d" % rc)
+
+
+def witness_map_fr377(a, b, c, log_n, consts, canonical=False):
+    """groth16_witness_map_bls12_377: a, b, c (n, 4) uint64 Montgomery limbs (copied); consts as for witness_map, (4,) limbs each."""
+    bufs = [np.ascontiguousarray(x, dtype=np.uint64).copy() for x in (a, b, c)]
+    assert all(x.shape == (1 << log_n, 4) for x in bufs)
+    k = [np.ascontiguousarray(consts[n], dtype=np.uint64) for n in ("omega", "omega_inv", "coset", "coset_inv", "size_inv", "vanishing_inv")]
+    rc = lib().groth16_witness_map_bls12_377(_p(bufs[0]), _p(bufs[1]), _p(bufs[2]), C.c_uint(log_n), *[_p(x) for x in k], C.c_int(1 if canonical else 0))
+    if rc != 0:
+        raise RuntimeError("groth16_witness_map_bls12_377 failed with code %d" % rc)
+    return bufs[0]
+
+
+def witness_map_fr377_dev(d_a, d_b, d_c, log_n, consts, canonical=False, stream=0):
+    k = [np.ascontiguousarray(consts[n], dtype=np.uint64) for n in ("omega", "omega_inv", "coset", "coset_inv", "size_inv", "vanishing_inv")]
+    rc = lib().groth16_witness_map_bls12_377_dev(C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c), C.c_uint(log_n), *[_p(x) for x in k],
+                                                 C.c_int(1 if canonical else 0), C.c_void_p(stream or 0))
+    if rc != 0:
+        raise RuntimeError("groth16_witness_map_bls12_377_dev failed with code %d" % rc)
+
+
+def groth16_prove_bls12_377(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, assignment, n_aux, h):
+    """create_proof_no_zk's group arithmetic over BLS12-377 (groth16_prove_bls12_377).  a / h / l queries: (k, 12) uint64, b_g2_query:
+    (k, 24); alpha (12,), beta (24,); assignment, h: (k, 4) canonical scalars.  Returns (A (18,), B (36,), C (18,)) Jacobian limbs."""
+    aq, hq, lq = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 12) for x in (a_query, h_query, l_query))
+    bq = np.ascontiguousarray(b_g2_query, dtype=np.uint64).reshape(-1, 24)
+    al = np.ascontiguousarray(alpha_g1, dtype=np.uint64).reshape(12)
+    be = np.ascontiguousarray(beta_g2, dtype=np.uint64).reshape(24)
+    asg = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 4)
+    hh = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 4)
+    out = [np.zeros(18, dtype=np.uint64), np.zeros(36, dtype=np.uint64), np.zeros(18, dtype=np.uint64)]
+    rc = lib().groth16_prove_bls12_377(_p(aq), C.c_size_t(aq.shape[0]), _p(bq), C.c_size_t(bq.shape[0]), _p(hq), C.c_size_t(hq.shape[0]),
+                                       _p(lq), C.c_size_t(lq.shape[0]), _p(al), _p(be), _p(asg), C.c_size_t(asg.shape[0]), C.c_size_t(n_aux),
+                                       _p(hh), C.c_size_t(hh.shape[0]), _p(out[0]), _p(out[1]), _p(out[2]))
+    if rc != 0:
+        raise RuntimeError("groth16_prove_bls12_377 failed with code %d" % rc)
+    return out
+
+
 def ntt_timings():
     ms = (C.c_float * 4)()
     n = C.c_int(0)

@@ -169,6 +169,23 @@ int groth16_prove_bw6_761(const uint64_t* a_query, size_t na, const uint64_t* b_
                           size_t nl, const uint64_t alpha_g1[24], const uint64_t beta_g2[24], const uint64_t* assignment, size_t n_assignment, size_t n_aux,
                           const uint64_t* h, size_t n_h, uint64_t out_a[36], uint64_t out_b[36], uint64_t out_c[36]);
 
+/* ---- the same three steps over BLS12-377: the hash-helper proof of an epoch (crates/epoch-snark/src/api/prover.rs:83-118,
+ * create_proof_no_zk::<BLSCurve, _> at :112), whose witness map runs over Fr(BLS12-377) (253 bits, 2-adicity 47; elements are 4 u64 in
+ * arkworks Montgomery form, R = 2^256) and whose queries are BLS12-377 points: a_query / h_query / l_query / alpha_g1 in G1 (affine
+ * 12 u64), b_g2_query / beta_g2 in G2 (24 u64); assignment and h are canonical 4-u64 scalars; A and C come back as G1 Jacobian
+ * (18 u64), B as G2 Jacobian (36 u64).  Same argument meaning, transforms and error behaviour as the BW6-761 entry points above. */
+int ntt_bls12_377_fr(uint64_t* data, unsigned log_n, const uint64_t omega[4], const uint64_t* coset, int coset_after, const uint64_t* scale);
+int ntt_bls12_377_fr_dev(uint64_t* d_data, unsigned log_n, const uint64_t omega[4], const uint64_t* coset, int coset_after,
+                         const uint64_t* scale, void* hip_stream);
+int groth16_witness_map_bls12_377(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, const uint64_t omega[4], const uint64_t omega_inv[4], const uint64_t coset[4],
+                                  const uint64_t coset_inv[4], const uint64_t size_inv[4], const uint64_t vanishing_inv[4], int out_canonical);
+int groth16_witness_map_bls12_377_dev(uint64_t* d_a, uint64_t* d_b, uint64_t* d_c, unsigned log_n, const uint64_t omega[4], const uint64_t omega_inv[4],
+                                      const uint64_t coset[4], const uint64_t coset_inv[4], const uint64_t size_inv[4], const uint64_t vanishing_inv[4],
+                                      int out_canonical, void* hip_stream);
+int groth16_prove_bls12_377(const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh, const uint64_t* l_query,
+                            size_t nl, const uint64_t alpha_g1[12], const uint64_t beta_g2[24], const uint64_t* assignment, size_t n_assignment, size_t n_aux,
+                            const uint64_t* h, size_t n_h, uint64_t out_a[18], uint64_t out_b[36], uint64_t out_c[18]);
+
 /* ---- bulk decoding of compressed points: n keys or signatures in arkworks 0.1 wire form
  * (G1: 48 B, G2: 96 B; x little-endian, flag bits 0x80 = "y is the larger root", 0x40 = infinity in the last byte) to
  * affine (x, y) in arkworks Montgomery limbs - the layout the MSM and pairing entry points take.  One point per GPU lane:

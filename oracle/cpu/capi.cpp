@@ -98,6 +98,42 @@ void store_gt761(const Fq6_761& g, u64* out) {
 }
 }  // namespace
 
+// radix-2 NTT, a template over the field: see the comment at orc_ntt_fq377 below
+template <class F> static int ntt_impl(u64* data, unsigned log_n, const u64* omega6, const u64* coset6, int coset_after, const u64* scale6) {
+  constexpr int A = F::N;
+  const size_t n = size_t(1) << log_n;
+  std::vector<F> a(n);
+  for (size_t i = 0; i < n; i++) memcpy(a[i].v, data + A * i, 8 * A);
+  F w, g, sc;
+  memcpy(w.v, omega6, 8 * A);
+  if (coset6) memcpy(g.v, coset6, 8 * A);
+  if (scale6) memcpy(sc.v, scale6, 8 * A);
+  if (coset6 && !coset_after) { F p = F::one(); for (size_t i = 0; i < n; i++) { a[i] = a[i] * p; p = p * g; } }
+  for (size_t i = 0; i < n; i++) {  // bit reversal
+    size_t r = 0;
+    for (unsigned b = 0; b < log_n; b++) r |= ((i >> b) & 1) << (log_n - 1 - b);
+    if (r > i) std::swap(a[i], a[r]);
+  }
+  for (unsigned s = 1; s <= log_n; s++) {
+    const size_t m = size_t(1) << s;
+    F wm = w;                                   // omega^(n/m)
+    for (unsigned k = s; k < log_n; k++) wm = wm * wm;
+    for (size_t k = 0; k < n; k += m) {
+      F t = F::one();
+      for (size_t j = 0; j < m / 2; j++) {
+        F u = a[k + j], v = a[k + j + m / 2] * t;
+        a[k + j] = u + v;
+        a[k + j + m / 2] = u - v;
+        t = t * wm;
+      }
+    }
+  }
+  if (coset6 && coset_after) { F p = F::one(); for (size_t i = 0; i < n; i++) { a[i] = a[i] * p; p = p * g; } }
+  if (scale6) for (size_t i = 0; i < n; i++) a[i] = a[i] * sc;
+  for (size_t i = 0; i < n; i++) memcpy(data + A * i, a[i].v, 8 * A);
+  return 0;
+}
+
 extern "C" {
 
 // ---- Montgomery conversion (count field elements)
@@ -126,37 +162,12 @@ int orc_from_mont_761(const u64* in, u64* out, size_t count) {
 // optional final scale (n^-1).  data: n = 2^log_n elements, arkworks Montgomery limbs.  PARITY UNPINNED against the
 // reference (it holds no NTT vector); pinned against the O(n^2) definition in oracle/py and by round-trip properties.
 int orc_ntt_fq377(u64* data, unsigned log_n, const u64* omega6, const u64* coset6, int coset_after, const u64* scale6) {
-  const size_t n = size_t(1) << log_n;
-  std::vector<Fq377> a(n);
-  for (size_t i = 0; i < n; i++) memcpy(a[i].v, data + 6 * i, 48);
-  Fq377 w, g, sc;
-  memcpy(w.v, omega6, 48);
-  if (coset6) memcpy(g.v, coset6, 48);
-  if (scale6) memcpy(sc.v, scale6, 48);
-  if (coset6 && !coset_after) { Fq377 p = Fq377::one(); for (size_t i = 0; i < n; i++) { a[i] = a[i] * p; p = p * g; } }
-  for (size_t i = 0; i < n; i++) {  // bit reversal
-    size_t r = 0;
-    for (unsigned b = 0; b < log_n; b++) r |= ((i >> b) & 1) << (log_n - 1 - b);
-    if (r > i) std::swap(a[i], a[r]);
-  }
-  for (unsigned s = 1; s <= log_n; s++) {
-    const size_t m = size_t(1) << s;
-    Fq377 wm = w;                                   // omega^(n/m)
-    for (unsigned k = s; k < log_n; k++) wm = wm * wm;
-    for (size_t k = 0; k < n; k += m) {
-      Fq377 t = Fq377::one();
-      for (size_t j = 0; j < m / 2; j++) {
-        Fq377 u = a[k + j], v = a[k + j + m / 2] * t;
-        a[k + j] = u + v;
-        a[k + j + m / 2] = u - v;
-        t = t * wm;
-      }
-    }
-  }
-  if (coset6 && coset_after) { Fq377 p = Fq377::one(); for (size_t i = 0; i < n; i++) { a[i] = a[i] * p; p = p * g; } }
-  if (scale6) for (size_t i = 0; i < n; i++) a[i] = a[i] * sc;
-  for (size_t i = 0; i < n; i++) memcpy(data + 6 * i, a[i].v, 48);
-  return 0;
+  return ntt_impl<Fq377>(data, log_n, omega6, coset6, coset_after, scale6);
+}
+// the same transform over Fr(BLS12-377) (4-limb Montgomery elements): the hash-helper proof's witness map
+// (crates/epoch-snark/src/api/prover.rs:83-118)
+int orc_ntt_fr253(u64* data, unsigned log_n, const u64* omega4, const u64* coset4, int coset_after, const u64* scale4) {
+  return ntt_impl<Fr253>(data, log_n, omega4, coset4, coset_after, scale4);
 }
 double orc_time_ntt_fq377(u64* data, unsigned log_n, const u64* omega6) {
   auto t0 = std::chrono::steady_clock::now();

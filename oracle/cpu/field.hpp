@@ -273,8 +273,14 @@ struct Tag761 {
     return "0122e824fb83ce0ad187c94004faff3eb926186a81d14688528275ef8087be41707ba638e584e91903cebaff25b423048689c8ed12f9fd9071dcd3dc73ebff2e98a116c25667a8f8160cf8aeeaf0a437e6913e6870000082f49d00000000008b";
   }
 };
+// Fr of BLS12-377 (253 bits, 2-adicity 47): the field of the hash-helper proof's witness map
+struct Tag253 {
+  static constexpr int N = 4;
+  static const char* hex() { return "12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001"; }
+};
 typedef Fp<Tag377> Fq377;
 typedef Fp<Tag761> Fq761;
+typedef Fp<Tag253> Fr253;
 
 // ---------------------------------------------------------------- Fq2 = Fq[u]/(u^2 - NR), NR a small int
 template <class F, int NR> struct Fp2T {

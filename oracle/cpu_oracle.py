@@ -8,7 +8,7 @@ import os
 import subprocess
 import numpy as np
 
-from .py.ecc import Q377, Q761
+from .py.ecc import Q377, Q761, R377
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "build", "liboracle.so")
@@ -56,15 +56,21 @@ def limbs_to_ints(arr, nlimbs):
     return [int.from_bytes(raw[i * 8 * nlimbs:(i + 1) * 8 * nlimbs], "little") for i in range(a.shape[0])]
 
 
+def _mont_shape(p):
+    """(u64 limbs, Montgomery radix) of arkworks' representation of the field of order p"""
+    if p == R377:
+        return 4, 1 << 256
+    return (6, R384) if p == Q377 else (12, R768)
+
+
 def to_mont(vals, p):
-    n = 6 if p == Q377 else 12
-    Rm = R384 if p == Q377 else R768
+    n, Rm = _mont_shape(p)
     return ints_to_limbs([(v * Rm) % p for v in vals], n)
 
 
 def from_mont(arr, p):
-    n = 6 if p == Q377 else 12
-    Rinv = pow(R384 if p == Q377 else R768, -1, p)
+    n, Rm = _mont_shape(p)
+    Rinv = pow(Rm, -1, p)
     return [(v * Rinv) % p for v in limbs_to_ints(arr, n)]
 
 
@@ -208,6 +214,16 @@ def ntt_fq377(data, log_n, omega, coset=None, coset_after=False, scale=None):
     g = None if coset is None else to_mont([coset], Q377)
     s = None if scale is None else to_mont([scale], Q377)
     assert lib().orc_ntt_fq377(_p(out), C.c_uint(log_n), _p(w), _p(g), C.c_int(1 if coset_after else 0), _p(s)) == 0
+    return out
+
+
+def ntt_fr253(data, log_n, omega, coset=None, coset_after=False, scale=None):
+    """The same transform over Fr(BLS12-377) (orc_ntt_fr253).  data: (n, 4) uint64 arkworks Montgomery limbs (copied)."""
+    out = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    w = to_mont([omega], R377)
+    g = None if coset is None else to_mont([coset], R377)
+    s = None if scale is None else to_mont([scale], R377)
+    assert lib().orc_ntt_fr253(_p(out), C.c_uint(log_n), _p(w), _p(g), C.c_int(1 if coset_after else 0), _p(s)) == 0
     return out
 
 

@@ -14,26 +14,29 @@ import numpy as np
 from . import ecc
 from .. import cpu_oracle as co
 
-Q = ecc.Q377          # Fr(BW6-761) = Fq(BLS12-377)
+Q = ecc.Q377          # Fr(BW6-761) = Fq(BLS12-377): the epoch proof's field (prover.rs:78)
+R = ecc.R377          # Fr(BLS12-377): the hash-helper proof's field (prover.rs:83-118, create_proof_no_zk::<BLSCurve, _> at :112)
 
 
-def domain_constants(log_n, omega, coset):
+def domain_constants(log_n, omega, coset, field=Q):
     n = 1 << log_n
-    return {"omega": omega, "omega_inv": pow(omega, -1, Q), "coset": coset, "coset_inv": pow(coset, -1, Q), "size_inv": pow(n, -1, Q),
-            "vanishing_inv": pow((pow(coset, n, Q) - 1) % Q, -1, Q)}
+    return {"omega": omega, "omega_inv": pow(omega, -1, field), "coset": coset, "coset_inv": pow(coset, -1, field), "size_inv": pow(n, -1, field),
+            "vanishing_inv": pow((pow(coset, n, field) - 1) % field, -1, field)}
 
 
-def witness_map(a, b, c, log_n, omega, coset):
-    """a, b, c: lists of n canonical ints (QAP evaluations over the domain).  Returns h as a list of n canonical ints."""
-    k = domain_constants(log_n, omega, coset)
+def witness_map(a, b, c, log_n, omega, coset, field=Q):
+    """a, b, c: lists of n canonical ints (QAP evaluations over the domain).  Returns h as a list of n canonical ints.
+    field = Q (BW6-761's scalar field, the default) or R (BLS12-377's)."""
+    k = domain_constants(log_n, omega, coset, field)
+    ntt = co.ntt_fq377 if field == Q else co.ntt_fr253
     def ifft(v):
-        return co.ntt_fq377(co.to_mont(v, Q), log_n, k["omega_inv"], scale=k["size_inv"])
+        return ntt(co.to_mont(v, field), log_n, k["omega_inv"], scale=k["size_inv"])
     def coset_fft(m):
-        return co.ntt_fq377(m, log_n, omega, coset=coset)
-    A, B, C = (co.from_mont(coset_fft(ifft(v)), Q) for v in (a, b, c))
-    ab = [((x * y - z) * k["vanishing_inv"]) % Q for x, y, z in zip(A, B, C)]
-    h = co.ntt_fq377(co.to_mont(ab, Q), log_n, k["omega_inv"], coset=k["coset_inv"], coset_after=True, scale=k["size_inv"])
-    return co.from_mont(h, Q)
+        return ntt(m, log_n, omega, coset=coset)
+    A, B, C = (co.from_mont(coset_fft(ifft(v)), field) for v in (a, b, c))
+    ab = [((x * y - z) * k["vanishing_inv"]) % field for x, y, z in zip(A, B, C)]
+    h = ntt(co.to_mont(ab, field), log_n, k["omega_inv"], coset=k["coset_inv"], coset_after=True, scale=k["size_inv"])
+    return co.from_mont(h, field)
 
 
 def prove_no_zk(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, assignment, n_aux, h, threads=8):
@@ -52,4 +55,26 @@ def prove_no_zk(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, assign
     A = E.add(E.add(pt(a_query[0]), msm(a_query[1:], assignment)), pt(alpha_g1))
     B = E.add(E.add(pt(b_g2_query[0]), msm(b_g2_query[1:], assignment)), pt(beta_g2))
     Cc = E.add(msm(l_query, aux), msm(h_query, h))
+    return A, B, Cc
+
+
+def prove_no_zk_bls12_377(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, assignment, n_aux, h, threads=8):
+    """The same composition over BLS12-377 (the hash-helper proof): a / h / l queries (k, 12) uint64 G1 points, b_g2_query (k, 24) G2
+    points, alpha (12,), beta (24,); assignment / h: lists of canonical ints below r.  Returns (A in G1, B in G2, C in G1) affine."""
+    def msm(group, kind, bases, scalars):
+        k = min(len(bases), len(scalars))
+        if k == 0:
+            return None
+        return co.jac_to_affine(co.msm(group, np.ascontiguousarray(bases[:k]), None, co.ints_to_limbs(scalars[:k], 4), threads=threads), kind)
+    def p1(limbs):
+        x, y = co.from_mont(np.asarray(limbs).reshape(2, 6), ecc.Q377)
+        return (x, y)
+    def p2(limbs):
+        v = co.from_mont(np.asarray(limbs).reshape(4, 6), ecc.Q377)
+        return ((v[0], v[1]), (v[2], v[3]))
+    E1, E2 = ecc.E1_377, ecc.E2_377
+    aux = assignment[len(assignment) - n_aux:]
+    A = E1.add(E1.add(p1(a_query[0]), msm("bls12_377_g1", "g1_377", a_query[1:], assignment)), p1(alpha_g1))
+    B = E2.add(E2.add(p2(b_g2_query[0]), msm("bls12_377_g2", "g2_377", b_g2_query[1:], assignment)), p2(beta_g2))
+    Cc = E1.add(msm("bls12_377_g1", "g1_377", l_query, aux), msm("bls12_377_g1", "g1_377", h_query, h))
     return A, B, Cc

@@ -25,7 +25,7 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-@pytest.mark.parametrize("prime,fn,n64", [(ecc.Q377, "ht_fq377", 6), (ecc.Q761, "ht_fq761", 12)])
+@pytest.mark.parametrize("prime,fn,n64", [(ecc.Q377, "ht_fq377", 6), (ecc.Q761, "ht_fq761", 12), (ecc.R377, "ht_fr377", 4)])
 def test_fp_ops(ht, prime, fn, n64):
     random.seed(7)
     f = getattr(ht, fn)
@@ -47,6 +47,22 @@ def test_fp_ops(ht, prime, fn, n64):
         assert op(5, a, b) == a
         if i < 8 and a:
             assert op(4, a, b) == pow(a, -1, prime)
+
+
+def test_fr377_weak_reduction_and_canonical_form(ht):
+    """the 10-limb field Fp<P253> (Fr of BLS12-377: the NTT of the hash-helper proof) under bounds tracking: a lazily grown sum goes
+    through the weak reduction (top limb of p is ONE bit there: the two-limb quotient estimate), and canonical integers round-trip."""
+    random.seed(253)
+    R = ecc.R377
+    for _ in range(200):
+        a, b = random.randrange(R), random.randrange(R)
+        A, B = co.to_mont([a], R).reshape(-1), co.to_mont([b], R).reshape(-1)
+        out = np.zeros(4, dtype=np.uint64)
+        ht.ht_fr377(7, _p(A), _p(B), _p(out))
+        assert co.from_mont(out, R)[0] == (5 * a + 4 * b) % R
+        c = co.ints_to_limbs([a], 4).reshape(-1)
+        ht.ht_fr377(8, _p(c), _p(c), _p(out))
+        assert co.limbs_to_ints(out, 4)[0] == a
 
 
 def test_fp2_ops(ht):

@@ -155,6 +155,8 @@ def main():
     subs = [(4, 1), (8, 1), (16, 1), (32, 1), (64, 1), (8, 3), (16, 3), (32, 3)]
     out += emit("P377", Q377, 28, 14, 6, subs)
     out += emit("P761", Q761, 28, 28, 12, subs)
+    # Fr of BLS12-377 (253 bits, 2-adicity 47): the field of the hash-helper proof's witness map (crates/epoch-snark/src/api/prover.rs:83-118)
+    out += emit("P253", R377, 28, 10, 4, subs)
     out += emit_tower377()
     out += emit_tower761()
     out += "}  // namespace celo\n"

@@ -1,4 +1,5 @@
 // Translation unit: bulk decoding of compressed BLS12-377 points (see wire.h), one point per lane.
+#include <type_traits>
 #include "wire.h"
 #include <hip/hip_runtime.h>
 #include <mutex>
@@ -42,41 +43,55 @@ template <bool G2> __global__ void __launch_bounds__(64) FROW_OCC k_decompress(c
 // inversion per K points, 3 products per point for the prefix / suffix products, then x = X z^-2, y = Y z^-3.  in: n x 3
 // coordinates (arkworks Montgomery limbs, identity = Z == 0); out: n x (x, y), zero rows + inf[i] = 1 for the identity.
 // Points that are already affine (Z == 1: everything that came off the wire) take part with z = 1; their x, y come out unchanged.
+template <int N, bool REVERSE, class Fn> __device__ __forceinline__ void norm_static_for(Fn&& f) {   // f(integral_constant<j>) for j = 0 .. N-1 (or N-1 .. 0)
+  if constexpr (N > 0) {
+    if constexpr (REVERSE) { f(std::integral_constant<int, N - 1>{}); norm_static_for<N - 1, true>(f); }
+    else { norm_static_for<N - 1, false>(f); f(std::integral_constant<int, N - 1>{}); }
+  }
+}
 template <class F, int K> __global__ void __launch_bounds__(64) FROW_OCC
 k_normalize(const uint64_t* __restrict__ jac, uint64_t* __restrict__ out, uint8_t* __restrict__ inf, uint32_t n) {
   constexpr int A = F::ARK64;
   const uint32_t lo = (blockIdx.x * blockDim.x + threadIdx.x) * K;
   if (lo >= n) return;
   const uint32_t cnt = n - lo < (uint32_t)K ? n - lo : (uint32_t)K;
-  F z[K], pre[K];
-  bool id[K];
+  // Only the prefix products stay in registers (K x 14 / 28 words); z_j is read again on the way back (one conversion product) instead
+  // of being kept: with both arrays alive the G1 instance (K = 8) held 224 words of state, the loops were not unrolled and the arrays
+  // went to private memory through run-time indices (912 B/lane).
+  F pre[K];
+  uint32_t idmask = 0;
   F acc = F::one();
-#pragma unroll
-  for (int j = 0; j < K; j++) {
-    id[j] = true;
-    z[j] = F::one();
-    if ((uint32_t)j < cnt) {
-      const F zj = F::norm(F::from_ark(jac + ((size_t)lo + j) * 3 * A + 2 * A));
-      id[j] = zj.is_zero_mod_p();
-      if (!id[j]) z[j] = zj;
-    }
+  auto load_z = [&](int j) { return F::norm(F::from_ark(jac + ((size_t)lo + j) * 3 * A + 2 * A)); };
+  // (unrolled by template recursion: `#pragma unroll` over bodies of this size is refused by the optimizer, and a rolled loop
+  // indexes pre[] at run time, i.e. in private memory)
+  norm_static_for<K, false>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
     pre[j] = acc;
-    acc = F::norm(F::mul(acc, z[j]));
-  }
+    if ((uint32_t)j < cnt) {
+      const F zj = load_z(j);
+      if (zj.is_zero_mod_p()) idmask |= 1u << j;
+      else acc = F::norm(F::mul(acc, zj));
+    }
+  });
   F inv = F::norm(F::inv(acc));
-#pragma unroll
-  for (int j = K - 1; j >= 0; j--) {
-    if ((uint32_t)j >= cnt) continue;
-    const F zi = F::norm(F::mul(inv, pre[j]));
-    inv = F::norm(F::mul(inv, z[j]));
-    uint64_t* o = out + ((size_t)lo + j) * 2 * A;
-    inf[lo + j] = id[j] ? 1 : 0;
-    if (id[j]) { for (int q = 0; q < 2 * A; q++) o[q] = 0; continue; }
-    const uint64_t* src = jac + ((size_t)lo + j) * 3 * A;
-    const F zi2 = F::norm(F::sqr(zi));
-    F::mul(F::from_ark(src), zi2).to_ark(o);
-    F::mul(F::from_ark(src + A), F::norm(F::mul(zi2, zi))).to_ark(o + A);
-  }
+  norm_static_for<K, true>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if ((uint32_t)j < cnt) {
+      uint64_t* o = out + ((size_t)lo + j) * 2 * A;
+      const bool id = (idmask >> j) & 1u;
+      inf[lo + j] = id ? 1 : 0;
+      if (id) {
+        for (int q = 0; q < 2 * A; q++) o[q] = 0;
+      } else {
+        const F zi = F::norm(F::mul(inv, pre[j]));
+        inv = F::norm(F::mul(inv, load_z(j)));
+        const uint64_t* src = jac + ((size_t)lo + j) * 3 * A;
+        const F zi2 = F::norm(F::sqr(zi));
+        F::mul(F::from_ark(src), zi2).to_ark(o);
+        F::mul(F::from_ark(src + A), F::norm(F::mul(zi2, zi))).to_ark(o + A);
+      }
+    }
+  });
 }
 
 // the constants with the discrete-log tables in device memory: one copy per device, uploaded on first use there

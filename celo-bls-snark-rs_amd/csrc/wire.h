@@ -72,22 +72,25 @@ HD bool wire_lex_largest(const Fq2& y) {  // arkworks orders Fq2 by c1 first, th
   return wire_lex_largest(y.c0);
 }
 
-// a^e for a multi-limb exponent, fixed 4-bit windows (MSB first): ~25 % fewer products than square-and-multiply for the
-// 331- and 377-bit exponents of the root and the inversion.  The 15-entry table lives in private memory (dynamic index).
-WIRE_FN Fq wire_pow_w4(const Fq& a_, const uint64_t* e, int nlimbs) {
-  Fq tab[16];
-  tab[0] = Fq::one();
-  tab[1] = Fq::norm(a_);
-  for (int j = 2; j < 16; j++) tab[j] = Fq::mul(tab[j - 1], tab[1]);
-  Fq r = Fq::one();
-  bool started = false;
-  for (int i = nlimbs * 16 - 1; i >= 0; i--) {
-    const uint32_t nib = (uint32_t)(e[i >> 4] >> (4 * (i & 15))) & 15u;
-    if (started) { r = Fq::sqr(r); r = Fq::sqr(r); r = Fq::sqr(r); r = Fq::sqr(r); }
-    if (nib) {
-      r = started ? Fq::mul(r, tab[nib]) : tab[nib];
-      started = true;
-    }
+// a^((t-1)/2), the exponentiation of the square root (q - 1 = 2^46 t).  The exponent is a constant, so its sliding-window program
+// (fp_consts.h SqrtChain377: 328 squarings, 83 products by a, a^3, a^5 or a^7) is the same in every lane: the four table entries
+// stay in registers and every branch is scalar.  (Round 2 kept a 16-entry table of fixed 4-bit windows in private memory, indexed
+// at run time: 896 of the 2812 B/lane of scratch of k_decompress<true>, re-read 83 times per root.)
+WIRE_FN Fq wire_pow_root_exponent(const Fq& a_) {
+  const Fq t1 = Fq::norm(a_), a2 = Fq::sqr(t1);
+  const Fq t3 = Fq::mul(t1, a2), t5 = Fq::mul(t3, a2), t7 = Fq::mul(t5, a2);
+  static_assert(SqrtChain377::FIRST == 1 || SqrtChain377::FIRST == 3 || SqrtChain377::FIRST == 5 || SqrtChain377::FIRST == 7, "odd leading window");
+  Fq r = SqrtChain377::FIRST == 1 ? t1 : SqrtChain377::FIRST == 3 ? t3 : SqrtChain377::FIRST == 5 ? t5 : t7;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int i = 0; i < SqrtChain377::LEN; i++) {
+    r = Fq::sqr(r);
+    const int d = SqrtChain377::STEP[i];
+    if (d == 1) r = Fq::mul(r, t1);
+    else if (d == 3) r = Fq::mul(r, t3);
+    else if (d == 5) r = Fq::mul(r, t5);
+    else if (d == 7) r = Fq::mul(r, t7);
   }
   return r;
 }
@@ -134,7 +137,7 @@ WIRE_FN bool wire_root_finish(Fq x, Fq b, const WireConsts& k, Fq& out) {
 WIRE_FN bool wire_fq_sqrt_keep(const Fq& a_, const WireConsts& k, Fq& out, WireRootParts& parts) {
   const Fq a = Fq::norm(a_);
   if (a.is_zero_mod_p()) { out = Fq::zero(); parts.x = Fq::zero(); parts.b = Fq::one(); return true; }
-  const Fq w = wire_pow_w4(a, k.tm1_half, 6);
+  const Fq w = wire_pow_root_exponent(a);
   parts.x = Fq::mul(a, w);
   parts.b = Fq::mul(parts.x, w);
   return wire_root_finish(parts.x, parts.b, k, out);

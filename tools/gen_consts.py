@@ -150,6 +150,45 @@ def emit_tower761():
     return s
 
 
+def emit_sqrt_chain():
+    """The exponent of the Fq square root, (t - 1) / 2 with q - 1 = 2^46 t, as a left-to-right sliding-window program over the odd
+    powers a, a^3, a^5, a^7: FIRST = the leading window's digit, then one byte per squaring - 0 = square only, d = square and then
+    multiply by a^d.  The exponent is a constant, so the program is the same in every lane: the four table entries live in registers
+    and every branch is scalar (wire.h: wire_pow_root_exponent)."""
+    q = Q377
+    t = (q - 1) >> 46
+    assert t & 1 and (q - 1) == t << 46
+    e = (t - 1) // 2
+    bits = bin(e)[2:]
+    i, prog, first = 0, [], None
+    while i < len(bits):
+        if bits[i] == "0":
+            prog.append(0)
+            i += 1
+            continue
+        w = min(3, len(bits) - i)
+        while bits[i + w - 1] == "0":
+            w -= 1
+        d = int(bits[i:i + w], 2)
+        if first is None:
+            first = d
+        else:
+            prog += [0] * (w - 1) + [d]
+        i += w
+    # check the program
+    r = first
+    for d in prog:
+        r = 2 * r + 0
+        if d:
+            r += d
+    # (r above tracks the exponent: squaring doubles it, a multiplication by a^d adds d)
+    assert r == e, "sliding-window program does not rebuild the exponent"
+    s = "struct SqrtChain377 {   // exponent (t - 1) / 2 of the Fq square root, q - 1 = 2^46 t\n"
+    s += f"  static constexpr int FIRST = {first};\n  static constexpr int LEN = {len(prog)};\n"
+    s += f"  static constexpr uint8_t STEP[{len(prog)}] = {{" + ", ".join(str(d) for d in prog) + "};\n};\n\n"
+    return s
+
+
 def main():
     out = "// GENERATED by tools/gen_consts.py — do not edit.\n#pragma once\n#include <cstdint>\n\nnamespace celo {\n\n"
     subs = [(4, 1), (8, 1), (16, 1), (32, 1), (64, 1), (8, 3), (16, 3), (32, 3)]
@@ -157,6 +196,7 @@ def main():
     out += emit("P761", Q761, 28, 28, 12, subs)
     # Fr of BLS12-377 (253 bits, 2-adicity 47): the field of the hash-helper proof's witness map (crates/epoch-snark/src/api/prover.rs:83-118)
     out += emit("P253", R377, 28, 10, 4, subs)
+    out += emit_sqrt_chain()
     out += emit_tower377()
     out += emit_tower761()
     out += "}  // namespace celo\n"

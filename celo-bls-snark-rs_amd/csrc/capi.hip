@@ -44,7 +44,7 @@ int api_bind_thread(int device) {
 #define DECL(TAG)                                                                                     \
   int msm_host_##TAG(const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*);            \
   int msm_dev_##TAG(const void*, const void*, const void*, size_t, uint64_t*, void*);                 \
-  int msm_batch_host_##TAG(const uint64_t*, const uint8_t*, const uint64_t*, const uint32_t*, size_t, uint64_t*); \
+  int msm_batch_host_##TAG(const uint64_t*, const uint8_t*, const uint64_t*, const uint32_t*, size_t, int, uint64_t*); \
   int msm_timings_##TAG(float*, int*);                                                                \
   int msm_set_c_##TAG(int);                                                                           \
   int gen_points_##TAG(void*, size_t, uint64_t, const uint64_t*, size_t, uint32_t, void*);                              \
@@ -121,10 +121,11 @@ int msm_bls12_377_g1_dev(const void* b, const void* inf, const void* s, size_t n
 int msm_bls12_377_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g2_377(); return msm_dev_g2_377(b, inf, s, n, out, st); }
 int msm_bw6_761_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_761(); return msm_dev_761(b, inf, s, n, out, st); }
 int msm_bw6_761_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_761(); return msm_dev_761(b, inf, s, n, out, st); }
-int msm_batch_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g1_377(b, inf, s, off, m, out); }
-int msm_batch_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g2_377(b, inf, s, off, m, out); }
-int msm_batch_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_761(b, inf, s, off, m, out); }
-int msm_batch_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_761(b, inf, s, off, m, out); }
+int msm_batch_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g1_377(b, inf, s, off, m, 0, out); }
+int msm_batch_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g2_377(b, inf, s, off, m, 0, out); }
+int msm_batch_bls12_377_g2_subgroup(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g2_377(b, inf, s, off, m, 1, out); }
+int msm_batch_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_761(b, inf, s, off, m, 0, out); }
+int msm_batch_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_761(b, inf, s, off, m, 0, out); }
 // Single-product checks from concurrent host threads are COMBINED: bls-snark-sys is synchronous and re-entrant and its callers
 // verify from many threads ("Threading"); one product keeps one lane group of the GPU busy for ~11 ms, so
 // serialising callers behind a mutex would cap the library at ~90 verifications/s.  The first caller to arrive becomes the

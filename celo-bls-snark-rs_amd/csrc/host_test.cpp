@@ -2,6 +2,7 @@
 // (-DCELO_FP_TRACK): every mul/sub asserts the limb/value bounds of fp.h's contract.
 // Driven by tests/test_host_field.py through ctypes; never shipped.
 #include "curve.h"
+#include "gls.h"
 #include "fp2.h"
 #include "pairing.h"
 #include "curve_lanes.h"
@@ -363,6 +364,23 @@ int ht_horner_ifma(int field, const uint64_t* pts, size_t stride, const int32_t*
   if (!celo_ifma_available()) return -1;
   int inf = 0;
   return field == 0 ? celo_ifma_horner_377(pts, stride, order, steps, out, &inf) : celo_ifma_horner_761(pts, stride, order, steps, out, &inf);
+}
+// base-x digits (gls.h) of a scalar of nw significant words into nd digits: d[4][2] words; the (nw, nd) pairs the batched MSM uses
+int ht_gls_digits(int nw, int nd, const uint32_t* k8, uint32_t* d8) {
+  uint32_t d[4][2];
+  switch (nw * 10 + nd) {
+    case 32: gls_digits_base_x<3, 2>(k8, d); break;
+    case 42: gls_digits_base_x<4, 2>(k8, d); break;
+    case 43: gls_digits_base_x<4, 3>(k8, d); break;
+    case 53: gls_digits_base_x<5, 3>(k8, d); break;
+    case 63: gls_digits_base_x<6, 3>(k8, d); break;
+    case 64: gls_digits_base_x<6, 4>(k8, d); break;
+    case 74: gls_digits_base_x<7, 4>(k8, d); break;
+    case 84: gls_digits_base_x<8, 4>(k8, d); break;
+    default: return 1;
+  }
+  for (int j = 0; j < 4; j++) { d8[2 * j] = d[j][0]; d8[2 * j + 1] = d[j][1]; }
+  return 0;
 }
 void ht_fq377_canon(const uint64_t* canon, uint64_t* out_ark, uint64_t* out_canon) {
   Fp<P377> x = Fp<P377>::from_canonical(canon);

@@ -32,6 +32,7 @@
 #include "pairing_lanes.h"
 #include "fp2.h"
 #include "runtime.h"
+#include "gls.h"
 
 namespace celo {
 
@@ -946,6 +947,70 @@ template <> struct BatchHornerLanes<G2_377> {
   }
 };
 
+// ---- GLS expansion of a batch of G2 instances (BLS12-377): psi = twist^-1 o Frobenius o twist acts on the prime-order subgroup of
+// E'(Fq2) as multiplication by the curve parameter x (proved in wire.h, where the same fact is the subgroup test), so
+//   [k]P = [d0]P + [d1]psi(P) + [d2]psi^2(P) + [d3]psi^3(P),   k = d0 + d1 x + d2 x^2 + d3 x^3,  0 <= d_j < x < 2^64.
+// psi^j(x, y) = (PSI_X^j conj^j(x), PSI_Y^j conj^j(y)) with PSI_X = (-5)^((q-1)/6), PSI_Y = (-5)^((q-1)/4) in Fq: four Fq products per
+// image.  One workgroup per instance; instance p of n_p points becomes one of nd n_p points, block j holding psi^j of the originals,
+// with 64-bit scalars in 16-byte containers; bases are written in device form (this replaces k_convert_bases).
+// Division by x (normalised: its top bit is set) is Knuth's algorithm D in base 2^32 with the two-digit divisor (x >> 32, 1).
+// One wave per block (blockIdx.y = which 64 points of the instance) and at most 128 registers: the expansion runs beside the other
+// group's accumulate kernel (Batch::verify starts both MSMs at once), whose waves leave less than half a SIMD's register file - a
+// 256-thread block of 334-register waves waited for four EMPTY SIMDs of one CU and took 4.5 ms for 0.6 ms of work.
+template <class G, int NW, int ND>   // G2_377 only (a template so that every translation unit including this header may hold a copy)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_gls_expand(const uint64_t* __restrict__ ark, const uint8_t* __restrict__ inf, const uint32_t* __restrict__ scalars,
+                                                    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ dev_bases,
+                                                    uint32_t* __restrict__ sc2, uint8_t* __restrict__ inf2) {
+  constexpr int nd = ND;
+  typedef PointIO<Fq2> IO;
+  const uint32_t inst = blockIdx.x;
+  const uint32_t lo = offsets[inst], n = offsets[inst + 1] - lo;
+  const Fq kx[3] = {Fq::from_limbs(T377::PSI_X1), Fq::from_limbs(T377::PSI_X2), Fq::from_limbs(T377::PSI_X3)};
+  const Fq ky[3] = {Fq::from_limbs(T377::PSI_Y1), Fq::from_limbs(T377::PSI_Y2), Fq::from_limbs(T377::PSI_Y3)};
+  for (uint32_t t = blockIdx.y * 64u + threadIdx.x; t < n; t += gridDim.y * 64u) {
+    const uint64_t* s = ark + (size_t)(lo + t) * 2 * IO::ARK64;
+    const Affine<Fq2> P = {Fq2::from_ark(s), Fq2::from_ark(s + IO::ARK64)};
+    uint32_t d[4][2];
+    gls_digits_base_x<NW, ND>(scalars + (size_t)(lo + t) * 8, d);
+    const uint8_t fl = inf ? inf[lo + t] : 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (j < nd) {
+      const size_t e = (size_t)nd * lo + (size_t)j * n + t;
+      Affine<Fq2> Q = P;
+      if (j > 0) {
+        // psi^j: conjugate j times, scale by the j-th powers of the constants
+        const Fq x1 = (j & 1) ? Fq::wred(Fq::norm(Fq::neg<4, 1>(P.x.c1))) : P.x.c1, y1 = (j & 1) ? Fq::wred(Fq::norm(Fq::neg<4, 1>(P.y.c1))) : P.y.c1;
+        Q.x = {Fq::mul(P.x.c0, kx[j - 1]), Fq::mul(x1, kx[j - 1])};
+        Q.y = {Fq::mul(P.y.c0, ky[j - 1]), Fq::mul(y1, ky[j - 1])};
+      }
+      IO::store_affine(dev_bases + e * IO::AFF_WORDS, Q);
+      uint4 w = {d[j][0], d[j][1], 0u, 0u};
+      reinterpret_cast<uint4*>(sc2)[e] = w;
+      if (inf2) inf2[e] = fl;
+      }
+    }
+  }
+}
+template <class G> struct GlsExpand {
+  static constexpr bool AVAILABLE = false;
+  static void launch(const uint64_t*, const uint8_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, int, int, uint32_t*, uint32_t*, uint8_t*, hipStream_t) {}
+};
+template <> struct GlsExpand<G2_377> {
+  static constexpr bool AVAILABLE = true;
+  // bits = length of the longest scalar: the number of significant words and of digits are compile-time constants of the kernel
+  static void launch(const uint64_t* ark, const uint8_t* inf, const uint32_t* sc, const uint32_t* off, uint32_t m, uint32_t max_n, int nd, int bits,
+                     uint32_t* dev_bases, uint32_t* sc2, uint8_t* inf2, hipStream_t st) {
+    const int nw = bits <= 96 ? 3 : (bits + 31) / 32;
+    const dim3 grid(m, (max_n + 63) / 64);
+#define CELO_GLS_CASE(NW_, ND_) \
+    if (nw == NW_ && nd == ND_) { hipLaunchKernelGGL((k_gls_expand<G2_377, NW_, ND_>), grid, dim3(64), 0, st, ark, inf, sc, off, dev_bases, sc2, inf2); return; }
+    CELO_GLS_CASE(3, 2) CELO_GLS_CASE(4, 2) CELO_GLS_CASE(4, 3) CELO_GLS_CASE(5, 3) CELO_GLS_CASE(6, 3) CELO_GLS_CASE(6, 4) CELO_GLS_CASE(7, 4)
+#undef CELO_GLS_CASE
+    hipLaunchKernelGGL((k_gls_expand<G2_377, 8, 4>), grid, dim3(64), 0, st, ark, inf, sc, off, dev_bases, sc2, inf2);
+  }
+};
+
 // ---------------------------------------------------------------- host driver
 // the IFMA Horner epilogue (host_ifma.cpp, host_cpu.cpp) exists for the two prime fields
 extern "C" int celo_ifma_available();
@@ -998,6 +1063,12 @@ template <class G> class MsmEngine {
   // bits instead of 29 x 13 (+ a carry window) 1.39 -> 1.88 ms, at 2^17 3.58 -> 3.79 ms.  CELO_NO_NARROW=1 is the A/B switch.
   bool narrow_windows = getenv("CELO_NO_NARROW") == nullptr;
   bool narrow_top(int c) const { return narrow_windows && c == 16; }
+  // batched path, G2 of BLS12-377: the caller vouches that every base lies in the prime-order subgroup (Batch::verify's public keys:
+  // PublicKey values only come from checked deserialisation, secret keys and sums of such), which is what makes psi(P) = [x]P
+  bool gls_subgroup_points = false;
+  bool use_gls = getenv("CELO_NO_GLS") == nullptr;     // A/B switch
+  bool gls_force = getenv("CELO_GLS_ALL") != nullptr;  // measurement hook (tools/bench_config3.py): split also for the plain msm_batch_* entry points
+  int last_gls_digits = 1;
   bool lane_horner = true;  // batched path: three lanes per instance in the Horner pass (tuning hook)
   bool lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;   // big path: three lanes per addition in the late levels of the bucket reduction (A/B hook)
   uint32_t BITSUM_LANES_MAX = getenv("CELO_LANE_BITSUM_MAX") ? (uint32_t)atoi(getenv("CELO_LANE_BITSUM_MAX")) : 21 * 1024;   // outputs of a launch: one wave of 21 additions per SIMD
@@ -1278,35 +1349,62 @@ template <class G> class MsmEngine {
     side_path = false;
     // window size ~ log2(n) - 3 (measured on 4096 x 256, 136-bit exponents: c = 5 beats 6 and 7; the per-(instance,window)
     // running sums and the per-instance Horner are latency-bound, so fewer buckets per window win)
-    int c = force_c ? force_c : 3;
-    if (!force_c) { while (c < 7 && (16u << c) <= max_n) c++; }
-    if (c > 7) c = 7;
-    if (c < 3) c = 3;
-    // stage the inputs at the front of the arena (sized for the full scalar length first), then let the scalars decide the
-    // number of windows: bits = length of the longest scalar present
-    const int nw_max = (G::SCALAR_BITS + c) / c;
-    const uint32_t B = 1u << (c - 1);
-    if (m * (size_t)nw_max * B >= (size_t(1) << 31) || (size_t)total_pts * nw_max >= (size_t(1) << 32)) return 2;
+    auto window_for = [&](uint32_t inst_n) {
+      int c_ = force_c ? force_c : 3;
+      if (!force_c) { while (c_ < 7 && (16u << c_) <= inst_n) c_++; }
+      if (c_ > 7) c_ = 7;
+      if (c_ < 3) c_ = 3;
+      return c_;
+    };
+    // GLS split (G2 of BLS12-377, subgroup points only: gls_subgroup_points): k = d0 + d1 x + d2 x^2 + d3 x^3 in base x, the curve
+    // parameter, and [x]P = psi(P) - so an instance of n points with b-bit scalars becomes one of nd n points psi^j(P) with 64-bit
+    // scalars, nd = 2 (b <= 126), 3 (b <= 189: Batch::verify's 136-bit exponents) or 4.  Same group element; what changes is the
+    // shape: a quarter to a half of the windows (13 x 5 bits instead of 28) over a larger instance, which takes a wider window
+    // (c = 6 for 768 points: 11 windows) - 14 % fewer mixed additions, less than half the per-(instance, window) running sums and
+    // a Horner chain of 66 doublings instead of 140.
+    const int gls_max = (GlsExpand<G>::AVAILABLE && (gls_subgroup_points || gls_force) && use_gls) ? 4 : 1;
+    auto gls_digits = [&](int bits) {
+      if (gls_max == 1 || bits <= 64 || bits > G::SCALAR_BITS) return 1;
+      const int nd_ = bits <= 126 ? 2 : bits <= 189 ? 3 : 4;
+      return (size_t)nd_ * max_n <= BATCH_MAX_N ? nd_ : 1;
+    };
+    // stage the inputs at the front of the arena, then let the scalars decide the number of windows: bits = length of the longest
+    // scalar present.  The arena is sized for the worst layout (full-length scalars, or the largest split that fits) beforehand.
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
     const size_t o_in_b = take(resident ? 0 : (size_t)total_pts * 2 * IO::ARK64 * 8), o_in_s = take(resident ? 0 : (size_t)total_pts * SW * 4),
                  o_in_i = take(resident ? 0 : total_pts + 8);
     const size_t o_off = take((m + 1) * 4), o_or = take(64 * 4);
     const size_t front = off;
-    auto rest = [&](int nw_, size_t* o) {     // the window-count dependent part of the arena; returns its end
+    auto rest = [&](int c_, int nw_, int nd_, size_t* o) {     // the part of the arena that depends on the layout; returns its end
       size_t save = off;
       off = front;
-      const size_t nvw_ = m * (size_t)nw_, nb = nvw_ * B, en = (size_t)total_pts * nw_;
-      o[0] = take((size_t)total_pts * IO::AFF_WORDS * 4); o[1] = take(en * 4 + 16);
+      const uint32_t B_ = 1u << (c_ - 1);
+      const size_t tot = (size_t)nd_ * total_pts;
+      const size_t nvw_ = m * (size_t)nw_, nb = nvw_ * B_, en = tot * nw_;
+      o[0] = take(tot * IO::AFF_WORDS * 4); o[1] = take(en * 4 + 16);
       o[2] = take(nb * 4); o[3] = take(nb * 4); o[4] = take(nb * 4);
       o[5] = take((size_t)SIZE_BINS * 4 + 256); o[6] = take(nb * IO::XYZZ_WORDS * 4);
       o[7] = take(nvw_ * IO::XYZZ_WORDS * 4); o[8] = take(m * 3 * IO::ARK64 * 8);
+      o[9] = take(nd_ > 1 ? tot * 16 : 0); o[10] = take(nd_ > 1 ? tot + 8 : 0); o[11] = take(nd_ > 1 ? (m + 1) * 4 : 0);
       const size_t end = off;
       off = save;
       return end;
     };
-    size_t o[9];
-    if (ensure(rest(nw_max, o))) return 1;     // sized for full-length scalars: the actual layout below can only be smaller
+    size_t o[12];
+    {
+      const int c1 = window_for(max_n);
+      const int nw1 = (G::SCALAR_BITS + c1) / c1;
+      if (m * (size_t)nw1 * (size_t(1) << (c1 - 1)) >= (size_t(1) << 31) || (size_t)total_pts * nw1 >= (size_t(1) << 32)) return 2;
+      size_t need = rest(c1, nw1, 1, o);
+      for (int nd_ = 2; nd_ <= gls_max; nd_++) {
+        if ((size_t)nd_ * max_n > BATCH_MAX_N) break;
+        const int c2 = window_for((uint32_t)nd_ * max_n);
+        const size_t e2 = rest(c2, (64 + c2) / c2, nd_, o);
+        if (e2 > need) need = e2;
+      }
+      if (ensure(need)) return 1;
+    }
     {
       char* A0 = arena;
       if (!resident) HIP_OK(hipMemcpyAsync(A0 + o_in_s, scalars, (size_t)total_pts * SW * 4, hipMemcpyHostToDevice, stream));
@@ -1318,12 +1416,18 @@ template <class G> class MsmEngine {
       HIP_OK(hipStreamSynchronize(stream));
       int bits = 1;
       for (int k = SW - 1; k >= 0; k--) if (h_or[k]) { bits = 32 * k + 32 - __builtin_clz(h_or[k]); break; }
-      if (bits > G::SCALAR_BITS) bits = G::SCALAR_BITS;
+      if (bits > G::SCALAR_BITS && gls_digits(bits) == 1) bits = G::SCALAR_BITS;
       batch_bits = bits;
     }
-    const int nw = (batch_bits + c) / c;
+    const int nd = gls_digits(batch_bits);
+    const uint32_t eff_max_n = (uint32_t)nd * max_n, eff_total = (uint32_t)nd * total_pts;
+    const int eff_bits = nd > 1 ? 64 : (batch_bits > G::SCALAR_BITS ? G::SCALAR_BITS : batch_bits);
+    const int c = window_for(eff_max_n);
+    const uint32_t B = 1u << (c - 1);
+    const int nw = (eff_bits + c) / c;
     const size_t nvw = m * (size_t)nw, nbuckets = nvw * B;
-    (void)rest(nw, o);
+    if (nbuckets >= (size_t(1) << 31) || (size_t)eff_total * nw >= (size_t(1) << 32)) return 2;
+    (void)rest(c, nw, nd, o);
     char* A = arena;
     const uint64_t* d_in_b = resident ? bases : (const uint64_t*)(A + o_in_b);
     const uint32_t* d_in_s = resident ? (const uint32_t*)scalars : (const uint32_t*)(A + o_in_s);
@@ -1339,10 +1443,23 @@ template <class G> class MsmEngine {
     }
     HIP_OK(hipMemcpyAsync(d_off, offsets, (m + 1) * 4, hipMemcpyHostToDevice, stream));
     HIP_OK(hipEventRecord(ev[0], stream));
-    hipLaunchKernelGGL((k_convert_bases<G>), dim3((total_pts + 255) / 256), dim3(256), 0, stream, d_in_b, d_bases, (size_t)total_pts);
-    HIP_OK(hipEventRecord(ev[1], stream));
     HIP_OK(hipMemsetAsync(d_bins, 0, (size_t)SIZE_BINS * 4 + 256, stream));
-    if (launch_batch_sort(c, max_n, d_in_s, inf ? d_in_i : nullptr, d_off, d_sorted, d_pstart, d_plen, (uint32_t)m, nw, stream)) return 3;
+    if (nd > 1) {
+      uint32_t* d_sc2 = (uint32_t*)(A + o[9]);
+      uint8_t* d_inf2 = (uint8_t*)(A + o[10]);
+      uint32_t* d_off2 = (uint32_t*)(A + o[11]);
+      gls_off.resize(m + 1);
+      for (size_t p = 0; p <= m; p++) gls_off[p] = (uint32_t)nd * offsets[p];
+      HIP_OK(hipMemcpyAsync(d_off2, gls_off.data(), (m + 1) * 4, hipMemcpyHostToDevice, stream));
+      GlsExpand<G>::launch(d_in_b, inf ? d_in_i : nullptr, d_in_s, d_off, (uint32_t)m, max_n, nd, batch_bits, d_bases, d_sc2, inf ? d_inf2 : nullptr, stream);
+      HIP_OK(hipEventRecord(ev[1], stream));
+      if (launch_batch_sort<4>(c, eff_max_n, d_sc2, inf ? d_inf2 : nullptr, d_off2, d_sorted, d_pstart, d_plen, (uint32_t)m, nw, stream)) return 3;
+    } else {
+      hipLaunchKernelGGL((k_convert_bases<G>), dim3((total_pts + 255) / 256), dim3(256), 0, stream, d_in_b, d_bases, (size_t)total_pts);
+      HIP_OK(hipEventRecord(ev[1], stream));
+      if (launch_batch_sort<SW>(c, max_n, d_in_s, inf ? d_in_i : nullptr, d_off, d_sorted, d_pstart, d_plen, (uint32_t)m, nw, stream)) return 3;
+    }
+    last_gls_digits = nd;
     const uint32_t slots = (uint32_t)nbuckets;
     hipLaunchKernelGGL((k_size_hist<G>), dim3(slots / 256 < 2048 ? (slots + 255) / 256 : 2048), dim3(256), 0, stream, d_plen, d_bins, slots);
     hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
@@ -1410,6 +1527,7 @@ template <class G> class MsmEngine {
   static constexpr size_t H_OUT_POINTS = 17 * 64;   // pinned result buffer: (LB + 1) * windows points; checked per call
   OwnedStream stream_;
   std::vector<int32_t> horner_steps;   // the host epilogue's step list (host64.h), rebuilt per call
+  std::vector<uint32_t> gls_off;       // instance offsets of the expanded (GLS) batch
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap_in = 0;
 
@@ -1428,25 +1546,25 @@ template <class G> class MsmEngine {
     return 0;
   }
 
-  template <int CB, int PT> int launch_batch_sort_cp(const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
+  template <int SWX, int CB, int PT> int launch_batch_sort_cp(const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
                                                      uint32_t* pstart, uint32_t* plen, uint32_t m, int nw, hipStream_t st) {
-    hipLaunchKernelGGL((k_batch_sort<SW, CB, PT>), dim3(m), dim3(256), 0, st, sc, inf, off, sorted, pstart, plen, nw);
+    hipLaunchKernelGGL((k_batch_sort<SWX, CB, PT>), dim3(m), dim3(256), 0, st, sc, inf, off, sorted, pstart, plen, nw);
     return 0;
   }
-  template <int CB> int launch_batch_sort_c(uint32_t max_n, const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
+  template <int SWX, int CB> int launch_batch_sort_c(uint32_t max_n, const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
                                             uint32_t* pstart, uint32_t* plen, uint32_t m, int nw, hipStream_t st) {
-    if (max_n <= 256) return launch_batch_sort_cp<CB, 1>(sc, inf, off, sorted, pstart, plen, m, nw, st);
-    if (max_n <= 512) return launch_batch_sort_cp<CB, 2>(sc, inf, off, sorted, pstart, plen, m, nw, st);
-    return launch_batch_sort_cp<CB, 4>(sc, inf, off, sorted, pstart, plen, m, nw, st);
+    if (max_n <= 256) return launch_batch_sort_cp<SWX, CB, 1>(sc, inf, off, sorted, pstart, plen, m, nw, st);
+    if (max_n <= 512) return launch_batch_sort_cp<SWX, CB, 2>(sc, inf, off, sorted, pstart, plen, m, nw, st);
+    return launch_batch_sort_cp<SWX, CB, 4>(sc, inf, off, sorted, pstart, plen, m, nw, st);
   }
-  int launch_batch_sort(int c, uint32_t max_n, const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
+  template <int SWX> int launch_batch_sort(int c, uint32_t max_n, const uint32_t* sc, const uint8_t* inf, const uint32_t* off, uint32_t* sorted,
                         uint32_t* pstart, uint32_t* plen, uint32_t m, int nw, hipStream_t st) {
     switch (c) {
-      case 3: return launch_batch_sort_c<3>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
-      case 4: return launch_batch_sort_c<4>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
-      case 5: return launch_batch_sort_c<5>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
-      case 6: return launch_batch_sort_c<6>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
-      case 7: return launch_batch_sort_c<7>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
+      case 3: return launch_batch_sort_c<SWX, 3>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
+      case 4: return launch_batch_sort_c<SWX, 4>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
+      case 5: return launch_batch_sort_c<SWX, 5>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
+      case 6: return launch_batch_sort_c<SWX, 6>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
+      case 7: return launch_batch_sort_c<SWX, 7>(max_n, sc, inf, off, sorted, pstart, plen, m, nw, st);
       default: return 1;
     }
   }

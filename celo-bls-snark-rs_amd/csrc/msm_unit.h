@@ -191,20 +191,22 @@ int msm_multi_host_impl(Pool& pool, int force_c, const int* devices, int ndev, c
   static std::atomic<int> last_was_batch_##TAG{0};                                                                       \
   void msm_big_timings_##TAG(float ms[5], int cfg[3]);                                                                   \
   void msm_big_set_c_##TAG(int c);                                                                                       \
-  int msm_batch_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { \
+  int msm_batch_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, int subgroup_points, uint64_t* out) { \
     if (int rc = api_enter()) return rc;                                                                                 \
     auto e = pool_aux_##TAG().lease();                                                                                   \
     e->force_c = force_c_aux_##TAG.load();                                                                               \
+    e->gls_subgroup_points = subgroup_points != 0;    /* 0: arbitrary curve points, VariableBaseMSM semantics, no endomorphism */ \
     last_was_batch_##TAG.store(1);                                                                                       \
     const int rc = e->run_batch_host(b, inf, s, off, m, out, e->own_stream());                                           \
     if (!rc && m) last_aux_##TAG().note(*e);                                                                             \
     return rc;                                                                                                           \
   }                                                                                                                      \
-  int msm_batch_begin_##TAG(const void* b, const void* inf, const void* s, int resident, const uint32_t* off, size_t m, BatchRun* run) { \
+  int msm_batch_begin_##TAG(const void* b, const void* inf, const void* s, int resident, const uint32_t* off, size_t m, int subgroup_points, BatchRun* run) { \
     if (int rc = api_enter()) return rc;                                                                                 \
     typedef EnginePool<MsmEngine<G>>::Lease L;                                                                           \
     L* l = new L(pool_aux_##TAG().lease());                                                                              \
     (*l)->force_c = force_c_aux_##TAG.load();                                                                            \
+    (*l)->gls_subgroup_points = subgroup_points != 0;                                                                    \
     uint64_t* d_out = nullptr;                                                                                           \
     const int rc = (*l)->run_batch((const uint64_t*)b, (const uint8_t*)inf, (const uint64_t*)s, resident, off, m, nullptr, &d_out, (*l)->own_stream()); \
     if (rc) { delete l; return rc; }                                                                                     \

@@ -12,8 +12,8 @@
 #include <thread>
 
 namespace celo {
-int msm_batch_begin_g1_377(const void*, const void*, const void*, int, const uint32_t*, size_t, BatchRun*);
-int msm_batch_begin_g2_377(const void*, const void*, const void*, int, const uint32_t*, size_t, BatchRun*);
+int msm_batch_begin_g1_377(const void*, const void*, const void*, int, const uint32_t*, size_t, int, BatchRun*);
+int msm_batch_begin_g2_377(const void*, const void*, const void*, int, const uint32_t*, size_t, int, BatchRun*);
 void msm_batch_end_g1_377(BatchRun*, int);
 void msm_batch_end_g2_377(BatchRun*, int);
 int pairing_stage_377(uint32_t, size_t, PairingStage*);
@@ -73,11 +73,13 @@ k_pack_verify_pairs(const uint64_t* __restrict__ sig_sum /* m x 18 */, const uin
 struct BvJob { BatchRun keys, sigs; };
 int bv_begin_keys(BvJob* j, const void* pk_xy, const void* pk_inf, const void* exponents, int resident, const uint32_t* offsets, size_t m) {
   if (int rc = api_enter()) return rc;
-  return msm_batch_begin_g2_377(pk_xy, pk_inf, exponents, resident, offsets, m, &j->keys);
+  // the keys of Batch::verify are PublicKey values: elements of the prime-order subgroup G2 by construction (checked deserialisation,
+  // secret keys, sums) - what lets the batched MSM split their exponents with the endomorphism psi (msm.h, k_gls_expand)
+  return msm_batch_begin_g2_377(pk_xy, pk_inf, exponents, resident, offsets, m, 1, &j->keys);
 }
 int bv_begin_sigs(BvJob* j, const void* sig_xy, const void* sig_inf, const void* exponents, int resident, const uint32_t* offsets, size_t m) {
   if (int rc = api_enter()) return rc;
-  return msm_batch_begin_g1_377(sig_xy, sig_inf, exponents, resident, offsets, m, &j->sigs);
+  return msm_batch_begin_g1_377(sig_xy, sig_inf, exponents, resident, offsets, m, 0, &j->sigs);
 }
 int bv_finish(BvJob* j, int begun_ok, const void* hash_xy, const void* hash_inf, int resident, const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
   BatchRun& r1 = j->sigs;
@@ -134,10 +136,11 @@ int batch_verify_377_run(const void* pk_xy, const void* pk_inf, const void* sig_
   int rc1 = 0, rc2 = 0;
   const int dev = api_device();
   {
-    // each begin has one host round trip (the exponents' bit length sizes the window count): two threads keep both in flight
-    std::thread t1([&] { rc1 = api_bind_thread(dev); if (!rc1) rc1 = bv_begin_sigs(&job, sig_xy, sig_inf, exponents, resident, offsets, m); });
+    // each begin has one host round trip (the exponents' bit length sizes the window count): two threads keep both in flight.  The
+    // key leg is the long one (G2 arithmetic) and goes first; the signature leg's latency-bound tail then hides under its accumulation.
     rc2 = bv_begin_keys(&job, pk_xy, pk_inf, exponents, resident, offsets, m);
-    t1.join();
+    rc1 = bv_begin_sigs(&job, sig_xy, sig_inf, exponents, resident, offsets, m);
+    (void)dev;
   }
   const int rc = bv_finish(&job, !rc1 && !rc2, hash_xy, hash_inf, resident, neg_g2_xy, m, out_ok);
   return rc1 ? rc1 : rc2 ? rc2 : rc;

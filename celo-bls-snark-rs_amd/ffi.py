@@ -380,8 +380,9 @@ def pairing_timings():
     return {"miller_ms": ms[0], "product_ms": ms[1], "final_exp_ms": ms[2], "total_ms": ms[3]}
 
 
-def msm_batch(group, bases_xy, inf, scalars, offsets):
-    """m independent MSMs in one call. offsets uint32 [m+1]. Returns uint64 [m, O] Jacobian results."""
+def msm_batch(group, bases_xy, inf, scalars, offsets, subgroup=False):
+    """m independent MSMs in one call. offsets uint32 [m+1]. Returns uint64 [m, O] Jacobian results.
+    subgroup=True (bls12_377_g2 only): the bases are vouched to lie in G2 (msm_batch_bls12_377_g2_subgroup: endomorphism split)."""
     A, S, O = GROUP_SHAPE[group]
     bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64)
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
@@ -389,7 +390,7 @@ def msm_batch(group, bases_xy, inf, scalars, offsets):
     m = offsets.size - 1
     assert bases_xy.size == int(offsets[-1]) * A and scalars.size == int(offsets[-1]) * S
     out = np.zeros((m, O), dtype=np.uint64)
-    rc = getattr(lib(), "msm_batch_" + group)(_p(bases_xy), _p(inf), _p(scalars), _p(offsets), C.c_size_t(m), _p(out))
+    rc = getattr(lib(), "msm_batch_" + group + ("_subgroup" if subgroup else ""))(_p(bases_xy), _p(inf), _p(scalars), _p(offsets), C.c_size_t(m), _p(out))
     if rc != 0:
         raise RuntimeError(f"msm_batch_{group} failed rc={rc}")
     return out

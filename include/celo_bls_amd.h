@@ -83,6 +83,12 @@ int msm_bw6_761_g2_multi_dev(const int* devices, int ndev, const void* const* d_
  * processed one at a time on the large-MSM pipeline. */
 int msm_batch_bls12_377_g1(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*18 */);
 int msm_batch_bls12_377_g2(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*36 */);
+/* The same call for bases the caller vouches to be elements of the prime-order subgroup G2 - public keys: a PublicKey of the reference is
+ * one by construction (checked deserialisation crates/bls-crypto/src/bls/public.rs:123-149, secret keys, sums) - which is what
+ * Batch::verify hands over (batch.rs:69).  Same result; the library may then split every scalar with the endomorphism psi (psi(P) = [x]P
+ * on G2): an instance of n points with up to 253-bit scalars becomes one of up to 4 n points with 64-bit scalars (csrc/msm.h, k_gls_expand).
+ * For a base outside the subgroup the result is unspecified (use msm_batch_bls12_377_g2, which is VariableBaseMSM on any curve point). */
+int msm_batch_bls12_377_g2_subgroup(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*36 */);
 int msm_batch_bw6_761_g1(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*36 */);
 int msm_batch_bw6_761_g2(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m, uint64_t* out_xyz /* m*36 */);
 

@@ -9,7 +9,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _check_batch(gpu, group, kind, curve, gen, packer, sizes, bits, seed):
+def _check_batch(gpu, group, kind, curve, gen, packer, sizes, bits, seed, subgroup=False):
     rng = ecc.SplitMix64(seed)
     offs = np.zeros(len(sizes) + 1, dtype=np.uint32)
     pts, sc = [], []
@@ -29,7 +29,7 @@ def _check_batch(gpu, group, kind, curve, gen, packer, sizes, bits, seed):
         sc += s
     xy, inf = packer(pts)
     s_np = H.scalars_np(sc, 4)
-    got = gpu.msm_batch(group, xy, inf, s_np, offs)
+    got = gpu.msm_batch(group, xy, inf, s_np, offs, subgroup=subgroup)
     for i, k in enumerate(sizes):
         lo, hi = int(offs[i]), int(offs[i + 1])
         exp = co.jac_to_affine(co.msm(group, xy[lo:hi], inf[lo:hi], s_np[lo:hi], threads=2), kind) if k else None
@@ -71,6 +71,16 @@ def test_batch_g1_full_scalars(gpu):
 
 def test_batch_g2(gpu):
     _check_batch(gpu, "bls12_377_g2", "g2_377", ecc.E2_377, ecc.G2_377, co.pack_g2_377, [5, 64, 256], 136, 3)
+
+
+@pytest.mark.parametrize("bits", [63, 64, 65, 96, 97, 126, 127, 128, 136, 160, 161, 189, 190, 192, 193, 224, 225, 252])
+def test_batch_g2_subgroup_points_endomorphism_split(gpu, bits):
+    """msm_batch_bls12_377_g2_subgroup: the GLS split k = d0 + d1 x + d2 x^2 + d3 x^3, [x]P = psi(P) (csrc/msm.h k_gls_expand, gls.h) for
+    every scalar length class - no split up to 64 bits, 2 digits to 126, 3 to 189 (Batch::verify's 136-bit exponents), 4 beyond - on both
+    sides of every border of the (significant words, digits) dispatch, with identities, repeated points, zero and unit scalars inside;
+    an instance too large to be expanded within the per-workgroup sort (300 points x 4 digits) takes the unsplit path.  Same sums as
+    the oracle's Pippenger, instance by instance."""
+    _check_batch(gpu, "bls12_377_g2", "g2_377", ecc.E2_377, ecc.G2_377, co.pack_g2_377, [1, 9, 64, 0, 256, 300 if bits > 189 else 130], bits, 500 + bits, subgroup=True)
 
 
 def test_batch_verify_strict_flow(gpu):

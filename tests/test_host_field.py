@@ -65,6 +65,33 @@ def test_fr377_weak_reduction_and_canonical_form(ht):
         assert co.limbs_to_ints(out, 4)[0] == a
 
 
+def test_gls_base_x_digits(ht):
+    """gls.h: k = d0 + d1 x + .. + d_{nd-1} x^(nd-1) (Knuth's algorithm D with the two-word divisor x; nd - 1 divisions, the last digit
+    is what is left) for every (significant words, digits) pair the batched G2 MSM dispatches on: Batch::verify's 136-bit exponents
+    (5 words, 3 digits), full-size scalars (8 words, 4 digits) and the values around the digit borders."""
+    X = 0x8508C00000000001
+    random.seed(64)
+    assert ecc.R377 < X ** 4
+    border = [0, 1, X - 1, X, X + 1, X * X - 1, X * X, X * X + 1, X ** 3 - 1, X ** 3, X ** 3 + 12345, (X - 1) * (1 + X + X * X + X ** 3),
+              0xFFFFFFFF << 32, (1 << 64) - 1, 1 << 64, X << 32, (X << 32) - 1, ecc.R377 - 1]
+    for nd, lo_bits, hi_bits in ((2, 65, 126), (3, 127, 189), (4, 190, 253)):
+        cases = [b for b in border if lo_bits - 1 <= b.bit_length() <= hi_bits] + [(1 << hi_bits) - 1, 1 << (lo_bits - 1)]
+        cases += [random.getrandbits(b) for b in range(lo_bits, hi_bits + 1, 3) for _ in range(12)]
+        for k in cases:
+            nw = max(3, (max(k.bit_length(), lo_bits) + 31) // 32)
+            for nwords in sorted({nw, min(8, nw + 1)}):
+                if (nwords, nd) not in ((3, 2), (4, 2), (4, 3), (5, 3), (6, 3), (6, 4), (7, 4), (8, 4)):
+                    continue
+                kin = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint32).copy()
+                d = np.zeros(8, dtype=np.uint32)
+                assert ht.ht_gls_digits(nwords, nd, _p(kin), _p(d)) == 0
+                dig = [int(d[2 * j]) | (int(d[2 * j + 1]) << 32) for j in range(4)]
+                assert sum(v * X ** j for j, v in enumerate(dig)) == k, (hex(k), nwords, nd)
+                assert all(v < X for v in dig[: nd - 1]) and all(v == 0 for v in dig[nd:]), hex(k)
+                if k < X ** nd:
+                    assert dig[nd - 1] < X
+
+
 def test_fp2_ops(ht):
     random.seed(8)
     p, f2 = ecc.Q377, ecc.F2_377

@@ -32,7 +32,7 @@ for grp, pts in (("bls12_377_g1", sigs), ("bls12_377_g2", pks)):
     ffi.msm_batch(grp, pts, None, sc, offs)
     t0 = time.perf_counter(); out = ffi.msm_batch(grp, pts, None, sc, offs); dt = time.perf_counter() - t0
     tm = ffi.msm_timings(grp)
-    res[grp] = {"wall_ms": dt * 1e3, "device_ms": tm["total_ms"], "accumulate_ms": tm["accumulate_ms"], "sort_ms": tm["sort_ms"], "reduce_ms": tm["reduce_ms"],
+    res[grp] = {"wall_ms": dt * 1e3, "device_ms": tm["total_ms"], "accumulate_ms": tm["accumulate_ms"], "convert_ms": tm["convert_ms"], "windows": tm["windows"], "sort_ms": tm["sort_ms"], "reduce_ms": tm["reduce_ms"],
                 "window_bits": tm["window_bits"], "scalar_muls_per_s_device": tot / (tm["total_ms"] * 1e-3)}
 # pairing part: 2 pairs per batch (inputs: any valid points)
 g1 = sigs[: 2 * m]; g2 = pks[: 2 * m]

@@ -107,6 +107,13 @@ def emit_tower377():
     s += arr("G1_GEN_X", dev(G1[0])); s += arr("G1_GEN_Y", dev(G1[1]))
     s += arr("G2_GEN_X0", dev(G2[0][0])); s += arr("G2_GEN_X1", dev(G2[0][1]))
     s += arr("G2_GEN_Y0", dev(G2[1][0])); s += arr("G2_GEN_Y1", dev(G2[1][1]))
+    # psi = twist^-1 o Frobenius o twist on G2: psi(x, y) = (PSI_X conj(x), PSI_Y conj(y)), PSI_X = (-5)^((q-1)/6), PSI_Y = (-5)^((q-1)/4) in Fq;
+    # psi acts on the r-torsion of E'(Fq2) as multiplication by the curve parameter x (wire.h proves it): the GLS split of the batched G2
+    # MSM (msm.h k_gls_expand) uses psi^j, j = 1..3: (PSI_X^j conj^j(x), PSI_Y^j conj^j(y))
+    psx, psy = pow(-5 % p, (p - 1) // 6, p), pow(-5 % p, (p - 1) // 4, p)
+    for j in (1, 2, 3):
+        s += arr(f"PSI_X{j}", dev(pow(psx, j, p)))
+        s += arr(f"PSI_Y{j}", dev(pow(psy, j, p)))
     s += arr("TWO_INV", dev(pow(2, -1, p)))
     s += arr("TWIST_B_C1", dev((-pow(5, -1, p)) % p))
     s += "  static constexpr uint64_t X = 0x8508c00000000001ULL;  // BLS12-377 seed\n"

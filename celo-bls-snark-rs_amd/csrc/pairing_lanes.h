@@ -91,18 +91,24 @@ namespace hex {
 // Every value of these backends is kept with normalised limbs (each operation below ends in a carry propagation or is a
 // Montgomery product), so the products take their operands as they are: no carry pass per operand (that was 6 x 42 of the
 // ~1400 instructions of a product half).  The bounds-tracking host build asserts it (Fp::mul2s: lb <= 1).
+// Operand selection (round 3): the pass is X * b + Ys * bo with b, bo the lane's own and the partner's half of the second operand AS
+// THEY ARE, and only the first operand's halves selected - X = own (half 0) / partner's (half 1), Ys = -5 * partner's (half 0) / own
+// (half 1): 28 selects per product instead of 42.  -5 x is (x << 2) + x negated - v_lshl_add_u32 + v_sub_u32, full rate - where the
+// compiler's v_mul_lo_u32 is a quarter-rate instruction (14 of them per product: 4 % of the Miller loop's issue slots).
+HD uint32_t times5(uint32_t x) {
+  return (x << 2) + x;
+}
 HD Fq mul(const Fq& a, const Fq& b, const Fq& ao, const Fq& bo, int h) {
-  TRK(assert(ao.lb <= 1);)
+  TRK(assert(ao.lb <= 1 && a.lb <= 1);)
   int32_t cs[14];
-  Fq Y, D;
+  Fq X;
 #pragma unroll
   for (int i = 0; i < 14; i++) {
-    cs[i] = h ? (int32_t)ao.l[i] : -5 * (int32_t)ao.l[i];
-    Y.l[i] = h ? bo.l[i] : b.l[i];
-    D.l[i] = h ? b.l[i] : bo.l[i];
+    cs[i] = h ? (int32_t)a.l[i] : (int32_t)(0u - times5(ao.l[i]));
+    X.l[i] = h ? ao.l[i] : a.l[i];
   }
-  TRK(Y.lb = 1; D.lb = 1; Y.vb = h ? bo.vb : b.vb; D.vb = h ? b.vb : bo.vb; assert(ao.vb <= 64);)
-  return Fq::mul2s(a, Y, cs, D);
+  TRK(X.lb = 1; X.vb = h ? ao.vb : a.vb; assert((h ? a.vb : ao.vb) <= 64);)
+  return Fq::mul2s(X, b, cs, bo);
 }
 // (x0 + x1 u) u = -5 x1 + x0 u: half 0 takes -5 * (partner), half 1 takes the partner as it is.  Needs vb(partner) <= 12.
 HD Fq mul_nr(const Fq& xo, int h) {

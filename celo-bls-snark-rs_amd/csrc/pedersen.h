@@ -4,7 +4,9 @@
 // padded); chunk ch uses generator ch of the window-major table (generator j of a window = 16^j * its base) and contributes
 // (1 + b0 + 2 b1) * g, negated when b2 is set; the hash is the affine x coordinate of the sum, 48 bytes little-endian.
 // The generator table itself is built on the host (seam_a.hip: ChaCha20 stream exactly as the reference consumes it) and
-// handed to the device once.  One source for Seam A's host path (hash_crh, the composite hashers) and the bulk GPU kernel
+// handed to the device once.  It holds FOUR entries per chunk - g, 2g, 3g, 4g (PEDERSEN_MULTIPLES) - so that a chunk's contribution
+// (1 + b0 + 2 b1) g is one table entry and costs ONE point addition; round 2 kept g alone and formed the multiple per chunk (up to two
+// additions and a doubling before the one that counts: 2.5 point operations per chunk on average).  Same group element, same hash.  One source for Seam A's host path (hash_crh, the composite hashers) and the bulk GPU kernel
 // (unit_hash.hip: k_pedersen_crh, one message per lane).
 #pragma once
 #include "wire.h"
@@ -36,7 +38,7 @@ WIRE_FN EdPoint ed_dbl(const EdPoint& p) {  // dbl-2008-hwcd (a = -1)
 HD EdPoint ed_neg(const EdPoint& p) { return {p.X.neg(), p.Y, p.Z, p.T.neg()}; }
 HD EdPoint ed_zero() { return {sf_small(0), sf_small(1), sf_small(1), sf_small(0)}; }
 
-constexpr int PEDERSEN_WINDOW_SIZE = 93, PEDERSEN_NUM_WINDOWS = 560;
+constexpr int PEDERSEN_WINDOW_SIZE = 93, PEDERSEN_NUM_WINDOWS = 560, PEDERSEN_MULTIPLES = 4;
 constexpr size_t PEDERSEN_MAX_BITS = (size_t)PEDERSEN_WINDOW_SIZE * PEDERSEN_NUM_WINDOWS * 3;
 
 // out48 = x coordinate of sum_ch enc_ch over the bytes src(0 .. src.size()); the caller has checked size * 8 <= PEDERSEN_MAX_BITS
@@ -57,10 +59,7 @@ template <class Src> HD void pedersen_crh_src(const EdPoint* gens, const Src& sr
     uint32_t two = src(b >> 3);
     if ((b >> 3) + 1 < len) two |= (uint32_t)src((b >> 3) + 1) << 8;
     const uint32_t bits = (two >> (b & 7)) & 7u;
-    const EdPoint g = gens[ch];
-    EdPoint enc = g;
-    if (bits & 1) enc = ed_add(enc, g);
-    if (bits & 2) enc = ed_add(enc, ed_dbl(g));
+    EdPoint enc = gens[(size_t)PEDERSEN_MULTIPLES * ch + (bits & 3u)];     // (1 + b0 + 2 b1) * generator ch
     if (bits & 4) enc = ed_neg(enc);
     total = ed_add(total, enc);
   }

@@ -303,7 +303,7 @@ bool os_seeded_rng(ChaCha20Rng& rng) {
   return true;
 }
 struct CompositeParams {
-  std::vector<EdPoint> gens;  // [NUM_WINDOWS * WINDOW_SIZE]: window-major, generator j = 16^j * base
+  std::vector<EdPoint> gens;  // [NUM_WINDOWS * WINDOW_SIZE][PEDERSEN_MULTIPLES]: window-major, generator j = 16^j * base, then its multiples 1..4
   static constexpr int WINDOW_SIZE = PEDERSEN_WINDOW_SIZE, NUM_WINDOWS = PEDERSEN_NUM_WINDOWS;
   CompositeParams() {
     static const uint8_t PERS[8] = {'U', 'L', '_', 'p', 'r', 'n', 'g', 's'};
@@ -313,7 +313,7 @@ struct CompositeParams {
     ChaCha20Rng rng;
     memcpy(rng.key, seed.data(), 32);
     const SF one = sf_small(1), dcoef = sf_small(79743);
-    gens.reserve((size_t)WINDOW_SIZE * NUM_WINDOWS);
+    gens.reserve((size_t)WINDOW_SIZE * NUM_WINDOWS * PEDERSEN_MULTIPLES);
     for (int w = 0; w < NUM_WINDOWS; w++) {
       EdPoint base;
       for (;;) {  // TEProjective::rand: x = Fq::rand (raw Montgomery limbs, top 7 bits masked, rejection), greatest = rng.gen::<bool>()
@@ -338,8 +338,9 @@ struct CompositeParams {
         break;
       }
       for (int j = 0; j < WINDOW_SIZE; j++) {
-        gens.push_back(base);
-        for (int k = 0; k < 4; k++) base = ed_dbl(base);
+        const EdPoint g2 = ed_dbl(base), g4 = ed_dbl(g2);
+        gens.push_back(base); gens.push_back(g2); gens.push_back(ed_add(g2, base)); gens.push_back(g4);   // (1 + b0 + 2 b1) g for the chunk's two low bits
+        base = ed_dbl(ed_dbl(g4));                                                                          // 16 g
       }
     }
   }

@@ -51,26 +51,32 @@ class Ctx:
     pass
 
 
-# launch shapes the committed PMC profiles were taken at (tools/profile_bench.sh: the default bench command; tools/bench_groups.py 20)
-PROFILED_SHAPE = {"k_accumulate<G1_377>": 20, "k_accumulate<G2_377>": 20, "k_accumulate<G_761>": 20,
-                  "k_miller_product_slots<LPH377, 2>": 81920, "k_miller_prepared_slots<LPH377>": 81920, "k_prepare_lines<LPH377>": 81920,
-                  "k_final_exp_slots<LPH377>": 81920}
+# launch shapes the committed PMC profiles were taken at, and the profile set (profiles/<tag>_traffic.json, written by
+# tools/summarise_profile.py from the separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/r3_profiles.sh) that holds each:
+# kernel -> {shape: tag}.  Shapes: log2 n of an MSM, the number of products of a pairing launch, "cfg3" = 4096 batches x 256 signers.
+PROFILED = {"k_accumulate<G1_377>": {20: "r3", 22: "r3_cfg5", "cfg3": "r3_cfg3"},
+            "k_accumulate<G2_377>": {20: "r3_groups", 22: "r3_cfg5", "cfg3": "r3_cfg3"},
+            "k_accumulate<G_761>": {20: "r3_groups", 21: "r3_cfg4"},
+            "k_miller_product_slots<LPH377, 2>": {81920: "r3_pairing"}, "k_miller_prepared_slots<LPH377>": {81920: "r3"},
+            "k_prepare_lines<LPH377>": {81920: "r3"}, "k_final_exp_slots<LPH377>": {81920: "r3"}}
 
 
 def committed_traffic(kernels, shape):
-    """HBM bytes per launch (summed over `kernels`) from the newest committed PMC profile that holds them at this launch shape
-    (profiles/r*_traffic.json, written by tools/summarise_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes), or (None, why)."""
+    """HBM bytes per launch (summed over `kernels`) from the committed PMC profile of this launch shape, or (None, why)."""
     kernels = [kernels] if isinstance(kernels, str) else list(kernels)
-    if any(PROFILED_SHAPE.get(k) != shape for k in kernels):
-        return None, "no committed PMC profile of this launch shape"
+    total, srcs = 0.0, []
     try:
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
-            tj = json.load(open(path)).get("kernels", {})
-            if all(k in tj for k in kernels):
-                return sum(tj[k]["hbm_bytes_per_launch"] for k in kernels), os.path.basename(path)
+        for k in kernels:
+            tag = PROFILED.get(k, {}).get(shape)
+            if tag is None:
+                return None, "no committed PMC profile of this launch shape"
+            tj = json.load(open(os.path.join(ROOT, "profiles", tag + "_traffic.json"))).get("kernels", {})
+            total += tj[k]["hbm_bytes_per_launch"]
+            if tag + "_traffic.json" not in srcs:
+                srcs.append(tag + "_traffic.json")
     except Exception:
-        pass
-    return None, "no committed PMC profile holds these kernels"
+        return None, "no committed PMC profile holds these kernels"
+    return total, " + ".join(srcs)
 
 
 # ===================================================================================================== MSM configurations (2 and 4)
@@ -365,8 +371,9 @@ class BatchVerifyConfig:
                                       % (self.m, self.n), "batches_per_gpu": self.m, "signers_per_batch": self.n,
                           "signatures_per_s": None, "miller_loops_per_step": 2 * self.m, "final_exps_per_step": self.m,
                           "sharding": "batches sharded by rank, no exchange" if cx.world > 1 else "single GPU"}
+        traffic, src = committed_traffic("k_accumulate<G2_377>", "cfg3") if (self.m, self.n) == (4096, 256) else (None, "no committed PMC profile of this launch shape")
         line["roofline"] = {"bound": "hbm", "kernel": "k_accumulate<G2_377> (batched path)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
                             "note": "integer-VALU bound; algorithmic bytes = signers*224 B per launch; median HIP-event ms: G2 MSM %.2f (accumulate %.2f), G1 MSM %.2f, "
                                     "pairings %.2f (Miller %.2f, final exp %.2f) - the two MSMs overlap on the GPU, so their event times include each other's work"
                                     % (d[0], d[1], d[2], d[3], d[4], d[5])}
@@ -485,8 +492,10 @@ class MixedConfig:
                                       "MSM inputs resident in HBM" % ((self.n - 1).bit_length(), (self.n - 1).bit_length(), self.loops, self.mprod),
                           "terms_per_group_per_gpu": self.n, "miller_loops_per_gpu": self.loops, "miller_loops_per_s": cx.world * self.loops / (line["ms_per_step"] * 1e-3),
                           "sequential_ms_per_step": t_seq, "overlap_gain": t_seq / line["ms_per_step"]}
+        traffic, src = committed_traffic(["k_accumulate<G1_377>", "k_accumulate<G2_377>"], (self.n - 1).bit_length())
         line["roofline"] = {"bound": "hbm", "kernel": "whole step (three concurrent legs)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
+                            "traffic_kernels": "k_accumulate<G1_377> + k_accumulate<G2_377> (the two dominant kernels of the step)",
                             "note": "BASELINE config 5 asks for the HBM-roofline fraction of the mixed job: algorithmic bytes (128 B per G1 term, 224 B per G2 term, 288 B per "
                                     "Miller loop) / step wall time; integer-VALU bound.  Median HIP-event ms of the legs while overlapped: G1 MSM %.2f, G2 MSM %.2f, pairings %.2f"
                                     % (d[0], d[1], d[2])}

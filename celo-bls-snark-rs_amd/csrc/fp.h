@@ -74,6 +74,23 @@ template <class P> struct Fp {
   }
   HD static Fp one() { return from_limbs(P::ONE); }
 
+  // The Montgomery quotient digit -p^-1 * lo mod 2^W.  p = 1 mod 2^W (BLS12-377's Fq and Fr): a negation.  Otherwise (BW6-761) a
+  // multiplication whose low word is all that is used - which the compiler narrows to v_mul_lo_u32, a QUARTER-rate instruction on
+  // gfx950 (one per column: 28 per product, 6 % of the issue slots of the BW6-761 kernels).  Keeping the 64-bit product opaque makes
+  // it a v_mad_u64_u32, which issues at the rate of every other multiply-add of the pass.
+  HD static uint32_t mont_digit(uint32_t lo) {
+    if constexpr (P::INV == MASK) return (0u - lo) & MASK;
+    else {
+#if defined(__HIP_DEVICE_COMPILE__)
+      uint64_t q = (uint64_t)lo * P::INV;
+      asm("" : "+v"(q));                       // no instruction: only hides from the optimiser that the high word is unused
+      return (uint32_t)q & MASK;
+#else
+      return (lo * P::INV) & MASK;
+#endif
+    }
+  }
+
   // ---- Montgomery multiplication, product scanning with interleaved reduction.
   // For L > 25 (BW6-761: 28 limbs) a column of 2L products only fits 64 bits when lb_a*lb_b <= 8, so the
   // un-normalised subtraction results (lb 3) the curve formulas feed in are normalised on entry there.
@@ -92,7 +109,7 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
       uint32_t lo = (uint32_t)acc;
-      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      m[k] = mont_digit(lo);
       acc += (uint64_t)m[k] * P::P[0];
       acc >>= W;
     }
@@ -125,7 +142,7 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
       uint32_t lo = (uint32_t)acc;
-      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      m[k] = mont_digit(lo);
       acc += (uint64_t)m[k] * P::P[0];
       acc >>= W;
     }
@@ -373,7 +390,7 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
       uint32_t lo = (uint32_t)acc;
-      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      m[k] = mont_digit(lo);
       acc += (uint64_t)m[k] * P::P[0];
       acc = (uint64_t)((int64_t)acc >> W);
     }
@@ -414,7 +431,7 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
       uint32_t lo = (uint32_t)acc;
-      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      m[k] = mont_digit(lo);
       acc += (uint64_t)m[k] * P::P[0];
       acc = (uint64_t)((int64_t)acc >> W);
     }
@@ -457,7 +474,7 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
       uint32_t lo = (uint32_t)acc;
-      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      m[k] = mont_digit(lo);
       acc += (uint64_t)m[k] * P::P[0];
       acc = (uint64_t)((int64_t)acc >> W);
     }
@@ -503,7 +520,7 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
       uint32_t lo = (uint32_t)acc;
-      m[k] = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);
+      m[k] = mont_digit(lo);
       acc += (uint64_t)m[k] * P::P[0];
       acc = (uint64_t)((int64_t)acc >> W);
     }

@@ -93,11 +93,12 @@ namespace hex {
 // ~1400 instructions of a product half).  The bounds-tracking host build asserts it (Fp::mul2s: lb <= 1).
 // Operand selection (round 3): the pass is X * b + Ys * bo with b, bo the lane's own and the partner's half of the second operand AS
 // THEY ARE, and only the first operand's halves selected - X = own (half 0) / partner's (half 1), Ys = -5 * partner's (half 0) / own
-// (half 1): 28 selects per product instead of 42.  -5 x is (x << 2) + x negated - v_lshl_add_u32 + v_sub_u32, full rate - where the
-// compiler's v_mul_lo_u32 is a quarter-rate instruction (14 of them per product: 4 % of the Miller loop's issue slots).
-HD uint32_t times5(uint32_t x) {
-  return (x << 2) + x;
-}
+// (half 1): 28 selects per product instead of 42.  (-5 x stays the compiler's v_mul_lo_u32, a quarter-rate instruction - 14 per product,
+// 4 % of the Miller loop's issue slots.  Both ways around it were built - v_lshl_add_u32 + v_sub_u32 through inline assembly, and a
+// 64-bit product kept opaque so that it becomes a v_mad_u64_u32 as in fp.h mont_digit - and both made the Miller kernel 35 % SLOWER
+// (fourteen extra live registers or register pairs at the head of every product in a 248-register kernel: spills) and made
+// k_miller_product_slots<LPH377, 4> return wrong values, i.e. tripped a code-generation problem on top: DESIGN.md section 5.)
+HD uint32_t times5(uint32_t x) { return (x << 2) + x; }
 HD Fq mul(const Fq& a, const Fq& b, const Fq& ao, const Fq& bo, int h) {
   TRK(assert(ao.lb <= 1 && a.lb <= 1);)
   int32_t cs[14];

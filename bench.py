@@ -135,6 +135,9 @@ class MsmConfig:
     def step(self):
         from celo_bls_snark_rs_amd import ffi
         cx = self.cx
+        if cx.args.subgroup_points and not cx.devices:
+            out = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n, self.cx.stream, subgroup=True)
+            return self.fold(out)
         if cx.devices:
             return ffi.msm_multi_dev(self.group, cx.devices, [b.data_ptr() for b in self.sh_bases], None, [s_.data_ptr() for s_ in self.sh_sc],
                                      [self.n] * len(cx.devices))
@@ -177,8 +180,12 @@ class MsmConfig:
         line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": ACC_KERNEL[self.group], "achieved": fq_ops / (acc * 1e-3) / 1e9,
                                  "peak": valu_peak, "unit": "G field-mul-or-sqr/s", "frac": fq_ops / (acc * 1e-3) / 1e9 / valu_peak,
                                  "note": "peak from tools/ubench_fp.hip (register-resident multiply loops, 8 waves/SIMD); achieved = n*windows mixed adds * (8M+2S) / accumulate time"}
+        if cx.args.subgroup_points:
+            line["config"]["entry_point"] = "msm_bls12_377_g1_subgroup_dev: bases vouched to lie in G1 (what Signature::batch hands over), GLV split"
         if cx.world == 1 and not cx.devices:
             line["two_callers"] = self.two_callers()
+            if self.group == "bls12_377_g1" and not cx.args.subgroup_points:
+                line["subgroup_entry"] = self.subgroup_entry(result)
         if not cx.args.no_cpu_baseline:
             line["cpu_baseline"] = self.cpu_baseline(result)
 
@@ -221,6 +228,28 @@ class MsmConfig:
         return {"value": 2 * reps * self.n / dt, "unit": "scalar-muls/s", "ms_per_msm": dt * 1e3 / (2 * reps),
                 "per_thread_median_call_ms": [float(np.median(x)) for x in lat], "per_thread_max_call_ms": [float(np.max(x)) for x in lat],
                 "note": "two host threads, %d MSMs each after a concurrent 3-call warm-up, engines and streams from the pool; results identical to the sequential call" % reps}
+
+    def subgroup_entry(self, plain_result):
+        """Secondary number (not `value`): the same job through msm_bls12_377_g1_subgroup_dev - the entry point for bases that are elements
+        of the prime-order group G1 (every Signature of the reference is one: crates/bls-crypto/src/bls/signature.rs:31-57, 70-89), where
+        the library may split the scalars with the GLV endomorphism.  Same affine result as the plain entry point."""
+        from celo_bls_snark_rs_amd import ffi, codec
+        reps = max(4, self.cx.args.steps)
+        out = None
+        for _ in range(2):
+            out = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n, self.cx.stream, subgroup=True)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n, self.cx.stream, subgroup=True)
+            ts.append(time.perf_counter() - t0)
+        tm = ffi.msm_timings(self.group)
+        if codec.jacobian_to_affine(out, codec.Q377, 1) != codec.jacobian_to_affine(plain_result, codec.Q377, 1):
+            raise SystemExit("PARITY FAILURE: msm_bls12_377_g1_subgroup_dev != msm_bls12_377_g1_dev")
+        ms = float(np.median(ts)) * 1e3
+        return {"value": self.n / (ms * 1e-3), "unit": "scalar-muls/s", "ms_per_msm": ms, "windows": tm["windows"], "window_bits": tm["window_bits"],
+                "kernel_ms": {k: tm[k] for k in ("convert_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")},
+                "note": "GLV split k = k0 + k1 x^2, [x^2]P = (beta x, -y): 2n terms of 127 bits, half the windows; same affine result as `value`'s entry point"}
 
     def cpu_baseline(self, gpu_result):
         """Full-size parity of the timed result (every rank's inputs gathered on rank 0), then bounded timings of the port."""
@@ -684,6 +713,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pairing", action="store_true", help="config 2, N = 1: skip the secondary pairing / NTT / wire legs")
     ap.add_argument("--balanced", action="store_true", help="diagnostic: scalars whose digits fill every bucket equally (not the headline workload)")
+    ap.add_argument("--subgroup-points", action="store_true", help="config 2: time msm_bls12_377_g1_subgroup_dev (bases vouched to lie in G1: GLV split) instead of the plain entry point")
     ap.add_argument("--in-process", action="store_true", help="configs 2 / 4, N > 1: one process drives the N devices through msm_*_multi_dev (no ranks, no collective)")
     ap.add_argument("--devices", default="", help="--in-process: comma-separated device ordinals (default 0..N-1; repeats allowed, e.g. 0,0 on a 1-GPU box)")
     args = ap.parse_args()

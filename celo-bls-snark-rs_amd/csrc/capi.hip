@@ -42,8 +42,8 @@ int api_bind_thread(int device) {
   return 0;
 }
 #define DECL(TAG)                                                                                     \
-  int msm_host_##TAG(const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*);            \
-  int msm_dev_##TAG(const void*, const void*, const void*, size_t, uint64_t*, void*);                 \
+  int msm_host_##TAG(const uint64_t*, const uint8_t*, const uint64_t*, size_t, int, uint64_t*);       \
+  int msm_dev_##TAG(const void*, const void*, const void*, size_t, int, uint64_t*, void*);            \
   int msm_batch_host_##TAG(const uint64_t*, const uint8_t*, const uint64_t*, const uint32_t*, size_t, int, uint64_t*); \
   int msm_timings_##TAG(float*, int*);                                                                \
   int msm_set_c_##TAG(int);                                                                           \
@@ -113,14 +113,16 @@ int celo_amd_device_name(char* buf, size_t buflen) {
   }
 MULTI(msm_bls12_377_g1, g1_377) MULTI(msm_bls12_377_g2, g2_377) MULTI(msm_bw6_761_g1, 761) MULTI(msm_bw6_761_g2, 761)
 #undef MULTI
-int msm_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g1_377(); return msm_host_g1_377(b, inf, s, n, out); }
-int msm_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g2_377(); return msm_host_g2_377(b, inf, s, n, out); }
-int msm_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_761(); return msm_host_761(b, inf, s, n, out); }
-int msm_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_761(); return msm_host_761(b, inf, s, n, out); }
-int msm_bls12_377_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g1_377(); return msm_dev_g1_377(b, inf, s, n, out, st); }
-int msm_bls12_377_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g2_377(); return msm_dev_g2_377(b, inf, s, n, out, st); }
-int msm_bw6_761_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_761(); return msm_dev_761(b, inf, s, n, out, st); }
-int msm_bw6_761_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_761(); return msm_dev_761(b, inf, s, n, out, st); }
+int msm_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g1_377(); return msm_host_g1_377(b, inf, s, n, 0, out); }
+int msm_bls12_377_g1_subgroup(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g1_377(); return msm_host_g1_377(b, inf, s, n, 1, out); }
+int msm_bls12_377_g1_subgroup_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g1_377(); return msm_dev_g1_377(b, inf, s, n, 1, out, st); }
+int msm_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g2_377(); return msm_host_g2_377(b, inf, s, n, 0, out); }
+int msm_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_761(); return msm_host_761(b, inf, s, n, 0, out); }
+int msm_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_761(); return msm_host_761(b, inf, s, n, 0, out); }
+int msm_bls12_377_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g1_377(); return msm_dev_g1_377(b, inf, s, n, 0, out, st); }
+int msm_bls12_377_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g2_377(); return msm_dev_g2_377(b, inf, s, n, 0, out, st); }
+int msm_bw6_761_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_761(); return msm_dev_761(b, inf, s, n, 0, out, st); }
+int msm_bw6_761_g2_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_761(); return msm_dev_761(b, inf, s, n, 0, out, st); }
 int msm_batch_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g1_377(b, inf, s, off, m, 0, out); }
 int msm_batch_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g2_377(b, inf, s, off, m, 0, out); }
 int msm_batch_bls12_377_g2_subgroup(const uint64_t* b, const uint8_t* inf, const uint64_t* s, const uint32_t* off, size_t m, uint64_t* out) { return msm_batch_host_g2_377(b, inf, s, off, m, 1, out); }

@@ -65,4 +65,31 @@ template <int NW, int ND> HD void gls_digits_base_x(const uint32_t* k, uint32_t 
   u[NW] = 0;
   gls_digits_rec<NW, ND>(u, d);
 }
+// GLV split for G1 of BLS12-377: k = k0 + k1 x^2 with 0 <= k0 < x^2 < 2^127 and k1 = floor(k / x^2) < 2^127 for k < r (two divisions by
+// x: k = r1 + x q1, q1 = r2 + x q2, so k0 = r1 + x r2 and k1 = q2).  [k]P = [k0]P + [k1]([x^2]P) and [x^2]P = (beta x, -y) on the subgroup.
+template <int NW> HD void glv_split_x2(const uint32_t* k, uint32_t k0[4], uint32_t k1[4]) {
+  static_assert(NW >= 5 && NW <= 8, "scalar words");
+  uint32_t u[NW + 1], q1[NW - 1];
+  for (int i = 0; i < NW; i++) u[i] = k[i];
+  u[NW] = 0;
+  gls_divmod_x<NW>(u, q1);
+  const uint32_t r1l = u[0], r1h = u[1];
+  uint32_t v[NW], q2[NW - 2];
+  for (int i = 0; i < NW - 1; i++) v[i] = q1[i];
+  v[NW - 1] = 0;
+  gls_divmod_x<NW - 1>(v, q2);
+  const uint32_t r2l = v[0], r2h = v[1];
+  for (int i = 0; i < 4; i++) k1[i] = i < NW - 2 ? q2[i] : 0u;
+  // k0 = r1 + x r2,  x = 0x8508c000 2^32 + 1:  x r2 = r2 + (0x8508c000 r2) 2^32
+  constexpr uint64_t V1 = 0x8508c000u;
+  const uint64_t p0 = V1 * r2l, p1 = V1 * r2h;                 // at words 1 and 2
+  uint64_t c = (uint64_t)r1l + r2l;
+  k0[0] = (uint32_t)c;
+  c = (c >> 32) + (uint64_t)r1h + r2h + (uint32_t)p0;
+  k0[1] = (uint32_t)c;
+  c = (c >> 32) + (p0 >> 32) + (uint32_t)p1;
+  k0[2] = (uint32_t)c;
+  c = (c >> 32) + (p1 >> 32);
+  k0[3] = (uint32_t)c;
+}
 }  // namespace celo

@@ -382,6 +382,7 @@ int ht_gls_digits(int nw, int nd, const uint32_t* k8, uint32_t* d8) {
   for (int j = 0; j < 4; j++) { d8[2 * j] = d[j][0]; d8[2 * j + 1] = d[j][1]; }
   return 0;
 }
+void ht_glv_split(const uint32_t* k8, uint32_t* k0, uint32_t* k1) { glv_split_x2<8>(k8, k0, k1); }
 void ht_fq377_canon(const uint64_t* canon, uint64_t* out_ark, uint64_t* out_canon) {
   Fp<P377> x = Fp<P377>::from_canonical(canon);
   x.to_ark(out_ark);

@@ -947,6 +947,45 @@ template <> struct BatchHornerLanes<G2_377> {
   }
 };
 
+// ---- GLV expansion of ONE G1 MSM over BLS12-377 for bases in the prime-order subgroup (msm_bls12_377_g1_subgroup): phi(x, y) =
+// (beta x, y) acts on the subgroup as multiplication by -x^2 (wire.h proves it: the G1 subgroup test), so with k = k0 + k1 x^2
+//   [k]P = [k0]P + [k1](beta x, -y),     0 <= k0, k1 < 2^127   (gls.h glv_split_x2).
+// n terms with 253-bit scalars become 2 n terms with 127-bit scalars: the same number of bucket additions (8 windows of 16 bits over
+// 2 n points instead of 16 over n), HALF the windows - half the buckets to reduce, half the host's Horner chain.  Point i and its image
+// sit at i and n + i; a base flagged as the identity gets zero scalars.  Replaces k_convert_bases on this path.
+template <class G>   // G1_377 only
+__global__ void __launch_bounds__(256) k_glv_expand(const uint64_t* __restrict__ ark, const uint8_t* __restrict__ inf, const uint32_t* __restrict__ scalars,
+                                                    uint32_t n, uint32_t* __restrict__ dev_bases, uint32_t* __restrict__ sc2) {
+  typedef PointIO<Fq> IO;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* s = ark + (size_t)i * 2 * IO::ARK64;
+  const Affine<Fq> P = {Fq::from_ark(s), Fq::from_ark(s + IO::ARK64)};
+  const Affine<Fq> Q = {Fq::mul(P.x, Fq::from_limbs(T377::BETA_GLV)), Fq::wred(Fq::norm(Fq::neg<4, 1>(P.y)))};
+  IO::store_affine(dev_bases + (size_t)i * IO::AFF_WORDS, P);
+  IO::store_affine(dev_bases + ((size_t)n + i) * IO::AFF_WORDS, Q);
+  uint32_t k[8], k0[4], k1[4];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 a = sp[0], b = sp[1];
+  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+  glv_split_x2<8>(k, k0, k1);
+  const uint32_t keep = (inf && inf[i]) ? 0u : 0xffffffffu;
+  reinterpret_cast<uint4*>(sc2)[i] = uint4{k0[0] & keep, k0[1] & keep, k0[2] & keep, k0[3] & keep};
+  reinterpret_cast<uint4*>(sc2)[(size_t)n + i] = uint4{k1[0] & keep, k1[1] & keep, k1[2] & keep, k1[3] & keep};
+}
+template <class G> struct GlvExpand {
+  static constexpr bool AVAILABLE = false;
+  static constexpr int BITS = 0;
+  static void launch(const uint64_t*, const uint8_t*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, hipStream_t) {}
+};
+template <> struct GlvExpand<G1_377> {
+  static constexpr bool AVAILABLE = true;
+  static constexpr int BITS = 127;          // both halves are below 2^127
+  static void launch(const uint64_t* ark, const uint8_t* inf, const uint32_t* sc, uint32_t n, uint32_t* dev_bases, uint32_t* sc2, hipStream_t st) {
+    hipLaunchKernelGGL((k_glv_expand<G1_377>), dim3((n + 255) / 256), dim3(256), 0, st, ark, inf, sc, n, dev_bases, sc2);
+  }
+};
+
 // ---- GLS expansion of a batch of G2 instances (BLS12-377): psi = twist^-1 o Frobenius o twist acts on the prime-order subgroup of
 // E'(Fq2) as multiplication by the curve parameter x (proved in wire.h, where the same fact is the subgroup test), so
 //   [k]P = [d0]P + [d1]psi(P) + [d2]psi^2(P) + [d3]psi^3(P),   k = d0 + d1 x + d2 x^2 + d3 x^3,  0 <= d_j < x < 2^64.
@@ -1063,6 +1102,14 @@ template <class G> class MsmEngine {
   // bits instead of 29 x 13 (+ a carry window) 1.39 -> 1.88 ms, at 2^17 3.58 -> 3.79 ms.  CELO_NO_NARROW=1 is the A/B switch.
   bool narrow_windows = getenv("CELO_NO_NARROW") == nullptr;
   bool narrow_top(int c) const { return narrow_windows && c == 16; }
+  // big path, G1 of BLS12-377: the caller vouches for bases in the prime-order subgroup (Signature values, proving-key points): GLV split
+  bool big_subgroup_points = false;
+  bool use_glv = getenv("CELO_NO_GLV") == nullptr;     // A/B switch
+  int seg_halves = getenv("CELO_SEG_HALVES") ? atoi(getenv("CELO_SEG_HALVES")) : 4;   // piece length in half mean-bucket lengths (tuning hook; 4 = twice the mean)
+  bool last_glv = false;
+  // window size for the 2 n points x 127-bit halves of the split (n = the expanded count)
+  // (measured, round 3: 127 = 8 x 16 - 1, so c = 16 leaves no ragged top window and wins at every size from 2^14 terms up)
+  static int window_bits_glv(size_t) { return 16; }
   // batched path, G2 of BLS12-377: the caller vouches that every base lies in the prime-order subgroup (Batch::verify's public keys:
   // PublicKey values only come from checked deserialisation, secret keys and sums of such), which is what makes psi(P) = [x]P
   bool gls_subgroup_points = false;
@@ -1077,15 +1124,21 @@ template <class G> class MsmEngine {
   int run_device(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, uint64_t* out_jac,
                  hipStream_t stream) {
     if (n_ == 0) { write_identity(out_jac); return 0; }
-    if (n_ >= (size_t(1) << 31)) return 2;
-    const uint32_t n = (uint32_t)n_;
-    const int c = force_c ? force_c : window_bits(n);
-    const int nw = (G::SCALAR_BITS + c) / c;
+    if (n_ >= (size_t(1) << 30)) return 2;
+    // GLV split (big_subgroup_points: the caller vouches for bases in the prime-order subgroup): 2 n_ terms of sbits-bit scalars
+    // (from 2^14 terms: below, the plain path's c = 11 is as fast - measured 0.53 / 0.59 ms at 2^12 / 2^13 either way)
+    const bool glv = GlvExpand<G>::AVAILABLE && big_subgroup_points && use_glv && n_ >= (size_t(1) << 14);
+    const uint32_t n = glv ? 2u * (uint32_t)n_ : (uint32_t)n_;
+    const int sbits = glv ? GlvExpand<G>::BITS : G::SCALAR_BITS;
+    const int c = force_c ? force_c : (glv ? window_bits_glv(n) : window_bits(n));
+    const int nw = (sbits + c) / c;
     if ((uint64_t)n * (uint64_t)nw >= (uint64_t(1) << 32)) return 2;  // run offsets are 32-bit (n*windows < 2^32: n <= 2^27 at c = 16)
     const uint32_t B = 1u << (c - 1);
     const uint32_t total = (uint32_t)nw * B;
     // piece length: twice the average bucket, within [32, SIZE_BINS-1]
-    uint32_t SEG = 2 * (n / B + 1);
+    // (the split's buckets are twice as long - 64 points at 2^20 - and fewer: pieces of 1.5 mean buckets balance its last round better:
+    // accumulate 2.64 -> 2.46 ms at 2^20; the plain path is flat between 1.5 and 3)
+    uint32_t SEG = (uint32_t)(glv && !getenv("CELO_SEG_HALVES") ? 3 : seg_halves) * (n / B + 1) / 2;
     if (SEG < 32) SEG = 32;
     if (SEG > SIZE_BINS - 1) SEG = SIZE_BINS - 1;
     const uint32_t PW = B + n / SEG + 1;       // static piece region per window
@@ -1098,6 +1151,7 @@ template <class G> class MsmEngine {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
     const size_t o_bases = take((size_t)n * IO::AFF_WORDS * 4);
+    const size_t o_sc2 = take(glv ? (size_t)n * 16 : 0);
     const size_t o_digits = take((size_t)n * nw * 2);
     const size_t o_sorted = take((size_t)n * nw * 4);
     // two-level sort: NBIN bins per window by the low HIB bucket bits, KB2 blocks per window in the partition pass
@@ -1154,10 +1208,12 @@ template <class G> class MsmEngine {
     uint32_t* d_work = (uint32_t*)(A + o_work);
 
     HIP_OK(hipEventRecord(ev[0], stream));
-    hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_ark_bases, d_bases, (size_t)n);
+    if (glv) GlvExpand<G>::launch(d_ark_bases, d_inf, d_scalars, (uint32_t)n_, d_bases, (uint32_t*)(A + o_sc2), stream);
+    else hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_ark_bases, d_bases, (size_t)n);
     HIP_OK(hipEventRecord(ev[1], stream));
     // ---- sort
-    if (launch_digits(c, d_scalars, d_inf, d_digits, n, stream)) return 3;
+    if (glv) { if (launch_digits<4, GlvExpand<G>::BITS>(c, (const uint32_t*)(A + o_sc2), nullptr, d_digits, n, stream)) return 3; }
+    else if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits, n, stream)) return 3;
     HIP_OK(hipMemsetAsync(d_counts, 0, o_zero_end - o_counts, stream));
     // mean region n / NBIN: the smallest workgroup whose tile capacity (TILE_EPT entries per lane) holds it with 20 % to spare
     const uint32_t region = n / NBIN;
@@ -1240,7 +1296,7 @@ template <class G> class MsmEngine {
     (void)hipEventElapsedTime(&tm.accumulate, ev[2], ev[3]);
     (void)hipEventElapsedTime(&tm.reduce, ev[3], ev[4]);
     (void)hipEventElapsedTime(&tm.total, ev[0], ev[5]);
-    last_c = c; last_nw = nw; last_buckets = total;
+    last_c = c; last_nw = nw; last_buckets = total; last_glv = glv;
     // ---- host epilogue: total = sum_w 2^(c w) (node_w + sum_l 2^(LB-l) O_{w,l}): one Horner pass, c doublings and c additions per
     // window (the results arrive as arkworks limbs), as a list of steps: on AVX-512 IFMA where the CPU has it (host_ifma.cpp: the
     // products of one point operation eight at a time, 0.24 -> ~0.1 ms for 253-bit scalars), else - or if that path meets equal or
@@ -1249,7 +1305,7 @@ template <class G> class MsmEngine {
     const uint64_t* h64 = reinterpret_cast<const uint64_t*>(h_out);
     constexpr size_t PT64 = (size_t)IO::XYZZ_WORDS / 2;
     horner_steps.clear();
-    const int kn = narrow_top(c) ? nw * c - (G::SCALAR_BITS + 1) : 0;    // the top kn windows are c - 1 bits wide (k_digits)
+    const int kn = narrow_top(c) ? nw * c - (sbits + 1) : 0;    // the top kn windows are c - 1 bits wide (k_digits)
     for (int w = nw - 1; w >= 0; w--) {
       horner_steps.push_back(-1);
       for (int l = (w >= nw - kn ? 2 : 1); l <= LB; l++) horner_steps.push_back(l * nw + w);
@@ -1568,28 +1624,30 @@ template <class G> class MsmEngine {
       default: return 1;
     }
   }
-  template <int CB> int launch_digits_c(const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {
-    constexpr int NW = (G::SCALAR_BITS + CB) / CB;
-    constexpr int KN = NW * CB - (G::SCALAR_BITS + 1);     // 0 <= KN < CB <= NW for every window size in use
-    if (narrow_top(CB) && KN > 0) hipLaunchKernelGGL((k_digits<SW, CB, NW, KN>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);
-    else hipLaunchKernelGGL((k_digits<SW, CB, NW, 0>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);
+  template <int SWX, int BITS, int CB> int launch_digits_c(const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {
+    constexpr int NW = (BITS + CB) / CB;
+    constexpr int KN = NW * CB - (BITS + 1);     // 0 <= KN < CB <= NW for every window size in use
+    if constexpr (KN > 0 && KN < NW) {
+      if (narrow_top(CB)) { hipLaunchKernelGGL((k_digits<SWX, CB, NW, KN>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n); return 0; }
+    }
+    hipLaunchKernelGGL((k_digits<SWX, CB, NW, 0>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);
     return 0;
   }
-  int launch_digits(int c, const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {
+  template <int SWX, int BITS> int launch_digits(int c, const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {
     switch (c) {
-      case 4: return launch_digits_c<4>(sc, inf, digits, n, st);
-      case 5: return launch_digits_c<5>(sc, inf, digits, n, st);
-      case 6: return launch_digits_c<6>(sc, inf, digits, n, st);
-      case 7: return launch_digits_c<7>(sc, inf, digits, n, st);
-      case 8: return launch_digits_c<8>(sc, inf, digits, n, st);
-      case 9: return launch_digits_c<9>(sc, inf, digits, n, st);
-      case 10: return launch_digits_c<10>(sc, inf, digits, n, st);
-      case 11: return launch_digits_c<11>(sc, inf, digits, n, st);
-      case 12: return launch_digits_c<12>(sc, inf, digits, n, st);
-      case 13: return launch_digits_c<13>(sc, inf, digits, n, st);
-      case 14: return launch_digits_c<14>(sc, inf, digits, n, st);
-      case 15: return launch_digits_c<15>(sc, inf, digits, n, st);
-      case 16: return launch_digits_c<16>(sc, inf, digits, n, st);
+      case 4: return launch_digits_c<SWX, BITS, 4>(sc, inf, digits, n, st);
+      case 5: return launch_digits_c<SWX, BITS, 5>(sc, inf, digits, n, st);
+      case 6: return launch_digits_c<SWX, BITS, 6>(sc, inf, digits, n, st);
+      case 7: return launch_digits_c<SWX, BITS, 7>(sc, inf, digits, n, st);
+      case 8: return launch_digits_c<SWX, BITS, 8>(sc, inf, digits, n, st);
+      case 9: return launch_digits_c<SWX, BITS, 9>(sc, inf, digits, n, st);
+      case 10: return launch_digits_c<SWX, BITS, 10>(sc, inf, digits, n, st);
+      case 11: return launch_digits_c<SWX, BITS, 11>(sc, inf, digits, n, st);
+      case 12: return launch_digits_c<SWX, BITS, 12>(sc, inf, digits, n, st);
+      case 13: return launch_digits_c<SWX, BITS, 13>(sc, inf, digits, n, st);
+      case 14: return launch_digits_c<SWX, BITS, 14>(sc, inf, digits, n, st);
+      case 15: return launch_digits_c<SWX, BITS, 15>(sc, inf, digits, n, st);
+      case 16: return launch_digits_c<SWX, BITS, 16>(sc, inf, digits, n, st);
       default: return 1;
     }
   }

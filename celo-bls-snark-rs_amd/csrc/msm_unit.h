@@ -122,6 +122,7 @@ int msm_multi_impl(Pool& pool, int force_c, const int* devices, int ndev, int re
       if (!rc) {
         auto e = pool.lease();
         e->force_c = force_c;
+        e->big_subgroup_points = false;
         uint64_t* o = partial.data() + (size_t)d * 3 * IO::ARK64;
         if (resident) rc = e->run_device((const uint64_t*)bases[d], infs ? (const uint8_t*)infs[d] : nullptr, (const uint32_t*)scalars[d], n_per[d], o, e->own_stream());
         else rc = e->run_host((const uint64_t*)bases[d], infs ? (const uint8_t*)infs[d] : nullptr, (const uint64_t*)scalars[d], n_per[d], o, e->own_stream());
@@ -156,18 +157,20 @@ int msm_multi_host_impl(Pool& pool, int force_c, const int* devices, int ndev, c
   static EnginePool<MsmEngine<G>>& pool_##TAG() { static auto* p = new EnginePool<MsmEngine<G>>(); return *p; }          \
   static MsmLast& last_##TAG() { static auto* p = new MsmLast(); return *p; }                                            \
   static std::atomic<int> force_c_##TAG{0};                                                                              \
-  int msm_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) {                \
+  int msm_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, int subgroup, uint64_t* out) {  \
     if (int rc = api_enter()) return rc;                                                                                 \
     auto e = pool_##TAG().lease();                                                                                       \
     e->force_c = force_c_##TAG.load();                                                                                   \
+    e->big_subgroup_points = subgroup != 0;                                                                              \
     const int rc = e->run_host(b, inf, s, n, out, e->own_stream());                                                      \
     if (!rc && n) last_##TAG().note(*e);                                                                                 \
     return rc;                                                                                                           \
   }                                                                                                                      \
-  int msm_dev_##TAG(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) {                  \
+  int msm_dev_##TAG(const void* b, const void* inf, const void* s, size_t n, int subgroup, uint64_t* out, void* st) {    \
     if (int rc = api_enter()) return rc;                                                                                 \
     auto e = pool_##TAG().lease();                                                                                       \
     e->force_c = force_c_##TAG.load();                                                                                   \
+    e->big_subgroup_points = subgroup != 0;                                                                              \
     const int rc = e->run_device((const uint64_t*)b, (const uint8_t*)inf, (const uint32_t*)s, n, out, (hipStream_t)st);  \
     if (!rc && n) last_##TAG().note(*e);                                                                                 \
     return rc;                                                                                                           \

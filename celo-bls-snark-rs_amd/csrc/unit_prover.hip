@@ -24,10 +24,10 @@ typedef Fp<P377> Fr761;          // the scalar field of BW6-761 is the base fiel
 typedef Fp<P253> Fr377;          // the scalar field of BLS12-377
 int ntt_run(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const uint64_t*, int, void*);
 int ntt_run_253(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const uint64_t*, int, void*);
-int msm_host_761(const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*);
+int msm_host_761(const uint64_t*, const uint8_t*, const uint64_t*, size_t, int, uint64_t*);
 int sum_jac_761(const uint64_t*, size_t, uint64_t*);
-int msm_host_g1_377(const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*);
-int msm_host_g2_377(const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*);
+int msm_host_g1_377(const uint64_t*, const uint8_t*, const uint64_t*, size_t, int, uint64_t*);
+int msm_host_g2_377(const uint64_t*, const uint8_t*, const uint64_t*, size_t, int, uint64_t*);
 int sum_jac_g1_377(const uint64_t*, size_t, uint64_t*);
 int sum_jac_g2_377(const uint64_t*, size_t, uint64_t*);
 template <class FR> struct NttOf;
@@ -128,7 +128,7 @@ int groth16_prove_761_run(const uint64_t* a_query, size_t na, const uint64_t* b_
   const int dev = api_device();
   auto run = [&](int i, const uint64_t* bases, const uint64_t* sc, size_t k) {
     rcs[i] = api_bind_thread(dev);
-    if (!rcs[i]) rcs[i] = msm_host_761(bases, nullptr, sc, k, acc[i]);
+    if (!rcs[i]) rcs[i] = msm_host_761(bases, nullptr, sc, k, 0, acc[i]);
   };
   {
     std::thread t0(run, 0, a_query + 24, assignment, ka), t1(run, 1, b_g2_query + 24, assignment, kb), t2(run, 2, l_query, aux, kl);
@@ -167,11 +167,11 @@ int groth16_prove_377_run(const uint64_t* a_query, size_t na, const uint64_t* b_
   const int dev = api_device();
   auto run1 = [&](int i, uint64_t* out, const uint64_t* bases, const uint64_t* sc, size_t k) {
     rcs[i] = api_bind_thread(dev);
-    if (!rcs[i]) rcs[i] = msm_host_g1_377(bases, nullptr, sc, k, out);
+    if (!rcs[i]) rcs[i] = msm_host_g1_377(bases, nullptr, sc, k, 1, out);      // a proving key's G1 queries are elements of G1: the GLV split applies (msm.h k_glv_expand)
   };
   auto run2 = [&]() {
     rcs[1] = api_bind_thread(dev);
-    if (!rcs[1]) rcs[1] = msm_host_g2_377(b_g2_query + 24, nullptr, assignment, kb, acc2);
+    if (!rcs[1]) rcs[1] = msm_host_g2_377(b_g2_query + 24, nullptr, assignment, kb, 0, acc2);
   };
   {
     std::thread t0(run1, 0, acc1[0], a_query + 12, assignment, ka), t1(run2), t2(run1, 2, acc1[1], l_query, aux, kl);

@@ -105,25 +105,26 @@ def msm_multi_dev(group, devices, d_bases, d_infs, d_scalars, n_per):
     return out
 
 
-def msm(group, bases_xy, inf, scalars):
-    """Host-buffer MSM. bases_xy: uint64 [n, A]; inf: uint8 [n] or None; scalars: uint64 [n, S]. Returns Jacobian limbs."""
+def msm(group, bases_xy, inf, scalars, subgroup=False):
+    """Host-buffer MSM. bases_xy: uint64 [n, A]; inf: uint8 [n] or None; scalars: uint64 [n, S]. Returns Jacobian limbs.
+    subgroup=True (bls12_377_g1 only): the bases are vouched to lie in G1 (msm_bls12_377_g1_subgroup: GLV split)."""
     A, S, O = GROUP_SHAPE[group]
     n = int(bases_xy.shape[0]) if bases_xy.ndim == 2 else int(bases_xy.size // A)
     bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64)
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
     assert bases_xy.size == n * A and scalars.size == n * S, "bases / scalars length mismatch"
     out = np.zeros(O, dtype=np.uint64)
-    rc = getattr(lib(), "msm_" + group)(_p(bases_xy), _p(inf), _p(scalars), C.c_size_t(n), _p(out))
+    rc = getattr(lib(), "msm_" + group + ("_subgroup" if subgroup else ""))(_p(bases_xy), _p(inf), _p(scalars), C.c_size_t(n), _p(out))
     if rc != 0:
         raise RuntimeError(f"msm_{group} failed rc={rc}")
     return out
 
 
-def msm_dev(group, d_bases, d_inf, d_scalars, n, stream=0):
-    """Device-pointer MSM: d_* are integer device addresses (e.g. torch tensor .data_ptr())."""
+def msm_dev(group, d_bases, d_inf, d_scalars, n, stream=0, subgroup=False):
+    """Device-pointer MSM: d_* are integer device addresses (e.g. torch tensor .data_ptr()).  subgroup: as for msm()."""
     O = GROUP_SHAPE[group][2]
     out = np.zeros(O, dtype=np.uint64)
-    rc = getattr(lib(), "msm_" + group + "_dev")(C.c_void_p(d_bases), C.c_void_p(d_inf or 0), C.c_void_p(d_scalars),
+    rc = getattr(lib(), "msm_" + group + ("_subgroup_dev" if subgroup else "_dev"))(C.c_void_p(d_bases), C.c_void_p(d_inf or 0), C.c_void_p(d_scalars),
                                                  C.c_size_t(n), _p(out), C.c_void_p(stream or 0))
     if rc != 0:
         raise RuntimeError(f"msm_{group}_dev failed rc={rc}")

@@ -54,6 +54,14 @@ int msm_bw6_761_g1(const uint64_t* bases_xy /* n*24 */, const uint8_t* inf, cons
 int msm_bw6_761_g2(const uint64_t* bases_xy /* n*24 */, const uint8_t* inf, const uint64_t* scalars /* n*6 */, size_t n,
                    uint64_t out_xyz[36]);
 int msm_bls12_377_g1_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[18], void* stream);
+/* The G1 MSM for bases the caller vouches to be elements of the prime-order subgroup G1 - what Signature::batch hands over
+ * (crates/bls-crypto/src/bls/signature.rs:70-89: a Signature of the reference is one by construction - checked deserialisation
+ * signature.rs:31-57, sign, sums) and what a Groth16 proving key holds.  Same result as msm_bls12_377_g1; the library may split every
+ * scalar with the endomorphism phi(x, y) = (beta x, y) = -[x^2](x, y): n terms of 253 bits become 2 n terms of 127 bits - half the
+ * windows, half the bucket reduction, half the final Horner chain (csrc/msm.h k_glv_expand, gls.h).  For a base outside the subgroup
+ * the result is unspecified (use msm_bls12_377_g1, which is VariableBaseMSM on any curve point). */
+int msm_bls12_377_g1_subgroup(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[18]);
+int msm_bls12_377_g1_subgroup_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[18], void* hip_stream);
 int msm_bls12_377_g2_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
 int msm_bw6_761_g1_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
 int msm_bw6_761_g2_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);

@@ -92,6 +92,21 @@ def test_gls_base_x_digits(ht):
                     assert dig[nd - 1] < X
 
 
+def test_glv_split_by_x_squared(ht):
+    """gls.h glv_split_x2: k = k0 + k1 x^2, k0 < x^2, both below 2^127 for every k < r (the G1 GLV split of msm_bls12_377_g1_subgroup)."""
+    X2 = 0x8508C00000000001 ** 2
+    random.seed(127)
+    cases = [0, 1, X2 - 1, X2, X2 + 1, ecc.R377 - 1, ecc.R377 // 2, (1 << 127) - 1, 1 << 127, (1 << 252) + 12345] + [random.randrange(ecc.R377) for _ in range(400)]
+    cases += [random.getrandbits(b) for b in (10, 64, 65, 126, 127, 128, 129, 200) for _ in range(20)]
+    for k in cases:
+        kin = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint32).copy()
+        a, b = np.zeros(4, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
+        ht.ht_glv_split(_p(kin), _p(a), _p(b))
+        k0 = int.from_bytes(a.tobytes(), "little"); k1 = int.from_bytes(b.tobytes(), "little")
+        assert (k0, k1) == (k % X2, k // X2), hex(k)
+        assert k0 < (1 << 127) and k1 < (1 << 127)
+
+
 def test_fp2_ops(ht):
     random.seed(8)
     p, f2 = ecc.Q377, ecc.F2_377

@@ -329,3 +329,57 @@ def test_gpu_reproduces_the_frozen_msm_fixtures(gpu):
         xy, inf = co.pack_g2_377(pts)
         got = _affine(gpu.msm("bls12_377_g2", xy, inf, H.scalars_np(sc, 4)), "g2_377")
         assert got == ((int(want[0][0], 16), int(want[0][1], 16)), (int(want[1][0], 16), int(want[1][1], 16))), n
+
+
+# ------------------------------------------------------------------------------------------------ msm_bls12_377_g1_subgroup (GLV split)
+@pytest.mark.parametrize("n", [1, 2, 33, 256, 1024, 5000])
+def test_g1_subgroup_entry_small_vs_python(gpu, n):
+    """msm_bls12_377_g1_subgroup (bases vouched to lie in G1: Signature::batch's inputs, crates/bls-crypto/src/bls/signature.rs:70-89):
+    the GLV split k = k0 + k1 x^2, [x^2]P = (beta x, -y) (csrc/msm.h k_glv_expand, gls.h) against the big-integer definition - edge
+    scalars on both sides of x^2 and of the halves' window borders, 0, 1, r - 1, an identity base, repeated and opposite points."""
+    X2 = 0x8508C00000000001 ** 2
+    pts = H.seeded_points(ecc.E1_377, ecc.G1_377, n, 7100 + n)
+    sc = H.seeded_scalars(n, 7200 + n, ecc.R377)
+    edge = [0, 1, ecc.R377 - 1, X2 - 1, X2, X2 + 1, 2 * X2 - 1, (1 << 127) - 1, 1 << 127, (1 << 126), (X2 - 1) + X2 * ((1 << 126) + 5), (1 << 16) - 1, 1 << 15,
+            X2 * ((1 << 112) - 1), (1 << 252) + 1]
+    for i, k in enumerate(edge):
+        if i < n:
+            sc[i] = k % ecc.R377
+    if n >= 33:
+        pts[17] = None
+        pts[22] = pts[23]; sc[22] = sc[23]
+        pts[25] = ecc.E1_377.neg(pts[26]); sc[25] = sc[26]
+    xy, inf = co.pack_g1_377(pts)
+    s = H.scalars_np(sc, 4)
+    exp = None
+    for P, k in zip(pts, sc):
+        exp = ecc.E1_377.add(exp, ecc.E1_377.mul(P, k))
+    assert _affine(gpu.msm("bls12_377_g1", xy, inf, s, subgroup=True), "g1_377") == exp
+    if n <= 33:
+        for P, k in zip(pts, sc):                  # one term at a time: a wrong half cannot cancel against another term
+            if P is None:
+                continue
+            pxy, pinf = co.pack_g1_377([P])
+            assert _affine(gpu.msm("bls12_377_g1", pxy, pinf, H.scalars_np([k], 4), subgroup=True), "g1_377") == ecc.E1_377.mul(P, k), hex(k)
+
+
+@pytest.mark.parametrize("logn", [14, 17, 20])
+def test_g1_subgroup_entry_large_device_resident(gpu, logn):
+    """the same entry point at the bench's sizes, device-resident, against the C++ oracle and against the plain entry point"""
+    n = 1 << logn
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    bases = _gen_points_gpu(gpu, "bls12_377_g1", n, 0x5EED0002, gen.reshape(-1), 12)
+    rng = np.random.default_rng(0x5EED0041)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    sc ^= rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)
+    sc[:1000] = co.ints_to_limbs([ecc.R377 - 1 - i for i in range(1000)], 4)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = gpu.msm_dev("bls12_377_g1", bases.data_ptr(), 0, d_sc.data_ptr(), n, subgroup=True)
+    tm = gpu.msm_timings("bls12_377_g1")
+    assert tm["windows"] <= 12                      # the split halves the window count (8 x 16 bits at 2^20)
+    plain = gpu.msm_dev("bls12_377_g1", bases.data_ptr(), 0, d_sc.data_ptr(), n)
+    assert _affine(out, "g1_377") == _affine(plain, "g1_377")
+    h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 12)
+    exp = co.msm("bls12_377_g1", h_bases, None, sc, threads=max(1, min(32, co.lib().orc_hardware_threads())))
+    assert _affine(out, "g1_377") == co.jac_to_affine(exp, "g1_377")

@@ -114,6 +114,9 @@ def emit_tower377():
     for j in (1, 2, 3):
         s += arr(f"PSI_X{j}", dev(pow(psx, j, p)))
         s += arr(f"PSI_Y{j}", dev(pow(psy, j, p)))
+    # beta = PSI_X^4, the cube root of unity with (beta x, y) = -[x^2](x, y) on the prime-order subgroup of E(Fq) (wire.h proves it; there it
+    # is the G1 subgroup test): the GLV split of the single G1 MSM for subgroup points (msm.h k_glv_expand) uses [x^2]P = (beta x, -y)
+    s += arr("BETA_GLV", dev(pow(psx, 4, p)))
     s += arr("TWO_INV", dev(pow(2, -1, p)))
     s += arr("TWIST_B_C1", dev((-pow(5, -1, p)) % p))
     s += "  static constexpr uint64_t X = 0x8508c00000000001ULL;  // BLS12-377 seed\n"

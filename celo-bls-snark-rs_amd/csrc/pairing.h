@@ -385,6 +385,7 @@ template <class PP> class PairingEngine {
     const size_t W = IO::WORDS;
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += (b + 255) & ~size_t(255); return o; };
+    if (lay.k != k || lay.m != m) lines_valid = false;      // another layout: whatever sat at the cached lines' place may be overwritten
     lay.k = k; lay.m = m;
     lay.o_g1 = take((size_t)k * PP::G1_ARK64 * 8 + 8); lay.o_g2 = take((size_t)k * PP::G2_ARK64 * 8 + 8); lay.o_i1 = take(k + 8); lay.o_i2 = take(k + 8);
     lay.o_off = take((m + 1) * 4); lay.o_f = take((4 * (size_t)k + 8) * W * 4); lay.o_f2 = take(((size_t)k / 2 + 2) * W * 4);
@@ -436,9 +437,19 @@ template <class PP> class PairingEngine {
       PAIR_HIP_OK(hipMemcpyAsync(d_flag, &h_flag, 4, hipMemcpyHostToDevice, stream));
       LL::first_q_same(d_g2, d_off, (uint32_t)m, d_flag, stream);
       PAIR_HIP_OK(hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, stream));
+      uint64_t h_q0[PP::G2_ARK64];
+      PAIR_HIP_OK(hipMemcpyAsync(h_q0, d_g2 + (size_t)offsets[0] * PP::G2_ARK64, sizeof h_q0, hipMemcpyDeviceToHost, stream));
       PAIR_HIP_OK(hipStreamSynchronize(stream));
       if (h_flag) {
-        LL::prepare_lines(d_g2 + (size_t)offsets[0] * PP::G2_ARK64, d_lines, stream);
+        // the shared point is -g2 in every verify / Batch::verify of the reference: its 69 line triples are kept between calls (what
+        // ark-ec's G2Prepared is for a caller that holds one) and k_prepare_lines - 0.7 ms on one wave - runs when the point changes
+        const bool hit = lines_valid && lines_at == (const void*)d_lines && memcmp(lines_q0, h_q0, sizeof h_q0) == 0;
+        if (!hit) {
+          LL::prepare_lines(d_g2 + (size_t)offsets[0] * PP::G2_ARK64, d_lines, stream);
+          memcpy(lines_q0, h_q0, sizeof h_q0);
+          lines_at = (const void*)d_lines;
+          lines_valid = true;
+        }
         LL::miller_prepared(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_lines, d_prod, (uint32_t)m, stream);
         prepared = true;
       }
@@ -478,6 +489,9 @@ template <class PP> class PairingEngine {
   static constexpr size_t SHARED_MIN_PRODUCTS = 16384;
 
  private:
+  uint64_t lines_q0[PP::G2_ARK64] = {};     // the G2 point whose prepared lines the arena holds at lines_at (run_staged)
+  const void* lines_at = nullptr;
+  bool lines_valid = false;
   struct Layout { uint32_t k = 0; size_t m = 0, o_g1 = 0, o_g2 = 0, o_i1 = 0, o_i2 = 0, o_off = 0, o_f = 0, o_f2 = 0, o_prod = 0, o_one = 0, o_gt = 0, o_lines = 0, o_flag = 0, o_wide = 0; } lay;
   char* arena = nullptr;
   size_t arena_bytes = 0;
@@ -489,6 +503,7 @@ template <class PP> class PairingEngine {
     if (bytes > arena_bytes) {
       if (arena) (void)hipFree(arena);
       arena = nullptr; arena_bytes = 0;
+      lines_valid = false;
       PAIR_HIP_OK(hipMalloc(&arena, bytes));
       arena_bytes = bytes;
     }

@@ -1064,6 +1064,27 @@ struct MsmTimings {  // milliseconds, HIP events on the MSM's stream (last call)
   float convert = 0, sort = 0, accumulate = 0, reduce = 0, total = 0;
 };
 
+// A/B switches and tuning hooks of the pipeline, read from the environment ONCE per process (not per engine, not per call)
+struct MsmTuning {
+  bool narrow_windows, use_glv, use_gls, gls_force, lane_bitsum;
+  int seg_halves;          // piece length in half mean-bucket lengths (4 = twice the mean); 0 = not set: the path's own default
+  uint32_t bitsum_lanes_max;
+  static const MsmTuning& get() {
+    static const MsmTuning t = [] {
+      MsmTuning v;
+      v.narrow_windows = getenv("CELO_NO_NARROW") == nullptr;
+      v.use_glv = getenv("CELO_NO_GLV") == nullptr;
+      v.use_gls = getenv("CELO_NO_GLS") == nullptr;
+      v.gls_force = getenv("CELO_GLS_ALL") != nullptr;       // measurement hook (tools/bench_config3.py): split also for the plain msm_batch_* entry points
+      v.lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;
+      v.seg_halves = getenv("CELO_SEG_HALVES") ? atoi(getenv("CELO_SEG_HALVES")) : 0;
+      v.bitsum_lanes_max = getenv("CELO_LANE_BITSUM_MAX") ? (uint32_t)atoi(getenv("CELO_LANE_BITSUM_MAX")) : 21 * 1024;   // outputs of a launch: one wave of 21 additions per SIMD
+      return v;
+    }();
+    return t;
+  }
+};
+
 template <class G> class MsmEngine {
  public:
   typedef typename G::F F;
@@ -1100,12 +1121,11 @@ template <class G> class MsmEngine {
   // and a ragged top window costs folds and balance (2^20 terms: G1 3.32 -> 3.31, G2 10.85 -> 10.75, BW6-761 19.5 -> 19.0 ms).
   // Small inputs are bound by their longest bucket run, and narrower windows mean longer runs: BW6-761 at 2^14 with 18 x 13 + 12 x 12
   // bits instead of 29 x 13 (+ a carry window) 1.39 -> 1.88 ms, at 2^17 3.58 -> 3.79 ms.  CELO_NO_NARROW=1 is the A/B switch.
-  bool narrow_windows = getenv("CELO_NO_NARROW") == nullptr;
+  bool narrow_windows = MsmTuning::get().narrow_windows;
   bool narrow_top(int c) const { return narrow_windows && c == 16; }
   // big path, G1 of BLS12-377: the caller vouches for bases in the prime-order subgroup (Signature values, proving-key points): GLV split
   bool big_subgroup_points = false;
-  bool use_glv = getenv("CELO_NO_GLV") == nullptr;     // A/B switch
-  int seg_halves = getenv("CELO_SEG_HALVES") ? atoi(getenv("CELO_SEG_HALVES")) : 4;   // piece length in half mean-bucket lengths (tuning hook; 4 = twice the mean)
+  bool use_glv = MsmTuning::get().use_glv;     // A/B switch (CELO_NO_GLV)
   bool last_glv = false;
   // window size for the 2 n points x 127-bit halves of the split (n = the expanded count)
   // (measured, round 3: 127 = 8 x 16 - 1, so c = 16 leaves no ragged top window and wins at every size from 2^14 terms up)
@@ -1113,12 +1133,12 @@ template <class G> class MsmEngine {
   // batched path, G2 of BLS12-377: the caller vouches that every base lies in the prime-order subgroup (Batch::verify's public keys:
   // PublicKey values only come from checked deserialisation, secret keys and sums of such), which is what makes psi(P) = [x]P
   bool gls_subgroup_points = false;
-  bool use_gls = getenv("CELO_NO_GLS") == nullptr;     // A/B switch
-  bool gls_force = getenv("CELO_GLS_ALL") != nullptr;  // measurement hook (tools/bench_config3.py): split also for the plain msm_batch_* entry points
+  bool use_gls = MsmTuning::get().use_gls;     // A/B switch (CELO_NO_GLS)
+  bool gls_force = MsmTuning::get().gls_force;
   int last_gls_digits = 1;
   bool lane_horner = true;  // batched path: three lanes per instance in the Horner pass (tuning hook)
-  bool lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;   // big path: three lanes per addition in the late levels of the bucket reduction (A/B hook)
-  uint32_t BITSUM_LANES_MAX = getenv("CELO_LANE_BITSUM_MAX") ? (uint32_t)atoi(getenv("CELO_LANE_BITSUM_MAX")) : 21 * 1024;   // outputs of a launch: one wave of 21 additions per SIMD
+  bool lane_bitsum = MsmTuning::get().lane_bitsum;   // big path (CELO_NO_LANE_BITSUM): three lanes per addition in the late levels of the bucket reduction (A/B hook)
+  uint32_t BITSUM_LANES_MAX = MsmTuning::get().bitsum_lanes_max;
 
   // bases/scalars/inf are DEVICE pointers (ark layout); result: Jacobian in ark Montgomery form (3*ARK64 u64) on host.
   int run_device(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, uint64_t* out_jac,
@@ -1138,7 +1158,8 @@ template <class G> class MsmEngine {
     // piece length: twice the average bucket, within [32, SIZE_BINS-1]
     // (the split's buckets are twice as long - 64 points at 2^20 - and fewer: pieces of 1.5 mean buckets balance its last round better:
     // accumulate 2.64 -> 2.46 ms at 2^20; the plain path is flat between 1.5 and 3)
-    uint32_t SEG = (uint32_t)(glv && !getenv("CELO_SEG_HALVES") ? 3 : seg_halves) * (n / B + 1) / 2;
+    const int seg_h = MsmTuning::get().seg_halves ? MsmTuning::get().seg_halves : (glv ? 3 : 4);
+    uint32_t SEG = (uint32_t)seg_h * (n / B + 1) / 2;
     if (SEG < 32) SEG = 32;
     if (SEG > SIZE_BINS - 1) SEG = SIZE_BINS - 1;
     const uint32_t PW = B + n / SEG + 1;       // static piece region per window

@@ -117,6 +117,8 @@ int msm_bls12_377_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, s
 int msm_bls12_377_g1_subgroup(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g1_377(); return msm_host_g1_377(b, inf, s, n, 1, out); }
 int msm_bls12_377_g1_subgroup_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g1_377(); return msm_dev_g1_377(b, inf, s, n, 1, out, st); }
 int msm_bls12_377_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g2_377(); return msm_host_g2_377(b, inf, s, n, 0, out); }
+int msm_bls12_377_g2_subgroup(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_g2_377(); return msm_host_g2_377(b, inf, s, n, 1, out); }
+int msm_bls12_377_g2_subgroup_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g2_377(); return msm_dev_g2_377(b, inf, s, n, 1, out, st); }
 int msm_bw6_761_g1(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_761(); return msm_host_761(b, inf, s, n, 0, out); }
 int msm_bw6_761_g2(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, uint64_t* out) { msm_note_big_call_761(); return msm_host_761(b, inf, s, n, 0, out); }
 int msm_bls12_377_g1_dev(const void* b, const void* inf, const void* s, size_t n, uint64_t* out, void* st) { msm_note_big_call_g1_377(); return msm_dev_g1_377(b, inf, s, n, 0, out, st); }

@@ -947,23 +947,34 @@ template <> struct BatchHornerLanes<G2_377> {
   }
 };
 
-// ---- GLV expansion of ONE G1 MSM over BLS12-377 for bases in the prime-order subgroup (msm_bls12_377_g1_subgroup): phi(x, y) =
-// (beta x, y) acts on the subgroup as multiplication by -x^2 (wire.h proves it: the G1 subgroup test), so with k = k0 + k1 x^2
-//   [k]P = [k0]P + [k1](beta x, -y),     0 <= k0, k1 < 2^127   (gls.h glv_split_x2).
+// ---- GLV expansion of ONE MSM over BLS12-377 for bases in the prime-order subgroup (msm_bls12_377_g1_subgroup / _g2_subgroup).  G1:
+// phi(x, y) = (beta x, y) acts on the subgroup as multiplication by -x^2 (wire.h proves it: the G1 subgroup test); G2: psi acts as [x],
+// so psi^2 as [x^2].  With k = k0 + k1 x^2
+//   [k]P = [k0]P + [k1] I(P),   I(P) = (beta x, -y) on G1, psi^2(P) on G2,     0 <= k0, k1 < 2^127   (gls.h glv_split_x2).
 // n terms with 253-bit scalars become 2 n terms with 127-bit scalars: the same number of bucket additions (8 windows of 16 bits over
 // 2 n points instead of 16 over n), HALF the windows - half the buckets to reduce, half the host's Horner chain.  Point i and its image
 // sit at i and n + i; a base flagged as the identity gets zero scalars.  Replaces k_convert_bases on this path.
-template <class G>   // G1_377 only
+template <class G> struct GlvImage;          // [x^2]P of a subgroup point P, four or fewer field products
+template <> struct GlvImage<G1_377> {        // (beta x, -y): phi(x, y) = (beta x, y) = -[x^2](x, y)
+  HD static Affine<Fq> of(const Affine<Fq>& P) { return {Fq::mul(P.x, Fq::from_limbs(T377::BETA_GLV)), Fq::wred(Fq::norm(Fq::neg<4, 1>(P.y)))}; }
+};
+template <> struct GlvImage<G2_377> {        // psi^2(x, y) = (PSI_X^2 x, PSI_Y^2 y): psi acts on G2 as [x] (the GLS expansion below uses psi^j)
+  HD static Affine<Fq2> of(const Affine<Fq2>& P) {
+    const Fq kx = Fq::from_limbs(T377::PSI_X2), ky = Fq::from_limbs(T377::PSI_Y2);
+    return {{Fq::mul(P.x.c0, kx), Fq::mul(P.x.c1, kx)}, {Fq::mul(P.y.c0, ky), Fq::mul(P.y.c1, ky)}};
+  }
+};
+template <class G>   // G1_377 and G2_377
 __global__ void __launch_bounds__(256) k_glv_expand(const uint64_t* __restrict__ ark, const uint8_t* __restrict__ inf, const uint32_t* __restrict__ scalars,
                                                     uint32_t n, uint32_t* __restrict__ dev_bases, uint32_t* __restrict__ sc2) {
-  typedef PointIO<Fq> IO;
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t* s = ark + (size_t)i * 2 * IO::ARK64;
-  const Affine<Fq> P = {Fq::from_ark(s), Fq::from_ark(s + IO::ARK64)};
-  const Affine<Fq> Q = {Fq::mul(P.x, Fq::from_limbs(T377::BETA_GLV)), Fq::wred(Fq::norm(Fq::neg<4, 1>(P.y)))};
+  const Affine<F> P = {F::from_ark(s), F::from_ark(s + IO::ARK64)};
   IO::store_affine(dev_bases + (size_t)i * IO::AFF_WORDS, P);
-  IO::store_affine(dev_bases + ((size_t)n + i) * IO::AFF_WORDS, Q);
+  IO::store_affine(dev_bases + ((size_t)n + i) * IO::AFF_WORDS, GlvImage<G>::of(P));
   uint32_t k[8], k0[4], k1[4];
   const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
   const uint4 a = sp[0], b = sp[1];
@@ -978,13 +989,15 @@ template <class G> struct GlvExpand {
   static constexpr int BITS = 0;
   static void launch(const uint64_t*, const uint8_t*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, hipStream_t) {}
 };
-template <> struct GlvExpand<G1_377> {
+template <class G> struct GlvExpandX2 {      // the two BLS12-377 groups: k = k0 + k1 x^2, both halves below 2^127
   static constexpr bool AVAILABLE = true;
-  static constexpr int BITS = 127;          // both halves are below 2^127
+  static constexpr int BITS = 127;
   static void launch(const uint64_t* ark, const uint8_t* inf, const uint32_t* sc, uint32_t n, uint32_t* dev_bases, uint32_t* sc2, hipStream_t st) {
-    hipLaunchKernelGGL((k_glv_expand<G1_377>), dim3((n + 255) / 256), dim3(256), 0, st, ark, inf, sc, n, dev_bases, sc2);
+    hipLaunchKernelGGL((k_glv_expand<G>), dim3((n + 255) / 256), dim3(256), 0, st, ark, inf, sc, n, dev_bases, sc2);
   }
 };
+template <> struct GlvExpand<G1_377> : GlvExpandX2<G1_377> {};
+template <> struct GlvExpand<G2_377> : GlvExpandX2<G2_377> {};
 
 // ---- GLS expansion of a batch of G2 instances (BLS12-377): psi = twist^-1 o Frobenius o twist acts on the prime-order subgroup of
 // E'(Fq2) as multiplication by the curve parameter x (proved in wire.h, where the same fact is the subgroup test), so

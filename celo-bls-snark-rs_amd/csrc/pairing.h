@@ -23,6 +23,7 @@
 #include "runtime.h"
 #endif
 #include <cstdio>
+#include <cstring>
 #include "tower.h"
 
 namespace celo {

@@ -171,7 +171,7 @@ int groth16_prove_377_run(const uint64_t* a_query, size_t na, const uint64_t* b_
   };
   auto run2 = [&]() {
     rcs[1] = api_bind_thread(dev);
-    if (!rcs[1]) rcs[1] = msm_host_g2_377(b_g2_query + 24, nullptr, assignment, kb, 0, acc2);
+    if (!rcs[1]) rcs[1] = msm_host_g2_377(b_g2_query + 24, nullptr, assignment, kb, 1, acc2);      // likewise elements of G2
   };
   {
     std::thread t0(run1, 0, acc1[0], a_query + 12, assignment, ka), t1(run2), t2(run1, 2, acc1[1], l_query, aux, kl);

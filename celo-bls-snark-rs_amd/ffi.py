@@ -107,7 +107,7 @@ def msm_multi_dev(group, devices, d_bases, d_infs, d_scalars, n_per):
 
 def msm(group, bases_xy, inf, scalars, subgroup=False):
     """Host-buffer MSM. bases_xy: uint64 [n, A]; inf: uint8 [n] or None; scalars: uint64 [n, S]. Returns Jacobian limbs.
-    subgroup=True (bls12_377_g1 only): the bases are vouched to lie in G1 (msm_bls12_377_g1_subgroup: GLV split)."""
+    subgroup=True (bls12_377_g1 / _g2): the bases are vouched to lie in the prime-order group (msm_bls12_377_g1_subgroup / _g2_subgroup: GLV split)."""
     A, S, O = GROUP_SHAPE[group]
     n = int(bases_xy.shape[0]) if bases_xy.ndim == 2 else int(bases_xy.size // A)
     bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64)

@@ -62,6 +62,10 @@ int msm_bls12_377_g1_dev(const void* d_bases_xy, const void* d_inf, const void* 
  * the result is unspecified (use msm_bls12_377_g1, which is VariableBaseMSM on any curve point). */
 int msm_bls12_377_g1_subgroup(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[18]);
 int msm_bls12_377_g1_subgroup_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[18], void* hip_stream);
+/* Likewise for G2 and bases that are elements of the prime-order subgroup G2 - what PublicKey::batch hands over
+ * (crates/bls-crypto/src/bls/public.rs:47-65: a PublicKey is one by construction): k = k0 + k1 x^2, [x^2]P = psi^2(P). */
+int msm_bls12_377_g2_subgroup(const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bls12_377_g2_subgroup_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* hip_stream);
 int msm_bls12_377_g2_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
 int msm_bw6_761_g1_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);
 int msm_bw6_761_g2_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, uint64_t out_xyz[36], void* stream);

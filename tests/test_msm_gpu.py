@@ -383,3 +383,43 @@ def test_g1_subgroup_entry_large_device_resident(gpu, logn):
     h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 12)
     exp = co.msm("bls12_377_g1", h_bases, None, sc, threads=max(1, min(32, co.lib().orc_hardware_threads())))
     assert _affine(out, "g1_377") == co.jac_to_affine(exp, "g1_377")
+
+
+@pytest.mark.parametrize("n", [1, 40, 700])
+def test_g2_subgroup_entry_small_vs_oracle(gpu, n):
+    """msm_bls12_377_g2_subgroup (bases vouched to lie in G2: PublicKey::batch's inputs, crates/bls-crypto/src/bls/public.rs:47-65): below
+    2^14 terms the plain path runs; same sums as the oracle with identities and repeated points inside."""
+    pts = H.seeded_points(ecc.E2_377, ecc.G2_377, n, 8100 + n)
+    sc = H.seeded_scalars(n, 8200 + n, ecc.R377)
+    if n >= 40:
+        pts[3] = None
+        pts[8] = pts[9]; sc[8] = sc[9]
+    xy, inf = co.pack_g2_377(pts)
+    s = H.scalars_np(sc, 4)
+    exp = co.jac_to_affine(co.msm("bls12_377_g2", xy, inf, s, threads=4), "g2_377")
+    assert _affine(gpu.msm("bls12_377_g2", xy, inf, s, subgroup=True), "g2_377") == exp
+
+
+@pytest.mark.parametrize("logn", [14, 17])
+def test_g2_subgroup_entry_glv_split_device_resident(gpu, logn):
+    """from 2^14 terms the split k = k0 + k1 x^2, [x^2]P = psi^2(P) runs (8 windows of 16 bits over 2n points): against the C++ oracle and
+    the plain entry point, with r - 1 - i, 0, 1, x^2 and x^2 - 1 among uniform scalars and identity-flagged bases"""
+    n = 1 << logn
+    gen, _ = co.pack_g2_377([ecc.G2_377])
+    bases = _gen_points_gpu(gpu, "bls12_377_g2", n, 0x5EED0052, gen.reshape(-1), 24)
+    rng = np.random.default_rng(0x5EED0051)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    sc ^= rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)
+    X2 = 0x8508C00000000001 ** 2
+    sc[:200] = co.ints_to_limbs([ecc.R377 - 1 - i for i in range(196)] + [0, 1, X2, X2 - 1], 4)
+    inf = np.zeros(n, dtype=np.uint8); inf[[5, 77, n - 1]] = 1
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    d_inf = torch.from_numpy(inf).cuda()
+    out = gpu.msm_dev("bls12_377_g2", bases.data_ptr(), d_inf.data_ptr(), d_sc.data_ptr(), n, subgroup=True)
+    assert gpu.msm_timings("bls12_377_g2")["windows"] == 8
+    plain = gpu.msm_dev("bls12_377_g2", bases.data_ptr(), d_inf.data_ptr(), d_sc.data_ptr(), n)
+    assert _affine(out, "g2_377") == _affine(plain, "g2_377")
+    h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 24)
+    exp = co.msm("bls12_377_g2", h_bases, inf, sc, threads=max(1, min(32, co.lib().orc_hardware_threads())))
+    assert _affine(out, "g2_377") == co.jac_to_affine(exp, "g2_377")

@@ -19,7 +19,8 @@ python bench.py --gpus 2 --in-process --devices 0,0 --steps 10 --warmup 2 --scal
 python bench.py --log-n 17 --steps 20 --warmup 3 --no-pairing 2>$OUT/2p17.err | tail -1 > $OUT/bench_cfg2_2p17_strong_scaling_shard.json
 python bench.py --log-n 17 --steps 20 --warmup 3 --no-pairing --no-cpu-baseline --subgroup-points 2>/dev/null | tail -1 > $OUT/bench_cfg2_2p17_strong_scaling_shard_subgroup_entry.json
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
-python tools/bench_glv.py 14 16 17 18 20 2>/dev/null > $OUT/glv.jsonl
+python tools/bench_glv.py g1 14 16 17 18 20 2>/dev/null > $OUT/glv_g1.jsonl
+python tools/bench_glv.py g2 14 16 17 18 20 2>/dev/null > $OUT/glv_g2.jsonl
 for l in 14 17 18 20; do python tools/bench_groups.py $l 2>/dev/null | tail -1 > $OUT/groups_2p$l.json; done
 python tools/bench_latency.py > $OUT/latency.json 2>$OUT/latency.err
 python tools/bench_seam_a_strict.py 4096 > $OUT/seam_a_strict.json 2>$OUT/seam_a_strict.err

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <thread>
 #include "curve.h"
 #include "host64.h"
 #include "curve_lanes.h"
@@ -1079,7 +1080,7 @@ struct MsmTimings {  // milliseconds, HIP events on the MSM's stream (last call)
 
 // A/B switches and tuning hooks of the pipeline, read from the environment ONCE per process (not per engine, not per call)
 struct MsmTuning {
-  bool narrow_windows, use_glv, use_gls, gls_force, lane_bitsum;
+  bool narrow_windows, use_glv, use_gls, gls_force, lane_bitsum, host_threads;
   int seg_halves;          // piece length in half mean-bucket lengths (4 = twice the mean); 0 = not set: the path's own default
   uint32_t bitsum_lanes_max;
   static const MsmTuning& get() {
@@ -1090,6 +1091,7 @@ struct MsmTuning {
       v.use_gls = getenv("CELO_NO_GLS") == nullptr;
       v.gls_force = getenv("CELO_GLS_ALL") != nullptr;       // measurement hook (tools/bench_config3.py): split also for the plain msm_batch_* entry points
       v.lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;
+      v.host_threads = getenv("CELO_NO_HOST_THREADS") == nullptr;
       v.seg_halves = getenv("CELO_SEG_HALVES") ? atoi(getenv("CELO_SEG_HALVES")) : 0;
       v.bitsum_lanes_max = getenv("CELO_LANE_BITSUM_MAX") ? (uint32_t)atoi(getenv("CELO_LANE_BITSUM_MAX")) : 21 * 1024;   // outputs of a launch: one wave of 21 additions per SIMD
       return v;
@@ -1149,6 +1151,8 @@ template <class G> class MsmEngine {
   bool use_gls = MsmTuning::get().use_gls;     // A/B switch (CELO_NO_GLS)
   bool gls_force = MsmTuning::get().gls_force;
   int last_gls_digits = 1;
+  static constexpr int HOST_HORNER_THREADS = 4;
+  bool host_threads = MsmTuning::get().host_threads;   // A/B switch (CELO_NO_HOST_THREADS) of the threaded host epilogue (Fq2 and BW6-761 groups)
   bool lane_horner = true;  // batched path: three lanes per instance in the Horner pass (tuning hook)
   bool lane_bitsum = MsmTuning::get().lane_bitsum;   // big path (CELO_NO_LANE_BITSUM): three lanes per addition in the late levels of the bucket reduction (A/B hook)
   uint32_t BITSUM_LANES_MAX = MsmTuning::get().bitsum_lanes_max;
@@ -1345,17 +1349,53 @@ template <class G> class MsmEngine {
       for (int l = (w >= nw - kn ? 2 : 1); l <= LB; l++) horner_steps.push_back(l * nw + w);
       horner_steps.push_back(w | HORNER_NODBL);
     }
-    HXyzz<HF> total_pt;
-    bool done = false;
-    if (IfmaHorner<F>::fn && celo_ifma_available()) {
-      uint64_t r[4 * IO::ARK64];
-      int inf = 0;
-      if (IfmaHorner<F>::fn(h64, PT64, horner_steps.data(), (int)horner_steps.size(), r, &inf) == 0) {
-        total_pt = inf ? HXyzz<HF>::identity() : HXyzz<HF>::load(r, IO::ARK64);
-        done = true;
+    auto run_list = [&](const int32_t* steps, int count) {
+      if (IfmaHorner<F>::fn && celo_ifma_available()) {
+        uint64_t r[4 * IO::ARK64];
+        int inf = 0;
+        if (IfmaHorner<F>::fn(h64, PT64, steps, count, r, &inf) == 0) return inf ? HXyzz<HF>::identity() : HXyzz<HF>::load(r, IO::ARK64);
       }
+      return host64_horner<HF>(h64, PT64, IO::ARK64, steps, count);
+    };
+    // The pass is linear in its windows: a group of windows run from the identity gives P_j, and the whole is ((P_0 2^d1 + P_1) 2^d2 +
+    // P_2) ... with d_j the doublings of group j's steps.  For the fields whose host products are slow - Fq2 (three 6-limb products and
+    // their reductions per product: 0.65 ms of every G2 call) and the 12-limb field of BW6-761 (0.6-0.8 ms) - the window groups run on
+    // HOST_HORNER_THREADS threads side by side and only the joining doublings stay serial: 0.65 -> 0.3 ms per G2 MSM, more than a
+    // quarter of a call below 2^16 terms.  The 6-limb prime field stays on one thread (0.15 ms: the joins would cost what the split saves).
+    constexpr int HT = (sizeof(HF) > 6 * 8) ? HOST_HORNER_THREADS : 1;
+    HXyzz<HF> total_pt;
+    if (HT > 1 && nw >= 2 * HT && host_threads) {
+      const int per_window = (int)horner_steps.size() / nw;       // uniform except for the narrow top windows: cut by counting steps
+      (void)per_window;
+      int start[HT + 1], dbls[HT];
+      {   // window boundaries in the step list: a window's steps end with its NODBL entry
+        int wdone = 0, g = 0;
+        start[0] = 0;
+        for (int k = 0; k < (int)horner_steps.size(); k++) {
+          if (horner_steps[k] >= 0 && (horner_steps[k] & HORNER_NODBL)) {
+            wdone++;
+            if (wdone == (g + 1) * nw / HT && g + 1 < HT) start[++g] = k + 1;
+          }
+        }
+        start[HT] = (int)horner_steps.size();
+        for (int j = 0; j < HT; j++) {
+          dbls[j] = 0;
+          for (int k = start[j]; k < start[j + 1]; k++) if (horner_steps[k] < 0 || !(horner_steps[k] & HORNER_NODBL)) dbls[j]++;
+        }
+      }
+      HXyzz<HF> part[HT];
+      std::thread th[HT - 1];
+      for (int j = 1; j < HT; j++) th[j - 1] = std::thread([&, j] { part[j] = run_list(horner_steps.data() + start[j], start[j + 1] - start[j]); });
+      part[0] = run_list(horner_steps.data() + start[0], start[1] - start[0]);
+      for (int j = 1; j < HT; j++) th[j - 1].join();
+      total_pt = part[0];
+      for (int j = 1; j < HT; j++) {
+        for (int d = 0; d < dbls[j]; d++) total_pt = hxyzz_dbl(total_pt);
+        hxyzz_add(total_pt, part[j]);
+      }
+    } else {
+      total_pt = run_list(horner_steps.data(), (int)horner_steps.size());
     }
-    if (!done) total_pt = host64_horner<HF>(h64, PT64, IO::ARK64, horner_steps.data(), (int)horner_steps.size());
     if (total_pt.is_identity()) { write_identity(out_jac); return 0; }
     (total_pt.X * total_pt.ZZ).store(out_jac);                 // (X ZZ, Y ZZZ, ZZ) is a Jacobian representative with Z = ZZ
     (total_pt.Y * total_pt.ZZZ).store(out_jac + IO::ARK64);

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint64_t* __restric
 // window full.  A narrow window uses the lower half of its bucket table; its top tree level is empty, so the host's Horner pass
 // leaves that level and its doubling out.  The extra bit is the headroom of the signed recoding: bits from SCALAR_BITS up are
 // ignored (as ark-ec's VariableBaseMSM ignores them), so the top digit plus its carry never exceeds 2^(width - 1).
-template <int SW, int CB, int NW, int KN>
+template <int SW, int CB, int NW, int KN, int BITS>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
                                                 uint16_t* __restrict__ digits, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,6 +114,11 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
     s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w;
   }
   s[SW] = 0;
+  if constexpr (BITS < 32 * SW) {          // bits from the scalar length up are not part of the scalar (ark-ec's windows never read them)
+    s[BITS / 32] &= (1u << (BITS % 32)) - 1u;
+#pragma unroll
+    for (int k = BITS / 32 + 1; k < SW; k++) s[k] = 0;
+  }
   const bool skip = inf && inf[i];
   constexpr int WIDE = NW - KN;
   uint32_t carry = 0;
@@ -979,7 +984,8 @@ __global__ void __launch_bounds__(256) k_glv_expand(const uint64_t* __restrict__
   uint32_t k[8], k0[4], k1[4];
   const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
   const uint4 a = sp[0], b = sp[1];
-  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z;
+  k[7] = b.w & ((1u << (G::SCALAR_BITS - 224)) - 1u);      // bits from Fr::MODULUS_BITS up are ignored, as on the plain path (k_digits) and in ark-ec
   glv_split_x2<8>(k, k0, k1);
   const uint32_t keep = (inf && inf[i]) ? 0u : 0xffffffffu;
   reinterpret_cast<uint4*>(sc2)[i] = uint4{k0[0] & keep, k0[1] & keep, k0[2] & keep, k0[3] & keep};
@@ -1702,9 +1708,9 @@ template <class G> class MsmEngine {
     constexpr int NW = (BITS + CB) / CB;
     constexpr int KN = NW * CB - (BITS + 1);     // 0 <= KN < CB <= NW for every window size in use
     if constexpr (KN > 0 && KN < NW) {
-      if (narrow_top(CB)) { hipLaunchKernelGGL((k_digits<SWX, CB, NW, KN>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n); return 0; }
+      if (narrow_top(CB)) { hipLaunchKernelGGL((k_digits<SWX, CB, NW, KN, BITS>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n); return 0; }
     }
-    hipLaunchKernelGGL((k_digits<SWX, CB, NW, 0>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);
+    hipLaunchKernelGGL((k_digits<SWX, CB, NW, 0, BITS>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);
     return 0;
   }
   template <int SWX, int BITS> int launch_digits(int c, const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {

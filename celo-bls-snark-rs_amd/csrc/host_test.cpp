@@ -1,6 +1,7 @@
 // Host-only build of the product's field/curve templates with run-time bounds tracking
 // (-DCELO_FP_TRACK): every mul/sub asserts the limb/value bounds of fp.h's contract.
 // Driven by tests/test_host_field.py through ctypes; never shipped.
+#include <vector>
 #include "curve.h"
 #include "gls.h"
 #include "fp2.h"
@@ -188,6 +189,17 @@ template <class H> static void pairing_op_lanes_t(int mode, const uint64_t* g1, 
     for (size_t i = 0; i < k && i < 4; i++) load_pair(i, px[i], py[i], Qc[i]);
     typename HQT::E12 acc = HQP::template miller_multi<4>((int)k, px, py, Qc);
     r = mode == 10 ? HQP::final_exponentiation(acc) : acc;
+  } else if (mode == 12) {         // the product tree of the GPU engine: Miller values multiplied with each other pairwise (bounds: value x value)
+    std::vector<typename HQT::E12> m(k);
+    for (size_t i = 0; i < k; i++) {
+      typename QB::F px, py;
+      typename QB::V Qc;
+      load_pair(i, px, py, Qc);
+      m[i] = HQP::miller(px, py, Qc);
+    }
+    for (size_t n = k; n > 1; n = (n + 1) / 2)
+      for (size_t t = 0; 2 * t < n; t++) m[t] = 2 * t + 1 < n ? HQT::mul12(m[2 * t], m[2 * t + 1]) : m[2 * t];
+    r = HQP::final_exponentiation(m[0]);
   } else if (mode <= 1) {
     typename HQT::E12 acc = HQT::one12();
     for (size_t i = 0; i < k; i++) {

@@ -44,6 +44,7 @@ template <class BP> struct QHostT {
   template <int K> static V sub(const V& a, const V& b) { return map2(a, b, [](const T& x, const T& y) { return BP::template sub<K>(x, y); }); }
   template <int K> static V neg(const V& a) { return map1(a, [](const T& x) { return BP::template neg<K>(x); }); }
   static V wred(const V& a) { return map1(a, [](const T& x) { return BP::wred(x); }); }
+  static V lred(const V& a) { return wred(a); }
   static V mul_nr(const V& a) { return map1(a, [](const T& x) { return BP::mul_nr(x); }); }
   // the "lazy" forms (result only ever handed to sub / wred, which carry-propagate themselves; mul_nr_k: operand vb <= K):
   // these backends keep every value normalised, the six-lane ones (pairing_lanes.h) skip the carry passes
@@ -86,6 +87,7 @@ template <class BP> struct QTriT {
   template <int K> QDEV static V sub(const V& a, const V& b) { return BP::template sub<K>(a, b); }
   template <int K> QDEV static V neg(const V& a) { return BP::template neg<K>(a); }
   QDEV static V wred(const V& a) { return BP::wred(a); }
+  QDEV static V lred(const V& a) { return BP::wred(a); }
   QDEV static V mul_nr(const V& a) { return BP::mul_nr(a); }
   static constexpr bool LAZY = false;
   QDEV static V add_l(const V& a, const V& b) { return BP::add(a, b); }      // lazy forms: see QHostT

@@ -174,6 +174,7 @@ struct QHostHex377 {
   template <int K> static V sub(const V& a, const V& b) { return map2(a, b, [](const Fq& x, const Fq& y) { return hex::sub<K>(x, y); }); }
   template <int K> static V neg(const V& a) { return map1(a, [](const Fq& x, int) { return hex::neg<K>(x); }); }
   static V wred(const V& a) { return map1(a, [](const Fq& x, int) { return Fq::wred(x); }); }
+  static V lred(const V& a) { return map1(a, [](const Fq& x, int) { return Fq::norm(x); }); }
   static V half(const V& a) { return map1(a, [](const Fq& x, int) { return Fq::half(x); }); }
   static V mul_nr(const V& a) { V r; for (int i = 0; i < 6; i++) r.v[i] = hex::mul_nr(a.v[i ^ 1], i & 1); return r; }
   static constexpr bool LAZY = true;
@@ -250,6 +251,7 @@ struct QHex377 {
   template <int K> QDEV static V sub(const V& a, const V& b) { return hex::sub<K>(a, b); }
   template <int K> QDEV static V neg(const V& a) { return hex::neg<K>(a); }
   QDEV static V wred(const V& a) { return Fq::wred(a); }
+  QDEV static V lred(const V& a) { return Fq::norm(a); }
   QDEV static V half(const V& a) { return Fq::half(a); }
   QDEV static V mul_nr(const V& a) {
     const V o = swap(a);
@@ -355,14 +357,17 @@ template <class QB> struct QTower {
     r.a = QB::wred(QB::add_l(v0, mul_by_gen_k<4>(v1)));
     return r;
   }
-  QFN static E12 sqr12(const E12& x) {  // complex squaring: 2 Fq6 products
+  // complex squaring: 2 Fq6 products.  lred = a carry pass where the six-lane backend's value bounds allow it (a weak reduction costs ~2.5x
+  // as much; lanes.h backends: lred = wred).  Contract (asserted by the host build, tests/test_host_tower.py): x.b <= 4 p, i.e. a
+  // weak-reduced value - the output's b = 2 ab (<= 6 p) goes to mul_by_034 / mul12 next, as in every Miller loop, not into sqr12 again.
+  QFN static E12 sqr12(const E12& x) {
     V ab = mul6(x.a, x.b);
-    V s2 = QB::wred(QB::add_l(x.a, mul_by_gen_k<4>(x.b)));
+    V s2 = QB::lred(QB::add_l(x.a, mul_by_gen_k<4>(x.b)));
     V t = mul6(QB::add(x.a, x.b), s2);
     V c0 = QB::template sub_l<64>(QB::template sub_l<4>(t, ab), mul_by_gen_k<4>(ab));
-    return {QB::wred(c0), QB::wred(QB::dbl_l(ab))};
+    return {QB::wred(c0), QB::lred(QB::dbl_l(ab))};
   }
-  QFN static E12 conj12(const E12& x) { return {x.a, QB::wred(QB::template neg<4>(x.b))}; }
+  QFN static E12 conj12(const E12& x) { return {x.a, QB::lred(QB::template neg<8>(x.b))}; }   // vb(x.b) <= 8: a squaring's doubled product included
   // x * (d0 + d1 v) for group-uniform d0, d1: lane j: x_j d0 + x_{j-1} d1 (xi on the wrapped term of lane 0)
   QFN static V mul6_by_01(const V& x, const V& d0, const V& d1) {
     V p = QB::mul(x, d0);
@@ -375,7 +380,7 @@ template <class QB> struct QTower {
     V b = mul6_by_01(f.b, s3, s4);
     V e = mul6_by_01(QB::add(f.a, f.b), QB::add(s0, s3), s4);
     f.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(e, A), b));
-    f.a = QB::wred(QB::add_l(A, mul_by_gen_k<4>(b)));
+    f.a = QB::lred(QB::add_l(A, mul_by_gen_k<4>(b)));
   }
   // Granger-Scott cyclotomic squaring: lane k squares the Fq4 pair k: (a0, b1), (b0, a2), (a1, b2)
   QNI static E12 cyclotomic_sqr(const E12& f) { return cyclotomic_sqr_inl(f); }
@@ -384,7 +389,7 @@ template <class QB> struct QTower {
     V y = QB::template sel<1>(QB::template perm<QP(1, 2, 2)>(f.a), QB::template perm<QP(1, 1, 2)>(f.b));
     V tmp = QB::mul(x, y);
     V m = QB::mul(QB::add(x, y), QB::add(QB::template mul_nr_k<4>(y), x));
-    V o0 = QB::wred(QB::template sub_l<64>(QB::template sub_l<4>(m, tmp), QB::template mul_nr_k<4>(tmp)));
+    V o0 = QB::lred(QB::template sub_l<64>(QB::template sub_l<4>(m, tmp), QB::template mul_nr_k<4>(tmp)));
     // a_j' = 3 o0 - 2 a_j on every lane;  b_j' = 3 u + 2 b_j with u = o1 = 2 tmp of the previous lane (xi on the wrap to lane 0)
     V u;
     if constexpr (QB::LAZY) {
@@ -392,7 +397,7 @@ template <class QB> struct QTower {
       u = QB::dbl_l(QB::template sel<0>(QB::template mul_nr_k<4>(ut), ut));
     } else {
       u = QB::template perm<QP(2, 0, 1)>(QB::dbl(tmp));
-      u = QB::template sel<0>(QB::wred(QB::mul_nr(u)), u);
+      u = QB::template sel<0>(QB::lred(QB::mul_nr(u)), u);
     }
     E12 z;
     z.a = QB::wred(QB::add_l(QB::dbl_l(QB::template sub_l<4>(o0, f.a)), o0));
@@ -410,7 +415,7 @@ template <class QB> struct QTower {
     V u2 = QB::template sel<0>(QB::mul_nr(m), m);
     V t = QB::wred(QB::template sub<64>(u1, u2));
     V pm = QB::mul(sA, t);                                     // x0 t0, x2 t1, x1 t2
-    V d = QB::wred(QB::add(QB::template bcast<0>(pm), QB::mul_nr(QB::add(QB::template bcast<1>(pm), QB::template bcast<2>(pm)))));
+    V d = QB::lred(QB::add(QB::template bcast<0>(pm), QB::mul_nr(QB::add(QB::template bcast<1>(pm), QB::template bcast<2>(pm)))));
     return QB::mul(t, QB::inv(d));
   }
   QFN static E12 inv12(const E12& x) {
@@ -420,7 +425,7 @@ template <class QB> struct QTower {
     V di = inv6(d);
     E12 r;
     r.a = mul6(x.a, di);
-    r.b = QB::wred(QB::template neg<4>(mul6(x.b, di)));
+    r.b = QB::lred(QB::template neg<4>(mul6(x.b, di)));
     return r;
   }
   QFN static bool is_one12(const E12& x) { return QB::is_one3(x.a, x.b); }
@@ -453,15 +458,15 @@ template <class QB> struct QPairing377 {
     V b, e;
     {
       const V r1 = QB::mul(Rc, Rc);                                   // X^2, Y^2, Z^2
-      l.c1 = QB::wred(QB::tpl(QB::template bcast<0>(r1)));
+      l.c1 = QB::lred(QB::tpl(QB::template bcast<0>(r1)));
       b = QB::template bcast<1>(r1);
       e = QB::twist_mul(QB::tpl(QB::template bcast<2>(r1)));          // B' * 3 Z^2: two Fq products, every lane
     }
     // round 2: lane 0: Y Z, lane 1: X Y, lane 2: e^2
     const V r2 = QB::mul(QB::pick(QB::template bcast<1>(Rc), QB::template bcast<0>(Rc), e), QB::pick(QB::template bcast<2>(Rc), QB::template bcast<1>(Rc), e));
     const V h = QB::dbl(QB::template bcast<0>(r2));    // 2YZ = (Y+Z)^2 - (b + c); vb 6
-    l.c0 = QB::wred(QB::template neg<16>(h));
-    l.c2 = QB::wred(QB::template sub<4>(e, b));
+    l.c0 = QB::lred(QB::template neg<16>(h));
+    l.c2 = QB::lred(QB::template sub<4>(e, b));
     const V f3 = QB::tpl(e);                           // vb 9
     const V e23 = QB::tpl(QB::template bcast<2>(r2));  // 3 e^2
     // round 3: lane 0: (XY/2) (b - f3) = X', lane 1: g^2 with g = (b + f3)/2, lane 2: b h = Z'
@@ -485,13 +490,13 @@ template <class QB> struct QPairing377 {
     V h = QB::template sub<8>(QB::add(e, QB::template bcast<1>(r3)), QB::dbl(g));  // vb 14
     // round 4: lane 0: lambda qy, lane 1: e Y, lane 2: Z e = Z'
     V r4 = QB::mul(QB::pick(lambda, e, Z), QB::pick(qy, Y, e));
-    l.c2 = QB::wred(QB::template sub<4>(QB::template bcast<2>(r2), QB::template bcast<0>(r4)));
+    l.c2 = QB::lred(QB::template sub<4>(QB::template bcast<2>(r2), QB::template bcast<0>(r4)));
     // round 5: lane 0: lambda h = X', lane 1: theta (g - h)
     V r5 = QB::mul(QB::template sel<0>(lambda, theta), QB::template sel<0>(h, QB::template sub<16>(g, h)));
-    V y3 = QB::wred(QB::template sub<4>(r5, r4));                         // lane 1: theta (g - h) - e Y
+    V y3 = QB::lred(QB::template sub<4>(r5, r4));                         // lane 1: theta (g - h) - e Y
     Rc = QB::pick(r5, y3, r4);
-    l.c0 = QB::wred(lambda);
-    l.c1 = QB::wred(QB::template neg<8>(theta));
+    l.c0 = QB::lred(lambda);
+    l.c1 = QB::lred(QB::template neg<8>(theta));
   }
   // f *= line evaluated at P (D-twist: c0 *= P.y, c1 *= P.x): lane 0 scales c0, lane 1 scales c1, then both are broadcast
   QFN static void ell(E12& f, const Line& l, const F& px, const F& py) {

@@ -50,18 +50,18 @@ __device__ __forceinline__ E12 mul12_w3(const E12& x, const E12& y) {           
   return r;
 }
 __device__ __forceinline__ E12 sqr12_w3(const E12& x) {                            // Tow::sqr12 (sub-group 2 repeats product 0)
-  const V s2 = QB::wred(QB::add_l(x.a, Tow::template mul_by_gen_k<4>(x.b)));
+  const V s2 = QB::lred(QB::add_l(x.a, Tow::template mul_by_gen_k<4>(x.b)));
   const V p = Tow::mul6(pick3(x.a, QB::add(x.a, x.b), x.a), pick3(x.b, s2, x.b));
   const V ab = from_sub<0>(p), t = from_sub<1>(p);
   const V c0 = QB::template sub_l<64>(QB::template sub_l<4>(t, ab), Tow::template mul_by_gen_k<4>(ab));
-  return {QB::wred(c0), QB::wred(QB::dbl_l(ab))};
+  return {QB::wred(c0), QB::lred(QB::dbl_l(ab))};
 }
 __device__ __forceinline__ E12 cyclo_w3(const E12& f) {                            // Tow::cyclotomic_sqr_inl: its two Fq2 product rounds side by side
   const V x = QB::template sel<1>(QB::template perm<QP(0, 0, 1)>(f.b), QB::template perm<QP(0, 0, 1)>(f.a));
   const V y = QB::template sel<1>(QB::template perm<QP(1, 2, 2)>(f.a), QB::template perm<QP(1, 1, 2)>(f.b));
   const V p = QB::mul(pick3(x, QB::add(x, y), x), pick3(y, QB::add(QB::template mul_nr_k<4>(y), x), y));
   const V tmp = from_sub<0>(p), m = from_sub<1>(p);
-  const V o0 = QB::wred(QB::template sub_l<64>(QB::template sub_l<4>(m, tmp), QB::template mul_nr_k<4>(tmp)));
+  const V o0 = QB::lred(QB::template sub_l<64>(QB::template sub_l<4>(m, tmp), QB::template mul_nr_k<4>(tmp)));
   const V ut = QB::template perm<QP(2, 0, 1)>(tmp);
   const V u = QB::dbl_l(QB::template sel<0>(QB::template mul_nr_k<4>(ut), ut));
   E12 z;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void ell_w3(E12& f, const Pair::Line& l, const LP::F&
   const V p = Tow::mul6_by_01(pick3(f.a, f.b, QB::add(f.a, f.b)), pick3(s0, s3, QB::add(s0, s3)), pick3(QB::zero(), s4, s4));
   const V A = from_sub<0>(p), b = from_sub<1>(p), e = from_sub<2>(p);
   f.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(e, A), b));
-  f.a = QB::wred(QB::add_l(A, Tow::template mul_by_gen_k<4>(b)));
+  f.a = QB::lred(QB::add_l(A, Tow::template mul_by_gen_k<4>(b)));
 }
 __device__ __forceinline__ void store12_w3(uint32_t* p, const E12& f) { if (sub3() == 0) LP::store12(p, f); }
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }

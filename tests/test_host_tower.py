@@ -61,6 +61,21 @@ def test_miller_loop_and_final_exp_match_oracle(hk):
         assert np.array_equal(fe, ogt)
 
 
+def test_product_tree_of_miller_values(ht):
+    """the GPU engine multiplies raw Miller values with each other (product tree) before the final exponentiation: same flow on
+    the six-lane host backend, whose bounds tracking asserts every value/limb bound on the way"""
+    rng = ecc.SplitMix64(12)
+    for k in (2, 3, 5):
+        Ps = [ecc.E1_377.mul(ecc.G1_377, rng.next()) for _ in range(k)]
+        Qs = [ecc.E2_377.mul(ecc.G2_377, rng.next()) for _ in range(k)]
+        g1, _ = co.pack_g1_377(Ps)
+        g2, _ = co.pack_g2_377(Qs)
+        for name in ("ht_pairing_377_lanes", "ht_pairing_377_hex"):
+            gt, _ = hp(_Hook(ht, name), 12, g1, g2, k)
+            ogt, _ = co.pairing_product_377(g1, None, g2, None)
+            assert np.array_equal(gt, ogt)
+
+
 def test_fq12_ops(hk):
     ht = hk
     P = ecc.E1_377.mul(ecc.G1_377, 77)

@@ -98,9 +98,9 @@ namespace hex {
 // 64-bit product kept opaque so that it becomes a v_mad_u64_u32 as in fp.h mont_digit - and both made the Miller kernel 35 % SLOWER
 // (fourteen extra live registers or register pairs at the head of every product in a 248-register kernel: spills) and made
 // k_miller_product_slots<LPH377, 4> return wrong values, i.e. tripped a code-generation problem on top: DESIGN.md section 5.)
-// (A third form, an opaque zero register so that `z - 5 x` cannot be folded, compiles to v_mad_u64_u32 x, -5, z - no quarter-rate multiply
-// left, same instruction count, results right - and measured 4 % SLOWER on both throughput kernels (Miller 18.7 -> 19.4 ms, final
-// exponentiation 15.2 -> 15.8): the 64-bit destination pairs cost more in this 255-register body than the 14 multiplies.)
+// (A third form, an opaque zero register so that `z - 5 x` cannot be folded, compiles to v_mad_u64_u32 x, -5, z - no v_mul_lo_u32 left,
+// same instruction count, results right - and measures THE SAME on one box, tools/ab_pairing.sh: Miller 18.8 vs 18.8 ms, final
+// exponentiation 15.3 vs 15.3.  The 14 multiplies per product are not what the issue slots go to; left as plain C.)
 HD uint32_t times5(uint32_t x) { return (x << 2) + x; }
 HD Fq mul(const Fq& a, const Fq& b, const Fq& ao, const Fq& bo, int h) {
   TRK(assert(ao.lb <= 1 && a.lb <= 1);)

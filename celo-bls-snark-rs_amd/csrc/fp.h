@@ -255,14 +255,30 @@ template <class P> struct Fp {
   // one multiply-subtract sweep, ~60-110 VALU ops: used by the pairing towers
   // to stop the value growth of lazy additions without paying a full Montgomery multiplication.
   HD static Fp wred(const Fp& a_) {
-    const Fp a = norm(a_);
-    TRK(assert(a.vb <= 300);)
+    TRK(assert(a_.vb <= 300);)
     uint32_t q;
-    if constexpr (P::P[L - 1] >= 4096) {                      // BLS12-377: 13-bit top limb, integer reciprocal
+    if constexpr (P::P[L - 1] >= 4096) {
+      // BLS12-377: 13-bit top limb, integer reciprocal - and NO carry pass first.  The quotient is estimated from the top limb AS IT
+      // IS: with lazy limbs (lb <= 15) it is at most 16 below the carried one, so q stays <= floor(a / p) and a - q p < 2.1 p still
+      // holds (16 / 6884 more); the sweep below carries while it subtracts and takes limbs of up to 32 bits.
+      TRK(assert(a_.lb <= 15);)
       constexpr uint64_t D = (uint64_t)P::P[L - 1] + 1;
-      constexpr uint64_t M = ((1ull << 34) + D - 1) / D;      // ceil(2^34 / D); exact floor(t/D) for t < 2^21
-      q = (uint32_t)(((uint64_t)a.l[L - 1] * M) >> 34);
-    } else {                                                  // BW6-761: 5-bit top limb -> estimate from the top two limbs
+      constexpr uint64_t M = ((1ull << 34) + D - 1) / D;      // ceil(2^34 / D); exact floor(t/D) for t < 2^34 / D (a < 362 p)
+      q = (uint32_t)(((uint64_t)a_.l[L - 1] * M) >> 34);
+      Fp r;
+      int64_t carry = 0;
+#pragma unroll
+      for (int i = 0; i < L - 1; i++) {
+        int64_t t = (int64_t)a_.l[i] - (int64_t)((uint64_t)q * P::P[i]) + carry;
+        r.l[i] = (uint32_t)t & MASK;
+        carry = t >> W;
+      }
+      r.l[L - 1] = (uint32_t)((int64_t)a_.l[L - 1] - (int64_t)((uint64_t)q * P::P[L - 1]) + carry);
+      TRK(r.lb = 1; r.vb = 3;)
+      return r;
+    }
+    const Fp a = norm(a_);
+    {                                                         // BW6-761: 5-bit top limb -> estimate from the top two limbs
       constexpr double DINV = 1.0 / (double)((((uint64_t)P::P[L - 1]) << W) + P::P[L - 2] + 1);
       const uint64_t t2 = (((uint64_t)a.l[L - 1]) << W) + a.l[L - 2];
       const uint32_t e = (uint32_t)((double)t2 * DINV);

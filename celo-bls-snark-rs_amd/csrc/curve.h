@@ -88,6 +88,27 @@ template <class F> HD void xyzz_madd(Xyzz<F>& a, const Affine<F>& p) {
   a.Y = Y3;
 }
 
+// p + q for two AFFINE points, result XYZZ (mmadd-2007-bl's shape: U2 = x2, S2 = y2, ZZ3 = PP, ZZZ3 = PPP): 4 products + 2 squares
+// where xyzz_madd on from_affine(p) spends 8 + 2.  The first addition of every bucket run (k_accumulate).  Coordinates < 4 p
+// (stored bases are < 2 p; affine_neg's y is < 4 p).
+template <class F> HD Xyzz<F> xyzz_add_affine(const Affine<F>& p, const Affine<F>& q) {
+  F Pd = F::prep(F::template sub<4, 1>(q.x, p.x));    // [3, <= 8]
+  F R = F::prep(F::template sub<4, 1>(q.y, p.y));
+  if (Pd.is_zero_mod_p()) {
+    if (R.is_zero_mod_p()) return xyzz_dbl_affine(p);
+    return Xyzz<F>::identity();
+  }
+  F PP = F::sqr_nn(Pd);
+  F PPP = F::mul_nn(Pd, PP);
+  F Q = F::mul_nn(p.x, PP);
+  F R2 = F::sqr_nn(R);
+  F s = F::add(F::add(PPP, Q), Q);
+  F X3 = F::norm(F::template sub<16, 3>(R2, s));
+  F t = F::prep(F::template sub<32, 1>(Q, X3));
+  F Y3 = F::mul_sub_nn(R, t, p.y, PPP);
+  return {X3, Y3, PP, PPP};
+}
+
 // a += b (add-2008-s), both XYZZ, either may be the identity
 template <class F> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& b) {
   if (b.is_identity()) return;

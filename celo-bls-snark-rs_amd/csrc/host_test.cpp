@@ -49,6 +49,10 @@ template <class F> static void point_op(int op, const uint64_t* p1, const uint64
     case 6: { for (uint32_t i = 0; i < k; i++) xyzz_madd(acc, b); } break;  // a + k*b by repeated madd
     case 7: { Xyzz<F> t = acc; xyzz_add(acc, t); } break;   // add-with-self (doubling branch of add)
     case 8: { for (uint32_t i = 0; i < k; i++) acc = xyzz_dbl(acc); xyzz_madd(acc, b); } break;  // 2^k a + b (a Horner step)
+    case 9: acc = xyzz_add_affine(a, b); break;             // a + b, both affine (the first addition of a bucket run)
+    case 10: acc = xyzz_add_affine(a, a); break;            // its doubling branch
+    case 11: acc = xyzz_add_affine(a, affine_neg(a)); break;  // its cancellation branch
+    case 12: { acc = xyzz_add_affine(affine_neg(a), affine_neg(b)); for (uint32_t i = 0; i < k; i++) xyzz_madd(acc, b); } break;  // -a - b + k b
     default: break;
   }
   xyzz_to_jac(acc, out);

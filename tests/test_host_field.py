@@ -156,6 +156,10 @@ def test_point_ops(ht, kind):
         assert op(5, A, B) == cur.add(A, A)        # madd hitting the doubling branch
         assert op(6, A, B, 37) == cur.add(A, cur.mul(B, 37))
         assert op(7, A, B) == cur.add(A, A)        # add-with-self
+        assert op(9, A, B) == cur.add(A, B)        # affine + affine (the first addition of a bucket run)
+        assert op(10, A, B) == cur.add(A, A)       # ... its doubling branch
+        assert op(11, A, B) is None                # ... its cancellation branch
+        assert op(12, A, B, 5) == cur.add(cur.neg(cur.add(A, B)), cur.mul(B, 5))   # negated operands, then mixed additions
 
 
 def test_point_ops_bw6(ht, golden):
@@ -176,6 +180,10 @@ def test_point_ops_bw6(ht, golden):
     assert op(3, A, B, 1000003) == cur.mul(A, 1000003)
     assert op(4, A, B) is None
     assert op(6, A, B, 9) == cur.add(A, cur.mul(B, 9))
+    assert op(9, A, B) == cur.add(A, B)
+    assert op(10, A, B) == cur.add(A, A)
+    assert op(11, A, B) is None
+    assert op(12, A, B, 3) == cur.add(cur.neg(cur.add(A, B)), cur.mul(B, 3))
 
 
 @pytest.mark.parametrize("kind", ["g1_377", "g2_377", "g2_377_hex"])

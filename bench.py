@@ -751,11 +751,11 @@ def main():
     elif cx.world > 1 and local_rank >= torch.cuda.device_count():
         raise SystemExit("rank %d: LOCAL_RANK %d but only %d device(s) visible (CELO_BENCH_BACKEND=gloo CELO_BENCH_DEVICE=0 shares one GPU for a smoke run)"
                          % (cx.rank, local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)      # before the process group: RCCL binds its communicator to the current device
     if cx.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend=backend, rank=cx.rank, world_size=cx.world)
-    torch.cuda.set_device(local_rank)
     cx.xdev = "cuda" if backend == "nccl" else "cpu"
     cx.stream = torch.cuda.current_stream().cuda_stream
 

@@ -232,7 +232,15 @@ struct QHex377 {
     for (int i = 0; i < NWORDS; i++) r.l[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)x.l[i]);
     return r;
   }
-  QDEV static V swap(const V& x) { return from_addr(x, (wave_lane() ^ 1) << 2); }
+  // the partner half: lane ^ 1, i.e. DPP quad_perm [1, 0, 3, 2] - a VALU move instead of a ds_bpermute through the LDS crossbar (28
+  // per product).  Same-box A/B (tools/ab_pairing.sh): Miller 19.72 -> 18.65 ms, final exponentiation 15.83 -> 15.07 ms per 81920
+  // products.  (The three-lane permutes stay ds_bpermute: two of a wave's ten groups straddle a 16-lane DPP row.)
+  QDEV static V swap(const V& x) {
+    V r;
+#pragma unroll
+    for (int i = 0; i < NWORDS; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.l[i], 0xB1, 0xF, 0xF, true);
+    return r;
+  }
   // Per-lane selection by MASK ARITHMETIC, one v_bfi_b32 per word.  Written as `c ? a : b` the compiler turns selections between
   // expensive operands into exec-masked branches (it sinks each operand's computation into "its" lanes' region: 466
   // s_and_saveexec regions in the Miller loop body) - no work is saved on a SIMD, the scalar bookkeeping is pure overhead, and

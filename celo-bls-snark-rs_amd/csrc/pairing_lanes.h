@@ -344,18 +344,24 @@ template <class QB> struct QTower {
   // Fq6 product, Karatsuba across lanes: lane j computes v_j = x_j y_j and the cross product it needs.  Inputs vb <= 40,
   // output weak-reduced.
   QFN static V mul6(const V& x, const V& y) {
+    // Lane j multiplies x_j y_j and the cross pair (j, j + 1): c_j = (x_j + x_{j+1})(y_j + y_{j+1}), t_j = c_j - v_j - v_{j+1}
+    // = x_j y_{j+1} + x_{j+1} y_j.  Every lane then needs ONE neighbour for its operands (the rotation R: lane j reads lane j + 1)
+    // and z0 = v0 + xi t1, z1 = t0 + xi v2, z2 = t2 + v1 take one exchange of t and one of v: five lane permutes per Fq6 product
+    // (with "lane k computes the cross product z_k needs" it was seven - lane 0 needed two neighbours for each operand).  Each
+    // permute is 14 ds_bpermute of the six-lane backend, whose waits are what its kernels lose time to.
+    constexpr int R = QP(1, 2, 0);
     V v = QB::mul(x, y);
-    // cross operands: lane 0 -> (1, 2), lane 1 -> (0, 1), lane 2 -> (0, 2)
-    V xs = QB::add(QB::template perm<QP(1, 0, 0)>(x), QB::template perm<QP(2, 1, 2)>(x));
-    V ys = QB::add(QB::template perm<QP(1, 0, 0)>(y), QB::template perm<QP(2, 1, 2)>(y));
+    V xs = QB::add(x, QB::template perm<R>(x));
+    V ys = QB::add(y, QB::template perm<R>(y));
     V c = QB::mul(xs, ys);
-    V t = QB::template sub<4>(QB::template sub_l<4>(c, QB::template perm<QP(1, 0, 0)>(v)), QB::template perm<QP(2, 1, 2)>(v));  // vb <= 11
-    V vr = QB::template perm<QP(0, 2, 1)>(v);   // lane 0: v0, lane 1: v2, lane 2: v1
-    V w = QB::template sel<0>(t, vr);              // what xi multiplies on lanes 0 and 1
+    V rv = QB::template perm<R>(v);                                            // lane 0: v1, lane 1: v2, lane 2: v0
+    V t = QB::template sub<4>(QB::template sub_l<4>(c, v), rv);                // vb <= 11
+    V ts = QB::template perm<QP(1, 0, 2)>(t);                                  // lane 0: t1, lane 1: t0, lane 2: t2
+    V v1 = QB::template perm<QP(0, 1, 1)>(v);                                  // lane 2: v1 (lanes 0, 1: their own, unused)
+    V w = QB::template sel<0>(ts, rv);                                         // what xi multiplies: t1 on lane 0, v2 on lane 1
     V xw = QB::template mul_nr_k<16>(w);
-    // z0 = v0 + xi (c12 - v1 - v2);  z1 = (c01 - v0 - v1) + xi v2;  z2 = (c02 - v0 - v2) + v1
-    V lhs = QB::template sel<0>(vr, t);
-    V rhs = QB::template sel<2>(vr, xw);
+    V lhs = QB::template sel<0>(v, ts);                                        // v0 | t0 | t2
+    V rhs = QB::template sel<2>(v1, xw);                                       // xi t1 | xi v2 | v1
     return QB::wred(QB::add_l(lhs, rhs));
   }
   QNI static E12 mul12(const E12& x, const E12& y) { return mul12_inl(x, y); }

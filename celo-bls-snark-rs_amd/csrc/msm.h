@@ -540,12 +540,31 @@ __global__ void __launch_bounds__(256) ACC_OCC k_accumulate(const uint32_t* __re
   } else {
     // the one-wave-per-SIMD kernels of the 28-word fields keep the plain loop, written exactly as it was: with the second inlined
     // body they lose (G2 8.15 -> 8.39 ms at 2^20, BW6-761 14.52 -> 14.72), and BW6-761 lost 7 % to a mere restructuring of this loop
+#ifdef CELO_ACC_NO_PREFETCH
     for (uint32_t k = 0; k < len; k++) {
       uint32_t v = run[k];
       Affine<F> p = IO::load_affine(bases + (size_t)(v & 0x7fffffffu) * IO::AFF_WORDS);
       if (v >> 31) p = affine_neg(p);
       xyzz_madd(acc, p);
     }
+#else
+    // one wave per SIMD: nothing else hides the two dependent global loads (index, then the point it names) at the head of an
+    // iteration - the next point is fetched before the current addition starts (it waits in AGPRs: 169 -> 222 for G2, no scratch).
+    // Same-box A/B (tools/ab_cmd_msm.sh): G2 8.32 -> 8.21 ms at 2^20, 1.186 -> 1.148 at 2^17, config 3 27.97 -> 27.71 ms;
+    // BW6-761 unchanged (14.70 vs 14.70 ms).  -DCELO_ACC_NO_PREFETCH restores the plain loop.
+    if (len) {
+      uint32_t v = run[0];
+      Affine<F> p = IO::load_affine(bases + (size_t)(v & 0x7fffffffu) * IO::AFF_WORDS);
+      for (uint32_t k = 0; k < len; k++) {
+        const uint32_t vn = run[k + 1 < len ? k + 1 : k];
+        const Affine<F> pn = IO::load_affine(bases + (size_t)(vn & 0x7fffffffu) * IO::AFF_WORDS);
+        if (v >> 31) p = affine_neg(p);
+        xyzz_madd(acc, p);
+        p = pn;
+        v = vn;
+      }
+    }
+#endif
   }
   IO::store_xyzz(partials + (size_t)pid * IO::XYZZ_WORDS, acc);
 }

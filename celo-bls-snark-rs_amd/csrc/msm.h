@@ -536,10 +536,11 @@ __global__ void __launch_bounds__(256) ACC_OCC k_accumulate(const uint32_t* __re
     };
     uint32_t k0 = 0;
     if (len >= 2) { acc = xyzz_add_affine(point(0), point(1)); k0 = 2; }
+    // (prefetching the next point, as the one-wave kernels below do, measures nothing here: two waves per SIMD hide the loads)
     for (uint32_t k = k0; k < len; k++) xyzz_madd(acc, point(k));
   } else {
-    // the one-wave-per-SIMD kernels of the 28-word fields keep the plain loop, written exactly as it was: with the second inlined
-    // body they lose (G2 8.15 -> 8.39 ms at 2^20, BW6-761 14.52 -> 14.72), and BW6-761 lost 7 % to a mere restructuring of this loop
+    // the one-wave-per-SIMD kernels of the 28-word fields do not take the affine start: with the second inlined body they lose
+    // (G2 8.15 -> 8.39 ms at 2^20, BW6-761 14.52 -> 14.72), and BW6-761 once lost 7 % to a mere restructuring of this loop
 #ifdef CELO_ACC_NO_PREFETCH
     for (uint32_t k = 0; k < len; k++) {
       uint32_t v = run[k];

@@ -91,6 +91,26 @@ template <class P> struct Fp {
     }
   }
 
+  // ---- one column of a Montgomery pass: the quotient digit m of the column sum, then (acc + m p_0) >> W.
+  // For p = 1 mod 2^W (both BLS12-377 fields: p_0 = 1, m = -acc mod 2^W) the sum acc + m is acc rounded UP to a multiple of 2^W, so
+  // (acc + m) >> W = (acc + 2^W - 1) >> W and m = ~(acc + 2^W - 1) mod 2^W: one 64-bit add of a constant (which the compiler folds
+  // into the column's multiply-add chain), a not-and and the shift - instead of a negation, a mask, a zero-extension move, a 64-bit
+  // add of m and the shift.  Two instructions less per column, 28 per product of the 14-limb field: DESIGN.md section 3.
+  template <bool SIGNED> HD static uint32_t mont_step(uint64_t& acc) {
+    uint32_t m;
+    if constexpr (P::INV == MASK) {
+      static_assert(P::INV != MASK || P::P[0] == 1, "p = 1 mod 2^W");
+      acc += MASK;
+      m = ~(uint32_t)acc & MASK;
+    } else {
+      m = mont_digit((uint32_t)acc);
+      acc += (uint64_t)m * P::P[0];
+    }
+    if constexpr (SIGNED) acc = (uint64_t)((int64_t)acc >> W);
+    else acc >>= W;
+    return m;
+  }
+
   // ---- Montgomery multiplication, product scanning with interleaved reduction.
   // For L > 25 (BW6-761: 28 limbs) a column of 2L products only fits 64 bits when lb_a*lb_b <= 8, so the
   // un-normalised subtraction results (lb 3) the curve formulas feed in are normalised on entry there.
@@ -108,10 +128,7 @@ template <class P> struct Fp {
       for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
-      uint32_t lo = (uint32_t)acc;
-      m[k] = mont_digit(lo);
-      acc += (uint64_t)m[k] * P::P[0];
-      acc >>= W;
+      m[k] = mont_step<false>(acc);
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; k++) {
@@ -141,10 +158,7 @@ template <class P> struct Fp {
       if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
-      uint32_t lo = (uint32_t)acc;
-      m[k] = mont_digit(lo);
-      acc += (uint64_t)m[k] * P::P[0];
-      acc >>= W;
+      m[k] = mont_step<false>(acc);
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; k++) {
@@ -405,10 +419,7 @@ template <class P> struct Fp {
       }
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
-      uint32_t lo = (uint32_t)acc;
-      m[k] = mont_digit(lo);
-      acc += (uint64_t)m[k] * P::P[0];
-      acc = (uint64_t)((int64_t)acc >> W);
+      m[k] = mont_step<true>(acc);
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; k++) {
@@ -446,10 +457,7 @@ template <class P> struct Fp {
       }
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
-      uint32_t lo = (uint32_t)acc;
-      m[k] = mont_digit(lo);
-      acc += (uint64_t)m[k] * P::P[0];
-      acc = (uint64_t)((int64_t)acc >> W);
+      m[k] = mont_step<true>(acc);
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; k++) {
@@ -489,10 +497,7 @@ template <class P> struct Fp {
       if ((k & 1) == 0) { acc += (uint64_t)a.l[k / 2] * a.l[k / 2]; acc -= (uint64_t)c5[k / 2] * c.l[k / 2]; }
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
-      uint32_t lo = (uint32_t)acc;
-      m[k] = mont_digit(lo);
-      acc += (uint64_t)m[k] * P::P[0];
-      acc = (uint64_t)((int64_t)acc >> W);
+      m[k] = mont_step<true>(acc);
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; k++) {
@@ -535,10 +540,7 @@ template <class P> struct Fp {
       }
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
-      uint32_t lo = (uint32_t)acc;
-      m[k] = mont_digit(lo);
-      acc += (uint64_t)m[k] * P::P[0];
-      acc = (uint64_t)((int64_t)acc >> W);
+      m[k] = mont_step<true>(acc);
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; k++) {

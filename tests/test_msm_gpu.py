@@ -77,6 +77,23 @@ def test_g1_skewed_scalars(gpu):
     assert _affine(gpu.msm("bls12_377_g1", xy, inf, s), "g1_377") == exp
 
 
+def test_g1_bucket_runs_of_equal_and_opposite_points(gpu):
+    """Every scalar equal and the bases in runs of copies and of (P, -P) pairs: each window's one bucket run starts with two equal
+    points (the affine + affine start of k_accumulate takes its doubling branch), continues with cancelling pairs (its identity
+    branch, then mixed additions onto the identity) - in every order the sort may leave them, since all keys are equal."""
+    rng = ecc.SplitMix64(31)
+    P = ecc.E1_377.mul(ecc.G1_377, rng.next())
+    Q = ecc.E1_377.mul(ecc.G1_377, rng.next())
+    k = 0x0F1E2D3C4B5A69788796A5B4C3D2E1F00F1E2D3C4B5A69788796A5B4C3D2E1 % ecc.R377
+    for pts in ([P, P], [P, ecc.E1_377.neg(P)], [P, P, P], [P, ecc.E1_377.neg(P), Q], [P] * 5 + [ecc.E1_377.neg(P)] * 5 + [Q, Q],
+                [ecc.E1_377.neg(P), P] * 40 + [Q] * 3, [P] * 97):
+        xy, inf = co.pack_g1_377(pts)
+        s = H.scalars_np([k] * len(pts), 4)
+        exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, inf, s, threads=2), "g1_377")
+        assert _affine(gpu.msm("bls12_377_g1", xy, inf, s), "g1_377") == exp
+        assert _affine(gpu.msm("bls12_377_g1", xy, inf, s, subgroup=True), "g1_377") == exp
+
+
 @pytest.mark.parametrize("logn", [16, 20])
 def test_g1_heavy_skew_large(gpu, logn):
     """Skew at sizes where runs are cut into many pieces (k_combine_mid / k_combine_big) and one region of the two-level sort

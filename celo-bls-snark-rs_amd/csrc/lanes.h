@@ -53,6 +53,7 @@ template <class BP> struct QHostT {
   static V dbl_l(const V& a) { return dbl(a); }
   template <int K> static V sub_l(const V& a, const V& b) { return sub<K>(a, b); }
   template <int K> static V mul_nr_k(const V& a) { return mul_nr(a); }
+  template <int K> static V mul_nr_k_l(const V& a) { return mul_nr(a); }
   static V half(const V& a) { return map1(a, [](const T& x) { return BP::half(x); }); }
   static V inv(const V& a) { return map1(a, [](const T& x) { return BP::inv_inl(x); }); }
   template <int CTRL> static V perm(const V& x) { V r; for (int i = 0; i < NL; i++) r.v[i] = x.v[(CTRL >> (2 * i)) & 3]; return r; }
@@ -94,6 +95,7 @@ template <class BP> struct QTriT {
   QDEV static V dbl_l(const V& a) { return BP::dbl(a); }
   template <int K> QDEV static V sub_l(const V& a, const V& b) { return BP::template sub<K>(a, b); }
   template <int K> QDEV static V mul_nr_k(const V& a) { return BP::mul_nr(a); }
+  template <int K> QDEV static V mul_nr_k_l(const V& a) { return BP::mul_nr(a); }
   QDEV static V half(const V& a) { return BP::half(a); }
   QDEV static V inv(const V& a) { return BP::inv_inl(a); }
   template <int CTRL> QDEV static int src_addr() {

@@ -126,6 +126,13 @@ template <int K> HD Fq mul_nr_k(const Fq& xo, int h) {
   const Fq n = Fq::neg<K, 1>(xo);
   return Fq::norm(Fq::add(Fq::dbl(Fq::dbl(n)), n));
 }
+// the same WITHOUT the carry pass (limbs up to 10 * 2^28): for results that go straight into an addition which is carried or weakly
+// reduced right after (42 instructions less; the host build asserts the limb bound of every such sum)
+template <int K> HD Fq mul_nr_k_l(const Fq& xo, int h) {
+  if (h) return xo;
+  const Fq n = Fq::neg<K, 1>(xo);
+  return Fq::add(Fq::dbl(Fq::dbl(n)), n);
+}
 HD Fq conj(const Fq& x, int h) { return h ? Fq::wred(Fq::norm(Fq::neg<4, 1>(x))) : x; }
 // B' x for the twist constant B' = (0, b1): (-5 b1 x1, b1 x0); p = b1 * (own half), po = the partner's p
 HD Fq twist_own(const Fq& x) { return Fq::mul(x, Fq::from_limbs(T377::TWIST_B_C1)); }
@@ -182,6 +189,7 @@ struct QHostHex377 {
   static V mul_nr(const V& a) { V r; for (int i = 0; i < 6; i++) r.v[i] = hex::mul_nr(a.v[i ^ 1], i & 1); return r; }
   static constexpr bool LAZY = true;
   template <int K> static V mul_nr_k(const V& a) { V r; for (int i = 0; i < 6; i++) r.v[i] = hex::mul_nr_k<K>(a.v[i ^ 1], i & 1); return r; }
+  template <int K> static V mul_nr_k_l(const V& a) { V r; for (int i = 0; i < 6; i++) r.v[i] = hex::mul_nr_k_l<K>(a.v[i ^ 1], i & 1); return r; }
   static V add_l(const V& a, const V& b) { return map2(a, b, [](const Fq& x, const Fq& y) { return hex::add_l(x, y); }); }
   static V dbl_l(const V& a) { return map1(a, [](const Fq& x, int) { return hex::dbl_l(x); }); }
   template <int K> static V sub_l(const V& a, const V& b) { return map2(a, b, [](const Fq& x, const Fq& y) { return hex::sub_l<K>(x, y); }); }
@@ -273,6 +281,10 @@ struct QHex377 {
     const V o = swap(a);
     return choose(hsel() != 0, o, hex::mul_nr_k<K>(o, 0));
   }
+  template <int K> QDEV static V mul_nr_k_l(const V& a) {
+    const V o = swap(a);
+    return choose(hsel() != 0, o, hex::mul_nr_k_l<K>(o, 0));
+  }
   QDEV static V add_l(const V& a, const V& b) { return hex::add_l(a, b); }
   QDEV static V dbl_l(const V& a) { return hex::dbl_l(a); }
   template <int K> QDEV static V sub_l(const V& a, const V& b) { return hex::sub_l<K>(a, b); }
@@ -341,6 +353,10 @@ template <class QB> struct QTower {
     V r = QB::template perm<QP(2, 0, 1)>(x);
     return QB::template sel<0>(QB::template mul_nr_k<K>(r), r);
   }
+  template <int K> QFN static V mul_by_gen_k_l(const V& x) {    // ... uncarried (mul_nr_k_l): for a sum that is carried right after
+    V r = QB::template perm<QP(2, 0, 1)>(x);
+    return QB::template sel<0>(QB::template mul_nr_k_l<K>(r), r);
+  }
   // Fq6 product, Karatsuba across lanes: lane j computes v_j = x_j y_j and the cross product it needs.  Inputs vb <= 40,
   // output weak-reduced.
   QFN static V mul6(const V& x, const V& y) {
@@ -359,7 +375,7 @@ template <class QB> struct QTower {
     V ts = QB::template perm<QP(1, 0, 2)>(t);                                  // lane 0: t1, lane 1: t0, lane 2: t2
     V v1 = QB::template perm<QP(0, 1, 1)>(v);                                  // lane 2: v1 (lanes 0, 1: their own, unused)
     V w = QB::template sel<0>(ts, rv);                                         // what xi multiplies: t1 on lane 0, v2 on lane 1
-    V xw = QB::template mul_nr_k<16>(w);
+    V xw = QB::template mul_nr_k_l<16>(w);
     V lhs = QB::template sel<0>(v, ts);                                        // v0 | t0 | t2
     V rhs = QB::template sel<2>(v1, xw);                                       // xi t1 | xi v2 | v1
     return QB::wred(QB::add_l(lhs, rhs));
@@ -371,7 +387,7 @@ template <class QB> struct QTower {
     V t = mul6(QB::add(x.a, x.b), QB::add(y.a, y.b));
     E12 r;
     r.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(t, v0), v1));
-    r.a = QB::wred(QB::add_l(v0, mul_by_gen_k<4>(v1)));
+    r.a = QB::wred(QB::add_l(v0, mul_by_gen_k_l<4>(v1)));
     return r;
   }
   // complex squaring: 2 Fq6 products.  lred = a carry pass where the six-lane backend's value bounds allow it (a weak reduction costs ~2.5x
@@ -379,7 +395,7 @@ template <class QB> struct QTower {
   // weak-reduced value - the output's b = 2 ab (<= 6 p) goes to mul_by_034 / mul12 next, as in every Miller loop, not into sqr12 again.
   QFN static E12 sqr12(const E12& x) {
     V ab = mul6(x.a, x.b);
-    V s2 = QB::lred(QB::add_l(x.a, mul_by_gen_k<4>(x.b)));
+    V s2 = QB::lred(QB::add_l(x.a, mul_by_gen_k_l<4>(x.b)));
     V t = mul6(QB::add(x.a, x.b), s2);
     V c0 = QB::template sub_l<64>(QB::template sub_l<4>(t, ab), mul_by_gen_k<4>(ab));
     return {QB::wred(c0), QB::lred(QB::dbl_l(ab))};
@@ -389,7 +405,7 @@ template <class QB> struct QTower {
   QFN static V mul6_by_01(const V& x, const V& d0, const V& d1) {
     V p = QB::mul(x, d0);
     V qv = QB::mul(QB::template perm<QP(2, 0, 1)>(x), d1);
-    return QB::wred(QB::add_l(p, QB::template sel<0>(QB::template mul_nr_k<4>(qv), qv)));
+    return QB::wred(QB::add_l(p, QB::template sel<0>(QB::template mul_nr_k_l<4>(qv), qv)));
   }
   // f *= s0 + (s3 + s4 v) w   (ark-ff Fp12::mul_by_034), s* group-uniform
   QFN static void mul_by_034(E12& f, const V& s0, const V& s3, const V& s4) {
@@ -397,7 +413,7 @@ template <class QB> struct QTower {
     V b = mul6_by_01(f.b, s3, s4);
     V e = mul6_by_01(QB::add(f.a, f.b), QB::add(s0, s3), s4);
     f.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(e, A), b));
-    f.a = QB::lred(QB::add_l(A, mul_by_gen_k<4>(b)));
+    f.a = QB::lred(QB::add_l(A, mul_by_gen_k_l<4>(b)));
   }
   // Granger-Scott cyclotomic squaring: lane k squares the Fq4 pair k: (a0, b1), (b0, a2), (a1, b2)
   QNI static E12 cyclotomic_sqr(const E12& f) { return cyclotomic_sqr_inl(f); }
@@ -405,7 +421,7 @@ template <class QB> struct QTower {
     V x = QB::template sel<1>(QB::template perm<QP(0, 0, 1)>(f.b), QB::template perm<QP(0, 0, 1)>(f.a));
     V y = QB::template sel<1>(QB::template perm<QP(1, 2, 2)>(f.a), QB::template perm<QP(1, 1, 2)>(f.b));
     V tmp = QB::mul(x, y);
-    V m = QB::mul(QB::add(x, y), QB::add(QB::template mul_nr_k<4>(y), x));
+    V m = QB::mul(QB::add(x, y), QB::add(QB::template mul_nr_k_l<4>(y), x));
     V o0 = QB::lred(QB::template sub_l<64>(QB::template sub_l<4>(m, tmp), QB::template mul_nr_k<4>(tmp)));
     // a_j' = 3 o0 - 2 a_j on every lane;  b_j' = 3 u + 2 b_j with u = o1 = 2 tmp of the previous lane (xi on the wrap to lane 0)
     V u;

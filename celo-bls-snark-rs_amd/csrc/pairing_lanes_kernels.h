@@ -202,7 +202,7 @@ template <class LP> struct Slots {
     const V b = Tow::mul6_by_01(ldv(sf, 1), s3, s4);
     fence();
     const V e = Tow::mul6_by_01(QB::add(ldv(sf, 0), ldv(sf, 1)), QB::add(s0, s3), s4);
-    const V nb = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(e, A), b)), na = QB::lred(QB::add_l(A, Tow::template mul_by_gen_k<4>(b)));
+    const V nb = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(e, A), b)), na = QB::lred(QB::add_l(A, Tow::template mul_by_gen_k_l<4>(b)));
     // branch-free: an uncommitted lane writes back what the slot holds (a divergent `if` around the stores made the register
     // allocator spill ~140 dwords per step in the surrounding 442 KB loop body; the select costs 56 instructions)
     stv(sf, 1, QB::choose(commit, nb, ldv(sf, 1)));
@@ -252,7 +252,7 @@ template <class LP> struct Slots {
     const V t = Tow::mul6(QB::add(ldv(a, 0), ldv(a, 1)), QB::add(ldv(b, 0), ldv(b, 1)));
     fence();
     stv(dst, 1, QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(t, v0), v1)));
-    stv(dst, 0, QB::wred(QB::add_l(v0, Tow::template mul_by_gen_k<4>(v1))));
+    stv(dst, 0, QB::wred(QB::add_l(v0, Tow::template mul_by_gen_k_l<4>(v1))));
   }
   __device__ __forceinline__ static void cyclo(int s) {        // Tow::cyclotomic_sqr_inl with f re-read for the last step
     typedef typename LP::QB QB;
@@ -264,7 +264,7 @@ template <class LP> struct Slots {
     }
     fence();
     const V tmp = QB::mul(x, y);
-    const V m = QB::mul(QB::add(x, y), QB::add(QB::template mul_nr_k<4>(y), x));
+    const V m = QB::mul(QB::add(x, y), QB::add(QB::template mul_nr_k_l<4>(y), x));
     const V o0 = QB::lred(QB::template sub_l<64>(QB::template sub_l<4>(m, tmp), QB::template mul_nr_k<4>(tmp)));
     static_assert(QB::LAZY, "the slot kernels run on the six-lane backend");
     const V ut = QB::template perm<QP(2, 0, 1)>(tmp);

@@ -46,11 +46,11 @@ __device__ __forceinline__ E12 mul12_w3(const E12& x, const E12& y) {           
   const V v0 = from_sub<0>(p), v1 = from_sub<1>(p), t = from_sub<2>(p);
   E12 r;
   r.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(t, v0), v1));
-  r.a = QB::wred(QB::add_l(v0, Tow::template mul_by_gen_k<4>(v1)));
+  r.a = QB::wred(QB::add_l(v0, Tow::template mul_by_gen_k_l<4>(v1)));
   return r;
 }
 __device__ __forceinline__ E12 sqr12_w3(const E12& x) {                            // Tow::sqr12 (sub-group 2 repeats product 0)
-  const V s2 = QB::lred(QB::add_l(x.a, Tow::template mul_by_gen_k<4>(x.b)));
+  const V s2 = QB::lred(QB::add_l(x.a, Tow::template mul_by_gen_k_l<4>(x.b)));
   const V p = Tow::mul6(pick3(x.a, QB::add(x.a, x.b), x.a), pick3(x.b, s2, x.b));
   const V ab = from_sub<0>(p), t = from_sub<1>(p);
   const V c0 = QB::template sub_l<64>(QB::template sub_l<4>(t, ab), Tow::template mul_by_gen_k<4>(ab));
@@ -59,7 +59,7 @@ __device__ __forceinline__ E12 sqr12_w3(const E12& x) {                         
 __device__ __forceinline__ E12 cyclo_w3(const E12& f) {                            // Tow::cyclotomic_sqr_inl: its two Fq2 product rounds side by side
   const V x = QB::template sel<1>(QB::template perm<QP(0, 0, 1)>(f.b), QB::template perm<QP(0, 0, 1)>(f.a));
   const V y = QB::template sel<1>(QB::template perm<QP(1, 2, 2)>(f.a), QB::template perm<QP(1, 1, 2)>(f.b));
-  const V p = QB::mul(pick3(x, QB::add(x, y), x), pick3(y, QB::add(QB::template mul_nr_k<4>(y), x), y));
+  const V p = QB::mul(pick3(x, QB::add(x, y), x), pick3(y, QB::add(QB::template mul_nr_k_l<4>(y), x), y));
   const V tmp = from_sub<0>(p), m = from_sub<1>(p);
   const V o0 = QB::lred(QB::template sub_l<64>(QB::template sub_l<4>(m, tmp), QB::template mul_nr_k<4>(tmp)));
   const V ut = QB::template perm<QP(2, 0, 1)>(tmp);
@@ -77,7 +77,7 @@ __device__ __forceinline__ void ell_w3(E12& f, const Pair::Line& l, const LP::F&
   const V p = Tow::mul6_by_01(pick3(f.a, f.b, QB::add(f.a, f.b)), pick3(s0, s3, QB::add(s0, s3)), pick3(QB::zero(), s4, s4));
   const V A = from_sub<0>(p), b = from_sub<1>(p), e = from_sub<2>(p);
   f.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(e, A), b));
-  f.a = QB::lred(QB::add_l(A, Tow::template mul_by_gen_k<4>(b)));
+  f.a = QB::lred(QB::add_l(A, Tow::template mul_by_gen_k_l<4>(b)));
 }
 __device__ __forceinline__ void store12_w3(uint32_t* p, const E12& f) { if (sub3() == 0) LP::store12(p, f); }
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }

@@ -263,7 +263,20 @@ struct QHex377 {
   }
   // (fetching Y = b's half 0 and D = b's half 1 by two pair-broadcasts instead of one exchange + 28 selects was measured: faster for a
   // lone wave, 4 % slower with the chip full - the LDS crossbar is shared by the CU's four SIMDs)
-  QDEV static V mul(const V& a, const V& b) { return hex::mul(a, b, swap(a), swap(b), hsel()); }
+  // hex::mul with its operand selection done by the exchange itself: X = (h ? partner : own) is the EVEN lane's half in both lanes
+  // of a pair (quad_perm [0, 0, 2, 2]), the other factor the ODD lane's (quad_perm [1, 1, 3, 3]), scaled by the lane's -5 or 1 -
+  // two DPP moves and a multiplication per limb where the swap + two selects + the multiplication by -5 were four instructions
+  QDEV static V mul(const V& a, const V& b) {
+    const uint32_t k = hsel() ? 1u : 0u - 5u;
+    int32_t cs[NWORDS];
+    V X;
+#pragma unroll
+    for (int i = 0; i < NWORDS; i++) {
+      X.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], 0xA0, 0xF, 0xF, true);
+      cs[i] = (int32_t)((uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], 0xF5, 0xF, 0xF, true) * k);
+    }
+    return Fq::mul2s(X, b, cs, swap(b));
+  }
   QDEV static V add(const V& a, const V& b) { return hex::add(a, b); }
   QDEV static V dbl(const V& a) { return hex::dbl(a); }
   QDEV static V tpl(const V& a) { return hex::tpl(a); }

@@ -396,6 +396,9 @@ template <class P> struct Fp {
     }
   }
 
+  // -(x*y) as one SIGNED multiply-add operand (v_mad_i64_i32) instead of an unsigned product chain merged by a 64-bit subtraction per
+  // column (v_sub_co + v_subb: 54 instructions per pass).  x, y < 2^31 as values.
+  HD static uint64_t nprod(uint32_t x, uint32_t y) { return (uint64_t)((int64_t)(0 - (int32_t)x) * (int64_t)(int32_t)y); }
   // ---- sum of two products in one reduction pass:  (a*b + KC*c*d)/R  (+ p when KC < 0, which keeps the result positive)
   // with KC in {+1, -1, -5}.  One Montgomery reduction for two limb-product sweeps.  Users: Fp2 (u^2 = -5: c0 = a0 b0 - 5 a1 b1,
   // c1 = a0 b1 + a1 b0) and the curve formulas (Y3 = R*t - Y1*PPP).  Column bound: L*(lb_a*lb_b + |KC|*lb_c*lb_d + 1) <= 255.
@@ -414,7 +417,8 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = 0; i <= k; i++) {
         acc += (uint64_t)a.l[i] * b.l[k - i];
-        if (NEG) acc -= (uint64_t)cc[i] * d.l[k - i];
+        if (KC == -1) acc += nprod(cc[i], d.l[k - i]);     // the curve formulas' R t - Y1 PPP (base field): signed multiply-adds
+        else if (NEG) acc -= (uint64_t)cc[i] * d.l[k - i];
         else acc += (uint64_t)cc[i] * d.l[k - i];
       }
 #pragma unroll
@@ -426,7 +430,8 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = k - L + 1; i < L; i++) {
         acc += (uint64_t)a.l[i] * b.l[k - i];
-        if (NEG) acc -= (uint64_t)cc[i] * d.l[k - i];
+        if (KC == -1) acc += nprod(cc[i], d.l[k - i]);     // the curve formulas' R t - Y1 PPP (base field): signed multiply-adds
+        else if (NEG) acc -= (uint64_t)cc[i] * d.l[k - i];
         else acc += (uint64_t)cc[i] * d.l[k - i];
       }
 #pragma unroll

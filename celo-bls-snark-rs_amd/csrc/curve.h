@@ -89,11 +89,14 @@ template <class F> HD void xyzz_madd(Xyzz<F>& a, const Affine<F>& p) {
 }
 
 // p + q for two AFFINE points, result XYZZ (mmadd-2007-bl's shape: U2 = x2, S2 = y2, ZZ3 = PP, ZZZ3 = PPP): 4 products + 2 squares
-// where xyzz_madd on from_affine(p) spends 8 + 2.  The first addition of every bucket run (k_accumulate).  Coordinates < 4 p
-// (stored bases are < 2 p; affine_neg's y is < 4 p).
+// where xyzz_madd on from_affine(p) spends 8 + 2.  The first addition of every bucket run (k_accumulate).  x < 2 p (stored
+// bases); y < 2 p, or in (2 p, 4 p) after affine_neg - which is why the y difference takes 8 p of slack: a subtrahend of up to K p
+// exactly can carry the top limb of K p itself, one more than the redundant form's (the low limbs borrowed from it), and
+// sub<4, 1> then wraps the top limb of the difference (a negated y below 0.57 * 2^364 against a y below 2^364;
+// tests/test_host_field.py::test_add_affine_negated_y_top_limb).  sub<K, M> needs its subtrahend strictly below K p - p.
 template <class F> HD Xyzz<F> xyzz_add_affine(const Affine<F>& p, const Affine<F>& q) {
   F Pd = F::prep(F::template sub<4, 1>(q.x, p.x));    // [3, <= 8]
-  F R = F::prep(F::template sub<4, 1>(q.y, p.y));
+  F R = F::prep(F::template sub<8, 1>(q.y, p.y));     // [3, <= 12]
   if (Pd.is_zero_mod_p()) {
     if (R.is_zero_mod_p()) return xyzz_dbl_affine(p);
     return Xyzz<F>::identity();

@@ -21,6 +21,8 @@
 //   mul(a,b), sqr(a):  L*(lb_a*lb_b + 1) <= 255  and  vb_a*vb_b <= 2^15  ->  lb = 1, vb < 2
 //   add(a,b):          lb = lb_a + lb_b,  vb = vb_a + vb_b
 //   sub<K,M>(a,b):     needs lb_b <= M, vb_b <= K                -> lb = lb_a + M + 1, vb = vb_a + K
+//                      and vb_b < K strictly unless a carry pass follows before any product (the top limb of K p's redundant form
+//                      is one below K p's own; the tracker's `topwrap` flag follows such a difference until norm() clears it)
 //   norm(a):           lb = 1 (top limb keeps the excess), vb unchanged
 #pragma once
 #include <cstdint>
@@ -56,7 +58,7 @@ template <class P> struct Fp {
   static constexpr int W = P::W;
   static constexpr uint32_t MASK = P::MASK;
   uint32_t l[L];
-  TRK(double lb = 1; double vb = 2;)
+  TRK(double lb = 1; double vb = 2; bool topwrap = false;)
 
   HD static Fp zero() {
     Fp r;
@@ -118,7 +120,7 @@ template <class P> struct Fp {
   // NIN = false: the caller hands over a first operand whose limbs already meet the column bound (the _nn forms below)
   template <bool NIN = NORM_IN> HD static Fp mul(const Fp& a_, const Fp& b) {
     const Fp a = NIN ? norm(a_) : a_;
-    TRK(assert(L * (a.lb * b.lb + 1) <= 255.5); assert(a.vb * b.vb <= 32768.0);)
+    TRK(assert(L * (a.lb * b.lb + 1) <= 255.5); assert(a.vb * b.vb <= 32768.0); assert(!a.topwrap && !b.topwrap);)
     Fp r;
     uint32_t m[L];
     uint64_t acc = 0;
@@ -145,7 +147,7 @@ template <class P> struct Fp {
   }
   template <bool NIN = NORM_IN> HD static Fp sqr(const Fp& a_) {
     const Fp a = NIN ? norm(a_) : a_;
-    TRK(assert(L * (a.lb * a.lb + 1) <= 255.5); assert(a.vb * a.vb <= 32768.0);)
+    TRK(assert(L * (a.lb * a.lb + 1) <= 255.5); assert(a.vb * a.vb <= 32768.0); assert(!a.topwrap);)
     Fp r;
     uint32_t m[L], a2[L];
 #pragma unroll
@@ -179,7 +181,7 @@ template <class P> struct Fp {
     Fp r;
 #pragma unroll
     for (int i = 0; i < L; i++) r.l[i] = a.l[i] + b.l[i];
-    TRK(r.lb = a.lb + b.lb; r.vb = a.vb + b.vb; assert(r.lb <= 15);)
+    TRK(r.lb = a.lb + b.lb; r.vb = a.vb + b.vb; assert(r.lb <= 15); r.topwrap = a.topwrap || b.topwrap;)
     return r;
   }
   HD static Fp dbl(const Fp& a) { return add(a, a); }
@@ -224,7 +226,10 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = 0; i < L; i++) r.l[i] = a.l[i] + P::KP32_M3[i] - b.l[i];
     }
-    TRK(r.lb = a.lb + M + 1; r.vb = a.vb + K; assert(r.lb <= 15);)
+    // a subtrahend that may reach K p itself can carry K p's own top limb, one more than the redundant form's: the difference's top
+    // limb then wraps modulo 2^32 when the minuend's is zero.  The value is still right modulo 2^32 per limb, so a carry pass (norm)
+    // repairs it; a product must not see it (topwrap: asserted by every product and by wred's uncarried quotient estimate).
+    TRK(r.lb = a.lb + M + 1; r.vb = a.vb + K; assert(r.lb <= 15); r.topwrap = a.topwrap || b.topwrap || !(b.vb < K);)
     return r;
   }
   template <int K, int M = 1> HD static Fp neg(const Fp& b) { return sub<K, M>(zero(), b); }
@@ -275,7 +280,7 @@ template <class P> struct Fp {
       // BLS12-377: 13-bit top limb, integer reciprocal - and NO carry pass first.  The quotient is estimated from the top limb AS IT
       // IS: with lazy limbs (lb <= 15) it is at most 16 below the carried one, so q stays <= floor(a / p) and a - q p < 2.1 p still
       // holds (16 / 6884 more); the sweep below carries while it subtracts and takes limbs of up to 32 bits.
-      TRK(assert(a_.lb <= 15);)
+      TRK(assert(a_.lb <= 15); assert(!a_.topwrap);)
       constexpr uint64_t D = (uint64_t)P::P[L - 1] + 1;
       constexpr uint64_t M = ((1ull << 34) + D - 1) / D;      // ceil(2^34 / D); exact floor(t/D) for t < 2^34 / D (a < 362 p)
       q = (uint32_t)(((uint64_t)a_.l[L - 1] * M) >> 34);
@@ -406,7 +411,8 @@ template <class P> struct Fp {
     static_assert(KC == 1 || KC == -1 || KC == -5, "unsupported multiplier");
     constexpr uint32_t AK = KC < 0 ? (uint32_t)(-KC) : (uint32_t)KC;
     constexpr bool NEG = KC < 0;
-    TRK(assert(L * (a.lb * b.lb + AK * c.lb * d.lb + 1) <= 255.5); assert(a.vb * b.vb + AK * c.vb * d.vb <= 32768.0);)
+    TRK(assert(L * (a.lb * b.lb + AK * c.lb * d.lb + 1) <= 255.5); assert(a.vb * b.vb + AK * c.vb * d.vb <= 32768.0);
+        assert(!a.topwrap && !b.topwrap && !c.topwrap && !d.topwrap);)
     Fp r;
     uint32_t m[L], cc[L];
 #pragma unroll
@@ -449,7 +455,7 @@ template <class P> struct Fp {
   // Fq2 product when the two halves sit in two different lanes (lanes.h, QHex: c0 = a0 b0 - 5 a1 b1 takes cs = -5 a1, c1 =
   // a0 b1 + a1 b0 takes cs = a1; v_mad_i64_i32 costs what v_mad_u64_u32 costs).  a, b, d normalised.  Column bound as mul2k<-5>.
   HD static Fp mul2s(const Fp& a, const Fp& b, const int32_t* cs, const Fp& d) {
-    TRK(assert(a.lb <= 1 && b.lb <= 1 && d.lb <= 1); assert(a.vb * b.vb + 5 * 64 * d.vb <= 32768.0);)
+    TRK(assert(a.lb <= 1 && b.lb <= 1 && d.lb <= 1); assert(a.vb * b.vb + 5 * 64 * d.vb <= 32768.0); assert(!a.topwrap && !b.topwrap && !d.topwrap);)
     Fp r;
     uint32_t m[L];
     uint64_t acc = 0;
@@ -489,7 +495,7 @@ template <class P> struct Fp {
   // ---- a^2 - 5 c^2 in one reduction pass with the symmetric limb products taken once (Fp2 squaring's real part, u^2 = -5): 2 x 105
   // limb products instead of the 2 x 196 of mul2k<-5>(a, a, c, c).  Inputs normalised; column bound as mul2k<-5>.
   HD static Fp sqr2m5(const Fp& a, const Fp& c) {
-    TRK(assert(a.lb <= 1 && c.lb <= 1); assert(L * 7 <= 255); assert(a.vb * a.vb + 5 * c.vb * c.vb <= 32768.0);)
+    TRK(assert(a.lb <= 1 && c.lb <= 1); assert(L * 7 <= 255); assert(a.vb * a.vb + 5 * c.vb * c.vb <= 32768.0); assert(!a.topwrap && !c.topwrap);)
     Fp r;
     uint32_t m[L], a2[L], c5[L], c10[L];
 #pragma unroll
@@ -528,7 +534,8 @@ template <class P> struct Fp {
     constexpr uint32_t AK = KC < 0 ? (uint32_t)(-KC) : (uint32_t)KC;
     static_assert(L * (2 * AK + 3) <= 255, "column bound");
     TRK(assert(a.lb <= 1 && b.lb <= 1 && c.lb <= 1 && d.lb <= 1 && e.lb <= 1 && f.lb <= 1 && g.lb <= 1 && h.lb <= 1);
-        assert(a.vb * b.vb + AK * c.vb * d.vb + e.vb * f.vb + AK * g.vb * h.vb <= 32768.0);)
+        assert(a.vb * b.vb + AK * c.vb * d.vb + e.vb * f.vb + AK * g.vb * h.vb <= 32768.0);
+        assert(!a.topwrap && !b.topwrap && !c.topwrap && !d.topwrap && !e.topwrap && !f.topwrap && !g.topwrap && !h.topwrap);)
     Fp r;
     uint32_t m[L], cc[L], gg[L];
 #pragma unroll

@@ -404,4 +404,19 @@ void ht_fq377_canon(const uint64_t* canon, uint64_t* out_ark, uint64_t* out_cano
   x.to_ark(out_ark);
   x.to_canonical(out_canon);
 }
+// xyzz_add_affine on RAW device limbs (14 x 28 bits per coordinate, not necessarily on the curve: the formulas are rational functions
+// of the coordinates): -(x1, y1) + (x2, y2) through the affine + affine start and through from_affine + xyzz_madd, both exported as
+// Jacobian ark limbs.  The top-limb edge of ADVICE r3 (a negated y whose top limb is 4 p's own against a y whose top limb is zero)
+// cannot be reached through from_ark, whose products pick the representative.
+void ht_add_affine_raw_377(const uint32_t* x1, const uint32_t* y1, const uint32_t* x2, const uint32_t* y2, uint64_t* out_start, uint64_t* out_madd,
+                           uint32_t* neg_y_top) {
+  typedef Fp<P377> F;
+  Affine<F> p = affine_neg(Affine<F>{F::from_limbs(x1), F::from_limbs(y1)}), q = {F::from_limbs(x2), F::from_limbs(y2)};
+  *neg_y_top = p.y.l[F::L - 1];
+  Xyzz<F> a = xyzz_add_affine(p, q);
+  Xyzz<F> b = Xyzz<F>::from_affine(p);
+  xyzz_madd(b, q);
+  xyzz_to_jac(a, out_start);
+  xyzz_to_jac(b, out_madd);
+}
 }

@@ -162,6 +162,34 @@ def test_point_ops(ht, kind):
         assert op(12, A, B, 5) == cur.add(cur.neg(cur.add(A, B)), cur.mul(B, 5))   # negated operands, then mixed additions
 
 
+def test_add_affine_negated_y_top_limb(ht):
+    """the affine + affine start of a G1 bucket run subtracted a negated y (norm(4 p - y), up to 4 p itself) with
+    4 p of slack, whose redundant form's top limb is one below 4 p's own: for y_rep below ~0.57 * 2^364 against a partner whose y_rep
+    is below 2^364 the difference's top limb wrapped and went un-carried into the 14-limb field's products (prep() is the identity
+    there).  Raw device limbs (the representative cannot be chosen through from_ark); the formulas are rational functions of the
+    coordinates, so the affine + affine start must agree with from_affine + xyzz_madd on any input.  The bounds-tracking build aborts
+    on the old code (topwrap), the values differ on a release build."""
+    random.seed(77)
+    p = ecc.Q377
+    top4p = (4 * p) >> (28 * 13)
+
+    def limbs(v):
+        return np.array([(v >> (28 * i)) & 0xFFFFFFF for i in range(13)] + [v >> (28 * 13)], dtype=np.uint32)
+
+    cases = []
+    for _ in range(20):                                   # the edge: tiny negated y (its negation carries 4 p's own top limb), partner top limb 0
+        cases.append((random.randrange(p), random.randrange(1, 1 << 363), random.randrange(p), random.randrange(1 << 364)))
+    for _ in range(20):                                   # ordinary representatives below 2 p
+        cases.append(tuple(random.randrange(2 * p) for _ in range(4)))
+    seen_edge = 0
+    for x1, y1, x2, y2 in cases:
+        a = np.zeros(18, dtype=np.uint64); b = np.zeros(18, dtype=np.uint64); top = np.zeros(1, dtype=np.uint32)
+        ht.ht_add_affine_raw_377(_p(limbs(x1)), _p(limbs(y1)), _p(limbs(x2)), _p(limbs(y2)), _p(a), _p(b), _p(top))
+        seen_edge += int(top[0] == top4p and (y2 >> 364) == 0)
+        assert co.jac_to_affine(a, "g1_377") == co.jac_to_affine(b, "g1_377"), (hex(y1), hex(y2))
+    assert seen_edge >= 20
+
+
 def test_point_ops_bw6(ht, golden):
     from oracle.py import epoch as ep
     vk = ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))

@@ -7,6 +7,10 @@
   --config 5            mixed: G1 MSM 2^22 + G2 MSM 2^22 + 2^14 Miller loops, the three legs issued concurrently
   --scaling weak        per-GPU work fixed as N grows (default; cfg4 weak = its per-GPU shard 2^21)
   --scaling strong      total work fixed (2^20 / 4096 batches / 2^24 / 2^22+2^22+2^14 split over the N ranks)
+  --partition P         how ONE MSM is cut over N GPUs (configs 2 / 4): index = contiguous index ranges, each GPU holds 1/N of the terms
+                        (the default for weak scaling and for the prover's 2^24 terms); windows = every GPU holds all
+                        terms and owns 1/N of the Pippenger windows (the default for --scaling strong up to 2^21 terms: an index-range
+                        shard of 2^20 / 8 terms is bound by the pipeline's fixed latencies, a window shard is not)
 
   --gpus N              N > 1 without a launcher around it: bench.py starts its own N ranks (torch.distributed.run, one process per GPU,
                         RCCL); under the driver's torch.distributed.run the ranks are already there.  A line whose n_gpus differs from
@@ -86,7 +90,11 @@ class MsmConfig:
         a = cx.args
         log_n = a.log_n if a.log_n else log_n_total
         n_total = 1 << log_n
-        self.n = n_total // cx.nshards if a.scaling == "strong" else n_total
+        # the window partition: every GPU holds ALL the terms of the ONE job and owns a range of the windows (strong scaling only)
+        self.by_windows = cx.nshards > 1 and a.scaling == "strong" and (a.partition == "windows" or (a.partition == "auto" and n_total <= (1 << 21)))
+        if a.partition == "windows" and cx.nshards > 1 and a.scaling != "strong":
+            raise SystemExit("--partition windows cuts ONE job: use it with --scaling strong")
+        self.n = n_total if self.by_windows else (n_total // cx.nshards if a.scaling == "strong" else n_total)
         if cx.cfg == 4 and a.scaling == "weak" and not a.log_n:
             self.n = 1 << 21                                   # cfg4's job is 2^24 over 8 GPUs: the per-GPU shard is the weak unit
         self.log_n = (self.n - 1).bit_length()
@@ -98,8 +106,9 @@ class MsmConfig:
             ffi.set_window_bits(self.group, cx.args.window_bits)
         if cx.devices:
             return self.setup_in_process()
-        self.bases = syn.device_points(self.group, self.n, 0x5EED0002 + 0x1000 * cx.rank)
-        sc = syn.witness_like_scalars(self.group, self.n, 0x5EED0001 + cx.rank) if cx.args.witness_like else syn.uniform_scalars(self.group, self.n, 0x5EED0001 + cx.rank)
+        sr = 0 if self.by_windows else cx.rank                 # window partition: every rank holds the SAME n terms
+        self.bases = syn.device_points(self.group, self.n, 0x5EED0002 + 0x1000 * sr)
+        sc = syn.witness_like_scalars(self.group, self.n, 0x5EED0001 + sr) if cx.args.witness_like else syn.uniform_scalars(self.group, self.n, 0x5EED0001 + sr)
         if cx.args.balanced and self.group == "bls12_377_g1":
             i = np.arange(self.n, dtype=np.uint64)
             sc = np.zeros((self.n, 4), dtype=np.uint64)
@@ -109,7 +118,7 @@ class MsmConfig:
         self.sc = sc
         self.d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
         self.O = ffi.GROUP_SHAPE[self.group][2]
-        self.fold = Folder(cx, self.group, self.O)
+        self.fold = WindowJoiner(cx, self.group) if self.by_windows else Folder(cx, self.group, self.O)
         self.acc_ms, self.tot_ms = [], []
         torch.cuda.synchronize()
 
@@ -121,6 +130,8 @@ class MsmConfig:
         for r, d in enumerate(cx.devices):
             torch.cuda.set_device(d)
             ffi.use_device(d)
+            if self.by_windows:
+                r = 0                                          # one replica of the same n terms per device
             self.sh_bases.append(syn.device_points(self.group, self.n, 0x5EED0002 + 0x1000 * r, device="cuda:%d" % d))
             sc = syn.witness_like_scalars(self.group, self.n, 0x5EED0001 + r) if cx.args.witness_like else syn.uniform_scalars(self.group, self.n, 0x5EED0001 + r)
             self.sc_host.append(sc)
@@ -135,6 +146,12 @@ class MsmConfig:
     def step(self):
         from celo_bls_snark_rs_amd import ffi
         cx = self.cx
+        sub = bool(cx.args.subgroup_points)
+        if self.by_windows and cx.devices:
+            return ffi.msm_multi_windows_dev(self.group, cx.devices, [b.data_ptr() for b in self.sh_bases], None, [s_.data_ptr() for s_ in self.sh_sc], self.n, subgroup=sub)
+        if self.by_windows:
+            rec, bit = ffi.msm_window_shard_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n, cx.rank, cx.world, self.cx.stream, subgroup=sub)
+            return self.fold(rec, bit)
         if cx.args.subgroup_points and not cx.devices:
             out = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n, self.cx.stream, subgroup=True)
             return self.fold(out)
@@ -150,7 +167,7 @@ class MsmConfig:
         self.acc_ms.append(tm["accumulate_ms"]); self.tot_ms.append(tm["total_ms"])
 
     def units_per_step(self):
-        return self.cx.nshards * self.n
+        return self.n if self.by_windows else self.cx.nshards * self.n
 
     def report(self, line, result):
         from celo_bls_snark_rs_amd import ffi, synthetic as syn
@@ -158,15 +175,25 @@ class MsmConfig:
         tm = ffi.msm_timings(self.group)
         acc = float(np.median(self.acc_ms))
         alg = syn.ALG_BYTES[self.group]
-        achieved = self.n * alg / (acc * 1e-3) / 1e9
-        traffic, src = committed_traffic(ACC_KERNEL[self.group], self.log_n)
+        # algorithmic bytes of ONE launch of the dominant kernel: a window shard reads its n points once per window it owns, i.e. its
+        # share windows_here / windows_of_the_job of the job's n * alg bytes
+        nw_job = tm["windows"] * (cx.nshards if self.by_windows else 1)
+        achieved = self.n * alg / (cx.nshards if self.by_windows else 1) / (acc * 1e-3) / 1e9
+        traffic, src = committed_traffic(ACC_KERNEL[self.group], self.log_n) if not self.by_windows else (None, "no committed PMC profile of this launch shape")
         line["metric"] = "%s MSM scalar-muls/sec" % {"bls12_377_g1": "BLS12-377 G1", "bw6_761_g1": "BW6-761 G1"}[self.group]
         line["unit"] = "scalar-muls/s"
         line["config"] = {"workload": "%s, 2^%d random bases/scalars per GPU%s, inputs resident in HBM" % (self.name, self.log_n, " (witness-like scalar mix)" if cx.args.witness_like else ""),
                           "bases_per_gpu": self.n, "window_bits": tm["window_bits"], "windows": tm["windows"], "buckets": tm["buckets"],
-                          "sharding": ("index-range shards resident on %d devices of ONE process (msm_%s_multi_dev: a host thread per device, host fold of %d-B partial sums)"
+                          "partition": ("windows" if self.by_windows else "index") if cx.nshards > 1 else None,
+                          "sharding": ("window ranges over %d replicas of the job (%s), %d-B partial sums joined with the doublings between the ranges (no data-path collective)"
+                                       % (cx.nshards, "one process: msm_%s_multi_windows_dev" % self.group if cx.devices else
+                                          "one rank per GPU: msm_*_window_shard_dev + one all_gather of the records + msm_*_join_windows", self.O * 8 * 4 // 3)) if self.by_windows else
+                                      ("index-range shards resident on %d devices of ONE process (msm_%s_multi_dev: a host thread per device, host fold of %d-B partial sums)"
                                        % (len(cx.devices), self.group, self.O * 8)) if cx.devices else
                                       "index-range shards + all_gather of %d-B partial sums" % (self.O * 8) if cx.world > 1 else "single GPU"}
+        if self.by_windows:
+            line["config"]["workload"] = "%s, ONE job of 2^%d random bases/scalars replicated on every GPU, windows partitioned, inputs resident in HBM" % (self.name, self.log_n)
+            line["config"]["windows_of_the_job"] = nw_job
         line["roofline"] = {"bound": "hbm", "kernel": ACC_KERNEL[self.group], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
                             "note": "integer-VALU bound, not HBM bound (SURVEY.md section 8d); algorithmic bytes = n*%d B per launch; kernel ms (median over the timed "
@@ -188,6 +215,11 @@ class MsmConfig:
                 line["subgroup_entry"] = self.subgroup_entry(result)
         if not cx.args.no_cpu_baseline:
             line["cpu_baseline"] = self.cpu_baseline(result)
+            pw = (line["cpu_baseline"] or {}).get("parity_with_gpu")
+            line["parity"] = {"checked": pw is True, "against": "the CPU port (oracle/cpu) on the whole job: every shard's inputs gathered on rank 0, affine results compared"
+                              if pw is True else str(pw)}
+        else:
+            line["parity"] = {"checked": False, "against": "--no-cpu-baseline"}
 
     def two_callers(self):
         """Secondary number (not `value`): the same MSM issued from TWO host threads at once (the library has no global lock: each call
@@ -256,7 +288,9 @@ class MsmConfig:
         from oracle import cpu_oracle as co
         cx = self.cx
         A = self.bases.numel() // self.n
-        if cx.devices:
+        if self.by_windows:                                    # one job, replicated: rank 0's copy IS the job
+            h_b, h_s = self.bases.view(self.n, A).cpu().numpy().view(np.uint64), self.d_sc.view(self.n, -1).cpu().numpy().view(np.uint64)
+        elif cx.devices:
             h_b = np.concatenate([b.view(self.n, A).cpu().numpy().view(np.uint64) for b in self.sh_bases])
             h_s = np.concatenate([s_.view(self.n, -1).cpu().numpy().view(np.uint64) for s_ in self.sh_sc])
         else:
@@ -339,6 +373,35 @@ class Folder:
         return ffi.sum_jacobian(self.group, parts.reshape(cx.world, -1))
 
 
+class WindowJoiner:
+    """Window partition, one rank per GPU: all_gather of the ranks' fixed-size records (X || Y || ZZ || ZZZ + the range's first bit) and the
+    join total = sum_g 2^bit_g P_g on every rank (msm_*_join_windows: host arithmetic, the doublings between the ranges)."""
+    def __init__(self, cx, group):
+        from celo_bls_snark_rs_amd import ffi
+        self.cx, self.group = cx, group
+        self.words = 2 * ffi.GROUP_SHAPE[group][0] + 1         # the record + bit_lo
+        self.mine = torch.empty(self.words, dtype=torch.int64, device=cx.xdev)
+        self.all = torch.empty(cx.world * self.words, dtype=torch.int64, device=cx.xdev)
+        self.host = torch.empty(cx.world * self.words, dtype=torch.int64).pin_memory() if cx.xdev == "cuda" else None
+        self.stage = torch.empty(self.words, dtype=torch.int64).pin_memory() if cx.xdev == "cuda" else torch.empty(self.words, dtype=torch.int64)
+
+    def __call__(self, rec, bit):
+        from celo_bls_snark_rs_amd import ffi
+        cx = self.cx
+        st = self.stage.numpy()
+        st[:-1] = rec.view(np.int64); st[-1] = bit
+        self.mine.copy_(self.stage, non_blocking=True)
+        dist.all_gather_into_tensor(self.all, self.mine)
+        if self.host is not None:
+            self.host.copy_(self.all, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            parts = self.host.numpy()
+        else:
+            parts = self.all.numpy()
+        parts = parts.reshape(cx.world, self.words)
+        return ffi.join_windows(self.group, np.ascontiguousarray(parts[:, :-1]).view(np.uint64), [int(b) for b in parts[:, -1]])
+
+
 def gather_to_rank0(cx, t):
     """Rows of every rank's tensor concatenated on rank 0 as a numpy uint64 array (one-off, outside the timed region)."""
     if cx.world == 1:
@@ -407,8 +470,10 @@ class BatchVerifyConfig:
                                     "pairings %.2f (Miller %.2f, final exp %.2f) - the two MSMs overlap on the GPU, so their event times include each other's work"
                                     % (d[0], d[1], d[2], d[3], d[4], d[5])}
         line["config"]["signatures_per_s"] = line["value"] * self.n
+        line["parity"] = {"checked": True, "against": "this rank's accept vector of the timed step == the one built into the workload (1 % of the batches corrupted)"}
         if not cx.args.no_cpu_baseline and cx.rank == 0:
             line["cpu_baseline"] = self.cpu_baseline(result)
+            line["parity"]["against"] += "; a sample of batches incl. rejected ones against the CPU port"
 
     def cpu_baseline(self, result):
         from oracle import cpu_oracle as co
@@ -705,6 +770,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configuration (default 2: the one the metric is quoted on)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--partition", default="auto", choices=["auto", "index", "windows"], help="configs 2 / 4, N > 1: how one MSM is cut over the GPUs (see the module docstring)")
     ap.add_argument("--log-n", type=int, default=0, help="override log2 of the MSM size (per GPU when weak, total when strong)")
     ap.add_argument("--batches", type=int, default=4096, help="config 3: batches")
     ap.add_argument("--signers", type=int, default=256, help="config 3: signers per batch")
@@ -801,6 +867,9 @@ def main():
                        "launcher": os.environ.get("CELO_BENCH_LAUNCHER", "external (torch.distributed.run)" if cx.world > 1 else "none"),
                        "device_of_rank0": local_rank})
     job.report(line, result)                                  # every rank takes part (gathers for the full-size parity check)
+    if "parity" not in line:
+        pw = (line.get("cpu_baseline") or {}).get("parity_with_gpu")
+        line["parity"] = {"checked": pw is True, "against": "the CPU port (oracle/cpu), see cpu_baseline" if pw is True else str(pw)}
     if line["n_gpus"] != args.gpus:
         raise SystemExit("bench.py: the job ran on %d GPU(s) but --gpus %d was asked for: no line" % (line["n_gpus"], args.gpus))
     if cx.rank == 0:

@@ -529,7 +529,10 @@ template <class P> struct Fp {
   // ---- four products in one reduction pass: (a b + KC c d - e f - KC g h)/R + p, KC in {-5, +1}: the two halves of an Fp2
   // difference of products a b - c d (Y3 of the curve formulas over Fp2: 8 limb-product sweeps and 2 reductions instead of 4).
   // Inputs normalised; columns: L (1 + |KC| + 1 + |KC| + 1) <= 255 needs L <= 19 (the 14-limb field).
-  template <int KC> HD static Fp mul4k(const Fp& a, const Fp& b, const Fp& c, const Fp& d, const Fp& e, const Fp& f, const Fp& g, const Fp& h) {
+  // SGN (round-3 open finding, kept for the reproducer tools/repro_mul4k.hip): the negative products as signed multiply-adds (nprod)
+  // instead of unsigned products subtracted per column.  The two forms are the same function modulo 2^64 per column; the shipped
+  // kernels use SGN = false.
+  template <int KC, bool SGN = false> HD static Fp mul4k(const Fp& a, const Fp& b, const Fp& c, const Fp& d, const Fp& e, const Fp& f, const Fp& g, const Fp& h) {
     static_assert(KC == 1 || KC == -5, "unsupported multiplier");
     constexpr uint32_t AK = KC < 0 ? (uint32_t)(-KC) : (uint32_t)KC;
     static_assert(L * (2 * AK + 3) <= 255, "column bound");
@@ -546,9 +549,9 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = 0; i <= k; i++) {
         acc += (uint64_t)a.l[i] * b.l[k - i];
-        acc -= (uint64_t)e.l[i] * f.l[k - i];
-        if (KC < 0) { acc -= (uint64_t)cc[i] * d.l[k - i]; acc += (uint64_t)gg[i] * h.l[k - i]; }
-        else { acc += (uint64_t)cc[i] * d.l[k - i]; acc -= (uint64_t)gg[i] * h.l[k - i]; }
+        if (SGN) acc += nprod(e.l[i], f.l[k - i]); else acc -= (uint64_t)e.l[i] * f.l[k - i];
+        if (KC < 0) { if (SGN) acc += nprod(cc[i], d.l[k - i]); else acc -= (uint64_t)cc[i] * d.l[k - i]; acc += (uint64_t)gg[i] * h.l[k - i]; }
+        else { acc += (uint64_t)cc[i] * d.l[k - i]; if (SGN) acc += nprod(gg[i], h.l[k - i]); else acc -= (uint64_t)gg[i] * h.l[k - i]; }
       }
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
@@ -559,9 +562,9 @@ template <class P> struct Fp {
 #pragma unroll
       for (int i = k - L + 1; i < L; i++) {
         acc += (uint64_t)a.l[i] * b.l[k - i];
-        acc -= (uint64_t)e.l[i] * f.l[k - i];
-        if (KC < 0) { acc -= (uint64_t)cc[i] * d.l[k - i]; acc += (uint64_t)gg[i] * h.l[k - i]; }
-        else { acc += (uint64_t)cc[i] * d.l[k - i]; acc -= (uint64_t)gg[i] * h.l[k - i]; }
+        if (SGN) acc += nprod(e.l[i], f.l[k - i]); else acc -= (uint64_t)e.l[i] * f.l[k - i];
+        if (KC < 0) { if (SGN) acc += nprod(cc[i], d.l[k - i]); else acc -= (uint64_t)cc[i] * d.l[k - i]; acc += (uint64_t)gg[i] * h.l[k - i]; }
+        else { acc += (uint64_t)cc[i] * d.l[k - i]; if (SGN) acc += nprod(gg[i], h.l[k - i]); else acc -= (uint64_t)gg[i] * h.l[k - i]; }
       }
 #pragma unroll
       for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::P[k - i];

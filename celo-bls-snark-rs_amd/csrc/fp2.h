@@ -10,6 +10,10 @@
 // Outputs: lb = 1, vb <= 3.
 #pragma once
 #include "fp.h"
+// -DCELO_MUL4K_SGN=true builds the curve formulas' Fq2 R t - Y1 PPP pass in its signed form (round-3 open finding: reproducer builds only)
+#ifndef CELO_MUL4K_SGN
+#define CELO_MUL4K_SGN false
+#endif
 
 namespace celo {
 
@@ -42,7 +46,8 @@ template <class P> struct Fp2 {
   }
   HD static Fp2 sqr_nn(const Fp2& a) { return {B::sqr2m5(a.c0, a.c1), B::mul(B::dbl(a.c0), a.c1)}; }
   HD static Fp2 mul_sub_nn(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) {
-    return {B::template mul4k<-5>(a.c0, b.c0, a.c1, b.c1, c.c0, d.c0, c.c1, d.c1), B::template mul4k<1>(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0)};
+    return {B::template mul4k<-5, CELO_MUL4K_SGN>(a.c0, b.c0, a.c1, b.c1, c.c0, d.c0, c.c1, d.c1),
+            B::template mul4k<1, CELO_MUL4K_SGN>(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0)};
   }
   HD static Fp2 mul_fp(const Fp2& a, const B& k) {  // k normalised or lb*lb within Fp::mul's bound
     return {B::mul(a.c0, k), B::mul(a.c1, k)};

@@ -25,8 +25,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #include <thread>
+#include <system_error>
 #include "curve.h"
 #include "host64.h"
 #include "curve_lanes.h"
@@ -91,6 +93,25 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint64_t* __restric
   const uint64_t* s = ark + i * 2 * IO::ARK64;
   Affine<F> a = {F::from_ark(s), F::from_ark(s + IO::ARK64)};
   IO::store_affine(dev + i * IO::AFF_WORDS, a);
+}
+
+// arkworks' GroupAffine::zero() is (x, y, infinity) = (0, 1, true); a caller that hands over coordinates only (a Groth16 proving key's
+// queries hold the identity for every variable absent from A / B / the auxiliary part: ark-groth16 generator.rs) encodes it as x = 0,
+// y = 1.  On the three curves of this library (0, 1) is never an element of the prime-order group (BLS12-377 G1: a point of order 3;
+// its G2 and both BW6-761 groups: not on the curve), so the prover's entry points flag such rows as the identity.
+// one_ark: y's arkworks limbs for 1 (Fq2: (1, 0)).
+template <int ARK64X> struct ArkCoord { uint64_t v[ARK64X]; };
+template <class G>
+__global__ void __launch_bounds__(256) k_flag_ark_zero(const uint64_t* __restrict__ ark, const uint8_t* __restrict__ inf_in, uint8_t* __restrict__ inf_out, size_t n,
+                                                       ArkCoord<PointIO<typename G::F>::ARK64> one_ark) {
+  constexpr int A = PointIO<typename G::F>::ARK64;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t* s = ark + i * 2 * A;
+  uint64_t o = 0;
+#pragma unroll
+  for (int k = 0; k < A; k++) o |= s[k] | (s[A + k] ^ one_ark.v[k]);
+  inf_out[i] = (o == 0 || (inf_in && inf_in[i])) ? 1 : 0;
 }
 
 // ---- 2a. signed-digit recoding, once per MSM: digits[w*n + i] (u16): 0xFFFF = zero digit, else (|d|-1) | (d<0)<<15.
@@ -1123,7 +1144,8 @@ struct MsmTimings {  // milliseconds, HIP events on the MSM's stream (last call)
 
 // A/B switches and tuning hooks of the pipeline, read from the environment ONCE per process (not per engine, not per call)
 struct MsmTuning {
-  bool narrow_windows, use_glv, use_gls, gls_force, lane_bitsum, host_threads;
+  bool narrow_windows, use_glv, use_gls, gls_force, lane_bitsum, host_threads, seg_occupancy, side_convert;
+  uint32_t seg_min, seg_min_shard, bitsum_lanes_max_shard;
   int seg_halves;          // piece length in half mean-bucket lengths (4 = twice the mean); 0 = not set: the path's own default
   uint32_t bitsum_lanes_max;
   static const MsmTuning& get() {
@@ -1132,10 +1154,19 @@ struct MsmTuning {
       v.narrow_windows = getenv("CELO_NO_NARROW") == nullptr;
       v.use_glv = getenv("CELO_NO_GLV") == nullptr;
       v.use_gls = getenv("CELO_NO_GLS") == nullptr;
+#ifdef CELO_BENCH_HOOKS
       v.gls_force = getenv("CELO_GLS_ALL") != nullptr;       // measurement hook (tools/bench_config3.py): split also for the plain msm_batch_* entry points
+#else
+      v.gls_force = false;       // the release library never applies psi to the plain entry points' arbitrary curve points
+#endif
       v.lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;
       v.host_threads = getenv("CELO_NO_HOST_THREADS") == nullptr;
       v.seg_halves = getenv("CELO_SEG_HALVES") ? atoi(getenv("CELO_SEG_HALVES")) : 0;
+      v.seg_min = getenv("CELO_SEG_MIN") ? (uint32_t)atoi(getenv("CELO_SEG_MIN")) : 32u;                     // shortest piece of a whole MSM
+      v.seg_min_shard = getenv("CELO_SEG_MIN_SHARD") ? (uint32_t)atoi(getenv("CELO_SEG_MIN_SHARD")) : 16u;   // ... of a window shard (8 / 12 / 16 measure alike)
+      v.seg_occupancy = getenv("CELO_NO_SEG_OCC") == nullptr;                                                  // A/B switch of the window shards' piece length
+      v.side_convert = getenv("CELO_SIDE_CONVERT") != nullptr;                                                // window shards: base conversion beside the sort
+      v.bitsum_lanes_max_shard = getenv("CELO_LANE_BITSUM_MAX_SHARD") ? (uint32_t)atoi(getenv("CELO_LANE_BITSUM_MAX_SHARD")) : 21 * 1024;
       v.bitsum_lanes_max = getenv("CELO_LANE_BITSUM_MAX") ? (uint32_t)atoi(getenv("CELO_LANE_BITSUM_MAX")) : 21 * 1024;   // outputs of a launch: one wave of 21 additions per SIMD
       return v;
     }();
@@ -1158,6 +1189,7 @@ template <class G> class MsmEngine {
     if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; }
     if (d_side_out) { (void)hipFree(d_side_out); d_side_out = nullptr; side_out_bytes = 0; }
     for (int i = 0; i < 6; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
+    for (int i = 0; i < 2; i++) if (ev_side[i]) { (void)hipEventDestroy(ev_side[i]); ev_side[i] = nullptr; }
   }
   // Measured on the MI355X (sweep over c at n = 2^8 .. 2^20, uniform scalars, all groups): with the log-depth bucket reduction
   // the buckets are cheap and the accumulate lanes are not - few long bucket runs are pure latency - so small and mid-size
@@ -1183,6 +1215,8 @@ template <class G> class MsmEngine {
   bool narrow_top(int c) const { return narrow_windows && c == 16; }
   // big path, G1 of BLS12-377: the caller vouches for bases in the prime-order subgroup (Signature values, proving-key points): GLV split
   bool big_subgroup_points = false;
+  // host-pointer entry (run_host), set by the Groth16 prover's entry points only: a base row x = 0, y = 1 is the identity (k_flag_ark_zero)
+  bool ark_zero_identity = false;
   bool use_glv = MsmTuning::get().use_glv;     // A/B switch (CELO_NO_GLV)
   bool last_glv = false;
   // window size for the 2 n points x 127-bit halves of the split (n = the expanded count)
@@ -1201,18 +1235,50 @@ template <class G> class MsmEngine {
   uint32_t BITSUM_LANES_MAX = MsmTuning::get().bitsum_lanes_max;
 
   // bases/scalars/inf are DEVICE pointers (ark layout); result: Jacobian in ark Montgomery form (3*ARK64 u64) on host.
-  int run_device(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, uint64_t* out_jac,
-                 hipStream_t stream) {
-    if (n_ == 0) { write_identity(out_jac); return 0; }
-    if (n_ >= (size_t(1) << 30)) return 2;
+  // The shape of a call: whether the GLV split is taken, the expanded term count, the scalar length, the window size and count.
+  struct Plan { bool glv; uint32_t n; int sbits, c, nw, kn; };
+  Plan plan(size_t n_) const {
+    Plan p;
     // GLV split (big_subgroup_points: the caller vouches for bases in the prime-order subgroup): 2 n_ terms of sbits-bit scalars
     // (from 2^14 terms: below, the plain path's c = 11 is as fast - measured 0.53 / 0.59 ms at 2^12 / 2^13 either way)
-    const bool glv = GlvExpand<G>::AVAILABLE && big_subgroup_points && use_glv && n_ >= (size_t(1) << 14);
-    const uint32_t n = glv ? 2u * (uint32_t)n_ : (uint32_t)n_;
-    const int sbits = glv ? GlvExpand<G>::BITS : G::SCALAR_BITS;
-    const int c = force_c ? force_c : (glv ? window_bits_glv(n) : window_bits(n));
-    const int nw = (sbits + c) / c;
-    if ((uint64_t)n * (uint64_t)nw >= (uint64_t(1) << 32)) return 2;  // run offsets are 32-bit (n*windows < 2^32: n <= 2^27 at c = 16)
+    p.glv = GlvExpand<G>::AVAILABLE && big_subgroup_points && use_glv && n_ >= (size_t(1) << 14);
+    p.n = p.glv ? 2u * (uint32_t)n_ : (uint32_t)n_;
+    p.sbits = p.glv ? GlvExpand<G>::BITS : G::SCALAR_BITS;
+    p.c = force_c ? force_c : (p.glv ? window_bits_glv(p.n) : window_bits(p.n));
+    p.nw = (p.sbits + p.c) / p.c;
+    p.kn = narrow_top(p.c) ? p.nw * p.c - (p.sbits + 1) : 0;    // the top kn windows are c - 1 bits wide (k_digits)
+    return p;
+  }
+  // first scalar bit of window w (windows of mixed width: the top kn of the nw are c - 1 bits wide)
+  static int window_bit(const Plan& p, int w) {
+    const int wide = p.nw - p.kn;
+    return w < wide ? w * p.c : wide * p.c + (w - wide) * (p.c - 1);
+  }
+  int run_device(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, uint64_t* out_jac,
+                 hipStream_t stream) {
+    return run_device_windows(d_ark_bases, d_inf, d_scalars, n_, 0, 0, out_jac, nullptr, stream);
+  }
+  // The same pipeline over the windows [win_lo, win_lo + win_cnt) of the call's plan only (win_cnt = 0: all of them): the WINDOW
+  // partition of one MSM over several devices (msm_unit.h msm_multi_windows_impl; SURVEY.md section 8e "alternative partitioning").
+  // The result is then the partial sum  sum_{w in range} 2^(bit(w) - bit(win_lo)) S_w  - the caller weighs it by 2^bit(win_lo).
+  // out_xyzz (optional, 4 * ARK64 u64: X, Y, ZZ, ZZZ in arkworks limbs, ZZ = 0 for the identity) hands the partial over in the host
+  // epilogue's own coordinates, so that the join needs no conversion.
+  int run_device_windows(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, int win_lo, int win_cnt,
+                         uint64_t* out_jac, uint64_t* out_xyzz, hipStream_t stream) {
+    if (n_ == 0) {
+      if (out_jac) write_identity(out_jac);
+      if (out_xyzz) memset(out_xyzz, 0, 4 * IO::ARK64 * 8);
+      return 0;
+    }
+    if (n_ >= (size_t(1) << 30)) return 2;
+    const Plan pl = plan(n_);
+    const bool glv = pl.glv;
+    const uint32_t n = pl.n;
+    const int sbits = pl.sbits, c = pl.c, nw_all = pl.nw;
+    if (win_cnt < 0 || win_lo < 0 || (win_cnt && win_lo + win_cnt > nw_all)) return 2;
+    const int w0 = win_cnt ? win_lo : 0;
+    const int nw = win_cnt ? win_cnt : nw_all;      // windows of THIS call: everything below the digits is sized by it
+    if ((uint64_t)n * (uint64_t)nw_all >= (uint64_t(1) << 32)) return 2;  // run offsets are 32-bit (n*windows < 2^32: n <= 2^27 at c = 16)
     const uint32_t B = 1u << (c - 1);
     const uint32_t total = (uint32_t)nw * B;
     // piece length: twice the average bucket, within [32, SIZE_BINS-1]
@@ -1220,7 +1286,18 @@ template <class G> class MsmEngine {
     // accumulate 2.64 -> 2.46 ms at 2^20; the plain path is flat between 1.5 and 3)
     const int seg_h = MsmTuning::get().seg_halves ? MsmTuning::get().seg_halves : (glv ? 3 : 4);
     uint32_t SEG = (uint32_t)seg_h * (n / B + 1) / 2;
-    if (SEG < 32) SEG = 32;
+    uint32_t seg_min = MsmTuning::get().seg_min;
+    if (win_cnt && MsmTuning::get().seg_occupancy) {
+      // a call that owns FEW windows (a window shard) has fewer additions than the chip has lanes x the usual piece length: a lane is
+      // one addition per ~17 us whatever its neighbours do, so pieces of twice the mean bucket leave most SIMDs with nothing after the
+      // first round.  Pieces as long as the additions per lane in flight (ACC_LANES) fill one round; the buckets cut in two or three
+      // are folded by k_combine_mid_lanes.  Measured at 2^20 terms, 2 of 16 windows: accumulate 0.55 -> see DESIGN.md section 9.
+      const uint64_t adds = (uint64_t)n * (uint64_t)nw;
+      const uint32_t lanes = (sizeof(F) <= 14 * sizeof(uint32_t)) ? 131072u : 65536u;      // 2 waves (14-limb field) or 1 per SIMD x 64 lanes x 1024 SIMDs
+      const uint32_t occ = (uint32_t)((adds + lanes - 1) / lanes);
+      if (occ < SEG) { SEG = occ; seg_min = MsmTuning::get().seg_min_shard; }
+    }
+    if (SEG < seg_min) SEG = seg_min;
     if (SEG > SIZE_BINS - 1) SEG = SIZE_BINS - 1;
     const uint32_t PW = B + n / SEG + 1;       // static piece region per window
     const uint32_t slots = (uint32_t)nw * PW;
@@ -1233,7 +1310,7 @@ template <class G> class MsmEngine {
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
     const size_t o_bases = take((size_t)n * IO::AFF_WORDS * 4);
     const size_t o_sc2 = take(glv ? (size_t)n * 16 : 0);
-    const size_t o_digits = take((size_t)n * nw * 2);
+    const size_t o_digits = take((size_t)n * nw_all * 2);
     const size_t o_sorted = take((size_t)n * nw * 4);
     // two-level sort: NBIN bins per window by the low HIB bucket bits, KB2 blocks per window in the partition pass
     const uint32_t HIB = LB < 8 ? 0u : (uint32_t)LB - 8u, NBIN = 1u << HIB;     // bins by the low HIB bucket bits, <= 8 key bits above
@@ -1265,7 +1342,8 @@ template <class G> class MsmEngine {
     if (res_pts > H_OUT_POINTS) return 2;
     char* A = arena;
     uint32_t* d_bases = (uint32_t*)(A + o_bases);
-    uint16_t* d_digits = (uint16_t*)(A + o_digits);
+    uint16_t* d_digits_all = (uint16_t*)(A + o_digits);
+    uint16_t* d_digits = d_digits_all + (size_t)w0 * n;          // this call's windows
     uint32_t* d_sorted = (uint32_t*)(A + o_sorted);
     uint32_t* d_blockcnt = (uint32_t*)(A + o_blockcnt);
     uint32_t* d_binstart = (uint32_t*)(A + o_binstart);
@@ -1289,12 +1367,20 @@ template <class G> class MsmEngine {
     uint32_t* d_work = (uint32_t*)(A + o_work);
 
     HIP_OK(hipEventRecord(ev[0], stream));
-    if (glv) GlvExpand<G>::launch(d_ark_bases, d_inf, d_scalars, (uint32_t)n_, d_bases, (uint32_t*)(A + o_sc2), stream);
+    // window shards (A/B hook CELO_SIDE_CONVERT): the conversion of ALL n bases is replicated on every shard while its sort shrinks to a
+    // handful of latency-bound launches - the two are independent until the accumulation, so the conversion may run on a second stream
+    const bool side = win_cnt && !glv && MsmTuning::get().side_convert && side_stream_.get() && ev_side[0];
+    if (side) {
+      HIP_OK(hipEventRecord(ev_side[0], stream));
+      HIP_OK(hipStreamWaitEvent(side_stream_.get(), ev_side[0], 0));
+      hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, side_stream_.get(), d_ark_bases, d_bases, (size_t)n);
+      HIP_OK(hipEventRecord(ev_side[1], side_stream_.get()));
+    } else if (glv) GlvExpand<G>::launch(d_ark_bases, d_inf, d_scalars, (uint32_t)n_, d_bases, (uint32_t*)(A + o_sc2), stream);
     else hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_ark_bases, d_bases, (size_t)n);
     HIP_OK(hipEventRecord(ev[1], stream));
     // ---- sort
-    if (glv) { if (launch_digits<4, GlvExpand<G>::BITS>(c, (const uint32_t*)(A + o_sc2), nullptr, d_digits, n, stream)) return 3; }
-    else if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits, n, stream)) return 3;
+    if (glv) { if (launch_digits<4, GlvExpand<G>::BITS>(c, (const uint32_t*)(A + o_sc2), nullptr, d_digits_all, n, stream)) return 3; }
+    else if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream)) return 3;
     HIP_OK(hipMemsetAsync(d_counts, 0, o_zero_end - o_counts, stream));
     // mean region n / NBIN: the smallest workgroup whose tile capacity (TILE_EPT entries per lane) holds it with 20 % to spare
     const uint32_t region = n / NBIN;
@@ -1310,13 +1396,16 @@ template <class G> class MsmEngine {
     hipLaunchKernelGGL((k_size_hist<G>), dim3(slots / 256 < 512 ? (slots + 255) / 256 : 512), dim3(256), 0, stream, d_plen, d_bins, slots);
     hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
     hipLaunchKernelGGL((k_size_scatter<G>), dim3((slots + 4095) / 4096), dim3(1024), 0, stream, d_plen, d_bins, d_order, slots);
+    if (side) HIP_OK(hipStreamWaitEvent(stream, ev_side[1], 0));
     HIP_OK(hipEventRecord(ev[2], stream));
     // ---- accumulate (grid covers every slot; lanes beyond the number of non-empty pieces exit)
     hipLaunchKernelGGL((k_accumulate<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order,
                        d_nwork, d_partials);
     HIP_OK(hipEventRecord(ev[3], stream));
     // ---- bucket reduction
-    if (lane_bitsum) hipLaunchKernelGGL((k_combine_mid_lanes<G>), dim3(1024), dim3(64), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
+    // (a window shard cuts EVERY bucket in two or three: one group of lanes per bucket of the call, not 21504 groups striding over them)
+    const uint32_t mid_blocks = win_cnt ? (total + 20) / 21 < 16384 ? (total + 20) / 21 : 16384 : 1024;
+    if (lane_bitsum) hipLaunchKernelGGL((k_combine_mid_lanes<G>), dim3(mid_blocks), dim3(64), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
     else hipLaunchKernelGGL((k_combine_mid<G>), dim3(256), dim3(128), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
     hipLaunchKernelGGL((k_combine_big<G>), dim3(256), dim3(256), 0, stream, d_big, d_nbig, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
     {
@@ -1359,7 +1448,7 @@ template <class G> class MsmEngine {
           tree = {dst, outs, true, tree.level - 1};
         }
         lists.swap(next_lists);
-        if (lane_bitsum && total_out <= BITSUM_LANES_MAX)
+        if (lane_bitsum && total_out <= (win_cnt ? MsmTuning::get().bitsum_lanes_max_shard : BITSUM_LANES_MAX))
           hipLaunchKernelGGL((k_bitsum_lanes<G>), dim3((total_out + 20) / 21), dim3(64), 0, stream, d_partials, d_counts, d_pfirst, d_piecesof, SEG, d_work, jobs);
         else
           hipLaunchKernelGGL((k_bitsum<G>), dim3((total_out + 127) / 128), dim3(128), 0, stream, d_partials, d_counts, d_pfirst, d_piecesof, SEG,
@@ -1386,10 +1475,11 @@ template <class G> class MsmEngine {
     const uint64_t* h64 = reinterpret_cast<const uint64_t*>(h_out);
     constexpr size_t PT64 = (size_t)IO::XYZZ_WORDS / 2;
     horner_steps.clear();
-    const int kn = narrow_top(c) ? nw * c - (sbits + 1) : 0;    // the top kn windows are c - 1 bits wide (k_digits)
+    const int kn = pl.kn;                                       // the top kn of the nw_all windows are c - 1 bits wide (k_digits)
+    (void)sbits;
     for (int w = nw - 1; w >= 0; w--) {
       horner_steps.push_back(-1);
-      for (int l = (w >= nw - kn ? 2 : 1); l <= LB; l++) horner_steps.push_back(l * nw + w);
+      for (int l = (w0 + w >= nw_all - kn ? 2 : 1); l <= LB; l++) horner_steps.push_back(l * nw + w);
       horner_steps.push_back(w | HORNER_NODBL);
     }
     auto run_list = [&](const int32_t* steps, int count) {
@@ -1428,9 +1518,17 @@ template <class G> class MsmEngine {
       }
       HXyzz<HF> part[HT];
       std::thread th[HT - 1];
-      for (int j = 1; j < HT; j++) th[j - 1] = std::thread([&, j] { part[j] = run_list(horner_steps.data() + start[j], start[j + 1] - start[j]); });
+      bool started[HT - 1];
+      for (int j = 1; j < HT; j++) {
+        started[j - 1] = true;
+        try { th[j - 1] = std::thread([&, j] { part[j] = run_list(horner_steps.data() + start[j], start[j + 1] - start[j]); }); }
+        catch (const std::system_error&) { started[j - 1] = false; }      // no thread to be had: that group runs here, serially
+      }
       part[0] = run_list(horner_steps.data() + start[0], start[1] - start[0]);
-      for (int j = 1; j < HT; j++) th[j - 1].join();
+      for (int j = 1; j < HT; j++) {
+        if (started[j - 1]) th[j - 1].join();
+        else part[j] = run_list(horner_steps.data() + start[j], start[j + 1] - start[j]);
+      }
       total_pt = part[0];
       for (int j = 1; j < HT; j++) {
         for (int d = 0; d < dbls[j]; d++) total_pt = hxyzz_dbl(total_pt);
@@ -1439,16 +1537,28 @@ template <class G> class MsmEngine {
     } else {
       total_pt = run_list(horner_steps.data(), (int)horner_steps.size());
     }
-    if (total_pt.is_identity()) { write_identity(out_jac); return 0; }
-    (total_pt.X * total_pt.ZZ).store(out_jac);                 // (X ZZ, Y ZZZ, ZZ) is a Jacobian representative with Z = ZZ
-    (total_pt.Y * total_pt.ZZZ).store(out_jac + IO::ARK64);
-    total_pt.ZZ.store(out_jac + 2 * IO::ARK64);
+    if (out_xyzz) {
+      if (total_pt.is_identity()) memset(out_xyzz, 0, 4 * IO::ARK64 * 8);
+      else { total_pt.X.store(out_xyzz); total_pt.Y.store(out_xyzz + IO::ARK64); total_pt.ZZ.store(out_xyzz + 2 * IO::ARK64); total_pt.ZZZ.store(out_xyzz + 3 * IO::ARK64); }
+    }
+    if (out_jac) write_host_jacobian(total_pt, out_jac);
     return 0;
+  }
+  typedef typename HostField<F>::type HostF;
+  static void write_host_jacobian(const HXyzz<HostF>& pt, uint64_t* out_jac) {
+    if (pt.is_identity()) { write_identity(out_jac); return; }
+    (pt.X * pt.ZZ).store(out_jac);                 // (X ZZ, Y ZZZ, ZZ) is a Jacobian representative with Z = ZZ
+    (pt.Y * pt.ZZZ).store(out_jac + IO::ARK64);
+    pt.ZZ.store(out_jac + 2 * IO::ARK64);
   }
 
   // host-pointer entry: stages inputs into (cached) device buffers, then run_device
   int run_host(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t* out_jac, hipStream_t stream) {
-    if (n == 0) { write_identity(out_jac); return 0; }
+    return run_host_windows(bases, inf, scalars, n, 0, 0, out_jac, nullptr, stream);
+  }
+  int run_host_windows(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, size_t n, int win_lo, int win_cnt, uint64_t* out_jac,
+                       uint64_t* out_xyzz, hipStream_t stream) {
+    if (n == 0) return run_device_windows(nullptr, nullptr, nullptr, 0, win_lo, win_cnt, out_jac, out_xyzz, stream);
     if (n > cap_in) {
       if (d_in_bases) (void)hipFree(d_in_bases);
       if (d_in_scalars) (void)hipFree(d_in_scalars);
@@ -1462,7 +1572,13 @@ template <class G> class MsmEngine {
     HIP_OK(hipMemcpyAsync(d_in_bases, bases, n * 2 * IO::ARK64 * 8, hipMemcpyHostToDevice, stream));
     HIP_OK(hipMemcpyAsync(d_in_scalars, scalars, n * SW * 4, hipMemcpyHostToDevice, stream));
     if (inf) HIP_OK(hipMemcpyAsync(d_in_inf, inf, n, hipMemcpyHostToDevice, stream));
-    return run_device(d_in_bases, inf ? d_in_inf : nullptr, (const uint32_t*)d_in_scalars, n, out_jac, stream);
+    if (ark_zero_identity) {       // the prover's queries: rows (0, 1) are arkworks' encoding of the identity
+      ArkCoord<IO::ARK64> one;
+      F::one().to_ark(one.v);
+      hipLaunchKernelGGL((k_flag_ark_zero<G>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_in_bases, inf ? d_in_inf : nullptr, d_in_inf, n, one);
+      return run_device_windows(d_in_bases, d_in_inf, (const uint32_t*)d_in_scalars, n, win_lo, win_cnt, out_jac, out_xyzz, stream);
+    }
+    return run_device_windows(d_in_bases, inf ? d_in_inf : nullptr, (const uint32_t*)d_in_scalars, n, win_lo, win_cnt, out_jac, out_xyzz, stream);
   }
 
   // ---- batched small MSMs (host pointers).  offsets[m+1]; every instance must have <= 1024 points (larger instances go
@@ -1699,14 +1815,18 @@ template <class G> class MsmEngine {
   bool side_path = false;
   static constexpr size_t H_OUT_POINTS = 17 * 64;   // pinned result buffer: (LB + 1) * windows points; checked per call
   OwnedStream stream_;
+  OwnedStream side_stream_;            // window shards: the base conversion beside the sort (CELO_SIDE_CONVERT)
+  hipEvent_t ev_side[2] = {nullptr, nullptr};
   std::vector<int32_t> horner_steps;   // the host epilogue's step list (host64.h), rebuilt per call
   std::vector<uint32_t> gls_off;       // instance offsets of the expanded (GLS) batch
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap_in = 0;
 
   int ensure(size_t bytes) {
-    if (!ev[0])
+    if (!ev[0]) {
       for (int i = 0; i < 6; i++) HIP_OK(hipEventCreate(&ev[i]));
+      for (int i = 0; i < 2; i++) HIP_OK(hipEventCreateWithFlags(&ev_side[i], hipEventDisableTiming));
+    }
     if (!h_out) {
       HIP_OK(hipHostMalloc(&h_out, H_OUT_POINTS * IO::XYZZ_WORDS * 4));
     }

@@ -135,6 +135,91 @@ int msm_multi_impl(Pool& pool, int force_c, const int* devices, int ndev, int re
   for (int rc : rcs) if (rc) return rc;
   return sum_jacobian_impl<F>(partial.data(), (size_t)ndev, out);
 }
+// join of the window partition's partial sums (shard order = ascending first bit), from the top range down:
+//   acc = 2^(bit(g+1) - bit(g)) acc + P_g      (host epilogue arithmetic on 64-bit limbs: host64.h)
+template <class G> int join_windows_impl(const uint64_t* xyzz, const int* bit_lo, int nshards, uint64_t* out) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  typedef typename HostField<F>::type HF;
+  if (nshards <= 0 || !xyzz || !bit_lo || !out) return 2;
+  HXyzz<HF> acc = HXyzz<HF>::identity();
+  for (int g = nshards - 1; g >= 0; g--) {
+    if (g < nshards - 1) {
+      if (bit_lo[g] > bit_lo[g + 1]) return 2;
+      for (int k = bit_lo[g]; k < bit_lo[g + 1]; k++) acc = hxyzz_dbl(acc);
+    }
+    hxyzz_add(acc, HXyzz<HF>::load(xyzz + (size_t)g * 4 * IO::ARK64, IO::ARK64));
+  }
+  MsmEngine<G>::write_host_jacobian(acc, out);
+  return 0;
+}
+// One MSM partitioned by WINDOW over several devices of this process (SURVEY.md section 8e "alternative partitioning"): every device
+// holds ALL n bases and scalars and owns a contiguous range of the Pippenger windows, so a device runs n additions per window it owns
+// (1/ndev of the accumulation), reduces only its windows' buckets and walks only its share of the Horner chain; nothing is exchanged but
+// the ndev partial sums (XYZZ, in the host epilogue's coordinates), which the host joins with the doublings between the ranges:
+//   total = sum_g 2^bit(first window of g) P_g.
+// This is the partition that scales ONE MSM of up to ~2^21 terms (strong scaling: an index-range shard of 2^20 / 8 terms is bound by
+// the pipeline's fixed latencies - sort, 15 reduction levels, the 253-doubling host chain - at ~1 ms, 3.2x at 8 devices); it costs
+// ndev-fold base memory and conversion, which is why the index-range form (msm_multi_impl) stays the one for the prover's 2^24 x 192 B.
+// resident = 0: host pointers (every shard stages the whole input); 1: per-device DEVICE pointers to that device's replica.
+// A device may be listed more than once (that many engines on it: how the path runs on a 1-GPU box).
+template <class G, class Pool>
+int msm_multi_windows_impl(Pool& pool, int force_c, const int* devices, int ndev, int resident, const void* const* bases, const void* const* infs,
+                           const void* const* scalars, size_t n, int subgroup, uint64_t* out, MsmLast* last) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  if (ndev <= 0 || ndev > 64 || !devices || !bases || !scalars || !out) return 2;
+  if (n == 0) { MsmEngine<G>::write_identity(out); return 0; }
+  std::vector<uint64_t> partial((size_t)ndev * 4 * IO::ARK64, 0);
+  std::vector<int> rcs((size_t)ndev, 0), bit_lo((size_t)ndev, 0);
+  std::vector<std::thread> th;
+  for (int d = 0; d < ndev; d++) {
+    th.emplace_back([&, d] {
+      int rc = api_bind_thread(devices[d]);
+      if (!rc) rc = api_enter();
+      if (!rc) {
+        auto e = pool.lease();
+        e->force_c = force_c;
+        e->big_subgroup_points = subgroup != 0;
+        const auto pl = e->plan(n);
+        // windows [lo, hi) of the plan's nw; more devices than windows: the surplus shards are empty (identity partials)
+        const int lo = (int)((long)pl.nw * d / ndev), hi = (int)((long)pl.nw * (d + 1) / ndev);
+        bit_lo[(size_t)d] = MsmEngine<G>::window_bit(pl, lo);
+        uint64_t* o = partial.data() + (size_t)d * 4 * IO::ARK64;
+        if (hi > lo) {
+          if (resident) rc = e->run_device_windows((const uint64_t*)bases[d], infs ? (const uint8_t*)infs[d] : nullptr, (const uint32_t*)scalars[d], n, lo, hi - lo, nullptr, o, e->own_stream());
+          else rc = e->run_host_windows((const uint64_t*)bases[d], infs ? (const uint8_t*)infs[d] : nullptr, (const uint64_t*)scalars[d], n, lo, hi - lo, nullptr, o, e->own_stream());
+          if (!rc && last && d == 0) last->note(*e);
+        }
+      }
+      rcs[(size_t)d] = rc;
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int rc : rcs) if (rc) return rc;
+  return join_windows_impl<G>(partial.data(), bit_lo.data(), ndev, out);
+}
+// one shard of the window partition on the calling thread's device (one process per GPU: the ranks exchange the records themselves)
+template <class G, class Pool>
+int msm_window_shard_impl(Pool& pool, int force_c, const void* b, const void* inf, const void* s, size_t n, int subgroup, int shard, int nshards,
+                          uint64_t* out_xyzz, int* bit_lo, void* st, MsmLast* last) {
+  typedef PointIO<typename G::F> IO;
+  if (nshards <= 0 || shard < 0 || shard >= nshards || !out_xyzz || !bit_lo) return 2;
+  if (int rc = api_enter()) return rc;
+  auto e = pool.lease();
+  e->force_c = force_c;
+  e->big_subgroup_points = subgroup != 0;
+  memset(out_xyzz, 0, 4 * IO::ARK64 * 8);
+  *bit_lo = 0;
+  if (n == 0) return 0;
+  const auto pl = e->plan(n);
+  const int lo = (int)((long)pl.nw * shard / nshards), hi = (int)((long)pl.nw * (shard + 1) / nshards);
+  *bit_lo = MsmEngine<G>::window_bit(pl, lo);
+  if (hi <= lo) return 0;
+  const int rc = e->run_device_windows((const uint64_t*)b, (const uint8_t*)inf, (const uint32_t*)s, n, lo, hi - lo, nullptr, out_xyzz, (hipStream_t)st);
+  if (!rc && last) last->note(*e);
+  return rc;
+}
 template <class G, class Pool>
 int msm_multi_host_impl(Pool& pool, int force_c, const int* devices, int ndev, const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n,
                         uint64_t* out, MsmLast* last) {
@@ -157,12 +242,15 @@ int msm_multi_host_impl(Pool& pool, int force_c, const int* devices, int ndev, c
   static EnginePool<MsmEngine<G>>& pool_##TAG() { static auto* p = new EnginePool<MsmEngine<G>>(); return *p; }          \
   static MsmLast& last_##TAG() { static auto* p = new MsmLast(); return *p; }                                            \
   static std::atomic<int> force_c_##TAG{0};                                                                              \
-  int msm_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, int subgroup, uint64_t* out) {  \
+  /* flags: bit 0 = bases vouched to lie in the prime-order subgroup, bit 1 = rows (0, 1) are the identity (the prover's queries) */ \
+  int msm_host_##TAG(const uint64_t* b, const uint8_t* inf, const uint64_t* s, size_t n, int flags, uint64_t* out) {     \
     if (int rc = api_enter()) return rc;                                                                                 \
     auto e = pool_##TAG().lease();                                                                                       \
     e->force_c = force_c_##TAG.load();                                                                                   \
-    e->big_subgroup_points = subgroup != 0;                                                                              \
+    e->big_subgroup_points = (flags & 1) != 0;                                                                           \
+    e->ark_zero_identity = (flags & 2) != 0;                                                                             \
     const int rc = e->run_host(b, inf, s, n, out, e->own_stream());                                                      \
+    e->ark_zero_identity = false;                                                                                        \
     if (!rc && n) last_##TAG().note(*e);                                                                                 \
     return rc;                                                                                                           \
   }                                                                                                                      \
@@ -181,6 +269,17 @@ int msm_multi_host_impl(Pool& pool, int force_c, const int* devices, int ndev, c
   int msm_multi_dev_##TAG(const int* devs, int nd, const void* const* b, const void* const* inf, const void* const* s,   \
                           const size_t* n_per, uint64_t* out) {                                                          \
     return msm_multi_impl<G>(pool_##TAG(), force_c_##TAG.load(), devs, nd, 1, b, inf, s, n_per, out, &last_##TAG());     \
+  }                                                                                                                      \
+  int msm_multi_windows_##TAG(const int* devs, int nd, int resident, const void* const* b, const void* const* inf, const void* const* s, \
+                              size_t n, int subgroup, uint64_t* out) {                                                   \
+    return msm_multi_windows_impl<G>(pool_##TAG(), force_c_##TAG.load(), devs, nd, resident, b, inf, s, n, subgroup, out, &last_##TAG()); \
+  }                                                                                                                      \
+  int msm_window_shard_##TAG(const void* b, const void* inf, const void* s, size_t n, int subgroup, int shard, int nshards, \
+                             uint64_t* out_xyzz, int* bit_lo, void* st) {                                                \
+    return msm_window_shard_impl<G>(pool_##TAG(), force_c_##TAG.load(), b, inf, s, n, subgroup, shard, nshards, out_xyzz, bit_lo, st, &last_##TAG()); \
+  }                                                                                                                      \
+  int msm_join_windows_##TAG(const uint64_t* xyzz, const int* bit_lo, int nshards, uint64_t* out) {                      \
+    return join_windows_impl<G>(xyzz, bit_lo, nshards, out);                                                             \
   }                                                                                                                      \
   void msm_big_timings_##TAG(float ms[5], int cfg[3]) { last_##TAG().read(ms, cfg); }                                    \
   void msm_big_set_c_##TAG(int c) { force_c_##TAG.store(c); }                                                            \

@@ -110,6 +110,12 @@ int witness_map_253_run(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, c
   return witness_map_t<Fr377>(a, b, c, log_n, omega, omega_inv, coset, coset_inv, n_inv, z_inv, out_canonical, dev, stream_);
 }
 
+// arkworks' GroupAffine::zero() handed over as coordinates: x = 0, y = 1 (never an element of a prime-order group here: msm.h)
+static bool is_ark_zero(const uint64_t* xy, const uint64_t* one, int coord64, int one64) {
+  uint64_t o = 0;
+  for (int k = 0; k < coord64; k++) o |= xy[k] | (xy[coord64 + k] ^ (k < one64 ? one[k] : 0));
+  return o == 0;
+}
 // all pointers HOST.  Queries: affine points, arkworks layout (24 u64 each).  assignment: n_assign = na - 1 canonical scalars (public
 // inputs without the leading one, then the witness); aux = its last n_aux entries; h: n_h canonical scalars (the witness map's
 // output).  Results: Jacobian (36 u64 each).
@@ -128,7 +134,7 @@ int groth16_prove_761_run(const uint64_t* a_query, size_t na, const uint64_t* b_
   const int dev = api_device();
   auto run = [&](int i, const uint64_t* bases, const uint64_t* sc, size_t k) {
     rcs[i] = api_bind_thread(dev);
-    if (!rcs[i]) rcs[i] = msm_host_761(bases, nullptr, sc, k, 0, acc[i]);
+    if (!rcs[i]) rcs[i] = msm_host_761(bases, nullptr, sc, k, 2, acc[i]);      // flags 2: a query row (0, 1) is arkworks' identity (msm.h k_flag_ark_zero)
   };
   {
     std::thread t0(run, 0, a_query + 24, assignment, ka), t1(run, 1, b_g2_query + 24, assignment, kb), t2(run, 2, l_query, aux, kl);
@@ -140,6 +146,7 @@ int groth16_prove_761_run(const uint64_t* a_query, size_t na, const uint64_t* b_
   auto affine_as_jac = [](const uint64_t* xy, uint64_t* j) {
     memcpy(j, xy, 192);
     Fq761d::one().to_ark(j + 24);
+    if (is_ark_zero(xy, j + 24, 12, 12)) memset(j + 24, 0, 96);          // query[0] / a key element given as arkworks' identity: Z = 0
   };
   uint64_t terms[3][36];
   affine_as_jac(a_query, terms[0]); memcpy(terms[1], acc[0], 288); affine_as_jac(alpha_g1, terms[2]);
@@ -167,11 +174,11 @@ int groth16_prove_377_run(const uint64_t* a_query, size_t na, const uint64_t* b_
   const int dev = api_device();
   auto run1 = [&](int i, uint64_t* out, const uint64_t* bases, const uint64_t* sc, size_t k) {
     rcs[i] = api_bind_thread(dev);
-    if (!rcs[i]) rcs[i] = msm_host_g1_377(bases, nullptr, sc, k, 1, out);      // a proving key's G1 queries are elements of G1: the GLV split applies (msm.h k_glv_expand)
+    if (!rcs[i]) rcs[i] = msm_host_g1_377(bases, nullptr, sc, k, 3, out);      // flags: 1 = a proving key's G1 queries are elements of G1 (the GLV split applies, msm.h k_glv_expand), 2 = rows (0, 1) are the identity
   };
   auto run2 = [&]() {
     rcs[1] = api_bind_thread(dev);
-    if (!rcs[1]) rcs[1] = msm_host_g2_377(b_g2_query + 24, nullptr, assignment, kb, 1, acc2);      // likewise elements of G2
+    if (!rcs[1]) rcs[1] = msm_host_g2_377(b_g2_query + 24, nullptr, assignment, kb, 3, acc2);      // likewise elements of G2 or the identity
   };
   {
     std::thread t0(run1, 0, acc1[0], a_query + 12, assignment, ka), t1(run2), t2(run1, 2, acc1[1], l_query, aux, kl);
@@ -180,13 +187,21 @@ int groth16_prove_377_run(const uint64_t* a_query, size_t na, const uint64_t* b_
   }
   for (int r : rcs) if (r) return r;
   uint64_t t1[3][18], t2[3][36];
-  memcpy(t1[0], a_query, 96); Fq377d::one().to_ark(t1[0] + 12);
+  auto g1_as_jac = [](const uint64_t* xy, uint64_t* j) {
+    memcpy(j, xy, 96); Fq377d::one().to_ark(j + 12);
+    if (is_ark_zero(xy, j + 12, 6, 6)) memset(j + 12, 0, 48);
+  };
+  auto g2_as_jac = [](const uint64_t* xy, uint64_t* j) {
+    memcpy(j, xy, 192); Fq377d::one().to_ark(j + 24); Fq377d::zero().to_ark(j + 30);
+    if (is_ark_zero(xy, j + 24, 12, 6)) memset(j + 24, 0, 96);
+  };
+  g1_as_jac(a_query, t1[0]);
   memcpy(t1[1], acc1[0], 144);
-  memcpy(t1[2], alpha_g1, 96); Fq377d::one().to_ark(t1[2] + 12);
+  g1_as_jac(alpha_g1, t1[2]);
   if (int rc = sum_jac_g1_377(&t1[0][0], 3, out_a)) return rc;
-  memcpy(t2[0], b_g2_query, 192); Fq377d::one().to_ark(t2[0] + 24); Fq377d::zero().to_ark(t2[0] + 30);
+  g2_as_jac(b_g2_query, t2[0]);
   memcpy(t2[1], acc2, 288);
-  memcpy(t2[2], beta_g2, 192); Fq377d::one().to_ark(t2[2] + 24); Fq377d::zero().to_ark(t2[2] + 30);
+  g2_as_jac(beta_g2, t2[2]);
   if (int rc = sum_jac_g2_377(&t2[0][0], 3, out_b)) return rc;
   memcpy(t1[0], acc1[1], 144); memcpy(t1[1], acc1[2], 144);
   return sum_jac_g1_377(&t1[0][0], 2, out_c);

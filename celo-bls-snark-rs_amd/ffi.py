@@ -17,6 +17,12 @@ EXPORTS = [
     "celo_amd_init", "celo_amd_use_device", "celo_amd_device_count", "celo_amd_device_name",
     "msm_bls12_377_g1_multi", "msm_bls12_377_g2_multi", "msm_bw6_761_g1_multi", "msm_bw6_761_g2_multi",
     "msm_bls12_377_g1_multi_dev", "msm_bls12_377_g2_multi_dev", "msm_bw6_761_g1_multi_dev", "msm_bw6_761_g2_multi_dev",
+    "msm_bls12_377_g1_multi_windows", "msm_bls12_377_g2_multi_windows", "msm_bw6_761_g1_multi_windows", "msm_bw6_761_g2_multi_windows",
+    "msm_bls12_377_g1_subgroup_multi_windows", "msm_bls12_377_g2_subgroup_multi_windows",
+    "msm_bls12_377_g1_multi_windows_dev", "msm_bls12_377_g2_multi_windows_dev", "msm_bw6_761_g1_multi_windows_dev", "msm_bw6_761_g2_multi_windows_dev",
+    "msm_bls12_377_g1_subgroup_multi_windows_dev", "msm_bls12_377_g2_subgroup_multi_windows_dev",
+    "msm_bls12_377_g1_window_shard_dev", "msm_bls12_377_g2_window_shard_dev", "msm_bw6_761_window_shard_dev",
+    "msm_bls12_377_g1_join_windows", "msm_bls12_377_g2_join_windows", "msm_bw6_761_join_windows",
     "msm_bls12_377_g1", "msm_bls12_377_g2", "msm_bw6_761_g1", "msm_bw6_761_g2",
     "msm_batch_bls12_377_g1", "msm_batch_bls12_377_g2", "msm_batch_bw6_761_g1", "msm_batch_bw6_761_g2",
     "msm_bls12_377_g1_dev", "msm_bls12_377_g2_dev", "msm_bw6_761_g1_dev", "msm_bw6_761_g2_dev",
@@ -102,6 +108,73 @@ def msm_multi_dev(group, devices, d_bases, d_infs, d_scalars, n_per):
     rc = getattr(lib(), "msm_" + group + "_multi_dev")(devs, C.c_int(k), pb, pi, ps, np_, _p(out))
     if rc != 0:
         raise RuntimeError(f"msm_{group}_multi_dev failed rc={rc}")
+    return out
+
+
+def msm_multi_windows(group, devices, bases_xy, inf, scalars, subgroup=False):
+    """One MSM partitioned by WINDOW over `devices` (repeats allowed): every shard stages all n terms and owns a range of the windows."""
+    A, S, O = GROUP_SHAPE[group]
+    bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = bases_xy.size // A
+    assert bases_xy.size == n * A and scalars.size == n * S, "bases / scalars length mismatch"
+    devs = (C.c_int * len(devices))(*devices)
+    out = np.zeros(O, dtype=np.uint64)
+    name = "msm_" + group + ("_subgroup" if subgroup else "") + "_multi_windows"
+    rc = getattr(lib(), name)(devs, C.c_int(len(devices)), _p(bases_xy), _p(inf), _p(scalars), C.c_size_t(n), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"{name} failed rc={rc}")
+    return out
+
+
+def msm_multi_windows_dev(group, devices, d_bases, d_infs, d_scalars, n, subgroup=False):
+    """The window partition over replicas already resident on their devices (lists of integer device addresses, n terms each)."""
+    O = GROUP_SHAPE[group][2]
+    k = len(devices)
+    devs = (C.c_int * k)(*devices)
+    pb = (C.c_void_p * k)(*d_bases)
+    ps = (C.c_void_p * k)(*d_scalars)
+    pi = (C.c_void_p * k)(*[x or 0 for x in d_infs]) if d_infs is not None else None
+    out = np.zeros(O, dtype=np.uint64)
+    name = "msm_" + group + ("_subgroup" if subgroup else "") + "_multi_windows_dev"
+    rc = getattr(lib(), name)(devs, C.c_int(k), pb, pi, ps, C.c_size_t(n), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"{name} failed rc={rc}")
+    return out
+
+
+_SHARD_NAME = {"bls12_377_g1": "bls12_377_g1", "bls12_377_g2": "bls12_377_g2", "bw6_761_g1": "bw6_761", "bw6_761_g2": "bw6_761"}
+
+
+def msm_window_shard_dev(group, d_bases, d_inf, d_scalars, n, shard, nshards, stream=0, subgroup=False):
+    """One rank's share of a window-partitioned MSM (one process per GPU): returns (record, bit_lo); record = X || Y || ZZ || ZZZ in
+    arkworks limbs (uint64[4 * A / 2]).  The ranks all-gather the records and join them with join_windows()."""
+    A = GROUP_SHAPE[group][0]
+    rec = np.zeros(2 * A, dtype=np.uint64)
+    bit = C.c_int(0)
+    fn = getattr(lib(), "msm_" + _SHARD_NAME[group] + "_window_shard_dev")
+    if group.startswith("bw6"):
+        rc = fn(C.c_void_p(d_bases), C.c_void_p(d_inf or 0), C.c_void_p(d_scalars), C.c_size_t(n), C.c_int(shard), C.c_int(nshards), _p(rec), C.byref(bit),
+                C.c_void_p(stream or 0))
+    else:
+        rc = fn(C.c_void_p(d_bases), C.c_void_p(d_inf or 0), C.c_void_p(d_scalars), C.c_size_t(n), C.c_int(1 if subgroup else 0), C.c_int(shard), C.c_int(nshards),
+                _p(rec), C.byref(bit), C.c_void_p(stream or 0))
+    if rc != 0:
+        raise RuntimeError(f"msm_{group}_window_shard_dev failed rc={rc}")
+    return rec, bit.value
+
+
+def join_windows(group, records, bit_lo):
+    """total = sum_g 2^bit_lo[g] P_g over the shards' records (shard order)."""
+    A, _, O = GROUP_SHAPE[group]
+    records = np.ascontiguousarray(records, dtype=np.uint64).reshape(-1)
+    k = len(bit_lo)
+    assert records.size == k * 2 * A
+    bits = (C.c_int * k)(*[int(b) for b in bit_lo])
+    out = np.zeros(O, dtype=np.uint64)
+    rc = getattr(lib(), "msm_" + _SHARD_NAME[group] + "_join_windows")(_p(records), bits, C.c_int(k), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"msm_{group}_join_windows failed rc={rc}")
     return out
 
 

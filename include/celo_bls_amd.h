@@ -87,6 +87,42 @@ int msm_bls12_377_g2_multi_dev(const int* devices, int ndev, const void* const* 
 int msm_bw6_761_g1_multi_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, const size_t* n_per, uint64_t out_xyz[36]);
 int msm_bw6_761_g2_multi_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, const size_t* n_per, uint64_t out_xyz[36]);
 
+/* ---- the same MSM partitioned by WINDOW instead of by index range ("alternative partitioning"): every listed
+ * device holds ALL n bases and scalars and owns a contiguous range of the Pippenger windows - 1/ndev of the bucket additions, only its
+ * windows' buckets to reduce, only its share of the final Horner chain; the ndev partial sums are joined on the host with the doublings
+ * between the ranges (total = sum_g 2^bit(g) P_g).  This is the form that scales ONE MSM of up to ~2^21 terms over the GPUs of a node
+ * (an index-range shard of 2^20 / 8 terms is bound by the pipeline's fixed latencies); it costs ndev-fold base memory, so the prover's
+ * 2^24-term MSMs keep the index-range form above.  Same conventions and results as the single-device entry points; the _subgroup
+ * forms take bases the caller vouches to be in the prime-order subgroup (see msm_bls12_377_g1_subgroup).
+ * _multi_windows: HOST pointers (each shard stages the whole input onto its device).
+ * _multi_windows_dev: d_bases[d] / d_inf[d] (or d_inf == NULL) / d_scalars[d] = the replica of the n terms resident on devices[d]. */
+int msm_bls12_377_g1_multi_windows(const int* devices, int ndev, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[18]);
+int msm_bls12_377_g1_subgroup_multi_windows(const int* devices, int ndev, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[18]);
+int msm_bls12_377_g2_multi_windows(const int* devices, int ndev, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bls12_377_g2_subgroup_multi_windows(const int* devices, int ndev, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bw6_761_g1_multi_windows(const int* devices, int ndev, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bw6_761_g2_multi_windows(const int* devices, int ndev, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bls12_377_g1_multi_windows_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, size_t n, uint64_t out_xyz[18]);
+int msm_bls12_377_g1_subgroup_multi_windows_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, size_t n, uint64_t out_xyz[18]);
+int msm_bls12_377_g2_multi_windows_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bls12_377_g2_subgroup_multi_windows_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bw6_761_g1_multi_windows_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, size_t n, uint64_t out_xyz[36]);
+int msm_bw6_761_g2_multi_windows_dev(const int* devices, int ndev, const void* const* d_bases, const void* const* d_inf, const void* const* d_scalars, size_t n, uint64_t out_xyz[36]);
+/* One rank's share of a window-partitioned MSM when the GPUs belong to DIFFERENT processes (one process per GPU, bench.py under
+ * torch.distributed.run): the partial sum over the windows shard `shard` of `nshards` owns, as X || Y || ZZ || ZZZ (arkworks limbs:
+ * 4 x 6 u64 for G1 of BLS12-377, 4 x 12 u64 for the other groups; ZZ = 0: the identity), and *bit_lo = the first scalar bit of the
+ * shard's range.  The ranks exchange the fixed-size records (one all-gather) and every rank joins them with msm_*_join_windows. */
+int msm_bls12_377_g1_window_shard_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, int subgroup, int shard, int nshards,
+                                      uint64_t out_xyzz[24], int* bit_lo, void* hip_stream);
+int msm_bls12_377_g2_window_shard_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, int subgroup, int shard, int nshards,
+                                      uint64_t out_xyzz[48], int* bit_lo, void* hip_stream);
+int msm_bw6_761_window_shard_dev(const void* d_bases_xy, const void* d_inf, const void* d_scalars, size_t n, int shard, int nshards,
+                                 uint64_t out_xyzz[48], int* bit_lo, void* hip_stream);
+/* total = sum_g 2^bit_lo[g] P_g over nshards records in shard order (bit_lo ascending); host-side, 64-bit limbs. */
+int msm_bls12_377_g1_join_windows(const uint64_t* xyzz /* nshards x 24 */, const int* bit_lo, int nshards, uint64_t out_xyz[18]);
+int msm_bls12_377_g2_join_windows(const uint64_t* xyzz /* nshards x 48 */, const int* bit_lo, int nshards, uint64_t out_xyz[36]);
+int msm_bw6_761_join_windows(const uint64_t* xyzz /* nshards x 48 */, const int* bit_lo, int nshards, uint64_t out_xyz[36]);
+
 /* ---- batched MSMs: m independent instances in one call; instance p owns points/scalars [offsets[p], offsets[p+1])
  * (offsets has m+1 entries), out_xyz holds m Jacobian results back to back.  This is the shape of Batch::verify
  * (crates/bls-crypto/src/bls/batch.rs:69,76 — one G2 and one G1 MSM over the batch's signers) when
@@ -112,7 +148,13 @@ int msm_batch_bw6_761_g2(const uint64_t* bases_xy, const uint8_t* inf, const uin
  * normalised ON the device straight into the pairing engine's input slots - nothing returns to the host but the m verdicts
  * out_ok[b] in {0, 1}.  *_inf: optional byte-per-point identity flags (NULL = none; a batch whose hash is flagged is checked without
  * that pair).  Exponents: canonical 4 x u64 (Batch::verify draws 128 + log2(n) random bits; the window count adapts
- * to the longest one present).  _dev: every pointer except offsets, neg_g2_xy and out_ok is a DEVICE pointer. */
+ * to the longest one present).  _dev: every pointer except offsets, neg_g2_xy and out_ok is a DEVICE pointer.
+ * PRECONDITION: every public key pk_xy[i] is an element of the prime-order subgroup G2 and every signature an element of G1 - what the
+ * reference's PublicKey / Signature values are by construction (checked deserialisation crates/bls-crypto/src/bls/public.rs:123-149,
+ * signature.rs:31-57; secret keys; sums of such) and what Batch::verify therefore assumes.  The key sums use the endomorphism psi(P) = [x]P,
+ * which holds on G2 only: for a key that is on the twist but outside G2 (e.g. decoded with decompress_bls12_377_g2(check_subgroup = 0))
+ * the verdict is unspecified.  A caller holding unchecked points must run them through decompress_*(check_subgroup = 1) first - or use
+ * msm_batch_bls12_377_g2 + msm_batch_bls12_377_g1 + pairing_product_is_one_batch_bls12_377, which are VariableBaseMSM on any curve point. */
 int batch_verify_bls12_377(const uint64_t* pk_xy /* tot x 24 */, const uint8_t* pk_inf /* tot or NULL */, const uint64_t* sig_xy /* tot x 12 */,
                            const uint8_t* sig_inf /* tot or NULL */, const uint64_t* exponents /* tot x 4 */, const uint32_t* offsets /* m+1 */,
                            const uint64_t* hash_xy /* m x 12 */, const uint8_t* hash_inf /* m or NULL */, const uint64_t neg_g2_xy[24], size_t m,
@@ -177,7 +219,12 @@ int celo_amd_ntt_last_timings(float ms[4], int* passes);
  *   C = MSM(l_query, aux) + MSM(h_query, h)
  * queries: affine points (24 u64 each); assignment: n_assignment canonical scalars (public inputs without the leading 1, then the
  * witness), aux = its last n_aux entries; h: n_h canonical scalars.  As in VariableBaseMSM::multi_scalar_mul the shorter of bases
- * and scalars decides each MSM's length.  The four MSMs run concurrently on four engines.  Results: Jacobian, arkworks layout. */
+ * and scalars decides each MSM's length.  The four MSMs run concurrently on four engines.  Results: Jacobian, arkworks layout.
+ * The point at infinity: a proving key holds it for every variable absent from A, B or the auxiliary part (ark-groth16 generator.rs), as
+ * GroupAffine::zero() = (x, y, infinity) = (0, 1, true).  These entry points take coordinates only, so a query row - or query[0], alpha, beta
+ * - with x = 0 and y = 1 IS the identity here (it contributes nothing whatever its scalar); on none of the groups involved is (0, 1) an
+ * element of the prime-order group, so no key element is shadowed (csrc/msm.h k_flag_ark_zero).  The plain msm_* entry points do NOT
+ * apply this rule: they take the identity through their `inf` byte arrays. */
 int groth16_witness_map_bw6_761(uint64_t* a, uint64_t* b, uint64_t* c, unsigned log_n, const uint64_t omega[6], const uint64_t omega_inv[6], const uint64_t coset[6],
                                 const uint64_t coset_inv[6], const uint64_t size_inv[6], const uint64_t vanishing_inv[6], int out_canonical);
 int groth16_witness_map_bw6_761_dev(uint64_t* d_a, uint64_t* d_b, uint64_t* d_c, unsigned log_n, const uint64_t omega[6], const uint64_t omega_inv[6],

@@ -39,6 +39,16 @@ def witness_map(a, b, c, log_n, omega, coset, field=Q):
     return co.from_mont(h, field)
 
 
+def ark_zero_rows(bases, p, n64):
+    """uint8 flags of the rows that hold arkworks' GroupAffine::zero() as coordinates: x = 0, y = 1 (ark-ec models/short_weierstrass_jacobian.rs:
+    zero() = (0, 1, infinity = true)); a proving key's queries hold it for every variable absent from the respective matrix."""
+    b = np.asarray(bases, dtype=np.uint64).reshape(len(bases), -1)
+    half = b.shape[1] // 2
+    one = np.zeros(half, dtype=np.uint64)
+    one[:n64] = co.to_mont([1], p)[0]
+    return (np.all(b[:, :half] == 0, axis=1) & np.all(b[:, half:] == one, axis=1)).astype(np.uint8)
+
+
 def prove_no_zk(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, assignment, n_aux, h, threads=8):
     """queries: (k, 24) uint64 affine Montgomery limbs; alpha / beta: (24,) limbs; assignment / h: lists of canonical ints.
     Returns (A, B, C) as affine python points (or None)."""
@@ -46,10 +56,11 @@ def prove_no_zk(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, assign
         k = min(len(bases), len(scalars))
         if k == 0:
             return None
-        return co.jac_to_affine(co.msm("bw6_761_g1", np.ascontiguousarray(bases[:k]), None, co.ints_to_limbs(scalars[:k], 6), threads=threads), "761")
+        b = np.ascontiguousarray(bases[:k])
+        return co.jac_to_affine(co.msm("bw6_761_g1", b, ark_zero_rows(b, ecc.Q761, 12), co.ints_to_limbs(scalars[:k], 6), threads=threads), "761")
     def pt(limbs):
         x, y = co.from_mont(np.asarray(limbs).reshape(2, 12), ecc.Q761)
-        return (x, y)
+        return None if (x, y) == (0, 1) else (x, y)
     E = ecc.E1_761                       # G2's group law is the same (a = 0; b is never used by it)
     aux = assignment[len(assignment) - n_aux:]
     A = E.add(E.add(pt(a_query[0]), msm(a_query[1:], assignment)), pt(alpha_g1))
@@ -65,13 +76,14 @@ def prove_no_zk_bls12_377(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_
         k = min(len(bases), len(scalars))
         if k == 0:
             return None
-        return co.jac_to_affine(co.msm(group, np.ascontiguousarray(bases[:k]), None, co.ints_to_limbs(scalars[:k], 4), threads=threads), kind)
+        b = np.ascontiguousarray(bases[:k])
+        return co.jac_to_affine(co.msm(group, b, ark_zero_rows(b, ecc.Q377, 6), co.ints_to_limbs(scalars[:k], 4), threads=threads), kind)
     def p1(limbs):
         x, y = co.from_mont(np.asarray(limbs).reshape(2, 6), ecc.Q377)
-        return (x, y)
+        return None if (x, y) == (0, 1) else (x, y)
     def p2(limbs):
         v = co.from_mont(np.asarray(limbs).reshape(4, 6), ecc.Q377)
-        return ((v[0], v[1]), (v[2], v[3]))
+        return None if tuple(v) == (0, 0, 1, 0) else ((v[0], v[1]), (v[2], v[3]))
     E1, E2 = ecc.E1_377, ecc.E2_377
     aux = assignment[len(assignment) - n_aux:]
     A = E1.add(E1.add(p1(a_query[0]), msm("bls12_377_g1", "g1_377", a_query[1:], assignment)), p1(alpha_g1))

@@ -2,7 +2,8 @@
 
 Each rank owns an index-range shard, produces its partial MSM result, the 144-byte Jacobian partials are exchanged with
 ONE all_gather and every rank folds them with the product's host-side `celo_amd_sum_jacobian_*`.  There is no GPU here,
-so the per-rank partial comes from the oracle; what is under test is the exchange + fold (product code)."""
+so the per-rank partial comes from the oracle; what is under test is the exchange + fold (product code) - for the index-range
+partition (Folder) and for the window partition (WindowJoiner + msm_*_join_windows)."""
 import os
 import numpy as np
 import pytest
@@ -49,7 +50,20 @@ def _worker(rank, world, port, q):
     if rank == 0:
         full, _ = co.pack_g1_377(pts)
         gathered_ok = np.array_equal(allxy, full)
-    q.put((rank, got == exp, co.jac_to_affine(total2, "g1_377") == exp and co.jac_to_affine(total3, "g1_377") == exp and gathered_ok))
+    # the WINDOW partition's exchange (bench.WindowJoiner: one all_gather of X || Y || ZZ || ZZZ + first bit, then msm_*_join_windows on
+    # every rank).  Rank g's record here: the sum over ALL points of the scalar bits [b_g, b_g+1) - from the oracle, there is no GPU.
+    bounds = [0, 130, 253] if world == 2 else [253 * g // world for g in range(world + 1)]
+    b0, b1 = bounds[rank], bounds[rank + 1]
+    sub = [(k >> b0) & ((1 << (b1 - b0)) - 1) for k in sc]
+    Pg = ecc.E1_377.msm(pts, sub)
+    rec = np.zeros(24, dtype=np.uint64)
+    if Pg is not None:
+        axy, _ = co.pack_g1_377([Pg])
+        one = co.to_mont([1], ecc.Q377)[0]
+        rec[:12] = axy.reshape(-1); rec[12:18] = one; rec[18:] = one
+    total4 = bench.WindowJoiner(cx, "bls12_377_g1")(rec, b0)
+    windows_ok = co.jac_to_affine(total4, "g1_377") == exp
+    q.put((rank, got == exp, co.jac_to_affine(total2, "g1_377") == exp and co.jac_to_affine(total3, "g1_377") == exp and gathered_ok and windows_ok))
     dist.barrier()
     dist.destroy_process_group()
 

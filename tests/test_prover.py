@@ -112,6 +112,22 @@ def test_prove_no_zk_on_gpu_matches_oracle(gpu):
     wa, wb, wc = gp.prove_no_zk(a_query, b_query, h_query, l_query, alpha, beta, co.limbs_to_ints(asg, 6), n_aux, h_ints)
     assert co.jac_to_affine(A, "761") == wa and co.jac_to_affine(B, "761") == wb and co.jac_to_affine(Cc, "761") == wc
     assert wa is not None and wc is not None
+    # a real proving key holds the point at infinity for every variable absent from A / B / the auxiliary part, as arkworks'
+    # GroupAffine::zero() = (0, 1, infinity): rows x = 0, y = 1 are the identity, whatever their scalar (here full-size ones) - in
+    # every query, in query[0] and in a key element
+    one = co.to_mont([1], ecc.Q761)[0]
+    zero_row = np.concatenate([np.zeros(12, dtype=np.uint64), one])
+    a2, b2, l2, h2 = a_query.copy(), b_query.copy(), l_query.copy(), h_query.copy()
+    asg2 = asg.copy()
+    big = co.ints_to_limbs([ecc.Q377 - 5, ecc.Q377 // 3, 12345678901234567890123], 6)
+    for rows, q in (((0, 6, 1000), a2), ((8, 1001), b2), ((4, 3499), l2), ((11, 4000), h2)):
+        for r_ in rows:
+            q[r_] = zero_row
+    asg2[5], asg2[7], asg2[n_inputs + 4] = big[0], big[1], big[2]
+    A, B, Cc = gpu.groth16_prove(a2, b2, h2, l2, alpha, zero_row, asg2, n_aux, h)
+    wa2, wb2, wc2 = gp.prove_no_zk(a2, b2, h2, l2, alpha, zero_row, co.limbs_to_ints(asg2, 6), n_aux, h_ints)
+    assert co.jac_to_affine(A, "761") == wa2 and co.jac_to_affine(B, "761") == wb2 and co.jac_to_affine(Cc, "761") == wc2
+    assert (wa2, wb2, wc2) != (wa, wb, wc)
 
 
 # ------------------------------------------------------------------------------------------------ the hash-helper proof: BLS12-377
@@ -258,3 +274,34 @@ def test_prove_no_zk_bls12_377_on_gpu_matches_oracle(gpu):
     A2, B2, C2 = gpu.groth16_prove_bls12_377(a_query, b_query, h_query, l_query, alpha, beta, asg, n_aux, h[: n - 101])
     _, _, wc2 = gp.prove_no_zk_bls12_377(a_query, b_query, h_query, l_query, alpha, beta, co.limbs_to_ints(asg, 4), n_aux, h_ints[: n - 101])
     assert co.jac_to_affine(C2, "g1_377") == wc2 and co.jac_to_affine(A2, "g1_377") == wa
+
+
+@pytest.mark.gpu
+def test_prove_bls12_377_identity_rows_under_the_glv_split(gpu):
+    """proving-key queries hold the point at infinity (arkworks' (0, 1, infinity)) for variables absent from a matrix.  Queries
+    of 2^14 terms and more take the GLV / psi^2 split of the subgroup entry points: identity rows (x = 0, y = 1) must contribute nothing
+    there either, with full-size scalars against them - in every query, in query[0] and in beta."""
+    from celo_bls_snark_rs_amd import synthetic as syn
+    n_inputs, n_aux, n_h = 2, 17000, (1 << 15) - 1
+    n_assign = n_inputs + n_aux
+    def pts(group, k, seed):
+        A = 12 if group.endswith("g1") else 24
+        return syn.device_points(group, k, seed).cpu().numpy().view(np.uint64).reshape(k, A)
+    a_query, b_query = pts("bls12_377_g1", n_assign + 1, 31), pts("bls12_377_g2", n_assign + 1, 32)
+    l_query, h_query = pts("bls12_377_g1", n_aux, 33), pts("bls12_377_g1", n_h, 34)
+    alpha = pts("bls12_377_g1", 1, 35)[0]
+    asg = syn.uniform_scalars("bls12_377_g1", n_assign, 37)
+    h = syn.uniform_scalars("bls12_377_g1", n_h, 38)
+    one = co.to_mont([1], ecc.Q377)[0]
+    z1 = np.concatenate([np.zeros(6, dtype=np.uint64), one])
+    z2 = np.concatenate([np.zeros(12, dtype=np.uint64), one, np.zeros(6, dtype=np.uint64)])
+    for r_ in (0, 9, 16000):
+        a_query[r_] = z1
+    for r_ in (3, 16999):
+        b_query[r_] = z2
+    l_query[5] = z1; l_query[16998] = z1
+    h_query[0] = z1; h_query[30000] = z1
+    A, B, Cc = gpu.groth16_prove_bls12_377(a_query, b_query, h_query, l_query, alpha, z2, asg, n_aux, h)
+    wa, wb, wc = gp.prove_no_zk_bls12_377(a_query, b_query, h_query, l_query, alpha, z2, co.limbs_to_ints(asg, 4), n_aux, co.limbs_to_ints(h, 4))
+    assert co.jac_to_affine(A, "g1_377") == wa and co.jac_to_affine(B, "g2_377") == wb and co.jac_to_affine(Cc, "g1_377") == wc
+    assert wa is not None and wb is not None and wc is not None

@@ -120,6 +120,11 @@ class MsmConfig:
         self.O = ffi.GROUP_SHAPE[self.group][2]
         self.fold = WindowJoiner(cx, self.group) if self.by_windows else Folder(cx, self.group, self.O)
         self.acc_ms, self.tot_ms = [], []
+        self.fixed = None
+        if cx.args.fixed_base:
+            # the prover's shape: the key's tables are built ONCE (outside the timed region, reported in the line), every step is a new
+            # scalar vector against them (msm_*_fixed_dev)
+            self.fixed = ffi.FixedBase(self.group, d_bases=self.bases.data_ptr(), n=self.n, window_bits=cx.args.fixed_window_bits)
         torch.cuda.synchronize()
 
     def setup_in_process(self):
@@ -147,6 +152,8 @@ class MsmConfig:
         from celo_bls_snark_rs_amd import ffi
         cx = self.cx
         sub = bool(cx.args.subgroup_points)
+        if self.fixed is not None:
+            return self.fold(self.fixed.msm_dev(self.d_sc.data_ptr(), self.n, self.cx.stream))
         if self.by_windows and cx.devices:
             return ffi.msm_multi_windows_dev(self.group, cx.devices, [b.data_ptr() for b in self.sh_bases], None, [s_.data_ptr() for s_ in self.sh_sc], self.n, subgroup=sub)
         if self.by_windows:
@@ -207,9 +214,20 @@ class MsmConfig:
         line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": ACC_KERNEL[self.group], "achieved": fq_ops / (acc * 1e-3) / 1e9,
                                  "peak": valu_peak, "unit": "G field-mul-or-sqr/s", "frac": fq_ops / (acc * 1e-3) / 1e9 / valu_peak,
                                  "note": "peak from tools/ubench_fp.hip (register-resident multiply loops, 8 waves/SIMD); achieved = n*windows mixed adds * (8M+2S) / accumulate time"}
+        if self.fixed is not None:
+            fi = self.fixed.info()
+            line["config"]["entry_point"] = "msm_%s_fixed_dev: per-key tables T[j][i] = 2^(c j) P_i built once by msm_%s_precompute_dev (the prover's queries stay, the assignment changes)" % (self.group, self.group)
+            line["config"]["fixed_base"] = {"window_bits": fi["window_bits"], "digits_per_scalar": fi["windows"], "virtual_windows": tm["windows"],
+                                            "table_bytes": fi["table_bytes"], "table_build_ms": fi["build_ms"],
+                                            "note": "the table build is outside the timed region: once per proving key (crates/epoch-snark/src/api/setup.rs:63-105)"}
+            fq_ops = self.n * fi["windows"] * 10
+            line["valu_roofline"]["achieved"] = fq_ops / (acc * 1e-3) / 1e9
+            line["valu_roofline"]["frac"] = line["valu_roofline"]["achieved"] / valu_peak
+            line["valu_roofline"]["note"] += "; fixed base: n * digits_per_scalar mixed adds"
+            line["roofline"]["traffic"], line["roofline"]["traffic_source"] = None, "no committed PMC profile of this launch shape"
         if cx.args.subgroup_points:
             line["config"]["entry_point"] = "msm_bls12_377_g1_subgroup_dev: bases vouched to lie in G1 (what Signature::batch hands over), GLV split"
-        if cx.world == 1 and not cx.devices:
+        if cx.world == 1 and not cx.devices and self.fixed is None:
             line["two_callers"] = self.two_callers()
             if self.group == "bls12_377_g1" and not cx.args.subgroup_points:
                 line["subgroup_entry"] = self.subgroup_entry(result)
@@ -321,7 +339,12 @@ class MsmConfig:
             t0 = time.perf_counter()
             out = co.msm(self.group, h_b[:k], None, h_s[:k], threads=T)
             secs = time.perf_counter() - t0
-            got = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), k, cx.stream)
+            got = (self.fixed.msm_dev(self.d_sc.data_ptr(), k, cx.stream) if self.fixed is not None else
+                   ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), k, cx.stream))
+            if self.fixed is not None:       # and the timed full-size result against the variable-base entry point on the same inputs
+                vb = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n, cx.stream)
+                if cx.world == 1 and co.jac_to_affine(vb, KIND[self.group]) != co.jac_to_affine(gpu_result, KIND[self.group]):
+                    raise SystemExit("PARITY FAILURE: msm_*_fixed_dev != msm_*_dev at full size")
             if co.jac_to_affine(out, KIND[self.group]) != co.jac_to_affine(got, KIND[self.group]):
                 raise SystemExit("PARITY FAILURE: GPU MSM result != CPU oracle result on the 2^18 sample")
             res = {"value": k / secs, "seconds": secs, "parity_with_gpu": "2^18 sample of rank 0's shard (full size: tests/test_configs_gpu.py)",
@@ -780,6 +803,8 @@ def main():
     ap.add_argument("--no-pairing", action="store_true", help="config 2, N = 1: skip the secondary pairing / NTT / wire legs")
     ap.add_argument("--balanced", action="store_true", help="diagnostic: scalars whose digits fill every bucket equally (not the headline workload)")
     ap.add_argument("--subgroup-points", action="store_true", help="config 2: time msm_bls12_377_g1_subgroup_dev (bases vouched to lie in G1: GLV split) instead of the plain entry point")
+    ap.add_argument("--fixed-base", action="store_true", help="configs 2 / 4: time msm_*_fixed_dev against per-key tables built once (msm_*_precompute_dev): the Groth16 prover's shape")
+    ap.add_argument("--fixed-window-bits", type=int, default=0, help="--fixed-base: table window size c (16..22; 0 = automatic)")
     ap.add_argument("--in-process", action="store_true", help="configs 2 / 4, N > 1: one process drives the N devices through msm_*_multi_dev (no ranks, no collective)")
     ap.add_argument("--devices", default="", help="--in-process: comma-separated device ordinals (default 0..N-1; repeats allowed, e.g. 0,0 on a 1-GPU box)")
     args = ap.parse_args()
@@ -787,6 +812,8 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "0"))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.fixed_base and (args.config not in (2, 4) or args.in_process or args.subgroup_points or (args.gpus > 1 and args.scaling == "strong" and args.partition != "index")):
+        raise SystemExit("--fixed-base: configs 2 and 4, one table per rank over its index-range shard (weak scaling, or strong with --partition index)")
     if args.in_process and args.config not in (2, 4):
         raise SystemExit("--in-process drives msm_*_multi_dev: configs 2 and 4 only")
     if args.gpus > 1 and not args.in_process and world_env == 0:

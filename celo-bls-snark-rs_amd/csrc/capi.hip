@@ -10,6 +10,14 @@
 #include "runtime.h"
 
 namespace celo {
+struct FixedTable;                       // msm.h: a key's fixed-base tables
+typedef FixedTable FixedTableHandle;
+struct ProvingKey;                       // unit_prover.hip: a loaded Groth16 proving key (fixed-base tables of its four queries)
+int groth16_key_load(int, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, const uint64_t*, int, ProvingKey**);
+int groth16_prove_keyed(const ProvingKey*, const uint64_t*, size_t, size_t, const uint64_t*, size_t, uint64_t*, uint64_t*, uint64_t*);
+void groth16_key_free(ProvingKey*);
+int fixed_table_release(FixedTable*);    // unit_g1_377.hip
+int fixed_table_info(const FixedTable*, size_t*, int*, int*, size_t*, float*);
 // Device binding.  HIP's current device is a per-thread setting, and this library is entered from many host threads (and
 // starts its own): every entry point passes through api_enter(), which applies the calling thread's device - the one bound
 // with celo_amd_use_device(), else the process default chosen by celo_amd_init() (device 0 if init was never called).
@@ -52,6 +60,8 @@ int api_bind_thread(int device) {
   int msm_multi_host_##TAG(const int*, int, const uint64_t*, const uint8_t*, const uint64_t*, size_t, uint64_t*); \
   int msm_multi_dev_##TAG(const int*, int, const void* const*, const void* const*, const void* const*, const size_t*, uint64_t*); \
   int msm_multi_windows_##TAG(const int*, int, int, const void* const*, const void* const*, const void* const*, size_t, int, uint64_t*); \
+  int msm_fixed_build_##TAG(const void*, const void*, size_t, int, int, FixedTableHandle**);          \
+  int msm_fixed_run_##TAG(const FixedTableHandle*, const void*, size_t, int, uint64_t*, void*);       \
   int msm_window_shard_##TAG(const void*, const void*, const void*, size_t, int, int, int, uint64_t*, int*, void*);   \
   int msm_join_windows_##TAG(const uint64_t*, const int*, int, uint64_t*);                            \
   void msm_note_big_call_##TAG();
@@ -140,6 +150,48 @@ int msm_bls12_377_g2_window_shard_dev(const void* b, const void* inf, const void
 }
 int msm_bw6_761_window_shard_dev(const void* b, const void* inf, const void* s, size_t n, int shard, int nshards, uint64_t* o, int* bit_lo, void* st) {
   msm_note_big_call_761(); return msm_window_shard_761(b, inf, s, n, 0, shard, nshards, o, bit_lo, st);
+}
+// ---- fixed-base MSM: per-key tables (include/celo_bls_amd.h)
+#define FIXED(NAME, TAG)                                                                                                              \
+  int NAME##_precompute(const uint64_t* b, const uint8_t* inf, size_t n, int window_bits, void** handle) {                            \
+    if (!handle) return 2;                                                                                                            \
+    *handle = nullptr;                                                                                                                \
+    return msm_fixed_build_##TAG(b, inf, n, 0, window_bits, (FixedTable**)handle);                                                    \
+  }                                                                                                                                   \
+  int NAME##_precompute_dev(const void* b, const void* inf, size_t n, int window_bits, void** handle) {                               \
+    if (!handle) return 2;                                                                                                            \
+    *handle = nullptr;                                                                                                                \
+    return msm_fixed_build_##TAG(b, inf, n, 1, window_bits, (FixedTable**)handle);                                                    \
+  }                                                                                                                                   \
+  int NAME##_fixed(const void* handle, const uint64_t* s, size_t n, uint64_t* out) {                                                  \
+    msm_note_big_call_##TAG(); return msm_fixed_run_##TAG((const FixedTable*)handle, s, n, 0, out, nullptr);                          \
+  }                                                                                                                                   \
+  int NAME##_fixed_dev(const void* handle, const void* s, size_t n, uint64_t* out, void* st) {                                        \
+    msm_note_big_call_##TAG(); return msm_fixed_run_##TAG((const FixedTable*)handle, s, n, 1, out, st);                               \
+  }
+FIXED(msm_bls12_377_g1, g1_377) FIXED(msm_bls12_377_g2, g2_377) FIXED(msm_bw6_761_g1, 761) FIXED(msm_bw6_761_g2, 761)
+#undef FIXED
+// ---- Groth16 prover against a loaded key (include/celo_bls_amd.h)
+int groth16_load_key_bw6_761(const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh, const uint64_t* l_query, size_t nl,
+                             const uint64_t alpha_g1[24], const uint64_t beta_g2[24], int window_bits, void** out_key) {
+  if (!out_key) return 2;
+  *out_key = nullptr;
+  return groth16_key_load(0, a_query, na, b_g2_query, nb, h_query, nh, l_query, nl, alpha_g1, beta_g2, window_bits, (ProvingKey**)out_key);
+}
+int groth16_load_key_bls12_377(const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh, const uint64_t* l_query, size_t nl,
+                               const uint64_t alpha_g1[12], const uint64_t beta_g2[24], int window_bits, void** out_key) {
+  if (!out_key) return 2;
+  *out_key = nullptr;
+  return groth16_key_load(1, a_query, na, b_g2_query, nb, h_query, nh, l_query, nl, alpha_g1, beta_g2, window_bits, (ProvingKey**)out_key);
+}
+int groth16_prove_with_key(const void* key, const uint64_t* assignment, size_t n_assignment, size_t n_aux, const uint64_t* h, size_t n_h, uint64_t* out_a, uint64_t* out_b,
+                           uint64_t* out_c) {
+  return groth16_prove_keyed((const ProvingKey*)key, assignment, n_assignment, n_aux, h, n_h, out_a, out_b, out_c);
+}
+int groth16_free_key(void* key) { if (!key) return 2; groth16_key_free((ProvingKey*)key); return 0; }
+int celo_amd_msm_fixed_release(void* handle) { return fixed_table_release((FixedTable*)handle); }
+int celo_amd_msm_fixed_info(const void* handle, size_t* n, int* window_bits, int* windows, size_t* table_bytes, float* build_ms) {
+  return fixed_table_info((const FixedTable*)handle, n, window_bits, windows, table_bytes, build_ms);
 }
 int msm_bls12_377_g1_join_windows(const uint64_t* xyzz, const int* bit_lo, int nshards, uint64_t* out) { return msm_join_windows_g1_377(xyzz, bit_lo, nshards, out); }
 int msm_bls12_377_g2_join_windows(const uint64_t* xyzz, const int* bit_lo, int nshards, uint64_t* out) { return msm_join_windows_g2_377(xyzz, bit_lo, nshards, out); }

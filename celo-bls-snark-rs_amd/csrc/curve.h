@@ -42,7 +42,7 @@ template <class F> HD Xyzz<F> xyzz_dbl_affine(const Affine<F>& p) {
   F M2 = F::sqr_nn(M);                                // 9 ok
   F X3 = F::norm(F::template sub<16, 3>(M2, F::dbl(S)));   // [1, 10]
   F t = F::prep(F::template sub<32, 1>(S, X3));       // [3, 18]
-  F Y3 = F::mul_sub_nn(M, t, W, p.y);                 // [1, <=7]
+  F Y3 = F::template mul_sub_nn_at<0>(M, t, W, p.y);  // [1, <=7]   (the _at<site> tag only matters to the signed-pass reproducer builds: fp2.h)
   return {X3, Y3, V, W};
 }
 
@@ -58,7 +58,7 @@ template <class F> HD Xyzz<F> xyzz_dbl(const Xyzz<F>& a) {
   F M2 = F::sqr_nn(M);
   F X3 = F::norm(F::template sub<16, 3>(M2, F::dbl(S)));
   F t = F::prep(F::template sub<32, 1>(S, X3));
-  F Y3 = F::mul_sub_nn(M, t, W, a.Y);
+  F Y3 = F::template mul_sub_nn_at<1>(M, t, W, a.Y);
   return {X3, Y3, F::mul_nn(V, a.ZZ), F::mul_nn(W, a.ZZZ)};
 }
 
@@ -81,7 +81,7 @@ template <class F> HD void xyzz_madd(Xyzz<F>& a, const Affine<F>& p) {
   F s = F::add(F::add(PPP, Q), Q);                    // [3, 6]
   F X3 = F::norm(F::template sub<16, 3>(R2, s));       // [1, 10]
   F t = F::prep(F::template sub<32, 1>(Q, X3));       // [3, 18]
-  F Y3 = F::mul_sub_nn(R, t, a.Y, PPP);               // R*t - Y1*PPP, one reduction pass: [1, <=7]
+  F Y3 = F::template mul_sub_nn_at<2>(R, t, a.Y, PPP); // R*t - Y1*PPP, one reduction pass: [1, <=7]
   a.ZZ = F::mul_nn(a.ZZ, PP);
   a.ZZZ = F::mul_nn(a.ZZZ, PPP);
   a.X = X3;
@@ -108,7 +108,7 @@ template <class F> HD Xyzz<F> xyzz_add_affine(const Affine<F>& p, const Affine<F
   F s = F::add(F::add(PPP, Q), Q);
   F X3 = F::norm(F::template sub<16, 3>(R2, s));
   F t = F::prep(F::template sub<32, 1>(Q, X3));
-  F Y3 = F::mul_sub_nn(R, t, p.y, PPP);
+  F Y3 = F::template mul_sub_nn_at<3>(R, t, p.y, PPP);
   return {X3, Y3, PP, PPP};
 }
 
@@ -134,7 +134,7 @@ template <class F> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& b) {
   F s = F::add(F::add(PPP, Q), Q);
   F X3 = F::norm(F::template sub<16, 3>(R2, s));
   F t = F::prep(F::template sub<32, 1>(Q, X3));
-  F Y3 = F::mul_sub_nn(R, t, S1, PPP);
+  F Y3 = F::template mul_sub_nn_at<4>(R, t, S1, PPP);
   a.ZZ = F::mul_nn(F::mul_nn(a.ZZ, b.ZZ), PP);
   a.ZZZ = F::mul_nn(F::mul_nn(a.ZZZ, b.ZZZ), PPP);
   a.X = X3;

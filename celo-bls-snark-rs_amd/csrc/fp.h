@@ -353,12 +353,25 @@ template <class P> struct Fp {
     uint32_t lo = l[0] & MASK;
     uint32_t t = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);  // = -j mod 2^W
     uint32_t j = (0u - t) & MASK;
+#if defined(CELO_ZERO_UNIFORM) && defined(__HIP_DEVICE_COMPILE__)
+    // reproducer builds only (tools/repro_acc, DESIGN.md section 3 "the signed pass"): the slow path entered by the whole wave on a vote.
+    // Together with the signed form of xyzz_madd's Fq2 pass this instantiation of k_accumulate<G2_377> gives wrong sums in ~0.7 % of
+    // its waves, deterministically - the compact form of the round-3 finding.  Not built into the library.
+    const bool maybe = j <= 130;
+    if (!__any(maybe ? 1 : 0)) return false;
+    Fp r = reduce(*this);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) o |= r.l[i];
+    return maybe && o == 0;
+#else
     if (j > 130) return false;
     Fp r = reduce(*this);
     uint32_t o = 0;
 #pragma unroll
     for (int i = 0; i < L; i++) o |= r.l[i];
     return o == 0;
+#endif
   }
   HD bool limbs_all_zero() const {
     uint32_t o = 0;
@@ -585,6 +598,7 @@ template <class P> struct Fp {
   HD static Fp mul_nn(const Fp& a, const Fp& b) { return mul<false>(a, b); }
   HD static Fp sqr_nn(const Fp& a) { return sqr<false>(a); }
   HD static Fp mul_sub_nn(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return mul2k<-1>(a, b, c, d); }
+  template <int SITE> HD static Fp mul_sub_nn_at(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return mul_sub_nn(a, b, c, d); }
   // a*b - c*d in ONE reduction pass.  The column bound L (lb_a lb_b + lb_c lb_d + 1) <= 255 holds for the 14-limb field with the
   // loosely reduced operands the curve formulas hand over (lb_a lb_b <= 9, lb_c lb_d <= 1); the 28-limb field first carries its
   // operands (two ~84-instruction passes for the 784 multiply-adds of the reduction saved: 5 % of a mixed addition)

@@ -10,9 +10,11 @@
 // Outputs: lb = 1, vb <= 3.
 #pragma once
 #include "fp.h"
-// -DCELO_MUL4K_SGN=true builds the curve formulas' Fq2 R t - Y1 PPP pass in its signed form (round-3 open finding: reproducer builds only)
-#ifndef CELO_MUL4K_SGN
-#define CELO_MUL4K_SGN false
+// Reproducer builds of the round-3 open finding only: -DCELO_MUL4K_SGN_SITES=<mask> builds the curve formulas' Fq2 pass a b - c d (Y3) in
+// its SIGNED form (Fp::mul4k<KC, true>) at the call sites whose bit is set - 1: xyzz_dbl_affine, 2: xyzz_dbl, 4: xyzz_madd, 8:
+// xyzz_add_affine, 16: xyzz_add (curve.h).  The shipped library builds with the mask 0: every site unsigned.
+#ifndef CELO_MUL4K_SGN_SITES
+#define CELO_MUL4K_SGN_SITES 0
 #endif
 
 namespace celo {
@@ -45,9 +47,11 @@ template <class P> struct Fp2 {
     return {B::template mul2<true>(a.c0, b.c0, a.c1, b.c1), B::template mul2<false>(a.c0, b.c1, a.c1, b.c0)};
   }
   HD static Fp2 sqr_nn(const Fp2& a) { return {B::sqr2m5(a.c0, a.c1), B::mul(B::dbl(a.c0), a.c1)}; }
-  HD static Fp2 mul_sub_nn(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) {
-    return {B::template mul4k<-5, CELO_MUL4K_SGN>(a.c0, b.c0, a.c1, b.c1, c.c0, d.c0, c.c1, d.c1),
-            B::template mul4k<1, CELO_MUL4K_SGN>(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0)};
+  template <bool SGN = false> HD static Fp2 mul_sub_nn(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) {
+    return {B::template mul4k<-5, SGN>(a.c0, b.c0, a.c1, b.c1, c.c0, d.c0, c.c1, d.c1), B::template mul4k<1, SGN>(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0)};
+  }
+  template <int SITE> HD static Fp2 mul_sub_nn_at(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) {
+    return mul_sub_nn<((CELO_MUL4K_SGN_SITES) >> SITE & 1) != 0>(a, b, c, d);
   }
   HD static Fp2 mul_fp(const Fp2& a, const B& k) {  // k normalised or lb*lb within Fp::mul's bound
     return {B::mul(a.c0, k), B::mul(a.c1, k)};

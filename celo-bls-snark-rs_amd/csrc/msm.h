@@ -1128,6 +1128,104 @@ template <> struct GlsExpand<G2_377> {
   }
 };
 
+// =====================================================================================================================
+// FIXED-BASE MSM: the Groth16 prover hands the SAME Parameters to every proof (crates/epoch-snark/src/api/prover.rs:78,112;
+// they are created once, crates/epoch-snark/src/api/setup.rs:63-105), so its queries can carry per-key tables T[j][i] = 2^(cf j) P_i.  Then
+//   sum_i k_i P_i = sum_i sum_j d_ij T[j][i]      (d_ij the signed cf-bit digits of k_i)
+// and ALL n W digit entries fall into ONE set of 2^(cf - 1) buckets: one bucket reduction instead of W, no Horner chain over the windows,
+// and cf is free to grow beyond the 16 bits of the variable-base windows (fewer digits per scalar = fewer additions: 19 instead of 24 for
+// the 377-bit scalars at cf = 20).  The pipeline below the digits is the variable-base one, unchanged: the table is handed to it as E = n W
+// bases, and the 2^(cf - 1) buckets as NV VIRTUAL windows of M buckets each (bucket b = v M + low) - entry p = j n + i carries its digit in
+// the virtual window it belongs to and a zero digit in the others.  M = 2^15 - 1 for cf > 16: the pipeline's 16-bit digit is 15 bits of
+// bucket + the sign + the value 0xFFFF for "no digit", and (low = 0x7FFF, negative) IS 0xFFFF - with cf = 16 a negative digit never
+// reaches that bucket, with virtual windows it does (caught by the scalar r - 1 at cf = 19), so the last bucket of every virtual window
+// stays empty and NV = floor((2^(cf-1) - 1) / M) + 1.  What changes is the end:
+//   total = sum_v [ S_v + v M T_v ],   S_v = the window's weighted sum (node + sum_l 2^(15 - l) O_l),   T_v = its plain sum (node),
+// one Horner pass of ~15 + log2(NV) doublings on the host (run_device_windows, fx branch): the bits of v M from the top, the plain sums
+// of the windows that have the bit added at each step, the levels' O_l joining in from bit 14 down.
+struct FixedTable {
+  uint32_t* table = nullptr;      // E affine points, device form, entry j n + i = 2^(cf j) P_i
+  uint8_t* tinf = nullptr;        // E flags: the entry is the identity (a flagged base; a base whose 2^(cf j) multiple is the identity)
+  uint32_t n = 0, W = 0, NV = 0, M = 0;      // M: buckets used per virtual window (the divisor of the bucket index)
+  int cf = 0, device = 0;
+  size_t bytes = 0;
+  float build_ms = 0;
+  uint32_t E() const { return n * W; }
+};
+// T[j] from T[j - 1]: cf doublings and one inversion per point (the inversion is ~20 % of the lane's work: no batching needed for a
+// table that is built once per key)
+template <class G>
+__global__ void __launch_bounds__(128) k_fixed_next(const uint32_t* __restrict__ prev, const uint8_t* __restrict__ pinf, uint32_t* __restrict__ next,
+                                                    uint8_t* __restrict__ ninf, uint32_t n, int cf) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> r = {F::zero(), F::zero()};
+  uint8_t fl = 1;
+  if (!pinf[i]) {
+    Xyzz<F> a = Xyzz<F>::from_affine(IO::load_affine(prev + (size_t)i * IO::AFF_WORDS));
+    for (int k = 0; k < cf; k++) xyzz_dbl_fn(a);
+    if (!a.is_identity() && !a.ZZ.is_zero_mod_p()) {
+      const F t = F::inv(F::mul(a.ZZ, a.ZZZ));          // x = X / ZZ, y = Y / ZZZ with one inversion
+      r = {F::mul(a.X, F::mul(t, a.ZZZ)), F::mul(a.Y, F::mul(t, a.ZZ))};
+      fl = 0;
+    }
+  }
+  IO::store_affine(next + (size_t)i * IO::AFF_WORDS, r);
+  ninf[i] = fl;
+}
+template <class G>
+__global__ void __launch_bounds__(256) k_fixed_first_flags(const uint8_t* __restrict__ inf, uint8_t* __restrict__ tinf, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tinf[i] = inf ? (inf[i] ? 1 : 0) : 0;
+}
+// signed cf-bit digits of the first n_sc scalars (a shorter scalar list leaves the remaining bases out: VariableBaseMSM zips), written
+// per virtual window: digits[v E + j n + i] = the low 15 bits of (|d| - 1) | sign << 15 if the entry belongs to v, else the zero digit.
+template <int SW, int BITS>
+__global__ void __launch_bounds__(256) k_fixed_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ tinf, uint16_t* __restrict__ digits,
+                                                      uint32_t n, uint32_t n_sc, int cf, uint32_t W, uint32_t NV, uint32_t M) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t E = (size_t)n * W;
+  uint32_t s[SW + 1];
+  if (i < n_sc) {
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * SW);
+#pragma unroll
+    for (int k = 0; k < SW / 4; k++) { const uint4 v = sp[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SW; k++) s[k] = 0;
+  }
+  s[SW] = 0;
+  if constexpr (BITS < 32 * SW) {          // bits from the scalar length up are not part of the scalar (k_digits, ark-ec)
+    s[BITS / 32] &= (1u << (BITS % 32)) - 1u;
+#pragma unroll
+    for (int k = BITS / 32 + 1; k < SW; k++) s[k] = 0;
+  }
+  const uint32_t half = 1u << (cf - 1);
+  uint32_t carry = 0;
+  for (uint32_t j = 0; j < W; j++) {
+    const uint32_t bit = j * (uint32_t)cf, wi = bit >> 5, off = bit & 31;
+    uint32_t raw = 0;
+    if (wi < (uint32_t)SW) {
+      uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+      for (int k = 0; k <= SW; k++) { if ((uint32_t)k == wi) w0 = s[k]; if ((uint32_t)k == wi + 1) w1 = s[k]; }
+      raw = (uint32_t)((((uint64_t)w1 << 32) | w0) >> off) & ((1u << cf) - 1u);
+    }
+    const uint32_t d = raw + carry;
+    const uint32_t neg = d > half ? 1u : 0u;
+    const uint32_t mag = neg ? (1u << cf) - d : d;
+    carry = neg;
+    const size_t p = (size_t)j * n + i;
+    const bool live = mag != 0 && !tinf[p];
+    const uint32_t full = mag - 1u, v = full / M;
+    const uint16_t dg = (uint16_t)((full - v * M) | (neg << 15));
+    for (uint32_t vv = 0; vv < NV; vv++) digits[(size_t)vv * E + p] = (live && vv == v) ? dg : (uint16_t)0xFFFF;
+  }
+}
+
 // ---------------------------------------------------------------- host driver
 // the IFMA Horner epilogue (host_ifma.cpp, host_cpu.cpp) exists for the two prime fields
 extern "C" int celo_ifma_available();
@@ -1188,6 +1286,7 @@ template <class G> class MsmEngine {
     d_in_bases = nullptr; d_in_scalars = nullptr; d_in_inf = nullptr; cap_in = 0;
     if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; }
     if (d_side_out) { (void)hipFree(d_side_out); d_side_out = nullptr; side_out_bytes = 0; }
+    if (d_fx_scalars) { (void)hipFree(d_fx_scalars); d_fx_scalars = nullptr; cap_fx = 0; }
     for (int i = 0; i < 6; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
     for (int i = 0; i < 2; i++) if (ev_side[i]) { (void)hipEventDestroy(ev_side[i]); ev_side[i] = nullptr; }
   }
@@ -1263,15 +1362,19 @@ template <class G> class MsmEngine {
   // The result is then the partial sum  sum_{w in range} 2^(bit(w) - bit(win_lo)) S_w  - the caller weighs it by 2^bit(win_lo).
   // out_xyzz (optional, 4 * ARK64 u64: X, Y, ZZ, ZZZ in arkworks limbs, ZZ = 0 for the identity) hands the partial over in the host
   // epilogue's own coordinates, so that the join needs no conversion.
+  // fx != nullptr: the FIXED-BASE form (FixedTable above): d_ark_bases / d_inf are unused, n_ = the number of scalars (<= fx->n), the
+  // pipeline runs over the table's E entries in NV virtual windows of 2^15 buckets.
   int run_device_windows(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, int win_lo, int win_cnt,
-                         uint64_t* out_jac, uint64_t* out_xyzz, hipStream_t stream) {
+                         uint64_t* out_jac, uint64_t* out_xyzz, hipStream_t stream, const FixedTable* fx = nullptr) {
     if (n_ == 0) {
       if (out_jac) write_identity(out_jac);
       if (out_xyzz) memset(out_xyzz, 0, 4 * IO::ARK64 * 8);
       return 0;
     }
     if (n_ >= (size_t(1) << 30)) return 2;
-    const Plan pl = plan(n_);
+    if (fx && (win_cnt || n_ > fx->n || fx->cf < 16 || fx->cf > 22)) return 2;
+    Plan pl = plan(n_);
+    if (fx) { pl.glv = false; pl.n = fx->E(); pl.sbits = G::SCALAR_BITS; pl.c = 16; pl.nw = (int)fx->NV; pl.kn = 0; }
     const bool glv = pl.glv;
     const uint32_t n = pl.n;
     const int sbits = pl.sbits, c = pl.c, nw_all = pl.nw;
@@ -1285,7 +1388,7 @@ template <class G> class MsmEngine {
     // (the split's buckets are twice as long - 64 points at 2^20 - and fewer: pieces of 1.5 mean buckets balance its last round better:
     // accumulate 2.64 -> 2.46 ms at 2^20; the plain path is flat between 1.5 and 3)
     const int seg_h = MsmTuning::get().seg_halves ? MsmTuning::get().seg_halves : (glv ? 3 : 4);
-    uint32_t SEG = (uint32_t)seg_h * (n / B + 1) / 2;
+    uint32_t SEG = (uint32_t)seg_h * ((fx ? n / (uint32_t)nw_all : n) / B + 1) / 2;      // (fixed base: a virtual window holds E / NV of the entries)
     uint32_t seg_min = MsmTuning::get().seg_min;
     if (win_cnt && MsmTuning::get().seg_occupancy) {
       // a call that owns FEW windows (a window shard) has fewer additions than the chip has lanes x the usual piece length: a lane is
@@ -1296,6 +1399,13 @@ template <class G> class MsmEngine {
       const uint32_t lanes = (sizeof(F) <= 14 * sizeof(uint32_t)) ? 131072u : 65536u;      // 2 waves (14-limb field) or 1 per SIMD x 64 lanes x 1024 SIMDs
       const uint32_t occ = (uint32_t)((adds + lanes - 1) / lanes);
       if (occ < SEG) { SEG = occ; seg_min = MsmTuning::get().seg_min_shard; }
+    }
+    if (fx && !MsmTuning::get().seg_halves) {
+      // fixed base: few virtual windows hold all n W entries (one at cf = 16: mean bucket 1536) - pieces of twice the mean bucket would be
+      // fewer than the chip has lanes; eight rounds of the lanes in flight bound the piece length instead (cf = 16: 72.9 -> see DESIGN.md)
+      const uint32_t lanes = (sizeof(F) <= 14 * sizeof(uint32_t)) ? 131072u : 65536u;
+      const uint32_t occ = n / (lanes * 8u) + 1u;
+      if (occ < SEG) SEG = occ;
     }
     if (SEG < seg_min) SEG = seg_min;
     if (SEG > SIZE_BINS - 1) SEG = SIZE_BINS - 1;
@@ -1308,7 +1418,7 @@ template <class G> class MsmEngine {
     // ---- workspace arena
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
-    const size_t o_bases = take((size_t)n * IO::AFF_WORDS * 4);
+    const size_t o_bases = take(fx ? 0 : (size_t)n * IO::AFF_WORDS * 4);
     const size_t o_sc2 = take(glv ? (size_t)n * 16 : 0);
     const size_t o_digits = take((size_t)n * nw_all * 2);
     const size_t o_sorted = take((size_t)n * nw * 4);
@@ -1341,7 +1451,7 @@ template <class G> class MsmEngine {
     if (ensure(off)) return 1;
     if (res_pts > H_OUT_POINTS) return 2;
     char* A = arena;
-    uint32_t* d_bases = (uint32_t*)(A + o_bases);
+    uint32_t* d_bases = fx ? fx->table : (uint32_t*)(A + o_bases);
     uint16_t* d_digits_all = (uint16_t*)(A + o_digits);
     uint16_t* d_digits = d_digits_all + (size_t)w0 * n;          // this call's windows
     uint32_t* d_sorted = (uint32_t*)(A + o_sorted);
@@ -1370,7 +1480,9 @@ template <class G> class MsmEngine {
     // window shards (A/B hook CELO_SIDE_CONVERT): the conversion of ALL n bases is replicated on every shard while its sort shrinks to a
     // handful of latency-bound launches - the two are independent until the accumulation, so the conversion may run on a second stream
     const bool side = win_cnt && !glv && MsmTuning::get().side_convert && side_stream_.get() && ev_side[0];
-    if (side) {
+    if (fx) {
+      // nothing to convert: the table is in device form
+    } else if (side) {
       HIP_OK(hipEventRecord(ev_side[0], stream));
       HIP_OK(hipStreamWaitEvent(side_stream_.get(), ev_side[0], 0));
       hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, side_stream_.get(), d_ark_bases, d_bases, (size_t)n);
@@ -1379,7 +1491,9 @@ template <class G> class MsmEngine {
     else hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_ark_bases, d_bases, (size_t)n);
     HIP_OK(hipEventRecord(ev[1], stream));
     // ---- sort
-    if (glv) { if (launch_digits<4, GlvExpand<G>::BITS>(c, (const uint32_t*)(A + o_sc2), nullptr, d_digits_all, n, stream)) return 3; }
+    if (fx) hipLaunchKernelGGL((k_fixed_digits<SW, G::SCALAR_BITS>), dim3((fx->n + 255) / 256), dim3(256), 0, stream, d_scalars, fx->tinf, d_digits_all, fx->n, (uint32_t)n_,
+                               fx->cf, fx->W, fx->NV, fx->M);
+    else if (glv) { if (launch_digits<4, GlvExpand<G>::BITS>(c, (const uint32_t*)(A + o_sc2), nullptr, d_digits_all, n, stream)) return 3; }
     else if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream)) return 3;
     HIP_OK(hipMemsetAsync(d_counts, 0, o_zero_end - o_counts, stream));
     // mean region n / NBIN: the smallest workgroup whose tile capacity (TILE_EPT entries per lane) holds it with 20 % to spare
@@ -1477,6 +1591,19 @@ template <class G> class MsmEngine {
     horner_steps.clear();
     const int kn = pl.kn;                                       // the top kn of the nw_all windows are c - 1 bits wide (k_digits)
     (void)sbits;
+    if (fx) {
+      // total = sum_v c_v node_v + sum_l 2^(15 - l) (sum_v O_{v,l}) + sum_v node_v,  c_v = v M: ONE chain over the bit positions t from the top
+      // of the largest c_v down to 0 - at step t the accumulator doubles, then takes node_v of every v with bit t of c_v set and, for
+      // t <= 14, the O_{v, 15 - t} of every virtual window
+      int top = LB - 1;
+      while (((uint64_t)(nw - 1) * fx->M) >> (top + 1)) top++;
+      for (int t = top; t >= 0; t--) {
+        horner_steps.push_back(-1);
+        for (int v = 0; v < nw; v++) if ((((uint64_t)v * fx->M) >> t) & 1) horner_steps.push_back(v | HORNER_NODBL);
+        if (t <= LB - 1) for (int v = 0; v < nw; v++) horner_steps.push_back(((LB - t) * nw + v) | HORNER_NODBL);
+      }
+      for (int v = 0; v < nw; v++) horner_steps.push_back(v | HORNER_NODBL);
+    } else
     for (int w = nw - 1; w >= 0; w--) {
       horner_steps.push_back(-1);
       for (int l = (w0 + w >= nw_all - kn ? 2 : 1); l <= LB; l++) horner_steps.push_back(l * nw + w);
@@ -1497,7 +1624,7 @@ template <class G> class MsmEngine {
     // quarter of a call below 2^16 terms.  The 6-limb prime field stays on one thread (0.15 ms: the joins would cost what the split saves).
     constexpr int HT = (sizeof(HF) > 6 * 8) ? HOST_HORNER_THREADS : 1;
     HXyzz<HF> total_pt;
-    if (HT > 1 && nw >= 2 * HT && host_threads) {
+    if (HT > 1 && nw >= 2 * HT && host_threads && !fx) {
       const int per_window = (int)horner_steps.size() / nw;       // uniform except for the narrow top windows: cut by counting steps
       (void)per_window;
       int start[HT + 1], dbls[HT];
@@ -1579,6 +1706,59 @@ template <class G> class MsmEngine {
       return run_device_windows(d_in_bases, d_in_inf, (const uint32_t*)d_in_scalars, n, win_lo, win_cnt, out_jac, out_xyzz, stream);
     }
     return run_device_windows(d_in_bases, inf ? d_in_inf : nullptr, (const uint32_t*)d_in_scalars, n, win_lo, win_cnt, out_jac, out_xyzz, stream);
+  }
+
+  // ---- fixed-base form (FixedTable): the scalars come from the host (staged into a buffer of their own) or are resident
+  int run_fixed(const FixedTable& T, const void* scalars, size_t n_sc, int resident, uint64_t* out_jac, hipStream_t stream) {
+    if (n_sc > T.n) n_sc = T.n;                                   // VariableBaseMSM zips bases with scalars: the shorter side decides
+    if (n_sc == 0) { write_identity(out_jac); return 0; }
+    const uint32_t* d_sc = (const uint32_t*)scalars;
+    if (!resident) {
+      if (n_sc > cap_fx) {
+        if (d_fx_scalars) (void)hipFree(d_fx_scalars);
+        d_fx_scalars = nullptr; cap_fx = 0;
+        HIP_OK(hipMalloc(&d_fx_scalars, n_sc * SW * 4));
+        cap_fx = n_sc;
+      }
+      HIP_OK(hipMemcpyAsync(d_fx_scalars, scalars, n_sc * SW * 4, hipMemcpyHostToDevice, stream));
+      d_sc = (const uint32_t*)d_fx_scalars;
+    }
+    return run_device_windows(nullptr, nullptr, d_sc, n_sc, 0, 0, out_jac, nullptr, stream, &T);
+  }
+  // window size of a key's table: buckets ~ entries / 64 within [2^15, 2^19] (measured sweep: DESIGN.md section 4 "Fixed base")
+  static int fixed_window_bits(size_t n) {
+    int lg = 0;
+    while ((size_t(1) << lg) < n * ((G::SCALAR_BITS + 16) / 16)) lg++;
+    int cf = lg - 4;      // 2^21 BW6-761 terms: 20 (27.9 ms against 33.7 variable-base); 2^20 G1 terms: 20 (level with variable-base: cheap additions)
+    return cf < 16 ? 16 : cf > 20 ? 20 : cf;
+  }
+  // builds T (device memory of the calling thread's device) from n affine bases in arkworks layout; d_* are DEVICE pointers
+  static int fixed_build(const uint64_t* d_ark_bases, const uint8_t* d_inf, size_t n_, int cf, FixedTable* T, hipStream_t stream) {
+    if (n_ == 0 || n_ >= (size_t(1) << 27)) return 2;
+    if (cf == 0) cf = fixed_window_bits(n_);
+    if (cf < 16 || cf > 22) return 2;
+    const uint32_t n = (uint32_t)n_, W = (uint32_t)((G::SCALAR_BITS + cf) / cf);      // W cf >= SCALAR_BITS + 1: room for the signed recoding's carry
+    const uint32_t M = cf == 16 ? 32768u : 32767u, NV = ((1u << (cf - 1)) - 1u) / M + 1u;
+    if ((uint64_t)n * W >= (uint64_t(1) << 31) || (uint64_t)n * W * NV >= (uint64_t(1) << 32)) return 2;
+    const size_t E = (size_t)n * W;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    T->n = n; T->W = W; T->NV = NV; T->M = M; T->cf = cf; T->device = api_device();
+    T->bytes = E * IO::AFF_WORDS * 4 + E;
+    HIP_OK(hipMalloc(&T->table, E * IO::AFF_WORDS * 4));
+    HIP_OK(hipMalloc(&T->tinf, E));
+    HIP_OK(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_ark_bases, T->table, (size_t)n);
+    hipLaunchKernelGGL((k_fixed_first_flags<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_inf, T->tinf, n);
+    for (uint32_t j = 1; j < W; j++)
+      hipLaunchKernelGGL((k_fixed_next<G>), dim3((n + 127) / 128), dim3(128), 0, stream, T->table + (size_t)(j - 1) * n * IO::AFF_WORDS, T->tinf + (size_t)(j - 1) * n,
+                         T->table + (size_t)j * n * IO::AFF_WORDS, T->tinf + (size_t)j * n, n, cf);
+    HIP_OK(hipEventRecord(e1, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipGetLastError());
+    (void)hipEventElapsedTime(&T->build_ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
   }
 
   // ---- batched small MSMs (host pointers).  offsets[m+1]; every instance must have <= 1024 points (larger instances go
@@ -1810,6 +1990,8 @@ template <class G> class MsmEngine {
   uint64_t* d_in_scalars = nullptr;
   uint8_t* d_in_inf = nullptr;
   uint32_t* h_out = nullptr;
+  uint64_t* d_fx_scalars = nullptr;    // staged scalars of the fixed-base form (run_fixed)
+  size_t cap_fx = 0;
   uint64_t* d_side_out = nullptr;      // results of a chained batch call that went through the big pipeline (run_batch)
   size_t side_out_bytes = 0;
   bool side_path = false;

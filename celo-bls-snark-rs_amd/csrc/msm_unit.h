@@ -281,6 +281,40 @@ int msm_multi_host_impl(Pool& pool, int force_c, const int* devices, int ndev, c
   int msm_join_windows_##TAG(const uint64_t* xyzz, const int* bit_lo, int nshards, uint64_t* out) {                      \
     return join_windows_impl<G>(xyzz, bit_lo, nshards, out);                                                             \
   }                                                                                                                      \
+  /* fixed-base form: per-key tables (msm.h FixedTable).  resident = 1: DEVICE pointers */                               \
+  int msm_fixed_build_##TAG(const void* b, const void* inf, size_t n, int resident, int cf, FixedTable** out) {          \
+    if (int rc = api_enter()) return rc;                                                                                 \
+    if (!b || !out || n == 0) return 2;                                                                                  \
+    typedef PointIO<G::F> IO_;                                                                                           \
+    auto e = pool_##TAG().lease();           /* an engine's stream; the table itself belongs to the handle */            \
+    void *db = nullptr, *di = nullptr;                                                                                   \
+    int rc = 0;                                                                                                          \
+    if (!resident) {                                                                                                     \
+      if (hipMalloc(&db, n * 2 * IO_::ARK64 * 8) != hipSuccess) return 1;                                                \
+      if (hipMemcpyAsync(db, b, n * 2 * IO_::ARK64 * 8, hipMemcpyHostToDevice, e->own_stream()) != hipSuccess) rc = 1;   \
+      if (!rc && inf) {                                                                                                  \
+        if (hipMalloc(&di, n) != hipSuccess || hipMemcpyAsync(di, inf, n, hipMemcpyHostToDevice, e->own_stream()) != hipSuccess) rc = 1; \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    FixedTable* T = new FixedTable();                                                                                    \
+    if (!rc) rc = MsmEngine<G>::fixed_build((const uint64_t*)(resident ? b : db), (const uint8_t*)(resident ? inf : di), n, cf, T, e->own_stream()); \
+    if (db) (void)hipFree(db);                                                                                           \
+    if (di) (void)hipFree(di);                                                                                           \
+    if (rc) { if (T->table) (void)hipFree(T->table); if (T->tinf) (void)hipFree(T->tinf); delete T; return rc; }         \
+    *out = T;                                                                                                            \
+    return 0;                                                                                                            \
+  }                                                                                                                      \
+  int msm_fixed_run_##TAG(const FixedTable* T, const void* s, size_t n_sc, int resident, uint64_t* out, void* st) {      \
+    if (int rc = api_enter()) return rc;                                                                                 \
+    if (!T || !T->table || (!s && n_sc) || !out) return 2;                                                               \
+    if (T->device != api_device()) return 101;        /* the table lives on the device it was built on */                \
+    auto e = pool_##TAG().lease();                                                                                       \
+    e->force_c = 0;                                                                                                      \
+    e->big_subgroup_points = false;                                                                                      \
+    const int rc = e->run_fixed(*T, s, n_sc, resident, out, resident && st ? (hipStream_t)st : e->own_stream());         \
+    if (!rc && n_sc) last_##TAG().note(*e);                                                                              \
+    return rc;                                                                                                           \
+  }                                                                                                                      \
   void msm_big_timings_##TAG(float ms[5], int cfg[3]) { last_##TAG().read(ms, cfg); }                                    \
   void msm_big_set_c_##TAG(int c) { force_c_##TAG.store(c); }                                                            \
   }

@@ -30,6 +30,14 @@ int msm_host_g1_377(const uint64_t*, const uint8_t*, const uint64_t*, size_t, in
 int msm_host_g2_377(const uint64_t*, const uint8_t*, const uint64_t*, size_t, int, uint64_t*);
 int sum_jac_g1_377(const uint64_t*, size_t, uint64_t*);
 int sum_jac_g2_377(const uint64_t*, size_t, uint64_t*);
+struct FixedTable;                                   // msm.h: a query's fixed-base tables
+int msm_fixed_build_761(const void*, const void*, size_t, int, int, FixedTable**);
+int msm_fixed_run_761(const FixedTable*, const void*, size_t, int, uint64_t*, void*);
+int msm_fixed_build_g1_377(const void*, const void*, size_t, int, int, FixedTable**);
+int msm_fixed_run_g1_377(const FixedTable*, const void*, size_t, int, uint64_t*, void*);
+int msm_fixed_build_g2_377(const void*, const void*, size_t, int, int, FixedTable**);
+int msm_fixed_run_g2_377(const FixedTable*, const void*, size_t, int, uint64_t*, void*);
+int fixed_table_release(FixedTable*);
 template <class FR> struct NttOf;
 template <> struct NttOf<Fr761> { static int run(uint64_t* d, unsigned l, const uint64_t* w, const uint64_t* g, int after, const uint64_t* sc, void* st) { return ntt_run(d, l, w, g, after, sc, 1, st); } };
 template <> struct NttOf<Fr377> { static int run(uint64_t* d, unsigned l, const uint64_t* w, const uint64_t* g, int after, const uint64_t* sc, void* st) { return ntt_run_253(d, l, w, g, after, sc, 1, st); } };
@@ -205,5 +213,100 @@ int groth16_prove_377_run(const uint64_t* a_query, size_t na, const uint64_t* b_
   if (int rc = sum_jac_g2_377(&t2[0][0], 3, out_b)) return rc;
   memcpy(t1[0], acc1[1], 144); memcpy(t1[1], acc1[2], 144);
   return sum_jac_g1_377(&t1[0][0], 2, out_c);
+}
+
+// ---- the same two compositions against a LOADED proving key: the queries' fixed-base tables are built once (msm.h FixedTable) and every
+// proof is four msm_*_fixed calls - the reference creates its Parameters once (crates/epoch-snark/src/api/setup.rs:63-105) and hands the
+// same ones to every create_proof_no_zk (prover.rs:78,112).  CURVE: 0 = BW6-761 (all coordinates 12 u64), 1 = BLS12-377 (G1 6, G2 12).
+struct ProvingKey {
+  int curve = 0;
+  FixedTable *a = nullptr, *b = nullptr, *l = nullptr, *h = nullptr;      // over a_query[1..], b_g2_query[1..], l_query, h_query
+  size_t na = 0, nb = 0, nl = 0, nh = 0;
+  std::vector<uint64_t> a0, b0, alpha, beta;                              // query[0] and the key elements, affine arkworks limbs
+  int device = 0;
+};
+static std::vector<uint8_t> ark_zero_flags(const uint64_t* q, size_t n, int coord64, int one64, const uint64_t* one) {
+  std::vector<uint8_t> f(n);
+  for (size_t i = 0; i < n; i++) f[i] = is_ark_zero(q + i * 2 * coord64, one, coord64, one64) ? 1 : 0;
+  return f;
+}
+void groth16_key_free(ProvingKey* k) {
+  if (!k) return;
+  for (FixedTable* t : {k->a, k->b, k->l, k->h}) if (t) (void)fixed_table_release(t);
+  delete k;
+}
+int groth16_key_load(int curve, const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh, const uint64_t* l_query,
+                     size_t nl, const uint64_t* alpha_g1, const uint64_t* beta_g2, int window_bits, ProvingKey** out) {
+  if (int rc0 = api_enter()) return rc0;
+  if (!a_query || !b_g2_query || !alpha_g1 || !beta_g2 || !out || na == 0 || nb == 0 || (nh && !h_query) || (nl && !l_query) || curve < 0 || curve > 1) return 2;
+  const int g1c = curve ? 6 : 12, g2c = 12;                // u64 per coordinate of a G1 / G2 point
+  uint64_t one[12];
+  memset(one, 0, sizeof one);
+  if (curve) Fq377d::one().to_ark(one); else Fq761d::one().to_ark(one);
+  const int one64 = curve ? 6 : 12;
+  ProvingKey* k = new ProvingKey();
+  k->curve = curve; k->na = na; k->nb = nb; k->nl = nl; k->nh = nh; k->device = api_device();
+  k->a0.assign(a_query, a_query + 2 * g1c); k->b0.assign(b_g2_query, b_g2_query + 2 * g2c);
+  k->alpha.assign(alpha_g1, alpha_g1 + 2 * g1c); k->beta.assign(beta_g2, beta_g2 + 2 * g2c);
+  auto build1 = [&](const uint64_t* q, size_t n, FixedTable** t) -> int {        // a G1 query
+    if (n == 0) return 0;
+    const std::vector<uint8_t> f = ark_zero_flags(q, n, g1c, one64, one);
+    return curve ? msm_fixed_build_g1_377(q, f.data(), n, 0, window_bits, t) : msm_fixed_build_761(q, f.data(), n, 0, window_bits, t);
+  };
+  int rc = build1(a_query + 2 * g1c, na - 1, &k->a);
+  if (!rc && nb > 1) {
+    const std::vector<uint8_t> f = ark_zero_flags(b_g2_query + 2 * g2c, nb - 1, g2c, one64, one);
+    rc = curve ? msm_fixed_build_g2_377(b_g2_query + 2 * g2c, f.data(), nb - 1, 0, window_bits, &k->b) : msm_fixed_build_761(b_g2_query + 2 * g2c, f.data(), nb - 1, 0, window_bits, &k->b);
+  }
+  if (!rc) rc = build1(l_query, nl, &k->l);
+  if (!rc) rc = build1(h_query, nh, &k->h);
+  if (rc) { groth16_key_free(k); return rc; }
+  *out = k;
+  return 0;
+}
+int groth16_prove_keyed(const ProvingKey* k, const uint64_t* assignment, size_t n_assign, size_t n_aux, const uint64_t* h, size_t n_h, uint64_t* out_a, uint64_t* out_b,
+                        uint64_t* out_c) {
+  if (int rc0 = api_enter()) return rc0;
+  if (!k || !out_a || !out_b || !out_c || (n_assign && !assignment) || n_aux > n_assign || (n_h && !h)) return 2;
+  if (k->device != api_device()) return 101;
+  const int curve = k->curve, sw = curve ? 4 : 6, g1c = curve ? 6 : 12, J1 = 3 * g1c, J2 = 36;
+  const size_t ka = (k->na - 1 < n_assign) ? k->na - 1 : n_assign, kb = (k->nb - 1 < n_assign) ? k->nb - 1 : n_assign;
+  const size_t kl = k->nl < n_aux ? k->nl : n_aux, kh = k->nh < n_h ? k->nh : n_h;
+  const uint64_t* aux = assignment + (n_assign - n_aux) * sw;
+  uint64_t acc[4][36];
+  int rcs[4] = {0, 0, 0, 0};
+  const int dev = api_device();
+  auto ident = [&](uint64_t* o, int words) { memset(o, 0, words * 8); if (curve) Fq377d::one().to_ark(o + words / 3); else Fq761d::one().to_ark(o + words / 3); };
+  auto run = [&](int i, const FixedTable* t, bool g2, const uint64_t* sc, size_t n) {
+    rcs[i] = api_bind_thread(dev);
+    if (rcs[i]) return;
+    if (!t || n == 0) { ident(acc[i], g2 ? J2 : J1); return; }
+    if (!curve) rcs[i] = msm_fixed_run_761(t, sc, n, 0, acc[i], nullptr);
+    else rcs[i] = g2 ? msm_fixed_run_g2_377(t, sc, n, 0, acc[i], nullptr) : msm_fixed_run_g1_377(t, sc, n, 0, acc[i], nullptr);
+  };
+  {
+    std::thread t0(run, 0, k->a, false, assignment, ka), t1(run, 1, k->b, true, assignment, kb), t2(run, 2, k->l, false, aux, kl);
+    run(3, k->h, false, h, kh);
+    t0.join(); t1.join(); t2.join();
+  }
+  for (int r : rcs) if (r) return r;
+  // affine (x, y) -> Jacobian (x, y, 1), or Z = 0 for arkworks' identity encoding
+  auto as_jac = [&](const uint64_t* xy, int c64, uint64_t* j) {
+    memcpy(j, xy, 2 * c64 * 8);
+    memset(j + 2 * c64, 0, c64 * 8);
+    uint64_t one[12];
+    if (curve) Fq377d::one().to_ark(one); else Fq761d::one().to_ark(one);
+    const int one64 = curve ? 6 : 12;
+    if (!is_ark_zero(xy, one, c64, one64)) memcpy(j + 2 * c64, one, one64 * 8);
+  };
+  uint64_t t1[3][36], t2[3][36];
+  as_jac(k->a0.data(), g1c, t1[0]); memcpy(t1[1], acc[0], J1 * 8); as_jac(k->alpha.data(), g1c, t1[2]);
+  uint64_t pack1[3 * 36];
+  for (int q = 0; q < 3; q++) memcpy(pack1 + q * J1, t1[q], J1 * 8);
+  if (int rc = curve ? sum_jac_g1_377(pack1, 3, out_a) : sum_jac_761(pack1, 3, out_a)) return rc;
+  as_jac(k->b0.data(), 12, t2[0]); memcpy(t2[1], acc[1], J2 * 8); as_jac(k->beta.data(), 12, t2[2]);
+  if (int rc = curve ? sum_jac_g2_377(&t2[0][0], 3, out_b) : sum_jac_761(&t2[0][0], 3, out_b)) return rc;
+  memcpy(pack1, acc[2], J1 * 8); memcpy(pack1 + J1, acc[3], J1 * 8);
+  return curve ? sum_jac_g1_377(pack1, 2, out_c) : sum_jac_761(pack1, 2, out_c);
 }
 }  // namespace celo

@@ -23,6 +23,12 @@ EXPORTS = [
     "msm_bls12_377_g1_subgroup_multi_windows_dev", "msm_bls12_377_g2_subgroup_multi_windows_dev",
     "msm_bls12_377_g1_window_shard_dev", "msm_bls12_377_g2_window_shard_dev", "msm_bw6_761_window_shard_dev",
     "msm_bls12_377_g1_join_windows", "msm_bls12_377_g2_join_windows", "msm_bw6_761_join_windows",
+    "msm_bls12_377_g1_precompute", "msm_bls12_377_g2_precompute", "msm_bw6_761_g1_precompute", "msm_bw6_761_g2_precompute",
+    "msm_bls12_377_g1_precompute_dev", "msm_bls12_377_g2_precompute_dev", "msm_bw6_761_g1_precompute_dev", "msm_bw6_761_g2_precompute_dev",
+    "msm_bls12_377_g1_fixed", "msm_bls12_377_g2_fixed", "msm_bw6_761_g1_fixed", "msm_bw6_761_g2_fixed",
+    "msm_bls12_377_g1_fixed_dev", "msm_bls12_377_g2_fixed_dev", "msm_bw6_761_g1_fixed_dev", "msm_bw6_761_g2_fixed_dev",
+    "celo_amd_msm_fixed_release", "celo_amd_msm_fixed_info",
+    "groth16_load_key_bw6_761", "groth16_load_key_bls12_377", "groth16_prove_with_key", "groth16_free_key",
     "msm_bls12_377_g1", "msm_bls12_377_g2", "msm_bw6_761_g1", "msm_bw6_761_g2",
     "msm_batch_bls12_377_g1", "msm_batch_bls12_377_g2", "msm_batch_bw6_761_g1", "msm_batch_bw6_761_g2",
     "msm_bls12_377_g1_dev", "msm_bls12_377_g2_dev", "msm_bw6_761_g1_dev", "msm_bw6_761_g2_dev",
@@ -176,6 +182,56 @@ def join_windows(group, records, bit_lo):
     if rc != 0:
         raise RuntimeError(f"msm_{group}_join_windows failed rc={rc}")
     return out
+
+
+class FixedBase:
+    """A key's fixed-base tables (msm_*_precompute): build once, then msm() / msm_dev() for every scalar vector.  window_bits 0 = automatic."""
+    def __init__(self, group, bases_xy=None, inf=None, window_bits=0, d_bases=None, d_inf=0, n=None):
+        A = GROUP_SHAPE[group][0]
+        self.group, self.h = group, C.c_void_p()
+        if d_bases is not None:
+            rc = getattr(lib(), "msm_" + group + "_precompute_dev")(C.c_void_p(d_bases), C.c_void_p(d_inf or 0), C.c_size_t(n), C.c_int(window_bits), C.byref(self.h))
+        else:
+            bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64)
+            n = bases_xy.size // A
+            rc = getattr(lib(), "msm_" + group + "_precompute")(_p(bases_xy), _p(inf), C.c_size_t(n), C.c_int(window_bits), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"msm_{group}_precompute failed rc={rc}")
+        self.n = n
+
+    def info(self):
+        n, wb, w, by, ms = C.c_size_t(), C.c_int(), C.c_int(), C.c_size_t(), C.c_float()
+        rc = lib().celo_amd_msm_fixed_info(self.h, C.byref(n), C.byref(wb), C.byref(w), C.byref(by), C.byref(ms))
+        if rc != 0:
+            raise RuntimeError(f"celo_amd_msm_fixed_info failed rc={rc}")
+        return {"n": n.value, "window_bits": wb.value, "windows": w.value, "table_bytes": by.value, "build_ms": ms.value}
+
+    def msm(self, scalars):
+        S, O = GROUP_SHAPE[self.group][1:]
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        out = np.zeros(O, dtype=np.uint64)
+        rc = getattr(lib(), "msm_" + self.group + "_fixed")(self.h, _p(scalars), C.c_size_t(scalars.size // S), _p(out))
+        if rc != 0:
+            raise RuntimeError(f"msm_{self.group}_fixed failed rc={rc}")
+        return out
+
+    def msm_dev(self, d_scalars, n_scalars, stream=0):
+        out = np.zeros(GROUP_SHAPE[self.group][2], dtype=np.uint64)
+        rc = getattr(lib(), "msm_" + self.group + "_fixed_dev")(self.h, C.c_void_p(d_scalars), C.c_size_t(n_scalars), _p(out), C.c_void_p(stream or 0))
+        if rc != 0:
+            raise RuntimeError(f"msm_{self.group}_fixed_dev failed rc={rc}")
+        return out
+
+    def release(self):
+        if self.h:
+            lib().celo_amd_msm_fixed_release(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 def msm(group, bases_xy, inf, scalars, subgroup=False):
@@ -379,6 +435,46 @@ def groth16_prove(a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, assi
     if rc != 0:
         raise RuntimeError("groth16_prove_bw6_761 failed with code %d" % rc)
     return out
+
+
+class ProvingKey:
+    """A loaded Groth16 proving key (groth16_load_key_bw6_761 / _bls12_377): the four queries' fixed-base tables, built once; prove() per
+    assignment.  curve: "bw6_761" (points (k, 24), scalars (k, 6)) or "bls12_377" (G1 (k, 12), G2 (k, 24), scalars (k, 4))."""
+    def __init__(self, curve, a_query, b_g2_query, h_query, l_query, alpha_g1, beta_g2, window_bits=0):
+        self.curve = curve
+        g1w = 24 if curve == "bw6_761" else 12
+        self.sw = 6 if curve == "bw6_761" else 4
+        self.ow = (36, 36, 36) if curve == "bw6_761" else (18, 36, 18)
+        q = [np.ascontiguousarray(a_query, dtype=np.uint64).reshape(-1, g1w), np.ascontiguousarray(b_g2_query, dtype=np.uint64).reshape(-1, 24),
+             np.ascontiguousarray(h_query, dtype=np.uint64).reshape(-1, g1w), np.ascontiguousarray(l_query, dtype=np.uint64).reshape(-1, g1w)]
+        al = np.ascontiguousarray(alpha_g1, dtype=np.uint64).reshape(g1w)
+        be = np.ascontiguousarray(beta_g2, dtype=np.uint64).reshape(24)
+        self.h = C.c_void_p()
+        fn = lib().groth16_load_key_bw6_761 if curve == "bw6_761" else lib().groth16_load_key_bls12_377
+        rc = fn(_p(q[0]), C.c_size_t(q[0].shape[0]), _p(q[1]), C.c_size_t(q[1].shape[0]), _p(q[2]), C.c_size_t(q[2].shape[0]), _p(q[3]), C.c_size_t(q[3].shape[0]),
+                _p(al), _p(be), C.c_int(window_bits), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("groth16_load_key_%s failed with code %d" % (curve, rc))
+
+    def prove(self, assignment, n_aux, h):
+        asg = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, self.sw)
+        hh = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, self.sw)
+        out = [np.zeros(w, dtype=np.uint64) for w in self.ow]
+        rc = lib().groth16_prove_with_key(self.h, _p(asg), C.c_size_t(asg.shape[0]), C.c_size_t(n_aux), _p(hh), C.c_size_t(hh.shape[0]), _p(out[0]), _p(out[1]), _p(out[2]))
+        if rc != 0:
+            raise RuntimeError("groth16_prove_with_key failed with code %d" % rc)
+        return out
+
+    def release(self):
+        if self.h:
+            lib().groth16_free_key(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 # ---- the hash-helper proof's field and curve: Fr(BLS12-377) elements are 4 u64, G1 points 12 u64 affine / 18 Jacobian, G2 24 / 36

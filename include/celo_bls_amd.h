@@ -123,6 +123,37 @@ int msm_bls12_377_g1_join_windows(const uint64_t* xyzz /* nshards x 24 */, const
 int msm_bls12_377_g2_join_windows(const uint64_t* xyzz /* nshards x 48 */, const int* bit_lo, int nshards, uint64_t out_xyz[36]);
 int msm_bw6_761_join_windows(const uint64_t* xyzz /* nshards x 48 */, const int* bit_lo, int nshards, uint64_t out_xyz[36]);
 
+/* ---- FIXED-BASE MSM: per-key tables for bases that stay while the scalars change - the Groth16 prover's queries
+ * (crates/epoch-snark/src/api/prover.rs:78,112 hand the SAME Parameters to every proof; they are created once,
+ * crates/epoch-snark/src/api/setup.rs:63-105).  _precompute builds, in the device memory of the calling thread's device, the table
+ * T[j][i] = 2^(c j) P_i for the W = ceil((scalar bits + 1) / c) digit positions of a scalar (affine, device form: n W x 128 B for G1 of
+ * BLS12-377, n W x 256 B for the other groups; window_bits c = 0 picks it from n, 16 <= c <= 22) and returns an opaque handle.
+ * _fixed then computes sum_i k_i P_i for the first n_scalars <= n bases (the shorter side decides, as VariableBaseMSM zips) with ALL
+ * signed c-bit digits in ONE set of 2^(c-1) buckets: one bucket reduction instead of W, no Horner chain over windows, and - c not being
+ * bound to the 16 bits of the variable-base windows - fewer digits per scalar, i.e. fewer bucket additions (19 instead of 24 per
+ * 377-bit scalar at c = 20).  Same result as msm_* (which stays VariableBaseMSM: nothing is cached behind its back).
+ * A base may be flagged as the identity (inf); a base whose 2^(c j) multiple is the identity is handled.  The handle is bound to the
+ * device it was built on (a call from a thread bound to another device returns 101) and may be used from several host threads at once.
+ * celo_amd_msm_fixed_info: the table's shape, its size in bytes and its build time (HIP events). */
+int msm_bls12_377_g1_precompute(const uint64_t* bases_xy /* n*12 */, const uint8_t* inf, size_t n, int window_bits, void** out_handle);
+int msm_bls12_377_g2_precompute(const uint64_t* bases_xy /* n*24 */, const uint8_t* inf, size_t n, int window_bits, void** out_handle);
+int msm_bw6_761_g1_precompute(const uint64_t* bases_xy /* n*24 */, const uint8_t* inf, size_t n, int window_bits, void** out_handle);
+int msm_bw6_761_g2_precompute(const uint64_t* bases_xy /* n*24 */, const uint8_t* inf, size_t n, int window_bits, void** out_handle);
+int msm_bls12_377_g1_precompute_dev(const void* d_bases_xy, const void* d_inf, size_t n, int window_bits, void** out_handle);
+int msm_bls12_377_g2_precompute_dev(const void* d_bases_xy, const void* d_inf, size_t n, int window_bits, void** out_handle);
+int msm_bw6_761_g1_precompute_dev(const void* d_bases_xy, const void* d_inf, size_t n, int window_bits, void** out_handle);
+int msm_bw6_761_g2_precompute_dev(const void* d_bases_xy, const void* d_inf, size_t n, int window_bits, void** out_handle);
+int msm_bls12_377_g1_fixed(const void* handle, const uint64_t* scalars /* n_scalars*4 */, size_t n_scalars, uint64_t out_xyz[18]);
+int msm_bls12_377_g2_fixed(const void* handle, const uint64_t* scalars /* n_scalars*4 */, size_t n_scalars, uint64_t out_xyz[36]);
+int msm_bw6_761_g1_fixed(const void* handle, const uint64_t* scalars /* n_scalars*6 */, size_t n_scalars, uint64_t out_xyz[36]);
+int msm_bw6_761_g2_fixed(const void* handle, const uint64_t* scalars /* n_scalars*6 */, size_t n_scalars, uint64_t out_xyz[36]);
+int msm_bls12_377_g1_fixed_dev(const void* handle, const void* d_scalars, size_t n_scalars, uint64_t out_xyz[18], void* hip_stream);
+int msm_bls12_377_g2_fixed_dev(const void* handle, const void* d_scalars, size_t n_scalars, uint64_t out_xyz[36], void* hip_stream);
+int msm_bw6_761_g1_fixed_dev(const void* handle, const void* d_scalars, size_t n_scalars, uint64_t out_xyz[36], void* hip_stream);
+int msm_bw6_761_g2_fixed_dev(const void* handle, const void* d_scalars, size_t n_scalars, uint64_t out_xyz[36], void* hip_stream);
+int celo_amd_msm_fixed_release(void* handle);
+int celo_amd_msm_fixed_info(const void* handle, size_t* n, int* window_bits, int* windows, size_t* table_bytes, float* build_ms);
+
 /* ---- batched MSMs: m independent instances in one call; instance p owns points/scalars [offsets[p], offsets[p+1])
  * (offsets has m+1 entries), out_xyz holds m Jacobian results back to back.  This is the shape of Batch::verify
  * (crates/bls-crypto/src/bls/batch.rs:69,76 — one G2 and one G1 MSM over the batch's signers) when
@@ -233,6 +264,20 @@ int groth16_witness_map_bw6_761_dev(uint64_t* d_a, uint64_t* d_b, uint64_t* d_c,
 int groth16_prove_bw6_761(const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh, const uint64_t* l_query,
                           size_t nl, const uint64_t alpha_g1[24], const uint64_t beta_g2[24], const uint64_t* assignment, size_t n_assignment, size_t n_aux,
                           const uint64_t* h, size_t n_h, uint64_t out_a[36], uint64_t out_b[36], uint64_t out_c[36]);
+
+/* ---- the proof against a LOADED key: groth16_load_key_* builds the fixed-base tables of the four queries once (msm_*_precompute above; the
+ * reference creates its Parameters once, crates/epoch-snark/src/api/setup.rs:63-105, and hands the same ones to every
+ * create_proof_no_zk, prover.rs:78,112); groth16_prove_with_key then computes A, B, C of groth16_prove_bw6_761 / _bls12_377 with four
+ * msm_*_fixed calls (concurrent, one engine each) and no query crossing PCIe again.  Same arguments, identity-row rule, results and
+ * error behaviour as the entry points above; a_query[0] / b_g2_query[0] / alpha / beta are kept with the key.  window_bits: the tables'
+ * window size (0 = automatic).  A key is bound to the device it was loaded on (101 from another) and may prove from several threads. */
+int groth16_load_key_bw6_761(const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh, const uint64_t* l_query, size_t nl,
+                             const uint64_t alpha_g1[24], const uint64_t beta_g2[24], int window_bits, void** out_key);
+int groth16_load_key_bls12_377(const uint64_t* a_query, size_t na, const uint64_t* b_g2_query, size_t nb, const uint64_t* h_query, size_t nh, const uint64_t* l_query, size_t nl,
+                               const uint64_t alpha_g1[12], const uint64_t beta_g2[24], int window_bits, void** out_key);
+int groth16_prove_with_key(const void* key, const uint64_t* assignment, size_t n_assignment, size_t n_aux, const uint64_t* h, size_t n_h, uint64_t* out_a, uint64_t* out_b,
+                           uint64_t* out_c);
+int groth16_free_key(void* key);
 
 /* ---- the same three steps over BLS12-377: the hash-helper proof of an epoch (crates/epoch-snark/src/api/prover.rs:83-118,
  * create_proof_no_zk::<BLSCurve, _> at :112), whose witness map runs over Fr(BLS12-377) (253 bits, 2-adicity 47; elements are 4 u64 in

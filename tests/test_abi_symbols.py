@@ -72,3 +72,19 @@ def test_no_device_fails_loudly():
         ffi.use_device(0)
     with pytest.raises(RuntimeError):
         ffi.device_count()
+
+
+def test_no_stray_c_symbols_exported():
+    """the library once exported unprefixed globals (q_mu, q_cv, q_pending, q_leader, run_products) next to the
+    reference-mandated `init` / `verify` - a collision waiting in a cgo host process.  Every unmangled dynamic symbol must be declared in
+    include/*.h or carry the celo_ prefix."""
+    import subprocess
+    from celo_bls_snark_rs_amd import ffi
+    out = subprocess.run(["nm", "-D", "--defined-only", ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    plain = [n for n in names if not n.startswith("_Z") and not n.startswith("__hip") and not n.startswith("_")]
+    hdr = ""
+    for h in ("celo_bls_amd.h", "celo_bls_snark_sys.h"):
+        hdr += open(os.path.join(ROOT, "include", h)).read()
+    stray = [n for n in plain if not n.startswith("celo_") and not re.search(r"\b%s\s*\(" % re.escape(n), hdr)]
+    assert stray == [], stray

@@ -492,6 +492,25 @@ def test_ifma_horner_matches_the_64_bit_epilogue(ht, field, prime, n64, stride):
             order.append(w | 0x40000000)
         rc, o1, o2 = both(pts, order)
         assert rc == 0 and (o1 == o2).all()
+    # the fixed-base epilogue (msm.h, fx branch): NV virtual windows' results added side by side at every step of ONE chain - the bits
+    # of v from the top, then the 15 levels, then the nodes - with most slots the identity when the input is small
+    for nv, ident in [(1, 0.0), (2, 0.0), (4, 0.5), (8, 0.0), (8, 0.7), (8, 0.95), (16, 0.3), (16, 0.9), (64, 0.5)]:
+        LB = 15
+        pts = slots((LB + 1) * nv, ident)
+        order, kb = [], 0
+        while (1 << kb) < nv:
+            kb += 1
+        for k in range(kb - 1, -1, -1):
+            order.append(-1)
+            order += [v | 0x40000000 for v in range(nv) if (v >> k) & 1]
+        for l in range(1, LB + 1):
+            order.append(-1)
+            order += [(l * nv + v) | 0x40000000 for v in range(nv)]
+        order += [v | 0x40000000 for v in range(nv)]
+        rc, o1, o2 = both(pts, order)
+        assert rc in (0, 1), (nv, ident)
+        if rc == 0:
+            assert (o1 == o2).all(), (nv, ident)
     # all slots the identity -> identity (all-zero output on both paths)
     rc, o1, o2 = both(np.zeros((4, stride), dtype=np.uint64), [0, 1, 2, 3])
     assert rc == 0 and not o1.any() and not o2.any()

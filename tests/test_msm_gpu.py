@@ -276,6 +276,53 @@ def test_g2_large_device_resident(gpu):
     assert _affine(out, "g2_377") == co.jac_to_affine(exp, "g2_377")
 
 
+@pytest.mark.parametrize("log_n,seed", [(17, 1), (17, 2), (17, 3), (20, 1), (20, 2), (20, 3)])
+def test_g2_plain_entry_two_to_17_and_20(gpu, log_n, seed):
+    """the PLAIN G2 entry point (msm_bls12_377_g2_dev, no endomorphism) at 2^17 and 2^20 terms, three seeds each - the
+    sizes where the round-3 signed form of the Fq2 R t - Y1 PPP pass produced wrong sums while every smaller test stayed green, and
+    which -m gpu did not cover (2^14 plain, 2^17 only through the _subgroup entry, 2^22 through config 5).  Uniform 253-bit scalars with
+    r - 1, 2^252 and runs of equal / opposite bases mixed in."""
+    n = 1 << log_n
+    gen, _ = co.pack_g2_377([ecc.G2_377])
+    bases = _gen_points_gpu(gpu, "bls12_377_g2", n, 0x5EED2000 + 97 * seed + log_n, gen.reshape(-1), 24)
+    rng = np.random.default_rng(1000 * log_n + seed)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    sc ^= rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)                       # below 2^252 < r
+    sc[:4] = H.scalars_np([ecc.R377 - 1, 1 << 252, 0, 1], 4)
+    h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 24).copy()
+    h_bases[100:108] = h_bases[100]                            # equal bases with equal scalars: the doubling branch inside a bucket
+    sc[100:108] = sc[100]
+    h_bases[200] = h_bases[201]; h_bases[200, 12:18] = co.to_mont([(ecc.Q377 - v) % ecc.Q377 for v in co.from_mont(h_bases[201, 12:18], ecc.Q377)], ecc.Q377)[0]
+    h_bases[200, 18:24] = co.to_mont([(ecc.Q377 - v) % ecc.Q377 for v in co.from_mont(h_bases[201, 18:24], ecc.Q377)], ecc.Q377)[0]
+    sc[200] = sc[201]                                          # opposite bases with equal scalars: the cancellation branch
+    d_b = torch.from_numpy(h_bases.view(np.int64)).cuda()
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = gpu.msm_dev("bls12_377_g2", d_b.data_ptr(), 0, d_sc.data_ptr(), n)
+    exp = co.msm("bls12_377_g2", h_bases, None, sc, threads=max(1, min(32, co.lib().orc_hardware_threads())))
+    assert _affine(out, "g2_377") == co.jac_to_affine(exp, "g2_377")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_bw6_761_g2_two_to_17(gpu, golden, seed):
+    """BW6-761 G2 (the prover's b_g2_query) at 2^17 terms, three seeds: -m gpu checked this group at n <= 2048 only."""
+    from oracle.py import epoch as ep
+    vk = ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))
+    n = 1 << 17
+    gen, _ = co.pack_761([vk["beta_g2"]])
+    bases = _gen_points_gpu(gpu, "bw6_761_g2", n, 0x5EED7612 + seed, gen.reshape(-1), 24)
+    rng = np.random.default_rng(7610 + seed)
+    sc = rng.integers(0, 1 << 63, size=(n, 6), dtype=np.int64).astype(np.uint64)
+    sc ^= rng.integers(0, 1 << 63, size=(n, 6), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    sc[:, 5] &= np.uint64((1 << 56) - 1)
+    sc[:3] = H.scalars_np([ecc.R761 - 1, 1 << 376, 1], 6)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = gpu.msm_dev("bw6_761_g2", bases.data_ptr(), 0, d_sc.data_ptr(), n)
+    h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 24)
+    exp = co.msm("bw6_761_g2", h_bases, None, sc, threads=max(1, min(32, co.lib().orc_hardware_threads())))
+    assert _affine(out, "761") == co.jac_to_affine(exp, "761")
+
+
 @pytest.mark.parametrize("n", [1, 40, 2048])
 def test_bw6_761_vs_oracle(gpu, golden, n):
     """BASELINE config 4 shape (Groth16 prover MSM over BW6-761 G1/G2) at oracle-checkable sizes; base points derived

@@ -128,6 +128,16 @@ def test_prove_no_zk_on_gpu_matches_oracle(gpu):
     wa2, wb2, wc2 = gp.prove_no_zk(a2, b2, h2, l2, alpha, zero_row, co.limbs_to_ints(asg2, 6), n_aux, h_ints)
     assert co.jac_to_affine(A, "761") == wa2 and co.jac_to_affine(B, "761") == wb2 and co.jac_to_affine(Cc, "761") == wc2
     assert (wa2, wb2, wc2) != (wa, wb, wc)
+    # the same proofs against a LOADED key (groth16_load_key_bw6_761 + groth16_prove_with_key: the queries' fixed-base tables built once),
+    # two assignments on one key, identity rows included
+    for wb_ in (0, 17):
+        key = gpu.ProvingKey("bw6_761", a2, b2, h2, l2, alpha, zero_row, window_bits=wb_)
+        A, B, Cc = key.prove(asg2, n_aux, h)
+        assert co.jac_to_affine(A, "761") == wa2 and co.jac_to_affine(B, "761") == wb2 and co.jac_to_affine(Cc, "761") == wc2
+        A, B, Cc = key.prove(asg, n_aux, h[: n - 50])
+        wa3, wb3, wc3 = gp.prove_no_zk(a2, b2, h2, l2, alpha, zero_row, co.limbs_to_ints(asg, 6), n_aux, h_ints[: n - 50])
+        assert co.jac_to_affine(A, "761") == wa3 and co.jac_to_affine(B, "761") == wb3 and co.jac_to_affine(Cc, "761") == wc3
+        key.release()
 
 
 # ------------------------------------------------------------------------------------------------ the hash-helper proof: BLS12-377
@@ -305,3 +315,8 @@ def test_prove_bls12_377_identity_rows_under_the_glv_split(gpu):
     wa, wb, wc = gp.prove_no_zk_bls12_377(a_query, b_query, h_query, l_query, alpha, z2, co.limbs_to_ints(asg, 4), n_aux, co.limbs_to_ints(h, 4))
     assert co.jac_to_affine(A, "g1_377") == wa and co.jac_to_affine(B, "g2_377") == wb and co.jac_to_affine(Cc, "g1_377") == wc
     assert wa is not None and wb is not None and wc is not None
+    # ... and against the loaded key (groth16_load_key_bls12_377): G1 tables for a / l / h, a G2 table for b
+    key = gpu.ProvingKey("bls12_377", a_query, b_query, h_query, l_query, alpha, z2)
+    A, B, Cc = key.prove(asg, n_aux, h)
+    assert co.jac_to_affine(A, "g1_377") == wa and co.jac_to_affine(B, "g2_377") == wb and co.jac_to_affine(Cc, "g1_377") == wc
+    key.release()

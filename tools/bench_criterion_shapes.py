@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""The reference's own benchmark - crates/bls-crypto/benches/batch_bls.rs:12-96 (criterion group "bls"): 300 blocks x 20 validators, 32-byte
+message + 32 bytes of extra data per block, the COMPOSITE CIP22 hasher (batch_bls.rs:19) - through the reference-named C ABI (Seam A,
+include/celo_bls_snark_sys.h), beside the CPU port (oracle/cpu) on this box's cores.  Four shapes, as the reference defines them:
+
+  1 "per-epoch aggregate screening"       300 x PublicKey::verify on a 20-validator aggregate                 (batch_bls.rs:62-72)
+  2 "all epoch aggregate screening"       ONE Signature::batch_verify over the 300 (aggregate key, message)   (:74-80)
+  3 "per-epoch batch verification"        300 x Batch::verify with n = 20                                     (:82-88)
+  4 "per-epoch individual verification"   300 x Batch::verify_each = 6000 x verify                            (:90-96)
+
+Seam A column: wall time of the FFI calls, hashing included (what criterion times).  Shape 3 is timed both as the reference's FFI would be
+driven for many batches (ONE batch_verify_strict call over the 300 batches, signatures.rs:343-400) and as 300 calls of one batch; shapes 1
+and 4 issue their verify_signature calls from one thread (as criterion does) and from 16 threads (the library combines concurrent single
+products into shared launches).
+CPU column ("port", not the Rust binary - no toolchain): the oracle's restatement of the arkworks pairing / MSM on the same points, hashes
+precomputed - i.e. WITHOUT the hash-to-G1 the reference's numbers include (the oracle's composite hasher is Python); one thread, as
+criterion runs the reference.  The n = 20 latency shapes are where the GPU path is weakest: the lines say so.
+usage: bench_criterion_shapes.py [blocks=300] [validators=20]"""
+import ctypes as C, json, os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from celo_bls_snark_rs_amd import ffi
+from oracle.py import ecc
+from oracle import cpu_oracle as co
+
+lib = C.CDLL(ffi.LIB_PATH)
+for f in ("init", "generate_private_key", "private_key_to_public_key", "sign_message", "verify_signature", "batch_verify_signature", "batch_verify_strict",
+          "aggregate_public_keys", "aggregate_signatures", "serialize_public_key_uncompressed", "serialize_signature_uncompressed", "free_vec", "celo_amd_hash_to_g1"):
+    getattr(lib, f).restype = C.c_bool
+assert lib.init()
+COMP, CIP = C.c_bool(True), C.c_bool(True)
+
+
+class Buffer(C.Structure):
+    _fields_ = [("ptr", C.c_char_p), ("len", C.c_size_t)]
+
+
+class MessageFFI(C.Structure):
+    _fields_ = [("data", Buffer), ("extra", Buffer), ("public_key", C.c_void_p), ("sig", C.c_void_p)]
+
+
+class BatchMessageFFI(C.Structure):
+    _fields_ = [("data", Buffer), ("extra", Buffer), ("public_keys", C.POINTER(C.c_void_p)), ("public_keys_len", C.c_size_t),
+                ("signatures", C.POINTER(C.c_void_p)), ("signatures_len", C.c_size_t)]
+
+
+def unc(handle, fn):
+    out, n = C.c_void_p(), C.c_int()
+    assert getattr(lib, fn)(handle, C.byref(out), C.byref(n))
+    data = bytes(C.cast(out, C.POINTER(C.c_ubyte * n.value)).contents)
+    lib.free_vec(out, n)
+    return data
+
+
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+NV = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+rng = np.random.default_rng(0xB15)
+blocks = []
+t_setup = time.perf_counter()
+for b in range(NB):
+    msg, extra = rng.bytes(32), rng.bytes(32)
+    pks, sigs = [], []
+    for _ in range(NV):
+        sk, pk, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        assert lib.generate_private_key(C.byref(sk)) and lib.private_key_to_public_key(sk, C.byref(pk))
+        assert lib.sign_message(sk, msg, 32, extra, 32, COMP, CIP, C.byref(s))
+        pks.append(pk); sigs.append(s)
+    pk_arr = (C.c_void_p * NV)(*[p.value for p in pks])
+    sg_arr = (C.c_void_p * NV)(*[s.value for s in sigs])
+    apk, asig = C.c_void_p(), C.c_void_p()
+    assert lib.aggregate_public_keys(pk_arr, C.c_int(NV), C.byref(apk)) and lib.aggregate_signatures(sg_arr, C.c_int(NV), C.byref(asig))
+    blocks.append({"msg": msg, "extra": extra, "pks": pks, "sigs": sigs, "pk_arr": pk_arr, "sg_arr": sg_arr, "apk": apk, "asig": asig})
+t_setup = time.perf_counter() - t_setup
+
+
+def best(fn, reps=3):
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return min(ts) * 1e3
+
+
+def verify_one(pk, msg, extra, sig):
+    ok = C.c_bool(False)
+    assert lib.verify_signature(pk, msg, 32, extra, 32, sig, COMP, CIP, C.byref(ok)) and ok.value
+
+
+def threaded(jobs, nthreads):
+    def run(chunk):
+        for j in chunk:
+            verify_one(*j)
+    th = [threading.Thread(target=run, args=(jobs[i::nthreads],)) for i in range(nthreads)]
+    for t in th: t.start()
+    for t in th: t.join()
+
+
+res = {"shape": "%d blocks x %d validators, composite CIP22 hasher, 32 B message + 32 B extra data" % (NB, NV), "setup_s": round(t_setup, 2)}
+# ---- 1: per-epoch aggregate screening
+jobs1 = [(b["apk"], b["msg"], b["extra"], b["asig"]) for b in blocks]
+res["1_per_epoch_aggregate_screening"] = {"seam_a_ms_one_thread": best(lambda: [verify_one(*j) for j in jobs1]), "seam_a_ms_16_threads": best(lambda: threaded(jobs1, 16)),
+                                          "calls": NB}
+# ---- 2: all epoch aggregate screening
+marr = (MessageFFI * NB)(*[MessageFFI(Buffer(b["msg"], 32), Buffer(b["extra"], 32), b["apk"].value, b["asig"].value) for b in blocks])
+
+
+def shape2():
+    ok = C.c_bool(False)
+    assert lib.batch_verify_signature(marr, C.c_size_t(NB), COMP, CIP, C.byref(ok)) and ok.value
+
+
+res["2_all_epoch_aggregate_screening"] = {"seam_a_ms": best(shape2), "calls": 1, "pairs": NB + 1}
+# ---- 3: per-epoch batch verification
+barr = (BatchMessageFFI * NB)(*[BatchMessageFFI(Buffer(b["msg"], 32), Buffer(b["extra"], 32), b["pk_arr"], NV, b["sg_arr"], NV) for b in blocks])
+out = (C.c_bool * NB)()
+
+
+def shape3_one_call():
+    assert lib.batch_verify_strict(barr, C.c_size_t(NB), COMP, CIP, out) and all(out)
+
+
+def shape3_per_batch():
+    o1 = (C.c_bool * 1)()
+    for i in range(NB):
+        one = (BatchMessageFFI * 1)(barr[i])
+        assert lib.batch_verify_strict(one, C.c_size_t(1), COMP, CIP, o1) and o1[0]
+
+
+res["3_per_epoch_batch_verification"] = {"seam_a_ms_one_call_all_batches": best(shape3_one_call), "seam_a_ms_one_call_per_batch": best(shape3_per_batch, reps=2), "batches": NB, "signers": NV}
+# ---- 4: per-epoch individual verification
+jobs4 = [(b["pks"][v], b["msg"], b["extra"], b["sigs"][v]) for b in blocks for v in range(NV)]
+sub = jobs4[: max(NV, len(jobs4) // 10)]                         # one thread: a tenth of the 6000 calls, scaled (2.7 ms each: the whole set is 16 s per repetition)
+ms_sub = best(lambda: [verify_one(*j) for j in sub], reps=2)
+res["4_per_epoch_individual_verification"] = {"seam_a_ms_one_thread": ms_sub * len(jobs4) / len(sub), "one_thread_sample_calls": len(sub),
+                                              "seam_a_ms_16_threads": best(lambda: threaded(jobs4, 16), reps=2), "calls": len(jobs4)}
+
+# ---- CPU port on the same points (hashes precomputed; one thread)
+neg_g2 = ecc.E2_377.neg(ecc.G2_377)
+
+
+def g1_of(handle):
+    return ecc.deser_point(ecc.E1_377, unc(handle, "serialize_signature_uncompressed"), compressed=False)
+
+
+def g2_of(handle):
+    return ecc.deser_point(ecc.E2_377, unc(handle, "serialize_public_key_uncompressed"), compressed=False)
+
+
+def hash_of(b):
+    out48, att = (C.c_uint8 * 48)(), C.c_int(0)
+    assert lib.celo_amd_hash_to_g1(COMP, CIP, b"ULforxof", b["msg"], 32, b["extra"], 32, out48, C.byref(att))
+    return ecc.deser_point(ecc.E1_377, bytes(out48))
+
+
+t0 = time.perf_counter()
+H = [hash_of(b) for b in blocks]
+res["product_host_hash_ms_per_message"] = (time.perf_counter() - t0) * 1e3 / NB
+samp = min(NB, 24)                                                # bounded CPU sample, scaled to the shape
+pairs1 = []
+for b, h in zip(blocks[:samp], H[:samp]):
+    g1, i1 = co.pack_g1_377([g1_of(b["asig"]), h]); g2, i2 = co.pack_g2_377([neg_g2, g2_of(b["apk"])])
+    pairs1.append((g1, i1, g2, i2))
+t0 = time.perf_counter()
+for g1, i1, g2, i2 in pairs1:
+    assert co.pairing_product_377(g1, i1, g2, i2)[1]
+cpu_verify_ms = (time.perf_counter() - t0) * 1e3 / samp
+res["1_per_epoch_aggregate_screening"]["cpu_port_ms_one_thread_no_hash"] = cpu_verify_ms * NB
+res["4_per_epoch_individual_verification"]["cpu_port_ms_one_thread_no_hash"] = cpu_verify_ms * NB * NV
+# shape 2: one (NB + 1)-pair product
+asig_all = None
+for b in blocks:
+    asig_all = ecc.E1_377.add(asig_all, g1_of(b["asig"]))
+g1, i1 = co.pack_g1_377([asig_all] + H); g2, i2 = co.pack_g2_377([neg_g2] + [g2_of(b["apk"]) for b in blocks])
+t0 = time.perf_counter()
+assert co.pairing_product_377(g1, i1, g2, i2)[1]
+res["2_all_epoch_aggregate_screening"]["cpu_port_ms_one_thread_no_hash"] = (time.perf_counter() - t0) * 1e3
+# shape 3: per batch two n-term MSMs with 136-bit exponents + one 2-pair product
+ex_rng = ecc.SplitMix64(0xE5)
+t_acc = 0.0
+for b, h in zip(blocks[:samp], H[:samp]):
+    pk_xy, _ = co.pack_g2_377([g2_of(p) for p in b["pks"]]); sg_xy, _ = co.pack_g1_377([g1_of(s) for s in b["sigs"]])
+    ex = co.ints_to_limbs([(ex_rng.next() | (ex_rng.next() << 64) | ((ex_rng.next() & 0xFF) << 128)) for _ in range(NV)], 4)
+    t0 = time.perf_counter()
+    P = co.jac_to_affine(co.msm("bls12_377_g2", pk_xy, None, ex, threads=1), "g2_377")
+    S = co.jac_to_affine(co.msm("bls12_377_g1", sg_xy, None, ex, threads=1), "g1_377")
+    a, ia = co.pack_g1_377([S, h]); q, iq = co.pack_g2_377([neg_g2, P])
+    assert co.pairing_product_377(a, ia, q, iq)[1]
+    t_acc += time.perf_counter() - t0
+res["3_per_epoch_batch_verification"]["cpu_port_ms_one_thread_no_hash"] = t_acc * 1e3 / samp * NB
+res["cpu_port"] = {"kind": "port", "cores": 1, "sample": "%d of the %d blocks, scaled; hash-to-G1 excluded (precomputed by the product's host hasher: product_host_hash_ms_per_message)" % (samp, NB)}
+res["reading"] = ("Seam A includes hashing, the CPU column does not: add NB (shapes 1-3) or NB * NV (shape 4) x the hash time for a like-for-like CPU figure.  "
+                  "Single verify calls are a latency path on the GPU (one lane group per product): from ONE thread the GPU loses to a CPU core per call; concurrent "
+                  "callers are combined into shared launches.  Batch::verify with n = 20 is two 20-term MSMs per batch: only many batches per call fill the chip.")
+print(json.dumps(res))

@@ -80,6 +80,34 @@ __global__ void __launch_bounds__(256) k_chain(const uint32_t* pts, uint32_t npt
   sink[tid] = x;
 }
 
+// the same comparison at xyzz_dbl_affine's pass M t - W y (the doubling branch of a mixed addition: equal points in one bucket), for every
+// table point and its negation
+__global__ void __launch_bounds__(256) k_dbl_affine_diag(const uint32_t* pts, uint32_t npts, uint32_t* recs, uint32_t* nrec, uint32_t cap, uint32_t* range_hits) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= 2 * npts) return;
+  const uint32_t* q = pts + (size_t)(tid >> 1) * AW;
+  Affine<F> p = {F::load(q), F::load(q + F::WORDS)};
+  if (tid & 1) p = affine_neg(p);
+  F U = F::prep(F::dbl(p.y)), V = F::sqr_nn(U), W = F::mul_nn(U, V), S = F::mul_nn(p.x, V), xx = F::sqr_nn(p.x);
+  F M = F::prep(F::add(F::add(xx, xx), xx)), M2 = F::sqr_nn(M);
+  F X3 = F::norm(F::template sub<16, 3>(M2, F::dbl(S)));
+  F t = F::prep(F::template sub<32, 1>(S, X3));
+  const Fq* ops[8] = {&M.c0, &t.c0, &M.c1, &t.c1, &W.c0, &p.y.c0, &W.c1, &p.y.c1};
+  uint32_t bad = 0;
+  for (int o = 0; o < 8; o++) for (int i = 0; i < Fq::L; i++) { const uint32_t v = ops[o]->l[i]; if (v >> 31 || ((o == 2 || o == 6) && v * 5ull >> 31)) bad = 1; if (i < Fq::L - 1 && v >> 28) bad |= 2; }
+  if (bad) atomicAdd(range_hits + (bad & 1 ? 0 : 1), 1u);
+  const Fq u0 = Fq::mul4k<-5, false>(M.c0, t.c0, M.c1, t.c1, W.c0, p.y.c0, W.c1, p.y.c1), s0 = Fq::mul4k<-5, true>(M.c0, t.c0, M.c1, t.c1, W.c0, p.y.c0, W.c1, p.y.c1);
+  const Fq u1 = Fq::mul4k<1, false>(M.c0, t.c1, M.c1, t.c0, W.c0, p.y.c1, W.c1, p.y.c0), s1 = Fq::mul4k<1, true>(M.c0, t.c1, M.c1, t.c0, W.c0, p.y.c1, W.c1, p.y.c0);
+  if (!same(u0, s0) || !same(u1, s1)) {
+    const uint32_t k = atomicAdd(nrec, 1u);
+    if (k < cap) {
+      uint32_t* r = recs + (size_t)k * REC;
+      for (int o = 0; o < 8; o++) put(r + 16 * o, *ops[o]);
+      put(r + 128, u0); put(r + 144, s0); put(r + 160, u1); put(r + 176, s1);
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const uint32_t lanes = 1u << (argc > 1 ? atoi(argv[1]) : 17), chain = argc > 2 ? (uint32_t)atoi(argv[2]) : 64, npts = 1u << 16, cap = 16;
   uint32_t *d_pts, *d_recs, *d_n, *d_sink, *d_rng;
@@ -93,9 +121,19 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(rng, d_rng, 8, hipMemcpyDeviceToHost));
   printf("%u lanes x %u mixed additions over Fq2: %u additions where the signed and the unsigned pass differ; operands with a limb >= 2^31 (or 5x one): %u, "
          "with a lower limb >= 2^28: %u\n", lanes, chain, n, rng[0], rng[1]);
+  {
+    CK(hipMemset(d_n, 0, 4)); CK(hipMemset(d_rng, 0, 8));
+    hipLaunchKernelGGL(k_dbl_affine_diag, dim3(2 * npts / 256), dim3(256), 0, 0, d_pts, npts, d_recs, d_n, cap, d_rng);
+    CK(hipDeviceSynchronize());
+    uint32_t n2 = 0, rng2[2];
+    CK(hipMemcpy(&n2, d_n, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(rng2, d_rng, 8, hipMemcpyDeviceToHost));
+    printf("xyzz_dbl_affine's pass on %u points and their negations: %u differences; operands with a limb >= 2^31 (or 5x one): %u, with a lower limb >= 2^28: %u\n",
+           npts, n2, rng2[0], rng2[1]);
+    if (n2) n = n2;      // print these records
+  }
   std::vector<uint32_t> recs((size_t)cap * REC);
   CK(hipMemcpy(recs.data(), d_recs, recs.size() * 4, hipMemcpyDeviceToHost));
-  const char* names[12] = {"R.c0", "t.c0", "R.c1", "t.c1", "Y.c0", "PPP.c0", "Y.c1", "PPP.c1", "c0 unsigned", "c0 signed", "c1 unsigned", "c1 signed"};
+  const char* names[12] = {"a.c0", "b.c0", "a.c1", "b.c1", "c.c0", "d.c0", "c.c1", "d.c1", "c0 unsigned", "c0 signed", "c1 unsigned", "c1 signed"};
   for (uint32_t k = 0; k < n && k < cap; k++) {
     printf("-- difference %u\n", k);
     for (int o = 0; o < 12; o++) { printf("  %-12s", names[o]); for (int i = 0; i < 14; i++) printf(" %08x", recs[(size_t)k * REC + 16 * o + i]); printf("\n"); }

@@ -56,31 +56,73 @@ class Ctx:
 
 
 # launch shapes the committed PMC profiles were taken at, and the profile set (profiles/<tag>_traffic.json, written by
-# tools/summarise_profile.py from the separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/r3_profiles.sh) that holds each:
+# tools/summarise_profile.py from the separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/r4_sweep.sh) that holds each:
 # kernel -> {shape: tag}.  Shapes: log2 n of an MSM, the number of products of a pairing launch, "cfg3" = 4096 batches x 256 signers.
-PROFILED = {"k_accumulate<G1_377>": {20: "r3", 22: "r3_cfg5", "cfg3": "r3_cfg3"},
-            "k_accumulate<G2_377>": {20: "r3_groups", 22: "r3_cfg5", "cfg3": "r3_cfg3"},
-            "k_accumulate<G_761>": {20: "r3_groups", 21: "r3_cfg4"},
-            "k_miller_product_slots<LPH377, 2>": {81920: "r3_pairing"}, "k_miller_prepared_slots<LPH377>": {81920: "r3"},
-            "k_prepare_lines<LPH377>": {81920: "r3"}, "k_final_exp_slots<LPH377>": {81920: "r3"}}
+PROFILED = {"k_accumulate<G1_377>": {20: "r4", 22: "r4_cfg5", "cfg3": "r4_cfg3"},
+            "k_accumulate<G2_377>": {20: "r4_groups", 22: "r4_cfg5", "cfg3": "r4_cfg3"},
+            "k_accumulate<G_761>": {20: "r4_groups", 21: "r4_cfg4"},
+            "k_miller_product_slots<LPH377, 2>": {81920: "r4_pairing"}, "k_miller_prepared_slots<LPH377>": {81920: "r4"},
+            "k_prepare_lines<LPH377>": {81920: "r4"}, "k_final_exp_slots<LPH377>": {81920: "r4"}}
+
+
+_BUILD_SIG = None
+
+
+def build_signature():
+    """{kernel: {VGPRs, AGPRs, ScratchSize, TotalSGPRs}} of the library this process runs, from the compiler's remarks next to it
+    (celo-bls-snark-rs_amd/build/unit_*.remarks.txt, written by the Makefile) - the same extraction tools/summarise_profile.py stores
+    beside a profile's traffic figures."""
+    global _BUILD_SIG
+    if _BUILD_SIG is not None:
+        return _BUILD_SIG
+    import re
+    import subprocess
+    sig = {}
+    for path in glob.glob(os.path.join(ROOT, "celo-bls-snark-rs_amd", "build", "unit_*.remarks.txt")):
+        cur = None
+        for ln in open(path, errors="replace"):
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                cur = m.group(1); sig.setdefault(cur, {}); continue
+            m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|TotalSGPRs): (\d+)", ln)
+            if m and cur:
+                sig[cur][m.group(1).split(" ")[0]] = int(m.group(2))
+    out = {}
+    if sig:
+        names = list(sig)
+        try:
+            dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, timeout=30).stdout.splitlines()
+        except Exception:
+            dem = []
+        for n, d in zip(names, dem):
+            out[d.replace("void celo::", "").replace("celo::", "").split("(")[0]] = sig[n]
+    _BUILD_SIG = out
+    return out
 
 
 def committed_traffic(kernels, shape):
-    """HBM bytes per launch (summed over `kernels`) from the committed PMC profile of this launch shape, or (None, why)."""
+    """HBM bytes per launch (summed over `kernels`) from the committed PMC profile of this launch shape, or (None, why).  The source string
+    says STALE when a kernel's registers / scratch in the build that runs differ from the profiled build's: the
+    figure then describes other code."""
     kernels = [kernels] if isinstance(kernels, str) else list(kernels)
-    total, srcs = 0.0, []
+    total, srcs, stale = 0.0, [], []
     try:
         for k in kernels:
             tag = PROFILED.get(k, {}).get(shape)
             if tag is None:
                 return None, "no committed PMC profile of this launch shape"
-            tj = json.load(open(os.path.join(ROOT, "profiles", tag + "_traffic.json"))).get("kernels", {})
-            total += tj[k]["hbm_bytes_per_launch"]
+            doc = json.load(open(os.path.join(ROOT, "profiles", tag + "_traffic.json")))
+            total += doc.get("kernels", {})[k]["hbm_bytes_per_launch"]
             if tag + "_traffic.json" not in srcs:
                 srcs.append(tag + "_traffic.json")
+            was, now = doc.get("build_signature", {}).get(k), build_signature().get(k)
+            if was is None or now is None:
+                stale.append("%s: no build signature to compare" % k)
+            elif was != now:
+                stale.append("%s: profiled build %s, this build %s" % (k, was, now))
     except Exception:
         return None, "no committed PMC profile holds these kernels"
-    return total, " + ".join(srcs)
+    return total, " + ".join(srcs) + (" - STALE (%s)" % "; ".join(stale) if stale else " (build signature matches the profiled build)")
 
 
 # ===================================================================================================== MSM configurations (2 and 4)
@@ -98,6 +140,7 @@ class MsmConfig:
         if cx.cfg == 4 and a.scaling == "weak" and not a.log_n:
             self.n = 1 << 21                                   # cfg4's job is 2^24 over 8 GPUs: the per-GPU shard is the weak unit
         self.log_n = (self.n - 1).bit_length()
+        self.fixed = None
 
     def setup(self):
         from celo_bls_snark_rs_amd import ffi, synthetic as syn

@@ -489,3 +489,20 @@ def test_g2_subgroup_entry_glv_split_device_resident(gpu, logn):
     h_bases = bases.cpu().numpy().view(np.uint64).reshape(n, 24)
     exp = co.msm("bls12_377_g2", h_bases, inf, sc, threads=max(1, min(32, co.lib().orc_hardware_threads())))
     assert _affine(out, "g2_377") == co.jac_to_affine(exp, "g2_377")
+
+
+def test_shipped_g2_accumulate_kernel_equals_the_host_replay(gpu):
+    """The regression guard that came out of the round-3 "signed pass" finding: the library's k_accumulate<G2_377>
+    - 256 VGPRs + 220 AGPRs, the kernel whose signed-pass instantiation computes wrong sums - in its SHIPPED (unsigned) instantiation,
+    on 16384 bucket runs of 24 random signed G2 points, against the host replay of the same templates for 2048 of the runs: every
+    partial sum limb for limb (tools/repro_acc, built by the Makefile).  The same tool runs the signed instantiation beside it; how
+    many of ITS runs differ depends on the compiler's register allocation and is printed, not asserted."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "celo-bls-snark-rs_amd", "build", "repro_acc")
+    assert os.path.exists(exe), "tools/repro_acc not built (make -C celo-bls-snark-rs_amd/csrc)"
+    r = subprocess.run([exe, "14", "24", "1", "2048"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-600:])
+    host = [ln for ln in r.stdout.splitlines() if ln.startswith("host replay")]
+    assert host and host[-1].endswith(": 0 differ"), r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode in (0, 2)          # 2: the signed instantiation differs somewhere (the finding itself), 4 would be the shipped kernel

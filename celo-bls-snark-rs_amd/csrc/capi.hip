@@ -82,6 +82,7 @@ float hash_last_ms();
 int pedersen_crh_run(const uint8_t*, const uint64_t*, size_t, uint8_t*);
 int pairing_run_761(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
 int batch_verify_377_run(const void*, const void*, const void*, const void*, const void*, int, const uint32_t*, const void*, const void*, const uint64_t*, size_t, uint8_t*);
+int draw_exponents_run(const uint32_t*, const uint32_t*, size_t, uint64_t*);
 int witness_map_run(uint64_t*, uint64_t*, uint64_t*, unsigned, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, int, int, void*);
 int groth16_prove_761_run(const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, const uint64_t*,
                           const uint64_t*, size_t, size_t, const uint64_t*, size_t, uint64_t*, uint64_t*, uint64_t*);
@@ -308,6 +309,7 @@ int batch_verify_bls12_377_dev(const void* d_pk_xy, const void* d_pk_inf, const 
                                const uint32_t* offsets, const void* d_hash_xy, const void* d_hash_inf, const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {
   return batch_verify_377_run(d_pk_xy, d_pk_inf, d_sig_xy, d_sig_inf, d_exponents, 1, offsets, d_hash_xy, d_hash_inf, neg_g2_xy, m, out_ok);
 }
+int celo_amd_draw_batch_exponents(const uint32_t key[8], const uint32_t* offsets, size_t m, uint64_t* out) { return draw_exponents_run(key, offsets, m, out); }
 int celo_amd_pairing_last_timings(float ms[4]) { return pairing_timings_377(ms); }
 int ntt_bw6_761_fr(uint64_t* data, unsigned log_n, const uint64_t omega[6], const uint64_t* coset, int coset_after, const uint64_t* scale) {
   return ntt_run(data, log_n, omega, coset, coset_after, scale, 0, nullptr);

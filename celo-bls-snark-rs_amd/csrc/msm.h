@@ -800,14 +800,28 @@ __global__ void __launch_bounds__(64) k_results_to_ark(uint32_t* __restrict__ wo
 // OR of every scalar, limb by limb: the batch path sizes its window count by the longest scalar actually present (Batch::verify
 // hands over 136-bit exponents in 253-bit containers: 28 windows of 5 bits instead of 51, and no idle lanes in the per-window
 // kernels)
+// (round 4: 16-byte loads on a grid that covers the chip several times over - the 65 536-lane, 4-byte-load version took 0.43 ms for the
+// 32 MB of config 3, on the critical path of both legs of every batch_verify call; limb q of a scalar sits in lane group q / 4)
 template <int SW>
 __global__ void __launch_bounds__(256) k_scalar_or(const uint32_t* __restrict__ scalars, size_t words, uint32_t* __restrict__ out) {
-  uint32_t acc = 0;                                   // thread t only ever sees limb position t % SW (the stride is a multiple of SW)
-  const size_t stride = (size_t)gridDim.x * blockDim.x / SW * SW;
+  static_assert(SW % 4 == 0, "scalars are whole 16-byte groups");
+  constexpr size_t G4 = SW / 4;
+  const size_t quads = words / 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x / G4 * G4;    // a multiple of G4: a lane only ever sees one 16-byte group of the scalar
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= stride) return;
-  for (; i < words; i += stride) acc |= scalars[i];
-  if (acc) atomicOr(out + (blockIdx.x * blockDim.x + threadIdx.x) % SW, acc);
+  const uint4* q = (const uint4*)scalars;
+  uint4 acc = {0u, 0u, 0u, 0u};
+  for (i = i < stride ? i : quads; i < quads; i += stride) { const uint4 v = q[i]; acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w; }
+  __shared__ uint32_t blk[SW];                                      // per block in LDS first: SW global atomics per block, not 4 per lane
+  if (threadIdx.x < SW) blk[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t* o = blk + 4 * (((size_t)blockIdx.x * blockDim.x + threadIdx.x) % G4);
+  if (acc.x) atomicOr(o, acc.x);
+  if (acc.y) atomicOr(o + 1, acc.y);
+  if (acc.z) atomicOr(o + 2, acc.z);
+  if (acc.w) atomicOr(o + 3, acc.w);
+  __syncthreads();
+  if (threadIdx.x < SW && blk[threadIdx.x]) atomicOr(out + threadIdx.x, blk[threadIdx.x]);
 }
 template <int SW, int CB, int PT>
 __global__ void __launch_bounds__(256) k_batch_sort(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
@@ -1878,7 +1892,7 @@ template <class G> class MsmEngine {
       char* A0 = arena;
       if (!resident) HIP_OK(hipMemcpyAsync(A0 + o_in_s, scalars, (size_t)total_pts * SW * 4, hipMemcpyHostToDevice, stream));
       HIP_OK(hipMemsetAsync(A0 + o_or, 0, 64 * 4, stream));
-      hipLaunchKernelGGL((k_scalar_or<SW>), dim3(256), dim3(256), 0, stream, resident ? (const uint32_t*)scalars : (const uint32_t*)(A0 + o_in_s),
+      hipLaunchKernelGGL((k_scalar_or<SW>), dim3(2048), dim3(256), 0, stream, resident ? (const uint32_t*)scalars : (const uint32_t*)(A0 + o_in_s),
                          (size_t)total_pts * SW, (uint32_t*)(A0 + o_or));
       uint32_t h_or[SW];
       HIP_OK(hipMemcpyAsync(h_or, A0 + o_or, SW * 4, hipMemcpyDeviceToHost, stream));

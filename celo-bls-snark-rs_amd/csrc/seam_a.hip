@@ -20,6 +20,8 @@
 #include <unordered_set>
 #include <thread>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <list>
 #include <string>
@@ -42,13 +44,100 @@ typedef Fp<P377> Fq_;
 typedef Fp2<P377> Fq2_;
 
 struct PrivateKey { uint64_t k[4]; };          // Fr, canonical
-struct PublicKey { uint64_t xyz[36]; };         // G2 Jacobian, arkworks Montgomery limbs (GroupProjective<g2>)
-struct Signature { uint64_t xyz[18]; };         // G1 Jacobian
+// PublicKey / Signature handles live in ARENAS (HandleArena below): a handle is its slot of the arena plus the serial number of the
+// allocation that filled the slot.  batch_verify_strict keeps a per-device mirror of the arenas' points in HBM (affine, one entry per
+// slot, tagged with the serial it was uploaded for), so a call over handles the device has already seen ships 4-byte slot numbers, not
+// 320 bytes per signer: validator keys recur epoch after epoch (the reason the reference memoises their decompression,
+// crates/bls-crypto/src/bls/cache.rs:36), and the handle types are opaque to every caller.
+struct PublicKey { uint64_t xyz[36]; uint64_t serial; uint32_t slot; };         // G2 Jacobian, arkworks Montgomery limbs (GroupProjective<g2>)
+struct Signature { uint64_t xyz[18]; uint64_t serial; uint32_t slot; };         // G1 Jacobian
 
 namespace {
 // errors are logged and mapped to `false` like the reference's convert_result_to_bool (log::error! + false)
 void log_err(const char* what) { if (getenv("CELO_AMD_LOG")) fprintf(stderr, "[celo-amd] %s\n", what); }
 const uint64_t R_ORDER[4] = {0x0a11800000000001ULL, 0x59aa76fed0000001ULL, 0x60b44d1e5c37b001ULL, 0x12ab655e9a2ca556ULL};
+
+// Chunked slab with a free list.  A handle's address never moves (chunks are never reallocated or released), its contents are written
+// once, by the entry point that creates it, before the caller sees it; release() puts the slot back and the next alloc() of that slot
+// carries a new serial, which is what marks the device mirrors' copy of the slot stale.  Serials are 64-bit and never 0.
+template <class T> struct HandleArena {
+  static constexpr uint32_t CHUNK = 1u << 14;
+  std::mutex mu;
+  std::vector<T*> chunks;
+  std::vector<uint32_t> free_slots;
+  uint32_t next = 0;
+  uint64_t serial = 0;
+  T* alloc() {
+    std::lock_guard<std::mutex> lk(mu);
+    uint32_t s;
+    if (!free_slots.empty()) { s = free_slots.back(); free_slots.pop_back(); }
+    else {
+      if (next == 0xffffffffu) return nullptr;
+      if ((size_t)next == chunks.size() * CHUNK) {
+        T* c = (T*)malloc((size_t)CHUNK * sizeof(T));
+        if (!c) return nullptr;
+        try { chunks.push_back(c); } catch (...) { free(c); return nullptr; }
+      }
+      s = next++;
+    }
+    T* p = &chunks[s / CHUNK][s % CHUNK];
+    p->slot = s;
+    p->serial = ++serial;
+    return p;
+  }
+  void release(T* p) {
+    std::lock_guard<std::mutex> lk(mu);
+    p->serial = 0;
+    try { free_slots.push_back(p->slot); } catch (...) {}       // out of memory: the slot is lost, nothing else
+  }
+  uint32_t high_water() { std::lock_guard<std::mutex> lk(mu); return next; }
+};
+// Persistent host workers for the per-call passes over 10^6 handles: creating 64 threads costs 1.5-4 ms per call (measured inside
+// batch_verify_strict at config-3 scale), waking 64 sleeping ones ~0.1 ms.  One job at a time; a caller that finds the pool busy (a
+// concurrent call on another device) or without threads runs its ranges on threads of its own / inline as before.  The pool object is
+// never destroyed and its threads are detached: nothing to join at process exit.
+struct HostPool {
+  std::mutex mu, busy;
+  std::condition_variable cv, cv_done;
+  std::function<void(unsigned)> job;
+  unsigned n = 0, next = 0, finished = 0, nthreads = 0;
+  static HostPool& get() { static HostPool* p = new HostPool; return *p; }
+  HostPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw > 64) hw = 64;
+    for (unsigned i = 0; i < hw; i++) {
+      try { std::thread([this]() { loop(); }).detach(); nthreads++; } catch (...) { break; }
+    }
+  }
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return next < n; });
+      const unsigned i = next++;
+      lk.unlock();
+      job(i);
+      lk.lock();
+      if (++finished == n) cv_done.notify_all();
+    }
+  }
+  bool try_begin(unsigned count, std::function<void(unsigned)> fn) {
+    if (count == 0 || count > nthreads || !busy.try_lock()) return false;
+    { std::lock_guard<std::mutex> lk(mu); job = std::move(fn); n = count; next = 0; finished = 0; }
+    cv.notify_all();
+    return true;
+  }
+  void finish() {
+    { std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return finished == n; }); n = 0; next = 0; finished = 0; job = nullptr; }
+    busy.unlock();
+  }
+};
+
+HandleArena<PublicKey>& pk_arena() { static HandleArena<PublicKey> a; return a; }
+HandleArena<Signature>& sig_arena() { static HandleArena<Signature> a; return a; }
+PublicKey* new_public_key() { return pk_arena().alloc(); }
+Signature* new_signature() { return sig_arena().alloc(); }
+void drop(PublicKey* p) { pk_arena().release(p); }
+void drop(Signature* p) { sig_arena().release(p); }
 
 int cmp_n(const uint64_t* a, const uint64_t* b, int n) {
   for (int i = n - 1; i >= 0; i--) {
@@ -645,6 +734,9 @@ struct BvJob { BatchRun keys, sigs; };      // unit_batchverify.hip: the chained
 int bv_begin_keys(BvJob*, const void*, const void*, const void*, int, const uint32_t*, size_t);
 int bv_begin_sigs(BvJob*, const void*, const void*, const void*, int, const uint32_t*, size_t);
 int bv_finish(BvJob*, int, const void*, const void*, int, const uint64_t*, size_t, uint8_t*);
+int bv_mirror_scatter(int, const uint64_t*, const uint8_t*, const uint32_t*, uint64_t*, uint8_t*, size_t, hipStream_t);
+int bv_mirror_gather(int, const uint64_t*, const uint8_t*, const uint32_t*, uint64_t*, uint8_t*, size_t, hipStream_t);
+int bv_draw_exponents(const uint32_t*, const uint32_t*, size_t, size_t, uint64_t*, hipStream_t);
 // the composite hasher's generator table for the bulk GPU kernel (unit_hash.hip: k_pedersen_crh)
 const EdPoint* celo_composite_gens(size_t* count) {
   const CompositeParams& cp = composite_params();
@@ -682,7 +774,8 @@ bool private_key_to_public_key(const PrivateKey* in_private_key, PublicKey** out
   if (!celo_amd_g2_generator(gen)) return false;
   Affine<Fq2_> g = {Fq2_::from_ark(gen), Fq2_::from_ark(gen + 12)};
   Xyzz<Fq2_> r = scalar_mul_host(g, in_private_key->k, 4);
-  PublicKey* pk = new PublicKey;
+  PublicKey* pk = new_public_key();
+  if (!pk) return false;
   if (r.is_identity()) identity_jac<Fq2_>(pk->xyz);
   else {
     Fq2_::mul(r.X, r.ZZ).to_ark(pk->xyz);
@@ -713,10 +806,11 @@ bool deserialize_public_key(const uint8_t* in_bytes, int in_len, PublicKey** out
   Affine<Fq2_> p;
   bool inf;
   if (!g2_decompress(in_bytes, p, inf)) { log_err("deserialize_public_key: not a valid compressed G2 point"); return false; }
-  PublicKey* pk = new PublicKey;
+  PublicKey* pk = new_public_key();
+  if (!pk) return false;
   if (inf) identity_jac<Fq2_>(pk->xyz);
   else {
-    if (!in_subgroup(p)) { delete pk; log_err("deserialize_public_key: point not in the prime-order subgroup"); return false; }
+    if (!in_subgroup(p)) { drop(pk); log_err("deserialize_public_key: point not in the prime-order subgroup"); return false; }
     affine_to_jac(p, pk->xyz);
   }
   *out = pk;
@@ -728,22 +822,28 @@ bool deserialize_public_key(const uint8_t* in_bytes, int in_len, PublicKey** out
 bool deserialize_public_key_cached(const uint8_t* in_bytes, int in_len, PublicKey** out) {
   if (!in_bytes || in_len != 96 || !out) return deserialize_public_key(in_bytes, in_len, out);
   static std::mutex mu;
-  static std::list<std::pair<std::string, PublicKey>> lru;                                   // front = most recent
-  static std::unordered_map<std::string, std::list<std::pair<std::string, PublicKey>>::iterator> index;
+  struct Limbs { uint64_t xyz[36]; };
+  static std::list<std::pair<std::string, Limbs>> lru;                                       // front = most recent
+  static std::unordered_map<std::string, std::list<std::pair<std::string, Limbs>>::iterator> index;
   const std::string key((const char*)in_bytes, 96);
   {
     std::lock_guard<std::mutex> lk(mu);
     auto it = index.find(key);
     if (it != index.end()) {
       lru.splice(lru.begin(), lru, it->second);
-      *out = new PublicKey(it->second->second);
+      PublicKey* pk = new_public_key();
+      if (!pk) return false;
+      memcpy(pk->xyz, it->second->second.xyz, 288);
+      *out = pk;
       return true;
     }
   }
   if (!deserialize_public_key(in_bytes, in_len, out)) return false;
   std::lock_guard<std::mutex> lk(mu);
   if (index.find(key) == index.end()) {
-    lru.emplace_front(key, **out);
+    Limbs v;
+    memcpy(v.xyz, (*out)->xyz, 288);
+    lru.emplace_front(key, v);
     index[key] = lru.begin();
     if (lru.size() > 512) { index.erase(lru.back().first); lru.pop_back(); }
   }
@@ -773,10 +873,11 @@ bool deserialize_signature(const uint8_t* in_bytes, int in_len, Signature** out)
   Affine<Fq_> p;
   bool inf;
   if (!g1_decompress(in_bytes, p, inf)) { log_err("deserialize_signature: not a valid compressed G1 point"); return false; }
-  Signature* s = new Signature;
+  Signature* s = new_signature();
+  if (!s) return false;
   if (inf) identity_jac<Fq_>(s->xyz);
   else {
-    if (!in_subgroup(p)) { delete s; log_err("deserialize_signature: point not in the prime-order subgroup"); return false; }
+    if (!in_subgroup(p)) { drop(s); log_err("deserialize_signature: point not in the prime-order subgroup"); return false; }
     affine_to_jac(p, s->xyz);
   }
   *out = s;
@@ -820,8 +921,8 @@ bool compress_pubkey(const uint8_t* in, int in_len, uint8_t** out, int* out_len)
 
 // ---------------------------------------------------------------- destructors (serialization.rs:224-268)
 bool destroy_private_key(PrivateKey* p) { if (!p) return false; delete p; return true; }
-bool destroy_public_key(PublicKey* p) { if (!p) return false; delete p; return true; }
-bool destroy_signature(Signature* p) { if (!p) return false; delete p; return true; }
+bool destroy_public_key(PublicKey* p) { if (!p) return false; drop(p); return true; }
+bool destroy_signature(Signature* p) { if (!p) return false; drop(p); return true; }
 bool free_vec(uint8_t* bytes, int len) { if (!bytes || len < 0) return false; free(bytes); return true; }   // buffers are malloc blocks: the length is not needed to release one
 
 // ---------------------------------------------------------------- aggregation (signatures.rs:428-505)
@@ -849,8 +950,9 @@ bool aggregate_public_keys(const PublicKey* const* in, int n, PublicKey** out) {
   if (!out || n < 0 || (n > 0 && !in)) return false;
   std::vector<uint64_t> buf;
   if (!unique_key_limbs(in, n, buf, 0)) return false;
-  PublicKey* pk = new PublicKey;
-  if (celo_amd_sum_jacobian_bls12_377_g2(buf.data(), buf.size() / 36, pk->xyz) != 0) { delete pk; return false; }
+  PublicKey* pk = new_public_key();
+  if (!pk) return false;
+  if (celo_amd_sum_jacobian_bls12_377_g2(buf.data(), buf.size() / 36, pk->xyz) != 0) { drop(pk); return false; }
   *out = pk;
   return true;
 }
@@ -865,8 +967,9 @@ bool aggregate_public_keys_subtract(const PublicKey* agg, const PublicKey* const
     Fq2_ ny = {fq_neg(y.c0), fq_neg(y.c1)};
     ny.to_ark(d + 12);
   }
-  PublicKey* pk = new PublicKey;
-  if (celo_amd_sum_jacobian_bls12_377_g2(buf.data(), buf.size() / 36, pk->xyz) != 0) { delete pk; return false; }
+  PublicKey* pk = new_public_key();
+  if (!pk) return false;
+  if (celo_amd_sum_jacobian_bls12_377_g2(buf.data(), buf.size() / 36, pk->xyz) != 0) { drop(pk); return false; }
   *out = pk;
   return true;
 }
@@ -874,8 +977,9 @@ bool aggregate_signatures(const Signature* const* in, int n, Signature** out) {
   if (!out || n < 0 || (n > 0 && !in)) return false;
   std::vector<uint64_t> buf((size_t)n * 18);
   for (int i = 0; i < n; i++) { if (!in[i]) return false; memcpy(&buf[(size_t)i * 18], in[i]->xyz, 144); }
-  Signature* s = new Signature;
-  if (celo_amd_sum_jacobian_bls12_377_g1(buf.data(), (size_t)n, s->xyz) != 0) { delete s; return false; }
+  Signature* s = new_signature();
+  if (!s) return false;
+  if (celo_amd_sum_jacobian_bls12_377_g1(buf.data(), (size_t)n, s->xyz) != 0) { drop(s); return false; }
   *out = s;
   return true;
 }
@@ -1007,7 +1111,8 @@ static bool sign_with(const PrivateKey* sk, bool composite, bool cip22, const ui
   Affine<Fq_> h; int c;
   if (!hash_to_g1(composite, cip22, dom, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
   Xyzz<Fq_> r = scalar_mul_host(h, sk->k, 4);                 // PrivateKey::sign_raw (crates/bls-crypto/src/bls/secret.rs:65)
-  Signature* s = new Signature;
+  Signature* s = new_signature();
+  if (!s) return false;
   if (r.is_identity() || r.ZZ.is_zero_mod_p()) identity_jac<Fq_>(s->xyz);
   else { Fq_::mul(r.X, r.ZZ).to_ark(s->xyz); Fq_::mul(r.Y, r.ZZZ).to_ark(s->xyz + 6); r.ZZ.to_ark(s->xyz + 12); }
   *out = s;
@@ -1092,40 +1197,68 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     offs[b + 1] = offs[b] + (uint32_t)blen[b];
   }
   const size_t tot = offs[m];
-  // staging: one grow-only PINNED host buffer kept by the library (allocating and releasing ~0.5 GB of pageable memory per call
-  // cost 50-100 ms at config-3 scale, and pinned pages halve the host-to-device copies of the two MSMs)
-  // (kept PER DEVICE: a caller bound to another device with celo_amd_use_device must not run its engines against device-0 memory
-  // and a device-0 stream)
+  // Per device (a caller bound to another device with celo_amd_use_device must not run its engines against device-0 memory and a
+  // device-0 stream): one grow-only PINNED host staging buffer, its device twin, one copy stream, and the MIRRORS of the two handle
+  // arenas - for every arena slot the affine point (192 / 96 bytes) and an identity byte in HBM, tagged on the host with the serial of
+  // the allocation they were uploaded for.  A call then moves, per signer, two 4-byte slot numbers and the 32-byte exponent; only
+  // handles the device has not seen in their present state (new since the last call, or a reused slot) are normalised and uploaded,
+  // and the dense point arrays the batch MSMs read are gathered on the GPU (unit_batchverify.hip: k_mirror_scatter / k_mirror_gather).
+  // Round 3 gathered and shipped 320 bytes per signer on every call: 8 ms before the G2 MSM - the longest leg - could start.
   if (api_enter() != 0) return false;
-  struct DevStage { std::mutex mu; uint8_t* stage = nullptr; size_t stage_cap = 0; uint8_t* d_stage = nullptr; size_t d_stage_cap = 0; hipStream_t copy_stream = nullptr; };
+  struct Mirror {
+    uint64_t* d_xy = nullptr; uint8_t* d_inf = nullptr; uint32_t cap = 0;
+    std::unique_ptr<std::atomic<uint64_t>[]> seen;                      // serial of the allocation whose point sits in the slot's row (0: none)
+    bool grow(uint32_t need, int words) {
+      if (need <= cap) return true;
+      uint64_t ncap64 = ((uint64_t)need + 0xffffu) & ~(uint64_t)0xffffu;
+      if (ncap64 < 2 * (uint64_t)cap) ncap64 = 2 * (uint64_t)cap;
+      if (ncap64 > 0xffffffffu) ncap64 = 0xffffffffu;
+      const uint32_t ncap = (uint32_t)ncap64;
+      uint64_t* nx = nullptr; uint8_t* ni = nullptr;
+      std::unique_ptr<std::atomic<uint64_t>[]> ns(new (std::nothrow) std::atomic<uint64_t>[ncap]);
+      if (!ns || hipMalloc((void**)&nx, (size_t)ncap * words * 8) != hipSuccess) return false;
+      if (hipMalloc((void**)&ni, ncap) != hipSuccess) { (void)hipFree(nx); return false; }
+      if (cap && (hipMemcpy(nx, d_xy, (size_t)cap * words * 8, hipMemcpyDeviceToDevice) != hipSuccess ||
+                  hipMemcpy(ni, d_inf, cap, hipMemcpyDeviceToDevice) != hipSuccess)) { (void)hipFree(nx); (void)hipFree(ni); return false; }
+      for (uint32_t i = 0; i < ncap; i++) ns[i].store(i < cap ? seen[i].load(std::memory_order_relaxed) : 0, std::memory_order_relaxed);
+      if (d_xy) (void)hipFree(d_xy);
+      if (d_inf) (void)hipFree(d_inf);
+      d_xy = nx; d_inf = ni; cap = ncap; seen = std::move(ns);
+      return true;
+    }
+    void forget() { for (uint32_t i = 0; i < cap; i++) seen[i].store(0, std::memory_order_relaxed); }
+  };
+  struct DevStage {
+    std::mutex mu; uint8_t* stage = nullptr; size_t stage_cap = 0; uint8_t* d_stage = nullptr; size_t d_stage_cap = 0;
+    uint8_t* d_up = nullptr; size_t d_up_cap = 0; hipStream_t copy_stream = nullptr; Mirror keys, sigs;
+  };
   static DevStage dev_stage[MAX_DEVICES];
   DevStage& DS = dev_stage[api_device()];
   std::lock_guard<std::mutex> stage_lk(DS.mu);
   uint8_t*& stage = DS.stage;
   size_t& stage_cap = DS.stage_cap;
-  const size_t need = tot * (24 + 12 + 4) * 8 + 2 * tot + 4096;
+  // host staging: rows of the handles to upload (worst case: every signer's), the exponents, the slot numbers
+  const size_t need = tot * (24 + 12) * 8 + tot * 16 + 2 * tot + 4096;
   if (need > stage_cap) {
-    if (api_enter() != 0) return false;
     if (stage) (void)hipHostFree(stage);
     stage = nullptr; stage_cap = 0;
     if (hipHostMalloc((void**)&stage, need + need / 4, hipHostMallocDefault) != hipSuccess) { log_err("batch_verify_strict: pinned staging allocation failed"); return false; }
     stage_cap = need + need / 4;
   }
-  uint64_t* pk_xy = (uint64_t*)stage;
-  uint64_t* sg_xy = pk_xy + tot * 24;
-  uint64_t* sc = sg_xy + tot * 12;
-  uint8_t* pk_inf = (uint8_t*)(sc + tot * 4);
-  uint8_t* sg_inf = pk_inf + tot;
-  // device mirror of the staging buffer (same layout, grow-only) + m hash points and flags behind it, and one copy stream: the
-  // gather runs in PHASES over the batch range (all threads share each phase), and the calling thread sends a finished phase on its
-  // way (hipMemcpyAsync from pinned memory) while the workers gather the next: the 320 bytes per signer cross PCIe WHILE the host
-  // cores are still gathering (6 ms of copies at 4096 x 256 that used to follow the gather).  (Copies issued by the 64 workers
-  // themselves - 1280 small hipMemcpyAsync calls - cost more in the driver than they hid: gather 8 -> 21 ms.)
+  uint64_t* up_pk_xy = (uint64_t*)stage;
+  uint64_t* up_sg_xy = up_pk_xy + tot * 24;
+  uint32_t* idx_pk = (uint32_t*)(up_sg_xy + tot * 12);
+  uint32_t* idx_sg = idx_pk + tot;
+  uint32_t* up_pk_slot = idx_sg + tot;
+  uint32_t* up_sg_slot = up_pk_slot + tot;
+  uint8_t* up_pk_inf = (uint8_t*)(up_sg_slot + tot);
+  uint8_t* up_sg_inf = up_pk_inf + tot;
+  // device staging: the gathered point arrays, the exponents, the slot numbers; m hash points and flags behind them
   uint8_t*& d_stage = DS.d_stage;
   size_t& d_stage_cap = DS.d_stage_cap;
   hipStream_t& copy_stream = DS.copy_stream;
-  const size_t d_need = need + m * 97 + 4096;
-  if (api_enter() != 0) return false;
+  const size_t d_body = tot * (24 + 12 + 4) * 8 + tot * 8 + 2 * tot;
+  const size_t d_need = d_body + 256 + m * 97 + 256 + (m + 1) * 4 + 4096;
   if (d_need > d_stage_cap) {
     if (d_stage) (void)hipFree(d_stage);
     d_stage = nullptr; d_stage_cap = 0;
@@ -1136,19 +1269,23 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   uint64_t* d_pk_xy = (uint64_t*)d_stage;
   uint64_t* d_sg_xy = d_pk_xy + tot * 24;
   uint64_t* d_sc = d_sg_xy + tot * 12;
-  uint8_t* d_pk_inf = (uint8_t*)(d_sc + tot * 4);
+  uint32_t* d_idx_pk = (uint32_t*)(d_sc + tot * 4);
+  uint32_t* d_idx_sg = d_idx_pk + tot;
+  uint8_t* d_pk_inf = (uint8_t*)(d_idx_sg + tot);
   uint8_t* d_sg_inf = d_pk_inf + tot;
-  uint64_t* d_hxy = (uint64_t*)(d_stage + ((need + 255) & ~size_t(255)));
+  uint64_t* d_hxy = (uint64_t*)(d_stage + ((d_body + 255) & ~size_t(255)));
   uint8_t* d_hinf = (uint8_t*)(d_hxy + m * 12);
-  const int dev = api_device();
-  std::atomic<bool> copy_failed(false);
-  constexpr size_t PHASES = 4;
-  std::atomic<unsigned> phase_done[2 * PHASES];
+  uint32_t* d_offs = (uint32_t*)(((uintptr_t)(d_hinf + m) + 255) & ~uintptr_t(255));
+  // the mirrors cover every slot either arena has handed out so far (a handle allocated by another thread DURING this call cannot be
+  // in this call's lists)
+  if (!DS.keys.grow(pk_arena().high_water(), 24) || !DS.sigs.grow(sig_arena().high_water(), 12)) { log_err("batch_verify_strict: device mirror allocation failed"); return false; }
+  Mirror& MK = DS.keys;
+  Mirror& MS = DS.sigs;
+  // `seen` is advanced by the workers BEFORE the rows are on the device: any failure between here and the last scatter drops both tag sets
+  bool mirrors_ok = false;
+  struct Undo { Mirror& a; Mirror& b; bool& ok; ~Undo() { if (!ok) { a.forget(); b.forget(); } } } undo{MK, MS, mirrors_ok};
   ChaCha20Rng master;
   if (!os_seeded_rng(master)) { log_err("batch_verify_strict: no OS randomness"); return false; }
-  for (size_t b = 0; b < m; b++)
-    for (size_t i = 0; i < blen[b]; i++)
-      if (!batches[b].public_keys[i] || !batches[b].signatures[i]) return false;
   ph.mark("validate + allocate");
   // the message hashes depend on nothing computed here: they run on the host cores while the GPU does the two MSMs
   std::vector<uint64_t> hxy(m * 12);
@@ -1158,98 +1295,128 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   std::vector<uint8_t> hash_failed(m, 0);
   std::thread hasher([&]() { hash_ok = hash_many(composite, cip22, SIG_DOMAIN, jobs, &hash_failed); });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } hasher_guard{hasher};   // early returns must not leave it running
-  // gather: ranges of batches across host threads; every thread draws its exponents from its own ChaCha20 stream (keys taken
-  // from the OS-seeded master stream).  Handles with Z = 1 (everything that came from the wire) are copied straight into the
-  // affine arrays; the others are normalised with one shared inversion per thread.
+  // Host pass over the handles, ranges of batches across host threads, keys and then signatures (the exponents are drawn on the device,
+  // from a ChaCha20 key taken from the OS-seeded master stream: bv_draw_exponents): a handle contributes its slot number; one whose
+  // serial differs from the mirror's tag is claimed by exactly one thread (atomic exchange on the tag) and staged for upload - copied
+  // straight if its Z is 1 (everything that came from the wire), otherwise normalised with one shared inversion per thread.
   unsigned nt = std::thread::hardware_concurrency();
   if (nt > 64) nt = 64;
   if (nt < 1 || tot < 8192) nt = 1;
-  std::vector<ChaCha20Rng> rngs(nt);
-  for (unsigned t = 0; t < nt; t++) for (int k = 0; k < 8; k++) rngs[t].key[k] = master.next_u32();
+  uint32_t exp_key[8];                                                  // this call's exponent stream (unit_batchverify.hip k_draw_exponents)
+  for (int k = 0; k < 8; k++) exp_key[k] = master.next_u32();
   uint64_t one2[12], one1[6];
   Fq2_::one().to_ark(one2);
   Fq_::one().to_ark(one1);
-  // The gather runs in two passes - the key handles with the exponents, then the signature handles - each in PHASES phases over
-  // the batch range that all worker threads share; the calling thread copies a finished phase to the device while the workers
-  // gather the next one, starts the G2 batch MSM (the longest leg of the chain) as soon as the keys are across, and the G1 batch MSM
-  // when the signatures are.  Handles with Z = 1 (everything that came from the wire) are copied straight into the affine arrays;
-  // the others are normalised with one shared inversion per thread and phase.
+  std::atomic<size_t> up_n[2];
+  std::atomic<unsigned> pass_done[2];
+  std::atomic<bool> bad_handle(false);
+  for (int q = 0; q < 2; q++) { up_n[q].store(0); pass_done[q].store(0); }
   auto work = [&](unsigned t, int pass) {
-   for (size_t q = 0; q < PHASES; q++) {
-    const size_t p_lo = m * q / PHASES, p_hi = m * (q + 1) / PHASES;                                             // phase q
-    const size_t b_lo = p_lo + (p_hi - p_lo) * t / nt, b_hi = p_lo + (p_hi - p_lo) * (t + 1) / nt;              // thread t's share of it
-    ChaCha20Rng& rng = rngs[t];
-    std::vector<uint32_t> todo;
+    const size_t b_lo = m * t / nt, b_hi = m * (t + 1) / nt;
+    const bool is_pk = pass == 0;
+    Mirror& M = is_pk ? MK : MS;
+    std::vector<const uint64_t*> todo;          // xyz of the handles this thread uploads (slot: behind the limbs, read again below)
+    std::vector<uint32_t> todo_slot;
     for (size_t b = b_lo; b < b_hi; b++) {
       const size_t n = blen[b];
-      size_t lg = 0;
-      while (((size_t)1 << lg) < n) lg++;                               // ark_std::log2 = ceil(log2)
-      size_t nbytes = (128 + lg + 7) / 8;                               // byte_count_from_target_batch_size (batch.rs:23-28)
-      if (nbytes > 31) nbytes = 31;
       for (size_t i = 0; i < n; i++) {
         const size_t at = offs[b] + i;
-        if (pass == 0) {
-          const uint64_t* pk = batches[b].public_keys[i]->xyz;
-          if (memcmp(pk + 24, one2, 96) == 0) { memcpy(pk_xy + at * 24, pk, 192); pk_inf[at] = 0; } else todo.push_back((uint32_t)at);
-          uint8_t rb[32];
-          memset(rb, 0, 32);
-          for (size_t k = 0; k < nbytes; k += 4) { uint32_t r = rng.next_u32(); memcpy(rb + k, &r, (nbytes - k) < 4 ? (nbytes - k) : 4); }
-          memcpy(sc + at * 4, rb, 32);
-        } else {
-          const uint64_t* sg = batches[b].signatures[i]->xyz;
-          if (memcmp(sg + 12, one1, 48) == 0) { memcpy(sg_xy + at * 12, sg, 96); sg_inf[at] = 0; } else todo.push_back((uint32_t)at);
+        uint32_t slot; uint64_t serial; const uint64_t* xyz;
+        if (is_pk) { const PublicKey* h = batches[b].public_keys[i]; if (h) { slot = h->slot; serial = h->serial; xyz = h->xyz; } else { slot = 0; serial = 0; xyz = nullptr; } }
+        else { const Signature* h = batches[b].signatures[i]; if (h) { slot = h->slot; serial = h->serial; xyz = h->xyz; } else { slot = 0; serial = 0; xyz = nullptr; } }
+        if (serial == 0 || slot >= M.cap) { bad_handle = true; slot = 0; }      // null, a destroyed handle, or not one of this library's
+        else if (M.seen[slot].load(std::memory_order_relaxed) != serial && M.seen[slot].exchange(serial, std::memory_order_relaxed) != serial) {
+          todo.push_back(xyz); todo_slot.push_back(slot);
+        }
+        (is_pk ? idx_pk : idx_sg)[at] = slot;
+      }
+    }
+    if (!todo.empty()) {
+      const int A3 = is_pk ? 36 : 18, A2 = is_pk ? 24 : 12;
+      const size_t base = up_n[pass].fetch_add(todo.size());
+      uint64_t* up_xy = is_pk ? up_pk_xy : up_sg_xy;
+      uint32_t* up_slot = is_pk ? up_pk_slot : up_sg_slot;
+      uint8_t* up_inf = is_pk ? up_pk_inf : up_sg_inf;
+      std::vector<uint32_t> nz;                                         // not affine yet (aggregates, fresh signatures, identities)
+      for (size_t k = 0; k < todo.size(); k++) {
+        up_slot[base + k] = todo_slot[k];
+        const bool affine = is_pk ? memcmp(todo[k] + 24, one2, 96) == 0 : memcmp(todo[k] + 12, one1, 48) == 0;
+        if (affine) { memcpy(up_xy + (base + k) * A2, todo[k], (size_t)A2 * 8); up_inf[base + k] = 0; } else nz.push_back((uint32_t)k);
+      }
+      if (!nz.empty()) {
+        std::vector<uint64_t> jac(nz.size() * A3), xy(nz.size() * A2);
+        std::vector<uint8_t> inf(nz.size());
+        for (size_t k = 0; k < nz.size(); k++) memcpy(&jac[k * A3], todo[nz[k]], (size_t)A3 * 8);
+        if (is_pk) batch_to_affine_range<Fq2_>(jac.data(), nz.size(), xy.data(), inf.data());
+        else batch_to_affine_range<Fq_>(jac.data(), nz.size(), xy.data(), inf.data());
+        for (size_t k = 0; k < nz.size(); k++) {
+          memcpy(up_xy + (base + nz[k]) * A2, &xy[k * A2], (size_t)A2 * 8);
+          up_inf[base + nz[k]] = inf[k];
         }
       }
     }
-    if (!todo.empty()) {                       // the handles that are not affine yet (aggregates, fresh signatures): gather, normalise, scatter
-      const bool is_pk = pass == 0;
-      const int A3 = is_pk ? 36 : 18, A2 = is_pk ? 24 : 12;
-      std::vector<uint64_t> jac(todo.size() * A3), xy(todo.size() * A2);
-      std::vector<uint8_t> inf(todo.size());
-      for (size_t k = 0; k < todo.size(); k++) {
-        size_t at = todo[k], b = std::upper_bound(offs.begin(), offs.end(), (uint32_t)at) - offs.begin() - 1, i = at - offs[b];
-        memcpy(&jac[k * A3], is_pk ? batches[b].public_keys[i]->xyz : batches[b].signatures[i]->xyz, A3 * 8);
+    pass_done[pass].fetch_add(1);
+  };
+  // calling thread: when a pass is through, the new rows go to their mirror slots, the slot numbers (and, with the keys, the exponents)
+  // cross PCIe, the GPU gathers the dense arrays, and that leg's batch MSM starts - the G2 leg (the longest of the chain) first, the
+  // signatures' host pass runs under it
+  bool copy_failed = false;
+  auto stage_pass = [&](int pass) -> bool {
+    const bool is_pk = pass == 0;
+    Mirror& M = is_pk ? MK : MS;
+    const int W = is_pk ? 24 : 12;
+    const size_t k = up_n[pass].load();
+    if (k) {
+      const size_t row = (size_t)W * 8, upb = k * (row + 5) + 256;
+      if (upb > DS.d_up_cap) {
+        if (DS.d_up) (void)hipFree(DS.d_up);
+        DS.d_up = nullptr; DS.d_up_cap = 0;
+        if (hipMalloc((void**)&DS.d_up, upb + upb / 4) != hipSuccess) return false;
+        DS.d_up_cap = upb + upb / 4;
       }
-      if (is_pk) batch_to_affine_range<Fq2_>(jac.data(), todo.size(), xy.data(), inf.data());
-      else batch_to_affine_range<Fq_>(jac.data(), todo.size(), xy.data(), inf.data());
-      for (size_t k = 0; k < todo.size(); k++) {
-        memcpy((is_pk ? pk_xy : sg_xy) + (size_t)todo[k] * A2, &xy[k * A2], A2 * 8);
-        (is_pk ? pk_inf : sg_inf)[todo[k]] = inf[k];
-      }
+      uint64_t* du_xy = (uint64_t*)DS.d_up;
+      uint32_t* du_slot = (uint32_t*)(du_xy + k * W);
+      uint8_t* du_inf = (uint8_t*)(du_slot + k);
+      if (hipMemcpyAsync(du_xy, is_pk ? up_pk_xy : up_sg_xy, k * row, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+          hipMemcpyAsync(du_slot, is_pk ? up_pk_slot : up_sg_slot, k * 4, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+          hipMemcpyAsync(du_inf, is_pk ? up_pk_inf : up_sg_inf, k, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+          bv_mirror_scatter(W, du_xy, du_inf, du_slot, M.d_xy, M.d_inf, k, copy_stream) != 0) return false;
     }
-    phase_done[pass * PHASES + q].fetch_add(1);
-   }
+    if (tot) {
+      if (hipMemcpyAsync(is_pk ? d_idx_pk : d_idx_sg, is_pk ? idx_pk : idx_sg, tot * 4, hipMemcpyHostToDevice, copy_stream) != hipSuccess) return false;
+      if (is_pk && (hipMemcpyAsync(d_offs, offs.data(), (m + 1) * 4, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+                    bv_draw_exponents(exp_key, d_offs, m, tot, d_sc, copy_stream) != 0)) return false;
+      if (bv_mirror_gather(W, M.d_xy, M.d_inf, is_pk ? d_idx_pk : d_idx_sg, is_pk ? d_pk_xy : d_sg_xy, is_pk ? d_pk_inf : d_sg_inf, tot, copy_stream) != 0) return false;
+    }
+    return hipStreamSynchronize(copy_stream) == hipSuccess;
   };
-  auto send_phase = [&](int pass, size_t q) {                          // calling thread: a gathered phase goes to the device
-    const size_t p_lo = m * q / PHASES, p_hi = m * (q + 1) / PHASES;
-    const size_t e_lo = offs[p_lo], e_n = offs[p_hi] - offs[p_lo];
-    if (!e_n) return;
-    bool bad;
-    if (pass == 0) bad = hipMemcpyAsync(d_pk_xy + e_lo * 24, pk_xy + e_lo * 24, e_n * 192, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
-                         hipMemcpyAsync(d_sc + e_lo * 4, sc + e_lo * 4, e_n * 32, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
-                         hipMemcpyAsync(d_pk_inf + e_lo, pk_inf + e_lo, e_n, hipMemcpyHostToDevice, copy_stream) != hipSuccess;
-    else bad = hipMemcpyAsync(d_sg_xy + e_lo * 12, sg_xy + e_lo * 12, e_n * 96, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
-               hipMemcpyAsync(d_sg_inf + e_lo, sg_inf + e_lo, e_n, hipMemcpyHostToDevice, copy_stream) != hipSuccess;
-    if (bad) copy_failed = true;
-  };
-  for (size_t q = 0; q < 2 * PHASES; q++) phase_done[q].store(0);
   BvJob job;
   int rc_keys = 0, rc_sigs = 0;
   {
     std::vector<std::thread> th;
     struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } guard{th};
-    for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() { work(t, 0); work(t, 1); });
+    HostPool& pool = HostPool::get();
+    const bool pooled = nt > 1 && pool.try_begin(nt, [&](unsigned t) { work(t, 0); work(t, 1); });
+    struct PoolWait { HostPool& p; bool on; ~PoolWait() { if (on) p.finish(); } } pool_wait{pool, pooled};   // the job holds references to this frame
+    if (!pooled) {
+      if (nt > 1) {
+        try { for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() { work(t, 0); work(t, 1); }); }
+        catch (...) { for (unsigned t = (unsigned)th.size(); t < nt; t++) { work(t, 0); work(t, 1); } }   // no more threads: the rest of the ranges here
+      } else { work(0, 0); work(0, 1); }
+    }
     for (int pass = 0; pass < 2; pass++) {
-      for (size_t q = 0; q < PHASES; q++) {
-        while (phase_done[pass * PHASES + q].load() < nt) std::this_thread::yield();
-        send_phase(pass, q);
-      }
-      if (copy_failed || hipStreamSynchronize(copy_stream) != hipSuccess) { copy_failed = true; break; }
-      if (pass == 0) { rc_keys = bv_begin_keys(&job, d_pk_xy, d_pk_inf, d_sc, 1, offs.data(), m); ph.mark("keys + exponents gathered and copied, G2 batch MSM started"); }
-      else { rc_sigs = bv_begin_sigs(&job, d_sg_xy, d_sg_inf, d_sc, 1, offs.data(), m); ph.mark("signatures gathered and copied, G1 batch MSM started"); }
+      while (pass_done[pass].load() < nt) std::this_thread::yield();
+      ph.mark(pass == 0 ? "  host pass over the key handles" : "  host pass over the signature handles");
+      if (bad_handle || !stage_pass(pass)) { copy_failed = true; break; }
+      ph.mark("  rows / slots across, gathered on the device");
+      if (pass == 0) { rc_keys = bv_begin_keys(&job, d_pk_xy, d_pk_inf, d_sc, 1, offs.data(), m); ph.mark("key slots + exponents across, G2 batch MSM started"); }
+      else { rc_sigs = bv_begin_sigs(&job, d_sg_xy, d_sg_inf, d_sc, 1, offs.data(), m); ph.mark("signature slots across, G1 batch MSM started"); }
     }
   }
+  mirrors_ok = !copy_failed;
+  if (bad_handle) log_err("batch_verify_strict: a destroyed or foreign handle in the batch lists");
   hasher.join();
+  ph.mark("  message hashes joined");
   std::vector<uint8_t> hinf(m, 0), ok(m, 0);
   if (hash_ok) for (size_t b = 0; b < m; b++) if (hash_failed[b]) hinf[b] = 1;   // no H(m): that pair is left out, the verdict is forced below
   uint64_t ng2[24];
@@ -1258,6 +1425,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
                       hipMemcpyAsync(d_hxy, hxy.data(), m * 96, hipMemcpyHostToDevice, copy_stream) == hipSuccess &&
                       hipMemcpyAsync(d_hinf, hinf.data(), m, hipMemcpyHostToDevice, copy_stream) == hipSuccess &&
                       hipStreamSynchronize(copy_stream) == hipSuccess;
+  ph.mark("  hashes across");
   if (bv_finish(&job, staged ? 1 : 0, d_hxy, d_hinf, 1, ng2, m, ok.data()) != 0 || !staged) return false;   // (bv_finish releases the engines either way)
   ph.mark("pairs -> pairing checks (GPU, chained)");
   bool all = true;

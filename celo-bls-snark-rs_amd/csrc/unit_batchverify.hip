@@ -65,6 +65,112 @@ k_pack_verify_pairs(const uint64_t* __restrict__ sig_sum /* m x 18 */, const uin
   }
 }
 
+// ---- the per-device mirror of Seam A's handle arenas (seam_a.hip, batch_verify_strict): W u64 of affine coordinates + an identity
+// byte per arena slot.  scatter: freshly staged entries go to their slots; gather: the call's slot numbers become the dense point
+// arrays the batch MSMs read.  One lane per 64-bit word: both sides of either copy move whole 96 / 192-byte rows.
+template <int W>
+__global__ void __launch_bounds__(256) k_mirror_scatter(const uint64_t* __restrict__ up_xy, const uint8_t* __restrict__ up_inf, const uint32_t* __restrict__ slots,
+                                                        uint64_t* __restrict__ mirror_xy, uint8_t* __restrict__ mirror_inf, uint32_t k) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t e = t / W;
+  const uint32_t w = (uint32_t)(t % W);
+  if (e >= k) return;
+  const uint32_t s = slots[e];
+  mirror_xy[(size_t)s * W + w] = up_xy[e * W + w];
+  if (w == 0) mirror_inf[s] = up_inf[e];
+}
+template <int W>
+__global__ void __launch_bounds__(256) k_mirror_gather(const uint64_t* __restrict__ mirror_xy, const uint8_t* __restrict__ mirror_inf, const uint32_t* __restrict__ slots,
+                                                       uint64_t* __restrict__ out_xy, uint8_t* __restrict__ out_inf, uint32_t n) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t e = t / W;
+  const uint32_t w = (uint32_t)(t % W);
+  if (e >= n) return;
+  const uint32_t s = slots[e];
+  out_xy[e * W + w] = mirror_xy[(size_t)s * W + w];
+  if (w == 0) out_inf[e] = mirror_inf[s];
+}
+// words = 24 (G2 keys) or 12 (G1 signatures); everything device memory; enqueued on `stream`
+int bv_mirror_scatter(int words, const uint64_t* up_xy, const uint8_t* up_inf, const uint32_t* slots, uint64_t* mirror_xy, uint8_t* mirror_inf, size_t k, hipStream_t stream) {
+  if (k == 0) return 0;
+  if (k > 0xffffffffu || (words != 24 && words != 12)) return 2;
+  const unsigned blocks = (unsigned)((k * (size_t)words + 255) / 256);
+  if (words == 24) hipLaunchKernelGGL((k_mirror_scatter<24>), dim3(blocks), dim3(256), 0, stream, up_xy, up_inf, slots, mirror_xy, mirror_inf, (uint32_t)k);
+  else hipLaunchKernelGGL((k_mirror_scatter<12>), dim3(blocks), dim3(256), 0, stream, up_xy, up_inf, slots, mirror_xy, mirror_inf, (uint32_t)k);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int bv_mirror_gather(int words, const uint64_t* mirror_xy, const uint8_t* mirror_inf, const uint32_t* slots, uint64_t* out_xy, uint8_t* out_inf, size_t n, hipStream_t stream) {
+  if (n == 0) return 0;
+  if (n > 0xffffffffu || (words != 24 && words != 12)) return 2;
+  const unsigned blocks = (unsigned)((n * (size_t)words + 255) / 256);
+  if (words == 24) hipLaunchKernelGGL((k_mirror_gather<24>), dim3(blocks), dim3(256), 0, stream, mirror_xy, mirror_inf, slots, out_xy, out_inf, (uint32_t)n);
+  else hipLaunchKernelGGL((k_mirror_gather<12>), dim3(blocks), dim3(256), 0, stream, mirror_xy, mirror_inf, slots, out_xy, out_inf, (uint32_t)n);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ---- Batch::verify's random exponents drawn ON THE DEVICE (crates/bls-crypto/src/bls/batch.rs:51-58: one exponent of
+// byte_count_from_target_batch_size(128, n) = (128 + ceil(log2 n) + 7) / 8 random bytes per signer, from rand::thread_rng(), itself a
+// ChaCha stream seeded by the OS).  Here: ChaCha20 (RFC 7539 block function, 64-bit block counter as rand_chacha) under a 256-bit key
+// the HOST takes from the OS per call; signer `at` of the call owns block `at` of the stream and keeps its first nbytes bytes,
+// little-endian, in a 4 x u64 container.  The call then ships 32 key bytes instead of 32 bytes per signer, and no host core draws them.
+__device__ __forceinline__ uint32_t cc_rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+__global__ void __launch_bounds__(256) k_draw_exponents(const uint32_t* __restrict__ offsets, uint32_t m, uint32_t tot, uint32_t k0, uint32_t k1, uint32_t k2,
+                                                        uint32_t k3, uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7, uint64_t* __restrict__ out) {
+  const uint32_t at = blockIdx.x * 256 + threadIdx.x;
+  if (at >= tot) return;
+  uint32_t lo = 0, hi = m;                                    // the batch of signer `at`: the last b with offsets[b] <= at
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (offsets[mid] <= at) lo = mid; else hi = mid; }
+  const uint32_t n = offsets[lo + 1] - offsets[lo];
+  const uint32_t lg = n <= 1 ? 0 : 32 - __builtin_clz(n - 1);  // ark_std::log2 = ceil(log2 n)
+  uint32_t nbytes = (128 + lg + 7) / 8;
+  if (nbytes > 31) nbytes = 31;
+  const uint32_t s[16] = {0x61707865u, 0x3320646Eu, 0x79622D32u, 0x6B206574u, k0, k1, k2, k3, k4, k5, k6, k7, at, 0u, 0u, 0u};
+  uint32_t w[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) w[i] = s[i];
+#define CC_QR(a, b, c, d) w[a] += w[b]; w[d] = cc_rotl(w[d] ^ w[a], 16); w[c] += w[d]; w[b] = cc_rotl(w[b] ^ w[c], 12); \
+                          w[a] += w[b]; w[d] = cc_rotl(w[d] ^ w[a], 8);  w[c] += w[d]; w[b] = cc_rotl(w[b] ^ w[c], 7);
+#pragma unroll 1
+  for (int r = 0; r < 10; r++) {
+    CC_QR(0, 4, 8, 12) CC_QR(1, 5, 9, 13) CC_QR(2, 6, 10, 14) CC_QR(3, 7, 11, 15)
+    CC_QR(0, 5, 10, 15) CC_QR(1, 6, 11, 12) CC_QR(2, 7, 8, 13) CC_QR(3, 4, 9, 14)
+  }
+#undef CC_QR
+  uint32_t v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint32_t x = w[i] + s[i];
+    const uint32_t keep = nbytes > 4u * i ? nbytes - 4u * i : 0u;      // bytes of word i that belong to the exponent
+    if (keep < 4) x = keep ? x & ((1u << (8 * keep)) - 1u) : 0u;
+    v[i] = x;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[(size_t)at * 4 + i] = (uint64_t)v[2 * i] | ((uint64_t)v[2 * i + 1] << 32);
+}
+// d_offsets: m + 1 device words; d_out: tot x 4 u64 on the device; enqueued on `stream`
+int bv_draw_exponents(const uint32_t key[8], const uint32_t* d_offsets, size_t m, size_t tot, uint64_t* d_out, hipStream_t stream) {
+  if (tot == 0) return 0;
+  if (tot > 0xffffffffu || m == 0 || m > 0x7fffffffu) return 2;
+  hipLaunchKernelGGL(k_draw_exponents, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, d_offsets, (uint32_t)m, (uint32_t)tot, key[0], key[1], key[2], key[3],
+                     key[4], key[5], key[6], key[7], d_out);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+// test / tooling entry (include/celo_bls_amd.h): the exponents of one call, returned to the host
+int draw_exponents_run(const uint32_t key[8], const uint32_t* offsets, size_t m, uint64_t* out) {
+  if (int rc = api_enter()) return rc;
+  if (!key || !offsets || !out || m == 0 || m > 0x7fffffffu) return 2;
+  const size_t tot = offsets[m];
+  if (tot == 0) return 0;
+  uint32_t* d_off = nullptr; uint64_t* d_out = nullptr;
+  int rc = 1;
+  if (hipMalloc((void**)&d_off, (m + 1) * 4) == hipSuccess && hipMalloc((void**)&d_out, tot * 32) == hipSuccess &&
+      hipMemcpy(d_off, offsets, (m + 1) * 4, hipMemcpyHostToDevice) == hipSuccess && (rc = bv_draw_exponents(key, d_off, m, tot, d_out, nullptr)) == 0)
+    rc = hipMemcpy(out, d_out, tot * 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+  if (d_off) (void)hipFree(d_off);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
+}
+
 // The chain in three steps, so that a caller whose inputs arrive in stages (Seam A gathers 10^6 key handles, then 10^6 signature
 // handles) can start the longest leg - the G2 MSM - as soon as ITS inputs are there:
 //   bv_begin_keys   enqueue the G2 batch MSM        bv_begin_sigs   enqueue the G1 batch MSM        bv_finish   pairs + products

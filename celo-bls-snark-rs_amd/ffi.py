@@ -38,7 +38,7 @@ EXPORTS = [
     "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
     "celo_amd_gen_points_grouped_bls12_377_g1_dev", "celo_amd_gen_points_grouped_bls12_377_g2_dev",
-    "batch_verify_bls12_377", "batch_verify_bls12_377_dev",
+    "batch_verify_bls12_377", "batch_verify_bls12_377_dev", "celo_amd_draw_batch_exponents",
     "ntt_bw6_761_fr", "ntt_bw6_761_fr_dev",
     "groth16_witness_map_bw6_761", "groth16_witness_map_bw6_761_dev", "groth16_prove_bw6_761",
     "decompress_bls12_377_g1", "decompress_bls12_377_g2", "decompress_bls12_377_g1_dev", "decompress_bls12_377_g2_dev",
@@ -323,6 +323,18 @@ def batch_verify_dev(d_pk, d_sig, d_exp, offsets, d_hash, neg_g2_xy):
                                           C.c_size_t(m), _p(out))
     if rc != 0:
         raise RuntimeError(f"batch_verify_bls12_377_dev failed rc={rc}")
+    return out
+
+
+def draw_batch_exponents(key, offsets):
+    """The exponents batch_verify_strict's device kernel draws for one call under `key` (8 uint32): uint64 [offsets[-1], 4]."""
+    key = np.ascontiguousarray(key, dtype=np.uint32).reshape(8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    m = offsets.size - 1
+    out = np.zeros((int(offsets[-1]), 4), dtype=np.uint64)
+    rc = lib().celo_amd_draw_batch_exponents(_p(key), _p(offsets), C.c_size_t(m), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"celo_amd_draw_batch_exponents failed rc={rc}")
     return out
 
 

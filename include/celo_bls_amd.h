@@ -194,6 +194,13 @@ int batch_verify_bls12_377_dev(const void* d_pk_xy, const void* d_pk_inf, const 
                                const uint32_t* offsets, const void* d_hash_xy, const void* d_hash_inf, const uint64_t neg_g2_xy[24], size_t m,
                                uint8_t* out_ok /* m */);
 
+/* The random exponents Seam A's batch_verify_strict draws for one call, as its device kernel produces them (tests / tooling): signer i
+ * of the call (i < offsets[m]) gets the first (128 + ceil(log2 n_b) + 7) / 8 bytes - n_b the size of its batch, as
+ * byte_count_from_target_batch_size, crates/bls-crypto/src/bls/batch.rs:23-28 - of block i of the ChaCha20 stream (RFC 7539 block
+ * function, 64-bit block counter, zero nonce) under `key`, little-endian in 4 x u64.  out: offsets[m] x 4 u64, host.  batch.rs:51-58 draws
+ * the same number of bytes per signer from rand::thread_rng(). */
+int celo_amd_draw_batch_exponents(const uint32_t key[8], const uint32_t* offsets /* m+1 */, size_t m, uint64_t* out);
+
 /* ---- pairing product check.  Replaces `Bls12_377::product_of_pairings(&pairs) == Fq12::one()` at
  *   crates/bls-crypto/src/bls/public.rs:102    (PublicKey::verify_sig: 2 pairs)
  *   crates/bls-crypto/src/bls/signature.rs:149 (Signature::batch_verify_hashes: n+1 pairs, one final exponentiation)

@@ -123,3 +123,47 @@ def test_batch_verify_strict_flow(gpu):
     with pytest.raises(bls.BLSError):
         bls.verify_hash(pks[1], h, sigs[0])
     assert bls.public_key_batch([1, 2], pks[:1]) is None      # length mismatch -> None (public.rs:53-56)
+
+
+@pytest.mark.gpu
+def test_device_exponent_kernel_is_chacha20_per_signer(gpu):
+    """celo_amd_draw_batch_exponents = what batch_verify_strict draws on the device (csrc/unit_batchverify.hip k_draw_exponents): signer i
+    keeps the first byte_count_from_target_batch_size(128, n) bytes (crates/bls-crypto/src/bls/batch.rs:23-28) of ChaCha20 block i under
+    the call's key.  Checked against a ChaCha20 block function written here and pinned on RFC 7539 section 2.3.2's test vector."""
+    import struct
+
+    def block(key_words, counter, nonce_words):
+        s = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key_words) + [counter & 0xFFFFFFFF] + list(nonce_words)
+        w = list(s)
+        rot = lambda x, n: ((x << n) | (x >> (32 - n))) & 0xFFFFFFFF
+
+        def qr(a, b, c, d):
+            w[a] = (w[a] + w[b]) & 0xFFFFFFFF; w[d] = rot(w[d] ^ w[a], 16)
+            w[c] = (w[c] + w[d]) & 0xFFFFFFFF; w[b] = rot(w[b] ^ w[c], 12)
+            w[a] = (w[a] + w[b]) & 0xFFFFFFFF; w[d] = rot(w[d] ^ w[a], 8)
+            w[c] = (w[c] + w[d]) & 0xFFFFFFFF; w[b] = rot(w[b] ^ w[c], 7)
+        for _ in range(10):
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        return struct.pack("<16I", *[(a + b) & 0xFFFFFFFF for a, b in zip(w, s)])
+
+    rfc_key = struct.unpack("<8I", bytes(range(32)))
+    rfc = block(rfc_key, 1, struct.unpack("<3I", bytes.fromhex("000000090000004a00000000")))
+    assert rfc[:16].hex() == "10f1e7e4d13b5915500fdd1fa32071c4" and rfc[-4:].hex() == "a2503c4e"
+    key = np.array([0x01234567, 0x89ABCDEF, 0xDEADBEEF, 0x0BADF00D, 7, 0, 0xFFFFFFFF, 0x5EED5EED], dtype=np.uint32)
+    sizes = [1, 2, 3, 0, 256, 257, 1024, 5, 0, 65, 70000]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    got = gpu.draw_batch_exponents(key, offsets)
+    assert got.shape == (sum(sizes), 4)
+    raw = got.view(np.uint8).reshape(-1, 32)
+    for b, n in enumerate(sizes):
+        lg = 0
+        while (1 << lg) < n:
+            lg += 1
+        nbytes = min(31, (128 + lg + 7) // 8)
+        picks = range(int(offsets[b]), int(offsets[b + 1])) if n <= 300 else [int(offsets[b]), int(offsets[b]) + 1, int(offsets[b + 1]) - 1, int(offsets[b]) + n // 2]
+        for at in picks:
+            want = block([int(k) for k in key], at, (0, 0, 0))[:nbytes] + bytes(32 - nbytes)
+            assert bytes(raw[at]) == want, (b, at)
+    # all exponents distinct, none zero, and the top byte count is what the MSM's window count will see (<= 8 * nbytes bits)
+    assert len({bytes(r) for r in raw}) == raw.shape[0]

@@ -439,6 +439,14 @@ def test_g1_subgroup_entry_large_device_resident(gpu, logn):
     sc[:, 3] &= np.uint64((1 << 60) - 1)
     sc[:1000] = co.ints_to_limbs([ecc.R377 - 1 - i for i in range(1000)], 4)
     sc[1000:1004, 3] |= np.uint64(0xE000000000000000)      # bits from Fr::MODULUS_BITS up: ignored by both entry points (and by ark-ec's windows)
+    # the split's edge scalars AT A SIZE WHERE THE SPLIT RUNS (n >= 2^14; the small test above takes the plain path - ADVICE r3): both
+    # sides of x^2 and of the halves' window borders, 0, 1, and their neighbours, spread over the index range
+    X2 = 0x8508C00000000001 ** 2
+    edge = [0, 1, 2, X2 - 1, X2, X2 + 1, 2 * X2 - 1, 2 * X2, (1 << 127) - 1, 1 << 127, (1 << 127) + 1, 1 << 126, (X2 - 1) + X2 * ((1 << 126) + 5),
+            (1 << 16) - 1, 1 << 16, 1 << 15, (1 << 15) - 1, X2 * ((1 << 112) - 1), X2 * ((1 << 126) - 1) + (X2 - 1), (1 << 252) + 1, ecc.R377 - X2, ecc.R377 - X2 - 1]
+    edge = [k % ecc.R377 for k in edge]
+    at = [1004 + 37 * i for i in range(len(edge))] + [n - 1 - 53 * i for i in range(len(edge))]
+    sc[at] = co.ints_to_limbs(edge + edge, 4)
     d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
     out = gpu.msm_dev("bls12_377_g1", bases.data_ptr(), 0, d_sc.data_ptr(), n, subgroup=True)
     tm = gpu.msm_timings("bls12_377_g1")

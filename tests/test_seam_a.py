@@ -898,3 +898,81 @@ def test_batch_verify_strict_config3_scale_through_the_ffi(sys_lib, gpu):
         arr[b] = _BatchMessageFFI(_Buffer(msg, len(msg)), _Buffer(b"", 0), pk_arr, NS, spoiled[b], NS)
     assert not sys_lib.batch_verify_strict(arr, C.c_size_t(m), CF, C22, out)
     assert [b for b in range(m) if not out[b]] == [17, 4001]
+
+
+@pytest.mark.gpu
+def test_batch_verify_strict_device_mirror_follows_the_handles(sys_lib, gpu):
+    """batch_verify_strict keeps the points of the handles it has seen in HBM, by arena slot (csrc/seam_a.hip HandleArena / Mirror), and
+    ships slot numbers.  What must hold whatever the mirror holds: a repeated call over the same handles gives the same verdicts; a
+    slot that is destroyed and handed out again carries its NEW point (the reused slot's stale row must not be paired with the new
+    handle); a destroyed handle in a list makes the call fail instead of verifying against a stale row; handles that are not affine
+    (aggregated keys and signatures, Z != 1) go through the same path.  Large enough (>= 8192 signers) for the threaded host pass."""
+    for f in ("sign_message", "batch_verify_strict", "generate_private_key", "aggregate_public_keys", "aggregate_signatures"):
+        getattr(sys_lib, f).restype = C.c_bool
+    CF, C22 = C.c_bool(False), C.c_bool(False)
+    NK, NS, m = 8, 128, 80
+
+    def fresh_key():
+        sk, pk = C.c_void_p(), C.c_void_p()
+        assert sys_lib.generate_private_key(C.byref(sk)) and sys_lib.private_key_to_public_key(sk, C.byref(pk))
+        return sk, pk
+
+    def sign(sk, msg):
+        s = C.c_void_p()
+        assert sys_lib.sign_message(sk, msg, C.c_int(len(msg)), b"", C.c_int(0), CF, C22, C.byref(s))
+        return s
+
+    keys = [fresh_key() for _ in range(NK)]                  # fresh public keys: Jacobian with Z != 1 (normalised on upload)
+    msgs = [b"mirror-%03d" % b for b in range(m)]
+    sigs = [[sign(sk, msg) for sk, _ in keys] for msg in msgs]
+
+    def call(pk_of, sig_of):
+        keep, arr = [], (_BatchMessageFFI * m)()
+        for b in range(m):
+            pks = (C.c_void_p * NS)(*[pk_of(b, i).value for i in range(NS)])
+            sgs = (C.c_void_p * NS)(*[sig_of(b, i).value for i in range(NS)])
+            keep.append((pks, sgs))
+            arr[b] = _BatchMessageFFI(_Buffer(msgs[b], len(msgs[b])), _Buffer(b"", 0), pks, NS, sgs, NS)
+        out = (C.c_bool * m)()
+        rc = sys_lib.batch_verify_strict(arr, C.c_size_t(m), CF, C22, out)
+        return rc, list(out)
+
+    plain = (lambda b, i: keys[i % NK][1], lambda b, i: sigs[b][i % NK])
+    assert call(*plain) == (True, [True] * m)
+    assert call(*plain) == (True, [True] * m)                # second call: nothing to upload, slot numbers only
+    # destroy key 3's public key and signer 3's signature of batch 5; the arenas hand the slots out again (LIFO free list)
+    old_pk, old_sig = keys[3][1], sigs[5][3]
+    assert sys_lib.destroy_public_key(old_pk) and sys_lib.destroy_signature(old_sig)
+    sk_new, pk_new = fresh_key()
+    assert pk_new.value == old_pk.value, "the arena reuses the released slot (this test relies on it)"
+    sig_new = sign(sk_new, msgs[5])
+    assert sig_new.value == old_sig.value
+    # the reused key slot now holds ANOTHER key: batches signed by the old key 3 must fail everywhere, except batch 5 whose signer-3
+    # signature slot now holds the new key's signature of that message
+    keys[3] = (keys[3][0], pk_new)
+    sigs[5][3] = sig_new
+    rc, out = call(*plain)
+    assert not rc and out == [b == 5 for b in range(m)]
+    # sign everything for the new key: all batches verify again
+    for b in range(m):
+        if b != 5:
+            sigs[b][3] = sign(sk_new, msgs[b])
+    assert call(*plain) == (True, [True] * m)
+    # a destroyed handle in the lists: the call fails, every verdict false - and the mirror is still right afterwards
+    victim = sigs[7][0]
+    assert sys_lib.destroy_signature(victim)
+    rc, out = call(*plain)
+    assert not rc and out == [False] * m
+    sigs[7][0] = sign(keys[0][0], msgs[7])
+    assert call(*plain) == (True, [True] * m)
+    # aggregated handles (sums: Z != 1): batch b = one aggregate key with one aggregate signature, NS times over
+    agg_pk = C.c_void_p()
+    arr_pk = (C.c_void_p * NK)(*[k[1].value for k in keys])
+    assert sys_lib.aggregate_public_keys(arr_pk, C.c_int(NK), C.byref(agg_pk))
+    agg_sigs = []
+    for b in range(m):
+        a = C.c_void_p()
+        assert sys_lib.aggregate_signatures((C.c_void_p * NK)(*[s.value for s in sigs[b]]), C.c_int(NK), C.byref(a))
+        agg_sigs.append(a)
+    assert call(lambda b, i: agg_pk, lambda b, i: agg_sigs[b]) == (True, [True] * m)
+    assert call(lambda b, i: agg_pk, lambda b, i: agg_sigs[(b + 1) % m]) == (False, [False] * m)

@@ -64,4 +64,43 @@ for composite, cip22, name in ((False, False, "direct"), (True, True, "composite
         assert lib.batch_verify_strict(arr, C.c_size_t(m), C.c_bool(composite), C.c_bool(cip22), out)
         dt = time.perf_counter() - t0
         res["%s_m%d" % (name, m)] = {"wall_ms": dt * 1e3, "batches_per_s": m / dt, "signatures_per_s": m * NS / dt}
+        if composite or os.environ.get("STRICT_DISTINCT", "1") == "0":
+            continue
+        # ---- the same call with a handle of its own behind EVERY position (m x 256 key handles + as many signature handles; copies made
+        # with aggregate_*([h]) - a one-term sum).  first: nothing of them on the device yet (every row normalised / copied / uploaded);
+        # steady: the same handles again (slot numbers only); fresh_sigs: the key handles stay, every signature handle is destroyed and
+        # re-created between calls - what a caller sees whose validator keys persist while each block brings new signatures.
+        for f in ("aggregate_public_keys", "aggregate_signatures", "destroy_signature"):
+            getattr(lib, f).restype = C.c_bool
+
+        def clone(h, fn):
+            o = C.c_void_p()
+            assert getattr(lib, fn)((C.c_void_p * 1)(h), C.c_int(1), C.byref(o))
+            return o.value
+
+        d_keep = []
+        darr = (BatchMessageFFI * m)()
+
+        def fill_sigs():
+            for b in range(m):
+                msg, pk_arr, sg_arr = per_msg[b % nmsg]
+                d_keep[b][1][:] = [clone(sg_arr[i], "aggregate_signatures") for i in range(NS)]
+
+        for b in range(m):
+            msg, pk_arr, sg_arr = per_msg[b % nmsg]
+            dp = (C.c_void_p * NS)(*[clone(pk_arr[i], "aggregate_public_keys") for i in range(NS)])
+            ds = (C.c_void_p * NS)()
+            d_keep.append((dp, ds))
+            darr[b] = BatchMessageFFI(Buffer(msg, len(msg)), Buffer(b"", 0), dp, NS, ds, NS)
+        fill_sigs()
+        for label in ("first", "steady", "steady2", "fresh_sigs", "fresh_sigs2"):
+            if label.startswith("fresh"):
+                for b in range(m):
+                    for i in range(NS):
+                        assert lib.destroy_signature(C.c_void_p(d_keep[b][1][i]))
+                fill_sigs()
+            t0 = time.perf_counter()
+            assert lib.batch_verify_strict(darr, C.c_size_t(m), C.c_bool(composite), C.c_bool(cip22), out) and all(out)
+            dt = time.perf_counter() - t0
+            res["%s_m%d_distinct_handles_%s" % (name, m, label)] = {"wall_ms": dt * 1e3, "batches_per_s": m / dt, "signatures_per_s": m * NS / dt}
 print(json.dumps(res))

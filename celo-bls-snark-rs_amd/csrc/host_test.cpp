@@ -193,6 +193,12 @@ template <class H> static void pairing_op_lanes_t(int mode, const uint64_t* g1, 
     for (size_t i = 0; i < k && i < 4; i++) load_pair(i, px[i], py[i], Qc[i]);
     typename HQT::E12 acc = HQP::template miller_multi<4>((int)k, px, py, Qc);
     r = mode == 10 ? HQP::final_exponentiation(acc) : acc;
+  } else if (mode == 13 || mode == 14) {  // exactly two pairs, the lines of every step multiplied first (miller_pair2); 13: GT value, 14: Miller value
+    typename QB::F px[2], py[2];
+    typename QB::V Qc[2];
+    for (size_t i = 0; i < 2; i++) load_pair(i, px[i], py[i], Qc[i]);
+    typename HQT::E12 acc = HQP::miller_pair2(px, py, Qc);
+    r = mode == 13 ? HQP::final_exponentiation(acc) : acc;
   } else if (mode == 12) {         // the product tree of the GPU engine: Miller values multiplied with each other pairwise (bounds: value x value)
     std::vector<typename HQT::E12> m(k);
     for (size_t i = 0; i < k; i++) {

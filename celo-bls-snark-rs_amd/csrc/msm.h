@@ -1780,6 +1780,10 @@ template <class G> class MsmEngine {
   static constexpr uint32_t BATCH_MAX_N = 1024;
   MsmTimings tm_batch;
   int batch_bits = 0;   // length of the longest scalar of the last batched call
+  // bits_hint > 0: the length of the longest scalar of the NEXT batched call, measured by the caller on the same scalars (spares the
+  // k_scalar_or round trip: with the chip full of another engine's accumulation that small kernel and its synchronisation waited 16 ms
+  // inside batch_verify_strict, and the G1 leg was enqueued only then); measured_bits: what the last call used, before clamping
+  int bits_hint = 0, measured_bits = 0;
   int run_batch_host(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, const uint32_t* offsets, size_t m,
                      uint64_t* out, hipStream_t stream) {
     return run_batch(bases, inf, scalars, 0, offsets, m, out, nullptr, stream);
@@ -1790,6 +1794,7 @@ template <class G> class MsmEngine {
   // caller chains its consumer behind it (batch verification: normalise + pairing inputs without a host round trip).
   int run_batch(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, int resident, const uint32_t* offsets, size_t m,
                 uint64_t* out, uint64_t** d_out_ret, hipStream_t stream) {
+    measured_bits = 0;                                     // stays 0 on the paths that do not measure (no hint to hand on)
     if (m == 0) return 0;
     const uint32_t total_pts = offsets[m];
     uint32_t max_n = 0;
@@ -1891,14 +1896,18 @@ template <class G> class MsmEngine {
     {
       char* A0 = arena;
       if (!resident) HIP_OK(hipMemcpyAsync(A0 + o_in_s, scalars, (size_t)total_pts * SW * 4, hipMemcpyHostToDevice, stream));
-      HIP_OK(hipMemsetAsync(A0 + o_or, 0, 64 * 4, stream));
-      hipLaunchKernelGGL((k_scalar_or<SW>), dim3(2048), dim3(256), 0, stream, resident ? (const uint32_t*)scalars : (const uint32_t*)(A0 + o_in_s),
-                         (size_t)total_pts * SW, (uint32_t*)(A0 + o_or));
-      uint32_t h_or[SW];
-      HIP_OK(hipMemcpyAsync(h_or, A0 + o_or, SW * 4, hipMemcpyDeviceToHost, stream));
-      HIP_OK(hipStreamSynchronize(stream));
       int bits = 1;
-      for (int k = SW - 1; k >= 0; k--) if (h_or[k]) { bits = 32 * k + 32 - __builtin_clz(h_or[k]); break; }
+      if (bits_hint > 0) bits = bits_hint;          // the caller measured these very scalars already (batch verification: the other leg's engine)
+      else {
+        HIP_OK(hipMemsetAsync(A0 + o_or, 0, 64 * 4, stream));
+        hipLaunchKernelGGL((k_scalar_or<SW>), dim3(2048), dim3(256), 0, stream, resident ? (const uint32_t*)scalars : (const uint32_t*)(A0 + o_in_s),
+                           (size_t)total_pts * SW, (uint32_t*)(A0 + o_or));
+        uint32_t h_or[SW];
+        HIP_OK(hipMemcpyAsync(h_or, A0 + o_or, SW * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        for (int k = SW - 1; k >= 0; k--) if (h_or[k]) { bits = 32 * k + 32 - __builtin_clz(h_or[k]); break; }
+      }
+      measured_bits = bits;
       if (bits > G::SCALAR_BITS && gls_digits(bits) == 1) bits = G::SCALAR_BITS;
       batch_bits = bits;
     }

@@ -343,10 +343,12 @@ int msm_multi_host_impl(Pool& pool, int force_c, const int* devices, int ndev, c
     L* l = new L(pool_aux_##TAG().lease());                                                                              \
     (*l)->force_c = force_c_aux_##TAG.load();                                                                            \
     (*l)->gls_subgroup_points = subgroup_points != 0;                                                                    \
+    (*l)->bits_hint = run->bits > 0 ? run->bits : 0;                                                                     \
     uint64_t* d_out = nullptr;                                                                                           \
     const int rc = (*l)->run_batch((const uint64_t*)b, (const uint8_t*)inf, (const uint64_t*)s, resident, off, m, nullptr, &d_out, (*l)->own_stream()); \
+    (*l)->bits_hint = 0;                                                                                                 \
     if (rc) { delete l; return rc; }                                                                                     \
-    run->lease = l; run->d_out = d_out; run->stream = (*l)->own_stream();                                                \
+    run->lease = l; run->d_out = d_out; run->stream = (*l)->own_stream(); run->bits = (*l)->measured_bits;               \
     return 0;                                                                                                            \
   }                                                                                                                      \
   void msm_batch_end_##TAG(BatchRun* run, int drained) {                                                                 \

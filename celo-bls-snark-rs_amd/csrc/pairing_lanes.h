@@ -428,6 +428,32 @@ template <class QB> struct QTower {
     f.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(e, A), b));
     f.a = QB::lred(QB::add_l(A, mul_by_gen_k_l<4>(b)));
   }
+  // Two line values of ONE Miller step multiplied with each other before they meet f (round 4): for group-uniform coefficients
+  //   (s0 + (s3 + s4 v) w)(t0 + (t3 + t4 v) w) = (s0 t0 + xi s4 t4) + s3 t3 v + (s3 t4 + s4 t3) v^2 + ((s0 t3 + s3 t0) + (s0 t4 + s4 t0) v) w
+  // is six Fq2 products - s0 t0, s3 t3, s4 t4 and the three Karatsuba cross products - i.e. TWO product rounds with every lane busy,
+  // and the result times f is one Fq12 product whose second Fq6 factor has no v^2 term (mul12_by_line_pair: 2 + 2 + 2 rounds): 8 rounds
+  // where two mul_by_034 are 10.  Same field elements: f l_a l_b either way.  Returned as {a = dense Fq6, b = (b0, b1, 0)}.
+  QFN static E12 mul_034_by_034(const V& s0, const V& s3, const V& s4, const V& t0, const V& t3, const V& t4) {
+    const V v = QB::mul(QB::pick(s0, s3, s4), QB::pick(t0, t3, t4));                          // s0 t0 | s3 t3 | s4 t4
+    const V c = QB::mul(QB::add(QB::pick(s0, s0, s3), QB::pick(s3, s4, s4)),
+                        QB::add(QB::pick(t0, t0, t3), QB::pick(t3, t4, t4)));                   // cross sums 03 | 04 | 34 (picked first: one carry pass each)
+    const V vr = QB::template perm<QP(2, 0, 1)>(v);                                           // s4 t4 | s0 t0 | s3 t3
+    const V vs = QB::template perm<QP(1, 2, 0)>(v);                                           // s3 t3 | s4 t4 | s0 t0
+    // lane 0: c03 - s0 t0 - s3 t3 = b0;  lane 1: c04 - s0 t0 - s4 t4 = b1;  lane 2: c34 - s3 t3 - s4 t4 = a2
+    const V d = QB::template sub<4>(QB::template sub_l<4>(c, QB::pick(v, vr, vr)), QB::pick(vs, vs, v));
+    const V a0 = QB::lred(QB::add_l(v, QB::template mul_nr_k_l<4>(vr)));                      // lane 0: s0 t0 + xi s4 t4
+    return {QB::pick(a0, v, d), QB::template sel<2>(QB::zero(), d)};
+  }
+  // x * L for L = mul_034_by_034(...): L.a dense, L.b = (b0, b1, 0) one coefficient per lane
+  QFN static E12 mul12_by_line_pair(const E12& x, const V& La, const V& Lb) {
+    const V v0 = mul6(x.a, La);
+    const V v1 = mul6_by_01(x.b, QB::template bcast<0>(Lb), QB::template bcast<1>(Lb));
+    const V t = mul6(QB::add(x.a, x.b), QB::add(La, Lb));
+    E12 r;
+    r.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(t, v0), v1));
+    r.a = QB::wred(QB::add_l(v0, mul_by_gen_k_l<4>(v1)));
+    return r;
+  }
   // Granger-Scott cyclotomic squaring: lane k squares the Fq4 pair k: (a0, b1), (b0, a2), (a1, b2)
   QNI static E12 cyclotomic_sqr(const E12& f) { return cyclotomic_sqr_inl(f); }
   QFN static E12 cyclotomic_sqr_inl(const E12& f) {
@@ -548,6 +574,39 @@ template <class QB> struct QPairing377 {
   QFN static void ell(E12& f, const Line& l, const F& px, const F& py) {
     V t = QB::mul_fp(QB::template sel<0>(l.c0, l.c1), QB::pickf(py, px, px));
     TW::mul_by_034(f, QB::template bcast<0>(t), QB::template bcast<1>(t), l.c2);
+  }
+  // the 034 coefficients of a line evaluated at P
+  QFN static void eval_line(const Line& l, const F& px, const F& py, V& s0, V& s3, V& s4) {
+    const V t = QB::mul_fp(QB::template sel<0>(l.c0, l.c1), QB::pickf(py, px, px));
+    s0 = QB::template bcast<0>(t); s3 = QB::template bcast<1>(t); s4 = l.c2;
+  }
+  // f *= l_a(P_a) * l_b(P_b), the two lines multiplied first (QTower::mul_034_by_034)
+  QFN static void ell2(E12& f, const Line& la, const F& pxa, const F& pya, const Line& lb, const F& pxb, const F& pyb) {
+    V s0, s3, s4, t0, t3, t4;
+    eval_line(la, pxa, pya, s0, s3, s4);
+    eval_line(lb, pxb, pyb, t0, t3, t4);
+    const E12 L = TW::mul_034_by_034(s0, s3, s4, t0, t3, t4);
+    f = TW::mul12_by_line_pair(f, L.a, L.b);
+  }
+  // Miller value of a product of exactly TWO pairs, shared accumulator, the lines of every step merged: the same field element as
+  // miller_multi<2> (and as ark-ec's multi-Miller loop) - what k_miller_prepared_slots computes with pair a on prepared lines
+  QFN static E12 miller_pair2(const F* px, const F* py, const V* Qc) {
+    V Ra = QB::template sel<2>(QB::one(), Qc[0]), Rb = QB::template sel<2>(QB::one(), Qc[1]);
+    E12 f = TW::one12();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = 62; i >= 0; i--) {
+      f = TW::sqr12(f);
+      Line la, lb;
+      double_step(Ra, la); double_step(Rb, lb);
+      ell2(f, la, px[0], py[0], lb, px[1], py[1]);
+      if ((T377::X >> i) & 1) {
+        add_step(Ra, Qc[0], la); add_step(Rb, Qc[1], lb);
+        ell2(f, la, px[0], py[0], lb, px[1], py[1]);
+      }
+    }
+    return f;
   }
   QNI static void step_double(V& Rc, E12& f, const F& px, const F& py) { Line l; double_step(Rc, l); ell(f, l, px, py); }
   QNI static void step_add(V& Rc, const V& Qc, E12& f, const F& px, const F& py) { Line l; add_step(Rc, Qc, l); ell(f, l, px, py); }

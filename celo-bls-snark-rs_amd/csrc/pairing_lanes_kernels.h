@@ -209,6 +209,40 @@ template <class LP> struct Slots {
     stv(sf, 0, QB::choose(commit, na, ldv(sf, 0)));
     fence();
   }
+  // f *= l_a(P_a) * l_b(P_b) with the two line values multiplied first (Pair::ell2 / Tow::mul_034_by_034: 8 product rounds where two
+  // ell_slot are 10).  The dense half of the line product waits in half `wl` of slot `sl` while the three Fq6 products run; its sparse
+  // half (b0, b1, 0) stays in 14 registers.  A pair that is not live contributes the line 1 = (1, 0, 0) - selected by mask arithmetic,
+  // no divergent region.  lfa() fetches pair a's line when it is needed (a prepared line comes from global memory: loading it before
+  // the point step of pair b would keep 42 registers alive across that step).
+  template <class LFA, class PFA, class PFB>
+  __device__ __forceinline__ static void ell2_slot(int sf, int sl, int wl, LFA lfa, PFA ldpa, bool live_a, const typename Pair::Line& lb, PFB ldpb, bool live_b) {
+    typedef typename LP::QB QB;
+    fence();
+    V Lb;
+    {
+      const V one = QB::one(), zero = QB::zero();
+      V t0, t3, t4;
+      {
+        const V tb = QB::mul_fp(QB::template sel<0>(lb.c0, lb.c1), QB::pickf(ldpb(1), ldpb(0), ldpb(0)));
+        t0 = QB::choose(live_b, QB::template bcast<0>(tb), one); t3 = QB::choose(live_b, QB::template bcast<1>(tb), zero); t4 = QB::choose(live_b, lb.c2, zero);
+      }
+      const typename Pair::Line la = lfa();
+      const V ta = QB::mul_fp(QB::template sel<0>(la.c0, la.c1), QB::pickf(ldpa(1), ldpa(0), ldpa(0)));
+      const E12 L = Tow::mul_034_by_034(QB::choose(live_a, QB::template bcast<0>(ta), one), QB::choose(live_a, QB::template bcast<1>(ta), zero),
+                                        QB::choose(live_a, la.c2, zero), t0, t3, t4);
+      stv(sl, wl, L.a);
+      Lb = L.b;
+    }
+    fence();
+    const V v0 = Tow::mul6(ldv(sf, 0), ldv(sl, wl));
+    fence();
+    const V v1 = Tow::mul6_by_01(ldv(sf, 1), QB::template bcast<0>(Lb), QB::template bcast<1>(Lb));
+    fence();
+    const V t = Tow::mul6(QB::add(ldv(sf, 0), ldv(sf, 1)), QB::add(ldv(sl, wl), Lb));
+    stv(sf, 1, QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(t, v0), v1)));
+    stv(sf, 0, QB::wred(QB::add_l(v0, Tow::template mul_by_gen_k_l<4>(v1))));
+    fence();
+  }
   // The routines of the inner loops are INLINED into them: an out-of-line call on gfx950 saves and restores the callee-saved
   // half of the ~250 live VGPRs (77 dwords each way per call, measured in the ISA) - the very private-memory traffic the slots
   // are there to remove.  Only whole loops (exp_loop: 63 squarings + 6 products) are out of line.
@@ -459,6 +493,7 @@ __global__ void __launch_bounds__(64) LANES_OCC k_miller_prepared_slots(const ui
   };
   auto ldp_a = [](int c) { return S::template ld_p<NS>(0, c); };
   auto ldp_b = [](int c) { return S::template ld_p<NS>(1, c); };
+#if defined(CELO_MILLER_UNMERGED)   // A/B switch (tools/ab_pairing.sh): the round-3 loop, one sparse product per line
 #pragma unroll 1
   for (int b = 62; b >= 0; b--) {
     S::sqr12(0);
@@ -478,6 +513,37 @@ __global__ void __launch_bounds__(64) LANES_OCC k_miller_prepared_slots(const ui
       S::fence();
     }
   }
+#else
+  // round 4: the two lines of a step are multiplied with each other first (Slots::ell2_slot); slot 1's second half - free in this
+  // kernel, pair a has no running point - holds the dense half of the line product
+#pragma unroll 1
+  for (int b = 62; b >= 0; b--) {
+    S::sqr12(0);
+    {
+      typename Pair::Line lb;
+      {
+        V Rb = S::ldv(1, 0);
+        Pair::double_step(Rb, lb);
+        S::stv(1, 0, Rb);
+      }
+      const int st = step;
+      S::ell2_slot(0, 1, 1, [&]() { return line_at(st); }, ldp_a, live_a, lb, ldp_b, live_b);
+      step++;
+    }
+    if ((T377::X >> b) & 1) {
+      typename Pair::Line lb;
+      {
+        const V Qc = LP::load_q(g2 + (size_t)ib * LP::G2W);
+        V Rb = S::ldv(1, 0);
+        Pair::add_step(Rb, Qc, lb);
+        S::stv(1, 0, Rb);
+      }
+      const int st = step;
+      S::ell2_slot(0, 1, 1, [&]() { return line_at(st); }, ldp_a, live_a, lb, ldp_b, live_b);
+      step++;
+    }
+  }
+#endif
   if (live) LP::store12(prod + (size_t)gi * lanes_gt_words<LP>(), S::ld12(0));
 }
 template <class LP>

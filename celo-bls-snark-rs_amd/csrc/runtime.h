@@ -85,7 +85,8 @@ struct OwnedStream {
 // ---- chaining engines on the device (batch verification: MSM results -> normalise -> pairing inputs, no host round trip)
 // A batched MSM that has been ENQUEUED on its engine's stream: d_out = m Jacobian results (arkworks form) in the engine's
 // arena; the engine stays leased until msm_batch_end_*.
-struct BatchRun { void* lease = nullptr; uint64_t* d_out = nullptr; hipStream_t stream = nullptr; };
+// bits: in - the length of the longest scalar if the caller knows it (0: measure); out - what the run used
+struct BatchRun { void* lease = nullptr; uint64_t* d_out = nullptr; hipStream_t stream = nullptr; int bits = 0; };
 // A pairing engine whose input slots (k pairs in m products) are handed to a producer kernel; pairing_run_staged_* runs the
 // check on what the slots hold (stream order) and returns the engine.
 struct PairingStage { void* lease = nullptr; uint64_t* d_g1 = nullptr; uint64_t* d_g2 = nullptr; uint8_t* d_i1 = nullptr; uint8_t* d_i2 = nullptr; hipStream_t stream = nullptr; };

@@ -185,6 +185,7 @@ int bv_begin_keys(BvJob* j, const void* pk_xy, const void* pk_inf, const void* e
 }
 int bv_begin_sigs(BvJob* j, const void* sig_xy, const void* sig_inf, const void* exponents, int resident, const uint32_t* offsets, size_t m) {
   if (int rc = api_enter()) return rc;
+  j->sigs.bits = j->keys.lease ? j->keys.bits : 0;     // the same exponents: the key leg has measured their length already
   return msm_batch_begin_g1_377(sig_xy, sig_inf, exponents, resident, offsets, m, 0, &j->sigs);
 }
 int bv_finish(BvJob* j, int begun_ok, const void* hash_xy, const void* hash_inf, int resident, const uint64_t neg_g2_xy[24], size_t m, uint8_t* out_ok) {

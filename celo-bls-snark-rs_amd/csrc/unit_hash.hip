@@ -86,6 +86,25 @@ static int ensure_device_gens(const EdPoint* h_gens, size_t ngens) {
   if (hipMemcpy(g_d_gens, h_gens, ngens * sizeof(EdPoint), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g_d_gens); g_d_gens = nullptr; return 10; }
   return 0;
 }
+// Device scratch and stream of the bulk hashers, per device, grow-only (under hash_mu).  Round 4: the calls used to hipMalloc / hipFree
+// eight buffers and run on the null stream - inside batch_verify_strict, whose hashing thread runs BESIDE the two batch MSMs, the null
+// stream's implicit joins and hipFree's device-wide wait held the hashes back until the MSMs had drained (hashes joined at 23.5 of
+// 29.9 ms) and the pairing leg was enqueued only then.  A non-blocking stream of their own and one cached allocation: they finish
+// under the G2 accumulation.
+struct HashScratch { hipStream_t stream = nullptr; uint8_t* buf = nullptr; size_t cap = 0; };
+static HashScratch g_hash_scratch[MAX_DEVICES];
+static int hash_scratch(size_t need, HashScratch** out) {
+  HashScratch& h = g_hash_scratch[api_device()];
+  if (!h.stream && hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking) != hipSuccess) { h.stream = nullptr; return 10; }
+  if (need > h.cap) {
+    if (h.buf) (void)hipFree(h.buf);
+    h.buf = nullptr; h.cap = 0;
+    if (hipMalloc((void**)&h.buf, need + need / 4) != hipSuccess) { h.buf = nullptr; return 10; }
+    h.cap = need + need / 4;
+  }
+  *out = &h;
+  return 0;
+}
 static float g_hash_ms = 0.f;
 static int g_hash_rounds = 0;
 
@@ -125,23 +144,25 @@ int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint
   hipEvent_t e0 = nullptr, e1 = nullptr;
   std::vector<uint8_t> redo(n);
   int rc = 0;
+  HashScratch* hs = nullptr;
+  hipStream_t st = nullptr;
   {
-    HASH_TRY(hipMalloc(&d_bytes, mb + eb + 8));
-    HASH_TRY(hipMalloc(&d_off, (n + 1) * 2 * 8));
-    HASH_TRY(hipMalloc(&d_out, n * 12 * 8));
-    HASH_TRY(hipMalloc(&d_cand, n * 12 * 8));
-    HASH_TRY(hipMalloc(&d_att, n));
-    HASH_TRY(hipMalloc(&d_redo, n));
-    HASH_TRY(hipMalloc(&d_list, 2 * n * 4));
-    HASH_TRY(hipMalloc(&d_cnt, 256 * 4));
-    if (mb) HASH_TRY(hipMemcpyAsync(d_bytes, msgs, mb, hipMemcpyHostToDevice, 0));
-    if (eb) HASH_TRY(hipMemcpyAsync(d_bytes + mb, extras, eb, hipMemcpyHostToDevice, 0));
-    HASH_TRY(hipMemcpyAsync(d_off, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, 0));
-    if (extra_off) HASH_TRY(hipMemcpyAsync(d_off + n + 1, extra_off, (n + 1) * 8, hipMemcpyHostToDevice, 0));
-    HASH_TRY(hipMemsetAsync(d_cnt, 0, 256 * 4, 0));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
+    const size_t o_off = take((n + 1) * 2 * 8), o_out = take(n * 12 * 8), o_cand = take(n * 12 * 8), o_list = take(2 * n * 4), o_cnt = take(256 * 4),
+                 o_att = take(n), o_redo = take(n), o_bytes = take(mb + eb + 8);
+    if (hash_scratch(off, &hs)) { rc = 10; goto done; }
+    st = hs->stream;
+    d_off = (uint64_t*)(hs->buf + o_off); d_out = (uint64_t*)(hs->buf + o_out); d_cand = (uint64_t*)(hs->buf + o_cand);
+    d_list = (uint32_t*)(hs->buf + o_list); d_cnt = (uint32_t*)(hs->buf + o_cnt); d_att = hs->buf + o_att; d_redo = hs->buf + o_redo; d_bytes = hs->buf + o_bytes;
+    if (mb) HASH_TRY(hipMemcpyAsync(d_bytes, msgs, mb, hipMemcpyHostToDevice, st));
+    if (eb) HASH_TRY(hipMemcpyAsync(d_bytes + mb, extras, eb, hipMemcpyHostToDevice, st));
+    HASH_TRY(hipMemcpyAsync(d_off, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    if (extra_off) HASH_TRY(hipMemcpyAsync(d_off + n + 1, extra_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HASH_TRY(hipMemsetAsync(d_cnt, 0, 256 * 4, st));
     HASH_TRY(hipEventCreate(&e0));
     HASH_TRY(hipEventCreate(&e1));
-    HASH_TRY(hipEventRecord(e0, 0));
+    HASH_TRY(hipEventRecord(e0, st));
     const HashIn in = {d_bytes, d_off, d_bytes + mb, extra_off ? d_off + n + 1 : nullptr};
     uint32_t count = (uint32_t)n, base = 0;
     int round = 0;
@@ -151,22 +172,22 @@ int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint
       const uint32_t* list = round ? d_list + (size_t)(round & 1) * n : nullptr;
       uint32_t* next = d_list + (size_t)((round + 1) & 1) * n;
       const size_t lanes = (size_t)count << cand_log;
-      hipLaunchKernelGGL(k_hash_candidates, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, 0, dom, in, list, count, cand_log, base, mode, d_gens, d_cand, d_att,
+      hipLaunchKernelGGL(k_hash_candidates, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, dom, in, list, count, cand_log, base, mode, d_gens, d_cand, d_att,
                          next, d_cnt + round, k);
       HASH_TRY(hipGetLastError());
-      HASH_TRY(hipMemcpyAsync(&count, d_cnt + round, 4, hipMemcpyDeviceToHost, 0));
-      HASH_TRY(hipStreamSynchronize(0));
+      HASH_TRY(hipMemcpyAsync(&count, d_cnt + round, 4, hipMemcpyDeviceToHost, st));
+      HASH_TRY(hipStreamSynchronize(st));
       base += 1u << cand_log;
       round++;
     }
     g_hash_rounds = round;
-    hipLaunchKernelGGL(k_hash_finish, dim3(((uint32_t)n + 63) / 64), dim3(64), 0, 0, d_cand, d_att, d_out, d_redo, (uint32_t)n);
+    hipLaunchKernelGGL(k_hash_finish, dim3(((uint32_t)n + 63) / 64), dim3(64), 0, st, d_cand, d_att, d_out, d_redo, (uint32_t)n);
     HASH_TRY(hipGetLastError());
-    HASH_TRY(hipEventRecord(e1, 0));
-    HASH_TRY(hipMemcpyAsync(out_xy, d_out, n * 12 * 8, hipMemcpyDeviceToHost, 0));
-    HASH_TRY(hipMemcpyAsync(attempts, d_att, n, hipMemcpyDeviceToHost, 0));
-    HASH_TRY(hipMemcpyAsync(redo.data(), d_redo, n, hipMemcpyDeviceToHost, 0));
-    HASH_TRY(hipStreamSynchronize(0));
+    HASH_TRY(hipEventRecord(e1, st));
+    HASH_TRY(hipMemcpyAsync(out_xy, d_out, n * 12 * 8, hipMemcpyDeviceToHost, st));
+    HASH_TRY(hipMemcpyAsync(attempts, d_att, n, hipMemcpyDeviceToHost, st));
+    HASH_TRY(hipMemcpyAsync(redo.data(), d_redo, n, hipMemcpyDeviceToHost, st));
+    HASH_TRY(hipStreamSynchronize(st));
     HASH_TRY(hipEventElapsedTime(&g_hash_ms, e0, e1));
     // the counter whose cofactor multiple was the identity is skipped like the reference's loop does: continue serially after it
     for (size_t i = 0; i < n; i++) {
@@ -182,8 +203,6 @@ int hash_to_g1_direct_run(const uint8_t* domain, const uint8_t* msgs, const uint
 done:
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
-  for (void* q : {(void*)d_bytes, (void*)d_off, (void*)d_out, (void*)d_cand, (void*)d_att, (void*)d_redo, (void*)d_list, (void*)d_cnt})
-    if (q) (void)hipFree(q);
   return rc;
 }
 // ---- bulk Pedersen CRH (pedersen.h): one message per lane; the 52080-generator table (11.7 MB) is uploaded on first use
@@ -214,25 +233,28 @@ int pedersen_crh_run(const uint8_t* msgs, const uint64_t* msg_off, size_t n, uin
   int rc = 0;
   if (int rcg = ensure_device_gens(gens, ngens)) return rcg;
   EdPoint* d_gens = g_d_gens;
-  HASH_TRY(hipMalloc(&d_bytes, mb + 8));
-  HASH_TRY(hipMalloc(&d_off, (n + 1) * 8));
-  HASH_TRY(hipMalloc(&d_out, n * 48));
-  if (mb) HASH_TRY(hipMemcpyAsync(d_bytes, msgs, mb, hipMemcpyHostToDevice, 0));
-  HASH_TRY(hipMemcpyAsync(d_off, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, 0));
+  HashScratch* hs = nullptr;
+  hipStream_t st = nullptr;
+  {
+    const size_t o_off = 0, o_out = ((n + 1) * 8 + 255) & ~size_t(255), o_bytes = o_out + ((n * 48 + 255) & ~size_t(255));
+    if (hash_scratch(o_bytes + mb + 8, &hs)) { rc = 10; goto done; }
+    st = hs->stream;
+    d_off = (uint64_t*)(hs->buf + o_off); d_out = hs->buf + o_out; d_bytes = hs->buf + o_bytes;
+  }
+  if (mb) HASH_TRY(hipMemcpyAsync(d_bytes, msgs, mb, hipMemcpyHostToDevice, st));
+  HASH_TRY(hipMemcpyAsync(d_off, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
   HASH_TRY(hipEventCreate(&e0));
   HASH_TRY(hipEventCreate(&e1));
-  HASH_TRY(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(k_pedersen_crh, dim3(((uint32_t)n + 63) / 64), dim3(64), 0, 0, d_gens, d_bytes, d_off, d_out, (uint32_t)n);
+  HASH_TRY(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(k_pedersen_crh, dim3(((uint32_t)n + 63) / 64), dim3(64), 0, st, d_gens, d_bytes, d_off, d_out, (uint32_t)n);
   HASH_TRY(hipGetLastError());
-  HASH_TRY(hipEventRecord(e1, 0));
-  HASH_TRY(hipMemcpyAsync(out48, d_out, n * 48, hipMemcpyDeviceToHost, 0));
-  HASH_TRY(hipStreamSynchronize(0));
+  HASH_TRY(hipEventRecord(e1, st));
+  HASH_TRY(hipMemcpyAsync(out48, d_out, n * 48, hipMemcpyDeviceToHost, st));
+  HASH_TRY(hipStreamSynchronize(st));
   HASH_TRY(hipEventElapsedTime(&g_hash_ms, e0, e1));
 done:
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
-  for (void* q : {(void*)d_bytes, (void*)d_off, (void*)d_out})
-    if (q) (void)hipFree(q);
   return rc;
 }
 float hash_last_ms() { return g_hash_ms; }

@@ -158,3 +158,25 @@ def test_shared_accumulator_product_matches_oracle(ht):
             assert np.array_equal(ml, co.miller_loop_377(g1[:k], None, g2[:k], None)), name
             gt, one = hp(hook, 10, g1[:k], g2[:k], k)
             assert np.array_equal(gt, co.pairing_product_377(g1[:k], None, g2[:k], None)[0]) and not one, name
+
+
+def test_merged_line_product_matches_oracle(ht):
+    """pairing_lanes.h miller_pair2 / QTower::mul_034_by_034 + mul12_by_line_pair (round 4): the two line values of every Miller step
+    multiplied with each other first (two product rounds) and their product into f by one Fq12 product - the same field elements as
+    the shared-accumulator loop and the oracle, bit for bit, under the host build's bound assertions, on both lane layouts."""
+    rng = ecc.SplitMix64(1704)
+    for rep in range(2):
+        P = [ecc.E1_377.mul(ecc.G1_377, rng.next()) for _ in range(2)]
+        Q = [ecc.E2_377.mul(ecc.G2_377, rng.next()) for _ in range(2)]
+        if rep == 1:                                  # verify-shaped: e(sk H, -g2) e(H, sk g2) = 1
+            sk = rng.next()
+            P = [ecc.E1_377.mul(P[1], sk), P[1]]
+            Q = [ecc.E2_377.neg(ecc.G2_377), ecc.E2_377.mul(ecc.G2_377, sk)]
+        g1, _ = co.pack_g1_377(P)
+        g2, _ = co.pack_g2_377(Q)
+        for name in ("ht_pairing_377_lanes", "ht_pairing_377_hex"):
+            hook = _Hook(ht, name)
+            ml, _ = hp(hook, 14, g1, g2, 2)
+            assert np.array_equal(ml, co.miller_loop_377(g1, None, g2, None)), name
+            gt, one = hp(hook, 13, g1, g2, 2)
+            assert np.array_equal(gt, co.pairing_product_377(g1, None, g2, None)[0]) and one == (rep == 1), name

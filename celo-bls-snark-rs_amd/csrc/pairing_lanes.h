@@ -433,14 +433,18 @@ template <class QB> struct QTower {
   // is six Fq2 products - s0 t0, s3 t3, s4 t4 and the three Karatsuba cross products - i.e. TWO product rounds with every lane busy,
   // and the result times f is one Fq12 product whose second Fq6 factor has no v^2 term (mul12_by_line_pair: 2 + 2 + 2 rounds): 8 rounds
   // where two mul_by_034 are 10.  Same field elements: f l_a l_b either way.  Returned as {a = dense Fq6, b = (b0, b1, 0)}.
-  QFN static E12 mul_034_by_034(const V& s0, const V& s3, const V& s4, const V& t0, const V& t3, const V& t4) {
-    const V v = QB::mul(QB::pick(s0, s3, s4), QB::pick(t0, t3, t4));                          // s0 t0 | s3 t3 | s4 t4
-    const V c = QB::mul(QB::add(QB::pick(s0, s0, s3), QB::pick(s3, s4, s4)),
-                        QB::add(QB::pick(t0, t0, t3), QB::pick(t3, t4, t4)));                   // cross sums 03 | 04 | 34 (picked first: one carry pass each)
+  // The lines arrive as the tower code produces them: ts / tt hold s0 | s3 (t0 | t3) on lanes 0 | 1 - the two scalings of Pair::ell's
+  // mul_fp, lane 2 unused - and s4 / t4 are group-uniform, so the operand patterns are two lane permutes and two selects per line
+  // instead of broadcasts and three-way picks.
+  QFN static E12 mul_034_by_034(const V& ts, const V& s4, const V& tt, const V& t4) {
+    const V v = QB::mul(QB::template sel<2>(s4, ts), QB::template sel<2>(t4, tt));           // s0 t0 | s3 t3 | s4 t4
+    const V xs = QB::add(QB::template perm<QP(0, 0, 1)>(ts), QB::template sel<0>(QB::template bcast<1>(ts), s4));   // s0 + s3 | s0 + s4 | s3 + s4
+    const V ys = QB::add(QB::template perm<QP(0, 0, 1)>(tt), QB::template sel<0>(QB::template bcast<1>(tt), t4));
+    const V c = QB::mul(xs, ys);                                                              // cross sums 03 | 04 | 34
     const V vr = QB::template perm<QP(2, 0, 1)>(v);                                           // s4 t4 | s0 t0 | s3 t3
     const V vs = QB::template perm<QP(1, 2, 0)>(v);                                           // s3 t3 | s4 t4 | s0 t0
     // lane 0: c03 - s0 t0 - s3 t3 = b0;  lane 1: c04 - s0 t0 - s4 t4 = b1;  lane 2: c34 - s3 t3 - s4 t4 = a2
-    const V d = QB::template sub<4>(QB::template sub_l<4>(c, QB::pick(v, vr, vr)), QB::pick(vs, vs, v));
+    const V d = QB::template sub<4>(QB::template sub_l<4>(c, QB::template sel<0>(v, vr)), QB::template sel<2>(v, vs));
     const V a0 = QB::lred(QB::add_l(v, QB::template mul_nr_k_l<4>(vr)));                      // lane 0: s0 t0 + xi s4 t4
     return {QB::pick(a0, v, d), QB::template sel<2>(QB::zero(), d)};
   }
@@ -575,17 +579,11 @@ template <class QB> struct QPairing377 {
     V t = QB::mul_fp(QB::template sel<0>(l.c0, l.c1), QB::pickf(py, px, px));
     TW::mul_by_034(f, QB::template bcast<0>(t), QB::template bcast<1>(t), l.c2);
   }
-  // the 034 coefficients of a line evaluated at P
-  QFN static void eval_line(const Line& l, const F& px, const F& py, V& s0, V& s3, V& s4) {
-    const V t = QB::mul_fp(QB::template sel<0>(l.c0, l.c1), QB::pickf(py, px, px));
-    s0 = QB::template bcast<0>(t); s3 = QB::template bcast<1>(t); s4 = l.c2;
-  }
+  // a line evaluated at P: lane 0: c0 P.y, lane 1: c1 P.x (the 034 coefficients s0, s3; s4 = l.c2 stays group-uniform)
+  QFN static V eval_line(const Line& l, const F& px, const F& py) { return QB::mul_fp(QB::template sel<0>(l.c0, l.c1), QB::pickf(py, px, px)); }
   // f *= l_a(P_a) * l_b(P_b), the two lines multiplied first (QTower::mul_034_by_034)
   QFN static void ell2(E12& f, const Line& la, const F& pxa, const F& pya, const Line& lb, const F& pxb, const F& pyb) {
-    V s0, s3, s4, t0, t3, t4;
-    eval_line(la, pxa, pya, s0, s3, s4);
-    eval_line(lb, pxb, pyb, t0, t3, t4);
-    const E12 L = TW::mul_034_by_034(s0, s3, s4, t0, t3, t4);
+    const E12 L = TW::mul_034_by_034(eval_line(la, pxa, pya), la.c2, eval_line(lb, pxb, pyb), lb.c2);
     f = TW::mul12_by_line_pair(f, L.a, L.b);
   }
   // Miller value of a product of exactly TWO pairs, shared accumulator, the lines of every step merged: the same field element as

@@ -220,16 +220,12 @@ template <class LP> struct Slots {
     fence();
     V Lb;
     {
-      const V one = QB::one(), zero = QB::zero();
-      V t0, t3, t4;
-      {
-        const V tb = QB::mul_fp(QB::template sel<0>(lb.c0, lb.c1), QB::pickf(ldpb(1), ldpb(0), ldpb(0)));
-        t0 = QB::choose(live_b, QB::template bcast<0>(tb), one); t3 = QB::choose(live_b, QB::template bcast<1>(tb), zero); t4 = QB::choose(live_b, lb.c2, zero);
-      }
+      const V zero = QB::zero(), one0 = QB::template sel<0>(QB::one(), zero);       // the line 1: s0 = 1 on lane 0, s3 = 0 on lane 1, s4 = 0
+      const V tb = QB::choose(live_b, QB::mul_fp(QB::template sel<0>(lb.c0, lb.c1), QB::pickf(ldpb(1), ldpb(0), ldpb(0))), one0);
+      const V t4 = QB::choose(live_b, lb.c2, zero);
       const typename Pair::Line la = lfa();
-      const V ta = QB::mul_fp(QB::template sel<0>(la.c0, la.c1), QB::pickf(ldpa(1), ldpa(0), ldpa(0)));
-      const E12 L = Tow::mul_034_by_034(QB::choose(live_a, QB::template bcast<0>(ta), one), QB::choose(live_a, QB::template bcast<1>(ta), zero),
-                                        QB::choose(live_a, la.c2, zero), t0, t3, t4);
+      const V ta = QB::choose(live_a, QB::mul_fp(QB::template sel<0>(la.c0, la.c1), QB::pickf(ldpa(1), ldpa(0), ldpa(0))), one0);
+      const E12 L = Tow::mul_034_by_034(ta, QB::choose(live_a, la.c2, zero), tb, t4);
       stv(sl, wl, L.a);
       Lb = L.b;
     }

@@ -976,3 +976,68 @@ def test_batch_verify_strict_device_mirror_follows_the_handles(sys_lib, gpu):
         agg_sigs.append(a)
     assert call(lambda b, i: agg_pk, lambda b, i: agg_sigs[b]) == (True, [True] * m)
     assert call(lambda b, i: agg_pk, lambda b, i: agg_sigs[(b + 1) % m]) == (False, [False] * m)
+
+
+def test_handle_arena_allocation_and_reuse(sys_lib, golden):
+    """Handles live in chunked arenas (csrc/seam_a.hip HandleArena): addresses are stable, a destroyed handle's slot is handed out again
+    (LIFO), contents never leak from one tenant of a slot to the next, and more handles than one chunk holds (2^14) keep their
+    contents - host only, through the reference-named symbols.  Concurrent create / destroy from several threads ends consistent."""
+    import threading
+    pts = [bytes.fromhex(h) for h in list(golden["hash_to_g1_non_compat"])[:6]] if "hash_to_g1_non_compat" in golden else None
+    if not pts:
+        rng = ecc.SplitMix64(4242)
+        pts = [ecc.ser_point(ecc.E1_377, ecc.E1_377.mul(ecc.G1_377, rng.next() | 1)) for _ in range(6)]
+    base = [_deser(sys_lib, "deserialize_signature", p) for p in pts]
+    assert all(base)
+    sys_lib.aggregate_signatures.restype = C.c_bool
+
+    def clone(h):
+        o = C.c_void_p()
+        assert sys_lib.aggregate_signatures((C.c_void_p * 1)(h), C.c_int(1), C.byref(o))
+        return o
+
+    n = (1 << 14) + 4000                                                  # crosses a chunk boundary
+    many = [clone(base[i % 6]) for i in range(n)]
+    assert len({h.value for h in many}) == n
+    for i in (0, 1, (1 << 14) - 1, 1 << 14, n - 1, 7777):
+        assert _ser(sys_lib, "serialize_signature", many[i]) == pts[i % 6]
+    # LIFO reuse, with the new tenant's contents
+    a = many[100].value
+    assert sys_lib.destroy_signature(many[100])
+    many[100] = clone(base[5])
+    assert many[100].value == a and _ser(sys_lib, "serialize_signature", many[100]) == pts[5]
+    assert _ser(sys_lib, "serialize_signature", many[99]) == pts[99 % 6] and _ser(sys_lib, "serialize_signature", many[101]) == pts[101 % 6]
+    for h in many:
+        assert sys_lib.destroy_signature(h)
+    again = [clone(base[(i + 1) % 6]) for i in range(n)]
+    assert {h.value for h in again} == {h.value for h in many}          # the same slots, no growth
+    for i in (0, 5000, n - 1):
+        assert _ser(sys_lib, "serialize_signature", again[i]) == pts[(i + 1) % 6]
+    for h in again:
+        assert sys_lib.destroy_signature(h)
+    # four threads creating and destroying at once: every handle reads back what its creator put in
+    errs = []
+
+    def worker(t):
+        try:
+            mine = []
+            for r in range(3000):
+                h = clone(base[(t + r) % 6])
+                mine.append((h, (t + r) % 6))
+                if r % 3 == 2:
+                    hh, k = mine.pop(0)
+                    if _ser(sys_lib, "serialize_signature", hh) != pts[k]:
+                        errs.append((t, r))
+                    assert sys_lib.destroy_signature(hh)
+            for hh, k in mine:
+                if _ser(sys_lib, "serialize_signature", hh) != pts[k]:
+                    errs.append((t, -1))
+                assert sys_lib.destroy_signature(hh)
+        except Exception as e:      # noqa: BLE001
+            errs.append((t, repr(e)))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs[:3]

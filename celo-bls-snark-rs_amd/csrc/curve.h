@@ -141,6 +141,55 @@ template <class F> HD void xyzz_add(Xyzz<F>& a, const Xyzz<F>& b) {
   a.Y = Y3;
 }
 
+// a += the XYZZ point stored at src (X | Y | ZZ | ZZZ, F::WORDS words apart; the identity stored as exact zeros), its coordinates
+// loaded WHERE THEY ARE USED instead of up front (round 4).  A full addition of Fq2 points holds the accumulator (112 registers), the
+// second point (112) and the addition's temporaries; with the point loaded first the one-lane kernels of the batched path spilled to
+// scratch (k_batch_reduce<G2_377>: 1264 B/lane, k_batch_bitsums: 180 B and 233 scratch reloads per addition, each waited for by a lone
+// wave: 230 us per addition against 24 us per mixed addition in k_accumulate).  Memory is the spill space: ZZ2 and ZZZ2 are read twice.
+template <class F> HD void xyzz_add_mem(Xyzz<F>& a, const uint32_t* src) {
+  constexpr int FW = F::WORDS;
+#define XAM_FENCE() asm volatile("" ::: "memory")
+  {
+    const F bzz = F::load(src + 2 * FW);
+    if (bzz.limbs_all_zero()) return;
+    if (a.is_identity()) { a = {F::load(src), F::load(src + FW), bzz, F::load(src + 3 * FW)}; return; }
+  }
+  XAM_FENCE();
+  F Pd, R, U1, S1;
+  {
+    U1 = F::mul_nn(a.X, F::load(src + 2 * FW));
+    const F U2 = F::mul_nn(F::load(src), a.ZZ);
+    Pd = F::prep(F::template sub<4, 1>(U2, U1));      // [3, 6]
+  }
+  XAM_FENCE();
+  {
+    S1 = F::mul_nn(a.Y, F::load(src + 3 * FW));
+    const F S2 = F::mul_nn(F::load(src + FW), a.ZZZ);
+    R = F::prep(F::template sub<4, 1>(S2, S1));
+  }
+  XAM_FENCE();
+  if (Pd.is_zero_mod_p()) {
+    if (R.is_zero_mod_p()) a = xyzz_dbl<F>(a);
+    else a = Xyzz<F>::identity();
+    return;
+  }
+  F PP = F::sqr_nn(Pd);
+  F PPP = F::mul_nn(Pd, PP);
+  F Q = F::mul_nn(U1, PP);
+  F R2 = F::sqr_nn(R);
+  F s = F::add(F::add(PPP, Q), Q);
+  F X3 = F::norm(F::template sub<16, 3>(R2, s));
+  F t = F::prep(F::template sub<32, 1>(Q, X3));
+  F Y3 = F::template mul_sub_nn_at<4>(R, t, S1, PPP);
+  XAM_FENCE();
+  a.ZZ = F::mul_nn(F::mul_nn(a.ZZ, F::load(src + 2 * FW)), PP);
+  XAM_FENCE();
+  a.ZZZ = F::mul_nn(F::mul_nn(a.ZZZ, F::load(src + 3 * FW)), PPP);
+  a.X = X3;
+  a.Y = Y3;
+#undef XAM_FENCE
+}
+
 // Out-of-line variants for the latency-bound reduction kernels (one code copy per translation unit instead of one per
 // call site: the inlined bodies are ~8-17k instructions each and dominated the build time).
 #if defined(__HIPCC__)

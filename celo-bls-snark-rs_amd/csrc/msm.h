@@ -905,6 +905,11 @@ __global__ void __launch_bounds__(256) k_batch_sort(const uint32_t* __restrict__
   }
 }
 
+// (Round 4, measured and not kept - DESIGN.md section 6: this kernel is NOT latency-bound at config 3's scale.  The G2 leg brings
+// 13 windows x 4096 instances = 53 248 running sums of 32 full additions, 1.7 M full additions of Fq2 points, and the chip does 0.4-0.55 G
+// of them per second in this one-lane form - the 3.1 ms are work.  Six lanes per running sum (LanePoint on the hex backend): 3.46 ms;
+// window sums by bit position - chains of 7 additions on 4x the lanes, the Horner pass taking one more addition per bit - 3.7 + 1.2 ms
+// against 3.1 + 0.6.  Kept from it: the bucket's coordinates are loaded where they are used, curve.h xyzz_add_mem - scratch 1264 -> 260 B.)
 template <class G>
 __global__ void __launch_bounds__(128) k_batch_reduce(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ plen,
                                                       uint32_t* __restrict__ wsum, uint32_t B, uint32_t nvw) {
@@ -915,10 +920,7 @@ __global__ void __launch_bounds__(128) k_batch_reduce(const uint32_t* __restrict
   Xyzz<F> running = Xyzz<F>::identity(), acc = Xyzz<F>::identity();
   for (int b = (int)B - 1; b >= 0; b--) {
     size_t bucket = (size_t)vw * B + b;
-    if (plen[bucket]) {
-      Xyzz<F> v = IO::load_xyzz(partials + bucket * IO::XYZZ_WORDS);
-      xyzz_add(running, v);
-    }
+    if (plen[bucket]) xyzz_add_mem(running, partials + bucket * IO::XYZZ_WORDS);   // the bucket's coordinates loaded where they are used (curve.h)
     xyzz_add(acc, running);
   }
   IO::store_xyzz(wsum + (size_t)vw * IO::XYZZ_WORDS, acc);

@@ -239,6 +239,24 @@ template <class LP> struct Slots {
     stv(sf, 0, QB::wred(QB::add_l(v0, Tow::template mul_by_gen_k_l<4>(v1))));
     fence();
   }
+  // the same for two pairs that both walk their own point (k_miller_product_slots<LP, 2>): every half slot is taken, so the line product
+  // stays in registers (28) across the three Fq6 products; ta / tb are the lines already evaluated at their P (lanes 0 | 1: s0 | s3),
+  // taken right after each pair's point step so that no line triple stays alive across the other pair's step
+  __device__ __forceinline__ static void ell2_regs(int sf, const V& ta, const V& a4, bool live_a, const V& tb, const V& b4, bool live_b) {
+    typedef typename LP::QB QB;
+    fence();
+    const V zero = QB::zero(), one0 = QB::template sel<0>(QB::one(), zero);
+    const E12 L = Tow::mul_034_by_034(QB::choose(live_a, ta, one0), QB::choose(live_a, a4, zero), QB::choose(live_b, tb, one0), QB::choose(live_b, b4, zero));
+    fence();
+    const V v0 = Tow::mul6(ldv(sf, 0), L.a);
+    fence();
+    const V v1 = Tow::mul6_by_01(ldv(sf, 1), QB::template bcast<0>(L.b), QB::template bcast<1>(L.b));
+    fence();
+    const V t = Tow::mul6(QB::add(ldv(sf, 0), ldv(sf, 1)), QB::add(L.a, L.b));
+    stv(sf, 1, QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(t, v0), v1)));
+    stv(sf, 0, QB::wred(QB::add_l(v0, Tow::template mul_by_gen_k_l<4>(v1))));
+    fence();
+  }
   // The routines of the inner loops are INLINED into them: an out-of-line call on gfx950 saves and restores the callee-saved
   // half of the ~250 live VGPRs (77 dwords each way per call, measured in the ISA) - the very private-memory traffic the slots
   // are there to remove.  Only whole loops (exp_loop: 63 squarings + 6 products) are out of line.
@@ -404,6 +422,57 @@ __global__ void __launch_bounds__(64) LANES_OCC k_miller_product_slots(const uin
     k++;
   }
   S::st12(0, Tow::one12());
+#if !defined(CELO_MILLER_UNMERGED)
+  if constexpr (MAXK == 2) {
+    // round 4: two pairs = the two lines of a step multiplied with each other first (Slots::ell2_regs), as in k_miller_prepared_slots
+    typedef typename LP::Pair Pair;
+    typedef typename QB::V V;
+    constexpr int NS = S::product_slots(2);
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+      S::sqr12(0);
+      V ta, a4, tb, b4;
+      {
+        typename Pair::Line l;
+        V R = S::ldv(1, 0);
+        Pair::double_step(R, l);
+        S::stv(1, 0, R);
+        ta = Pair::eval_line(l, S::template ld_p<NS>(0, 0), S::template ld_p<NS>(0, 1)); a4 = l.c2;
+      }
+      S::fence();
+      {
+        typename Pair::Line l;
+        V R = S::ldv(1, 1);
+        Pair::double_step(R, l);
+        S::stv(1, 1, R);
+        tb = Pair::eval_line(l, S::template ld_p<NS>(1, 0), S::template ld_p<NS>(1, 1)); b4 = l.c2;
+      }
+      S::ell2_regs(0, ta, a4, k > 0, tb, b4, k > 1);
+      if ((T377::X >> b) & 1) {
+        {
+          typename Pair::Line l;
+          const V Qc = LP::load_q(g2 + (size_t)idx[0] * LP::G2W);
+          V R = S::ldv(1, 0);
+          Pair::add_step(R, Qc, l);
+          S::stv(1, 0, R);
+          ta = Pair::eval_line(l, S::template ld_p<NS>(0, 0), S::template ld_p<NS>(0, 1)); a4 = l.c2;
+        }
+        S::fence();
+        {
+          typename Pair::Line l;
+          const V Qc = LP::load_q(g2 + (size_t)idx[1] * LP::G2W);
+          V R = S::ldv(1, 1);
+          Pair::add_step(R, Qc, l);
+          S::stv(1, 1, R);
+          tb = Pair::eval_line(l, S::template ld_p<NS>(1, 0), S::template ld_p<NS>(1, 1)); b4 = l.c2;
+        }
+        S::ell2_regs(0, ta, a4, k > 0, tb, b4, k > 1);
+      }
+    }
+    if (live) LP::store12(prod + (size_t)gi * lanes_gt_words<LP>(), S::ld12(0));
+    return;
+  }
+#endif
 #pragma unroll 1
   for (int b = 62; b >= 0; b--) {
     S::sqr12(0);

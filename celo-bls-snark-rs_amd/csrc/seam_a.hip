@@ -1194,6 +1194,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   for (size_t b = 0; b < m; b++) {
     // Batch::verify zips keys with signatures (batch.rs:60-64): a longer side is truncated to the shorter
     blen[b] = batches[b].public_keys_len < batches[b].signatures_len ? batches[b].public_keys_len : batches[b].signatures_len;
+    if (blen[b] && (!batches[b].public_keys || !batches[b].signatures)) return false;    // a length without its array
     offs[b + 1] = offs[b] + (uint32_t)blen[b];
   }
   const size_t tot = offs[m];

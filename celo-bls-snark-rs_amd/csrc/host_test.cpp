@@ -53,6 +53,18 @@ template <class F> static void point_op(int op, const uint64_t* p1, const uint64
     case 10: acc = xyzz_add_affine(a, a); break;            // its doubling branch
     case 11: acc = xyzz_add_affine(a, affine_neg(a)); break;  // its cancellation branch
     case 12: { acc = xyzz_add_affine(affine_neg(a), affine_neg(b)); for (uint32_t i = 0; i < k; i++) xyzz_madd(acc, b); } break;  // -a - b + k b
+    // 13 .. 17: xyzz_add_mem (the second point read from its stored form where its coordinates are used): t = 2b + a stored, then
+    // a + t; the identity stored as zeros; into an identity accumulator; the doubling and the cancellation branch
+    case 13: case 14: case 15: case 16: case 17: {
+      Xyzz<F> t = Xyzz<F>::from_affine(b); t = xyzz_dbl(t); xyzz_madd(t, a);
+      if (op == 14) t = Xyzz<F>::identity();
+      if (op == 16) t = acc;                                           // a + a
+      if (op == 17) t = Xyzz<F>::from_affine(affine_neg(a));           // a - a
+      if (op == 15) acc = Xyzz<F>::identity();                         // 0 + t
+      alignas(16) uint32_t buf[4 * F::WORDS];
+      t.X.store(buf); t.Y.store(buf + F::WORDS); t.ZZ.store(buf + 2 * F::WORDS); t.ZZZ.store(buf + 3 * F::WORDS);
+      xyzz_add_mem(acc, buf);
+    } break;
     default: break;
   }
   xyzz_to_jac(acc, out);

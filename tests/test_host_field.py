@@ -160,6 +160,12 @@ def test_point_ops(ht, kind):
         assert op(10, A, B) == cur.add(A, A)       # ... its doubling branch
         assert op(11, A, B) is None                # ... its cancellation branch
         assert op(12, A, B, 5) == cur.add(cur.neg(cur.add(A, B)), cur.mul(B, 5))   # negated operands, then mixed additions
+        T = cur.add(cur.add(B, B), A)
+        assert op(13, A, B) == cur.add(A, T)       # xyzz_add_mem: the second point read from its stored form (curve.h, round 4)
+        assert op(14, A, B) == A                   # ... stored identity
+        assert op(15, A, B) == T                   # ... into an identity accumulator
+        assert op(16, A, B) == cur.add(A, A)       # ... its doubling branch
+        assert op(17, A, B) is None                # ... its cancellation branch
 
 
 def test_add_affine_negated_y_top_limb(ht):
@@ -212,6 +218,9 @@ def test_point_ops_bw6(ht, golden):
     assert op(10, A, B) == cur.add(A, A)
     assert op(11, A, B) is None
     assert op(12, A, B, 3) == cur.add(cur.neg(cur.add(A, B)), cur.mul(B, 3))
+    T = cur.add(cur.add(B, B), A)
+    assert op(13, A, B) == cur.add(A, T) and op(14, A, B) == A and op(15, A, B) == T      # xyzz_add_mem on the 28-limb field
+    assert op(16, A, B) == cur.add(A, A) and op(17, A, B) is None
 
 
 @pytest.mark.parametrize("kind", ["g1_377", "g2_377", "g2_377_hex"])

@@ -906,9 +906,9 @@ __global__ void __launch_bounds__(256) k_batch_sort(const uint32_t* __restrict__
 }
 
 // (Round 4, measured and not kept - DESIGN.md section 6: this kernel is NOT latency-bound at config 3's scale.  The G2 leg brings
-// 13 windows x 4096 instances = 53 248 running sums of 32 full additions, 1.7 M full additions of Fq2 points, and the chip does 0.4-0.55 G
-// of them per second in this one-lane form - the 3.1 ms are work.  Six lanes per running sum (LanePoint on the hex backend): 3.46 ms;
-// window sums by bit position - chains of 7 additions on 4x the lanes, the Horner pass taking one more addition per bit - 3.7 + 1.2 ms
+// 11 windows x 4096 instances = 45 056 running sums of 64 full additions, 2.9 M full additions of Fq2 points in 3.1 ms = 0.93 G/s, 1.6x
+// what a mixed addition costs k_accumulate - the 3.1 ms are work.  Six lanes per running sum (LanePoint on the hex backend): 3.46 ms;
+// window sums by bit position - chains of 15 additions on 5x the lanes, the Horner pass taking one addition per bit - 3.7 + 1.2 ms
 // against 3.1 + 0.6.  Kept from it: the bucket's coordinates are loaded where they are used, curve.h xyzz_add_mem - scratch 1264 -> 260 B.)
 template <class G>
 __global__ void __launch_bounds__(128) k_batch_reduce(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ plen,

@@ -1098,30 +1098,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   typedef PointIO<Fq2> IO;
   const uint32_t inst = blockIdx.x;
   const uint32_t lo = offsets[inst], n = offsets[inst + 1] - lo;
-  const Fq kx[3] = {Fq::from_limbs(T377::PSI_X1), Fq::from_limbs(T377::PSI_X2), Fq::from_limbs(T377::PSI_X3)};
-  const Fq ky[3] = {Fq::from_limbs(T377::PSI_Y1), Fq::from_limbs(T377::PSI_Y2), Fq::from_limbs(T377::PSI_Y3)};
   for (uint32_t t = blockIdx.y * 64u + threadIdx.x; t < n; t += gridDim.y * 64u) {
     const uint64_t* s = ark + (size_t)(lo + t) * 2 * IO::ARK64;
-    const Affine<Fq2> P = {Fq2::from_ark(s), Fq2::from_ark(s + IO::ARK64)};
     uint32_t d[4][2];
     gls_digits_base_x<NW, ND>(scalars + (size_t)(lo + t) * 8, d);
     const uint8_t fl = inf ? inf[lo + t] : 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       if (j < nd) {
-      const size_t e = (size_t)nd * lo + (size_t)j * n + t;
-      Affine<Fq2> Q = P;
-      if (j > 0) {
-        // psi^j: conjugate j times, scale by the j-th powers of the constants
-        const Fq x1 = (j & 1) ? Fq::wred(Fq::norm(Fq::neg<4, 1>(P.x.c1))) : P.x.c1, y1 = (j & 1) ? Fq::wred(Fq::norm(Fq::neg<4, 1>(P.y.c1))) : P.y.c1;
-        Q.x = {Fq::mul(P.x.c0, kx[j - 1]), Fq::mul(x1, kx[j - 1])};
-        Q.y = {Fq::mul(P.y.c0, ky[j - 1]), Fq::mul(y1, ky[j - 1])};
+        const size_t e = (size_t)nd * lo + (size_t)j * n + t;
+        uint4 w = {d[j][0], d[j][1], 0u, 0u};
+        reinterpret_cast<uint4*>(sc2)[e] = w;
+        if (inf2) inf2[e] = fl;
       }
-      IO::store_affine(dev_bases + e * IO::AFF_WORDS, Q);
-      uint4 w = {d[j][0], d[j][1], 0u, 0u};
-      reinterpret_cast<uint4*>(sc2)[e] = w;
-      if (inf2) inf2[e] = fl;
+    }
+    // the images ONE COORDINATE HALF AT A TIME (round 4): psi^j(x0 + x1 u) = (kx_j x0, +-kx_j x1), so a half of P is read, scaled by the
+    // nd - 1 constants and stored before the next is touched - 14 live registers of input instead of the point and its three images
+    // (the first form kept them all alive: 1232 B/lane of scratch at the 128 registers this kernel has, 1.1 ms for config 3's 10^6 keys)
+    uint32_t* out0 = dev_bases + ((size_t)nd * lo + t) * IO::AFF_WORDS;
+#pragma unroll
+    for (int h = 0; h < 4; h++) {                        // x.c0, x.c1, y.c0, y.c1
+      const Fq v = Fq::from_ark(s + (size_t)h * Fq::ARK64);
+      v.store(out0 + h * Fq::WORDS);
+      const Fq vn = (h & 1) ? Fq::wred(Fq::norm(Fq::neg<4, 1>(v))) : v;     // conjugation: the u half changes sign for odd j
+#pragma unroll
+      for (int j = 1; j < 4; j++) {
+        if (j < nd) {
+          const uint32_t* kc = h < 2 ? (j == 1 ? T377::PSI_X1 : j == 2 ? T377::PSI_X2 : T377::PSI_X3) : (j == 1 ? T377::PSI_Y1 : j == 2 ? T377::PSI_Y2 : T377::PSI_Y3);
+          Fq::mul((j & 1) ? vn : v, Fq::from_limbs(kc)).store(out0 + (size_t)j * n * IO::AFF_WORDS + h * Fq::WORDS);
+        }
       }
+      asm volatile("" ::: "memory");
     }
   }
 }

@@ -200,7 +200,51 @@ __global__ void __launch_bounds__(64) LANES_OCC k377_wide_final(const uint32_t* 
   if (is_one && LP::writer()) is_one[p] = one ? 1 : 0;
   if (gt_ark) LP::to_ark12(f, gt_ark + (size_t)p * 72);
 }
+// The final exponentiation of a few thousand products (round 4: Batch::verify's 4096 verdicts, the exposed tail of config 3): the same
+// chain on the side-by-side operations, THREE products per wave (super-group sg of a block takes product 3 * blockIdx.x + sg; groups
+// 9 of a wave idles).  k_final_exp_slots gives a product one six-lane group - 205 waves for 2048 products, one per SIMD on a fifth of the
+// chip, every Fq12 product 6 rounds and every cyclotomic squaring 2 in sequence; here they are 2 and 1 on 683 waves (used up to 3072
+// products, while every wave still has a SIMD to itself: unit_pairing_lf.hip).
+__device__ __forceinline__ E12 final_exp_w3(const E12& f_in) {
+  E12 f2 = Tow::inv12(f_in);
+  E12 r = mul12_w3(Tow::conj12(f_in), f2);
+  f2 = r;
+  r = mul12_w3(Pair::template frob12<2>(r), f2);
+  E12 y0 = Tow::conj12(cyclo_w3(r));
+  E12 y5 = exp_by_x_w3(r);
+  E12 y1 = cyclo_w3(y5);
+  E12 y3 = mul12_w3(y0, y5);
+  y0 = exp_by_x_w3(y3);
+  E12 y2 = exp_by_x_w3(y0);
+  E12 y4 = mul12_w3(exp_by_x_w3(y2), y1);
+  y1 = exp_by_x_w3(y4);
+  y3 = Tow::conj12(y3);
+  y1 = mul12_w3(mul12_w3(y1, y3), r);
+  y3 = Tow::conj12(r);
+  y0 = Pair::template frob12<3>(mul12_w3(y0, r));
+  y4 = Pair::template frob12<1>(mul12_w3(y4, y3));
+  y5 = Pair::template frob12<2>(mul12_w3(y5, y2));
+  y5 = mul12_w3(mul12_w3(y5, y0), y4);
+  return mul12_w3(y5, y1);
+}
+__global__ void __launch_bounds__(64) LANES_OCC k377_w3_final_products(const uint32_t* __restrict__ prod, uint8_t* __restrict__ is_one, uint64_t* __restrict__ gt_ark,
+                                                                       uint32_t m) {
+  const int g = QB::group();
+  if (g >= 3 * SUPER) return;
+  const uint32_t p = blockIdx.x * (uint32_t)SUPER + (uint32_t)(g / 3);
+  const bool live = p < m;
+  const E12 f = final_exp_w3(LP::load12(prod + (size_t)(live ? p : 0) * W377));          // a surplus super-group walks product 0 and stores nothing
+  const bool one = Tow::is_one12(f);
+  if (!live || sub3() != 0) return;
+  if (is_one && LP::writer()) is_one[p] = one ? 1 : 0;
+  if (gt_ark) LP::to_ark12(f, gt_ark + (size_t)p * 72);
+}
 }  // namespace
+
+// m products (GT-shaped Miller values at prod, six-lane device form) -> verdicts and / or GT values; enqueued on `s`
+void final_exp_w3_377(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint32_t m, hipStream_t s) {
+  hipLaunchKernelGGL(k377_w3_final_products, dim3((m + SUPER - 1) / SUPER), dim3(64), 0, s, prod, is_one, gt, m);
+}
 
 size_t wide_lines_words_377(uint32_t kt) { return (size_t)LINE_STEPS * kt * LINE_WORDS; }
 // m products of <= 3 pairs each (kt pairs in all, d_off: their offsets on the device), everything enqueued on `s`.

@@ -28,6 +28,7 @@
 #include <unordered_map>
 #include <algorithm>
 #include <sys/random.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include "curve.h"
 #include "fp2.h"
@@ -85,10 +86,12 @@ template <class T> struct HandleArena {
     p->serial = ++serial;
     return p;
   }
-  void release(T* p) {
+  bool release(T* p) {
     std::lock_guard<std::mutex> lk(mu);
+    if (p->serial == 0) return false;                           // destroyed already: the slot must not enter the free list twice
     p->serial = 0;
     try { free_slots.push_back(p->slot); } catch (...) {}       // out of memory: the slot is lost, nothing else
+    return true;
   }
   uint32_t high_water() { std::lock_guard<std::mutex> lk(mu); return next; }
 };
@@ -101,8 +104,11 @@ struct HostPool {
   std::condition_variable cv, cv_done;
   std::function<void(unsigned)> job;
   unsigned n = 0, next = 0, finished = 0, nthreads = 0;
+  std::atomic<bool> job_failed{false};          // a range of the current job threw (out of memory): the submitter treats the call as failed
+  pid_t owner = 0;                              // a fork()ed child has this object but none of its threads: it must not wait for them
   static HostPool& get() { static HostPool* p = new HostPool; return *p; }
   HostPool() {
+    owner = getpid();
     unsigned hw = std::thread::hardware_concurrency();
     if (hw > 64) hw = 64;
     for (unsigned i = 0; i < hw; i++) {
@@ -115,20 +121,22 @@ struct HostPool {
       cv.wait(lk, [&] { return next < n; });
       const unsigned i = next++;
       lk.unlock();
-      job(i);
+      try { job(i); } catch (...) { job_failed = true; }
       lk.lock();
       if (++finished == n) cv_done.notify_all();
     }
   }
   bool try_begin(unsigned count, std::function<void(unsigned)> fn) {
-    if (count == 0 || count > nthreads || !busy.try_lock()) return false;
-    { std::lock_guard<std::mutex> lk(mu); job = std::move(fn); n = count; next = 0; finished = 0; }
+    if (count == 0 || count > nthreads || getpid() != owner || !busy.try_lock()) return false;
+    { std::lock_guard<std::mutex> lk(mu); job = std::move(fn); n = count; next = 0; finished = 0; job_failed = false; }
     cv.notify_all();
     return true;
   }
-  void finish() {
-    { std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return finished == n; }); n = 0; next = 0; finished = 0; job = nullptr; }
+  bool finish() {      // false: a range of the job threw
+    bool ok;
+    { std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return finished == n; }); n = 0; next = 0; finished = 0; job = nullptr; ok = !job_failed.load(); }
     busy.unlock();
+    return ok;
   }
 };
 
@@ -136,8 +144,8 @@ HandleArena<PublicKey>& pk_arena() { static HandleArena<PublicKey> a; return a; 
 HandleArena<Signature>& sig_arena() { static HandleArena<Signature> a; return a; }
 PublicKey* new_public_key() { return pk_arena().alloc(); }
 Signature* new_signature() { return sig_arena().alloc(); }
-void drop(PublicKey* p) { pk_arena().release(p); }
-void drop(Signature* p) { sig_arena().release(p); }
+bool drop(PublicKey* p) { return pk_arena().release(p); }
+bool drop(Signature* p) { return sig_arena().release(p); }
 
 int cmp_n(const uint64_t* a, const uint64_t* b, int n) {
   for (int i = n - 1; i >= 0; i--) {
@@ -921,8 +929,8 @@ bool compress_pubkey(const uint8_t* in, int in_len, uint8_t** out, int* out_len)
 
 // ---------------------------------------------------------------- destructors (serialization.rs:224-268)
 bool destroy_private_key(PrivateKey* p) { if (!p) return false; delete p; return true; }
-bool destroy_public_key(PublicKey* p) { if (!p) return false; drop(p); return true; }
-bool destroy_signature(Signature* p) { if (!p) return false; drop(p); return true; }
+bool destroy_public_key(PublicKey* p) { return p && drop(p); }   // false for a handle destroyed before (its slot stays out of the free list)
+bool destroy_signature(Signature* p) { return p && drop(p); }
 bool free_vec(uint8_t* bytes, int len) { if (!bytes || len < 0) return false; free(bytes); return true; }   // buffers are malloc blocks: the length is not needed to release one
 
 // ---------------------------------------------------------------- aggregation (signatures.rs:428-505)
@@ -1393,12 +1401,13 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   };
   BvJob job;
   int rc_keys = 0, rc_sigs = 0;
+  bool pool_failed = false;
   {
     std::vector<std::thread> th;
     struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } guard{th};
     HostPool& pool = HostPool::get();
     const bool pooled = nt > 1 && pool.try_begin(nt, [&](unsigned t) { work(t, 0); work(t, 1); });
-    struct PoolWait { HostPool& p; bool on; ~PoolWait() { if (on) p.finish(); } } pool_wait{pool, pooled};   // the job holds references to this frame
+    struct PoolWait { HostPool& p; bool on; bool& failed; ~PoolWait() { if (on && !p.finish()) failed = true; } } pool_wait{pool, pooled, pool_failed};   // the job holds references to this frame
     if (!pooled) {
       if (nt > 1) {
         try { for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() { work(t, 0); work(t, 1); }); }
@@ -1414,6 +1423,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
       else { rc_sigs = bv_begin_sigs(&job, d_sg_xy, d_sg_inf, d_sc, 1, offs.data(), m); ph.mark("signature slots across, G1 batch MSM started"); }
     }
   }
+  if (pool_failed) copy_failed = true;                                  // a worker's range threw (out of memory): rows may be missing
   mirrors_ok = !copy_failed;
   if (bad_handle) log_err("batch_verify_strict: a destroyed or foreign handle in the batch lists");
   hasher.join();

@@ -1015,6 +1015,7 @@ def test_handle_arena_allocation_and_reuse(sys_lib, golden):
         assert _ser(sys_lib, "serialize_signature", again[i]) == pts[(i + 1) % 6]
     for h in again:
         assert sys_lib.destroy_signature(h)
+    assert not sys_lib.destroy_signature(again[0])                       # destroyed twice: refused, the slot enters the free list once
     # four threads creating and destroying at once: every handle reads back what its creator put in
     errs = []
 

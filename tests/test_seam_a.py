@@ -1042,3 +1042,63 @@ def test_handle_arena_allocation_and_reuse(sys_lib, golden):
     for x in th:
         x.join()
     assert not errs, errs[:3]
+
+
+@pytest.mark.gpu
+def test_batch_verify_strict_mirror_randomised_lifecycle(sys_lib, gpu):
+    """Six rounds of create / destroy / re-create of key and signature handles between batch_verify_strict calls of ~9000 signers (the
+    threaded host pass), batches drawn at random over the live handles with some deliberately mismatched pairs: every verdict must be
+    what the handles' CONTENTS say, whatever rows earlier calls left in the device mirror."""
+    import random
+    for f in ("sign_message", "batch_verify_strict", "generate_private_key"):
+        getattr(sys_lib, f).restype = C.c_bool
+    CF, C22 = C.c_bool(False), C.c_bool(False)
+    rnd = random.Random(20260930)
+    NK, NM = 10, 5
+    msgs = [b"lifecycle-%d" % i for i in range(NM)]
+
+    def fresh_key():
+        sk, pk = C.c_void_p(), C.c_void_p()
+        assert sys_lib.generate_private_key(C.byref(sk)) and sys_lib.private_key_to_public_key(sk, C.byref(pk))
+        return sk, pk
+
+    def sign(sk, msg):
+        s = C.c_void_p()
+        assert sys_lib.sign_message(sk, msg, C.c_int(len(msg)), b"", C.c_int(0), CF, C22, C.byref(s))
+        return s
+
+    keys = [fresh_key() for _ in range(NK)]
+    gen = [0] * NK                                             # generation of key k's secret
+    sigs = {(k, j): (sign(keys[k][0], msgs[j]), 0) for k in range(NK) for j in range(NM)}    # handle, generation it was signed under
+    for rnd_no in range(6):
+        # lifecycle: replace two keys (their old signatures become wrong for the new key until re-signed), re-sign some, re-create some handles as they are
+        for k in rnd.sample(range(NK), 2):
+            assert sys_lib.destroy_public_key(keys[k][1])
+            keys[k] = fresh_key(); gen[k] += 1
+        for (k, j) in rnd.sample(sorted(sigs), 12):
+            h, g = sigs[(k, j)]
+            assert sys_lib.destroy_signature(h)
+            sigs[(k, j)] = (sign(keys[k][0], msgs[j]), gen[k])
+        m = 300
+        arr, keep, want = (_BatchMessageFFI * m)(), [], []
+        for b in range(m):
+            j = rnd.randrange(NM)
+            n = rnd.randrange(1, 60)
+            ks = [rnd.randrange(NK) for _ in range(n)]
+            ok = True
+            pl, sl = [], []
+            for k in ks:
+                pl.append(keys[k][1].value)
+                if rnd.random() < 0.01:                        # a signature of another message: a deliberate mismatch
+                    h, g = sigs[(k, (j + 1) % NM)]; ok = False
+                else:
+                    h, g = sigs[(k, j)]; ok = ok and g == gen[k]
+                sl.append(h.value)
+            pa, sa = (C.c_void_p * n)(*pl), (C.c_void_p * n)(*sl)
+            keep.append((pa, sa))
+            arr[b] = _BatchMessageFFI(_Buffer(msgs[j], len(msgs[j])), _Buffer(b"", 0), pa, n, sa, n)
+            want.append(ok)
+        out = (C.c_bool * m)()
+        rc = sys_lib.batch_verify_strict(arr, C.c_size_t(m), CF, C22, out)
+        assert list(out) == want, (rnd_no, [b for b in range(m) if out[b] != want[b]][:5])
+        assert rc == all(want)

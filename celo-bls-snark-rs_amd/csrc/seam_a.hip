@@ -1209,7 +1209,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   // Per device (a caller bound to another device with celo_amd_use_device must not run its engines against device-0 memory and a
   // device-0 stream): one grow-only PINNED host staging buffer, its device twin, one copy stream, and the MIRRORS of the two handle
   // arenas - for every arena slot the affine point (192 / 96 bytes) and an identity byte in HBM, tagged on the host with the serial of
-  // the allocation they were uploaded for.  A call then moves, per signer, two 4-byte slot numbers and the 32-byte exponent; only
+  // the allocation they were uploaded for.  A call then moves, per signer, two 4-byte slot numbers (the exponents are drawn on the device); only
   // handles the device has not seen in their present state (new since the last call, or a reused slot) are normalised and uploaded,
   // and the dense point arrays the batch MSMs read are gathered on the GPU (unit_batchverify.hip: k_mirror_scatter / k_mirror_gather).
   // Round 3 gathered and shipped 320 bytes per signer on every call: 8 ms before the G2 MSM - the longest leg - could start.
@@ -1246,7 +1246,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   std::lock_guard<std::mutex> stage_lk(DS.mu);
   uint8_t*& stage = DS.stage;
   size_t& stage_cap = DS.stage_cap;
-  // host staging: rows of the handles to upload (worst case: every signer's), the exponents, the slot numbers
+  // host staging: rows of the handles to upload (worst case: every signer's) and the slot numbers
   const size_t need = tot * (24 + 12) * 8 + tot * 16 + 2 * tot + 4096;
   if (need > stage_cap) {
     if (stage) (void)hipHostFree(stage);

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(1024) k_part_scan(uint32_t* __restrict__ block
 template <class G>
 __global__ void __launch_bounds__(1024) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ blockoff,
                                                        uint32_t* __restrict__ rec_idx, uint8_t* __restrict__ rec_key, uint32_t n,
-                                                       uint32_t chunk, uint32_t HIB, uint32_t NBIN) {
+                                                       uint32_t chunk, uint32_t HIB, uint32_t NBIN, const uint32_t* __restrict__ remap = nullptr) {
   constexpr uint32_t SB = 8 * 1024;   // entries per batch
   __shared__ uint32_t cur[128], lcnt[128], loff[128], wt[2];
   __shared__ uint32_t st_idx[SB];
@@ -302,7 +302,8 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const uint16_t* __restric
       if (d[k] != 0xFFFFu) {
         const uint32_t b = d[k] & 0x7FFFu, bin = b & (NBIN - 1);
         const uint32_t s_ = loff[bin] + r[k];
-        st_idx[s_] = (i0 + k * 1024 + t) | ((d[k] >> 15) << 31);
+        const uint32_t e_ = i0 + k * 1024 + t;        // remap (fixed base, compacted virtual windows): slot e_ of window w holds table entry remap[w n + e_]
+        st_idx[s_] = (remap ? remap[(size_t)w * n + e_] : e_) | ((d[k] >> 15) << 31);
         st_key[s_] = (uint8_t)(b >> HIB);
         st_bin[s_] = (uint8_t)bin;
       }
@@ -1249,6 +1250,86 @@ __global__ void __launch_bounds__(256) k_fixed_digits(const uint32_t* __restrict
   }
 }
 
+// ---- the same digits COMPACTED BY VIRTUAL WINDOW (round 4).  k_fixed_digits hands the pipeline NV windows of E slots each, all but one of
+// an entry's slots holding "no digit": at cf = 20 the two partition passes and the digit kernel move 17 x 4 10^7 x 2 bytes three times and
+// the sort costs 1.7 ms where the variable-base sort of as many real entries costs 0.45.  Here every entry gets ONE record (window id,
+// digit), the records are placed window by window - window v's entries in slots [0, count_v) of a row of Ep >= max_v count_v slots, the
+// rest padded with "no digit" - and the partition pass carries the table index of a slot along (k_part_scatter's remap): the pipeline
+// then sees NV windows of Ep ~ E / (NV - 1) slots.  The order of a window's slots is whatever the atomics give; sums do not care.
+template <int SW, int BITS>
+__global__ void __launch_bounds__(256) k_fixed_digits_c(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ tinf, uint8_t* __restrict__ v8,
+                                                        uint16_t* __restrict__ dg16, uint32_t* __restrict__ counts, uint32_t n, uint32_t n_sc, int cf, uint32_t W,
+                                                        uint32_t NV, uint32_t M) {
+  __shared__ uint32_t lc[128];
+  if (threadIdx.x < 128) lc[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    uint32_t s[SW + 1];
+    if (i < n_sc) {
+      const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * SW);
+#pragma unroll
+      for (int k = 0; k < SW / 4; k++) { const uint4 v = sp[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SW; k++) s[k] = 0;
+    }
+    s[SW] = 0;
+    if constexpr (BITS < 32 * SW) {
+      s[BITS / 32] &= (1u << (BITS % 32)) - 1u;
+#pragma unroll
+      for (int k = BITS / 32 + 1; k < SW; k++) s[k] = 0;
+    }
+    const uint32_t half = 1u << (cf - 1);
+    uint32_t carry = 0;
+    for (uint32_t j = 0; j < W; j++) {
+      const uint32_t bit = j * (uint32_t)cf, wi = bit >> 5, off = bit & 31;
+      uint32_t raw = 0;
+      if (wi < (uint32_t)SW) {
+        uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+        for (int k = 0; k <= SW; k++) { if ((uint32_t)k == wi) w0 = s[k]; if ((uint32_t)k == wi + 1) w1 = s[k]; }
+        raw = (uint32_t)((((uint64_t)w1 << 32) | w0) >> off) & ((1u << cf) - 1u);
+      }
+      const uint32_t d = raw + carry;
+      const uint32_t neg = d > half ? 1u : 0u;
+      const uint32_t mag = neg ? (1u << cf) - d : d;
+      carry = neg;
+      const size_t p = (size_t)j * n + i;
+      const bool live = mag != 0 && !tinf[p];
+      const uint32_t full = mag - 1u, v = full / M;
+      v8[p] = live ? (uint8_t)v : (uint8_t)0xFF;
+      dg16[p] = (uint16_t)((full - v * M) | (neg << 15));
+      if (live) atomicAdd(&lc[v], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NV && lc[threadIdx.x]) atomicAdd(counts + threadIdx.x, lc[threadIdx.x]);
+}
+// record p -> slot of its window's row: ranks within a batch by LDS atomics, one global reservation per (batch, window)
+template <class G>   // (a template only so that every translation unit including this header may hold a copy)
+__global__ void __launch_bounds__(1024) k_fixed_place(const uint8_t* __restrict__ v8, const uint16_t* __restrict__ dg16, uint32_t* __restrict__ cursor,
+                                                      uint16_t* __restrict__ digits, uint32_t* __restrict__ remap, uint32_t E, uint32_t Ep, uint32_t NV) {
+  __shared__ uint32_t lc[128], lb[128];
+  for (uint32_t p0 = blockIdx.x * 1024u; p0 < E; p0 += gridDim.x * 1024u) {
+    if (threadIdx.x < 128) lc[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t p = p0 + threadIdx.x;
+    const uint32_t v = p < E ? v8[p] : 0xFFu;
+    uint32_t r = 0;
+    if (v != 0xFFu) r = atomicAdd(&lc[v], 1u);
+    __syncthreads();
+    if (threadIdx.x < NV && lc[threadIdx.x]) lb[threadIdx.x] = atomicAdd(cursor + threadIdx.x, lc[threadIdx.x]);
+    __syncthreads();
+    if (v != 0xFFu) {
+      const size_t at = (size_t)v * Ep + lb[v] + r;
+      digits[at] = dg16[p];
+      remap[at] = p;
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- host driver
 // the IFMA Horner epilogue (host_ifma.cpp, host_cpu.cpp) exists for the two prime fields
 extern "C" int celo_ifma_available();
@@ -1265,7 +1346,7 @@ struct MsmTimings {  // milliseconds, HIP events on the MSM's stream (last call)
 
 // A/B switches and tuning hooks of the pipeline, read from the environment ONCE per process (not per engine, not per call)
 struct MsmTuning {
-  bool narrow_windows, use_glv, use_gls, gls_force, lane_bitsum, host_threads, seg_occupancy, side_convert;
+  bool narrow_windows, use_glv, use_gls, gls_force, lane_bitsum, host_threads, seg_occupancy, side_convert, fx_compact;
   uint32_t seg_min, seg_min_shard, bitsum_lanes_max_shard;
   int seg_halves;          // piece length in half mean-bucket lengths (4 = twice the mean); 0 = not set: the path's own default
   uint32_t bitsum_lanes_max;
@@ -1281,6 +1362,7 @@ struct MsmTuning {
       v.gls_force = false;       // the release library never applies psi to the plain entry points' arbitrary curve points
 #endif
       v.lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;
+      v.fx_compact = getenv("CELO_FX_NO_COMPACT") == nullptr;        // A/B switch: fixed base, digits compacted by virtual window
       v.host_threads = getenv("CELO_NO_HOST_THREADS") == nullptr;
       v.seg_halves = getenv("CELO_SEG_HALVES") ? atoi(getenv("CELO_SEG_HALVES")) : 0;
       v.seg_min = getenv("CELO_SEG_MIN") ? (uint32_t)atoi(getenv("CELO_SEG_MIN")) : 32u;                     // shortest piece of a whole MSM
@@ -1304,6 +1386,7 @@ template <class G> class MsmEngine {
   ~MsmEngine() { release(); }
   void release() {
     if (arena) { (void)hipFree(arena); arena = nullptr; arena_bytes = 0; }
+    if (fxs) { (void)hipFree(fxs); fxs = nullptr; fxs_bytes = 0; }
     for (void* p : {(void*)d_in_bases, (void*)d_in_scalars, (void*)d_in_inf})
       if (p) (void)hipFree(p);
     d_in_bases = nullptr; d_in_scalars = nullptr; d_in_inf = nullptr; cap_in = 0;
@@ -1397,7 +1480,32 @@ template <class G> class MsmEngine {
     if (n_ >= (size_t(1) << 30)) return 2;
     if (fx && (win_cnt || n_ > fx->n || fx->cf < 16 || fx->cf > 22)) return 2;
     Plan pl = plan(n_);
-    if (fx) { pl.glv = false; pl.n = fx->E(); pl.sbits = G::SCALAR_BITS; pl.c = 16; pl.nw = (int)fx->NV; pl.kn = 0; }
+    // fixed base with several virtual windows: the digits are taken first, compacted by window (k_fixed_digits_c), and the pipeline is
+    // sized by the fullest window's row, Ep, instead of by all E entries per window
+    uint32_t fx_Ep = 0;
+    uint8_t* d_fx_v8 = nullptr; uint16_t* d_fx_dg = nullptr; uint32_t* d_fx_cnt = nullptr;
+    if (fx && fx->NV > 2 && fx->NV <= 128 && !win_cnt && n_ <= fx->n && fx->cf >= 16 && fx->cf <= 22 && MsmTuning::get().fx_compact) {
+      const size_t E = fx->E();
+      const size_t o_dg = (E + 255) & ~size_t(255), o_cnt = o_dg + ((E * 2 + 255) & ~size_t(255)), need = o_cnt + 256 * 4;
+      if (need > fxs_bytes) {
+        if (fxs) (void)hipFree(fxs);
+        fxs = nullptr; fxs_bytes = 0;
+        HIP_OK(hipMalloc((void**)&fxs, need + need / 8));
+        fxs_bytes = need + need / 8;
+      }
+      d_fx_v8 = fxs; d_fx_dg = (uint16_t*)(fxs + o_dg); d_fx_cnt = (uint32_t*)(fxs + o_cnt);
+      HIP_OK(hipMemsetAsync(d_fx_cnt, 0, 256 * 4, stream));
+      hipLaunchKernelGGL((k_fixed_digits_c<SW, G::SCALAR_BITS>), dim3((fx->n + 255) / 256), dim3(256), 0, stream, d_scalars, fx->tinf, d_fx_v8, d_fx_dg, d_fx_cnt, fx->n,
+                         (uint32_t)n_, fx->cf, fx->W, fx->NV, fx->M);
+      uint32_t h_cnt[128];
+      HIP_OK(hipMemcpyAsync(h_cnt, d_fx_cnt, fx->NV * 4, hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      uint32_t mx = 0;
+      for (uint32_t v = 0; v < fx->NV; v++) mx = h_cnt[v] > mx ? h_cnt[v] : mx;
+      const uint64_t ep = ((uint64_t)mx + 4095) & ~uint64_t(4095);
+      if (ep >= 4096 && ep * 2 <= E) fx_Ep = (uint32_t)ep;       // (a window that holds most entries - tiny scalars - gains nothing: the uncompacted form)
+    }
+    if (fx) { pl.glv = false; pl.n = fx_Ep ? fx_Ep : fx->E(); pl.sbits = G::SCALAR_BITS; pl.c = 16; pl.nw = (int)fx->NV; pl.kn = 0; }
     const bool glv = pl.glv;
     const uint32_t n = pl.n;
     const int sbits = pl.sbits, c = pl.c, nw_all = pl.nw;
@@ -1411,7 +1519,7 @@ template <class G> class MsmEngine {
     // (the split's buckets are twice as long - 64 points at 2^20 - and fewer: pieces of 1.5 mean buckets balance its last round better:
     // accumulate 2.64 -> 2.46 ms at 2^20; the plain path is flat between 1.5 and 3)
     const int seg_h = MsmTuning::get().seg_halves ? MsmTuning::get().seg_halves : (glv ? 3 : 4);
-    uint32_t SEG = (uint32_t)seg_h * ((fx ? n / (uint32_t)nw_all : n) / B + 1) / 2;      // (fixed base: a virtual window holds E / NV of the entries)
+    uint32_t SEG = (uint32_t)seg_h * ((fx && !fx_Ep ? n / (uint32_t)nw_all : n) / B + 1) / 2;      // (fixed base: a virtual window holds E / NV of the entries; compacted: its row)
     uint32_t seg_min = MsmTuning::get().seg_min;
     if (win_cnt && MsmTuning::get().seg_occupancy) {
       // a call that owns FEW windows (a window shard) has fewer additions than the chip has lanes x the usual piece length: a lane is
@@ -1427,7 +1535,7 @@ template <class G> class MsmEngine {
       // fixed base: few virtual windows hold all n W entries (one at cf = 16: mean bucket 1536) - pieces of twice the mean bucket would be
       // fewer than the chip has lanes; eight rounds of the lanes in flight bound the piece length instead (cf = 16: 72.9 -> see DESIGN.md)
       const uint32_t lanes = (sizeof(F) <= 14 * sizeof(uint32_t)) ? 131072u : 65536u;
-      const uint32_t occ = n / (lanes * 8u) + 1u;
+      const uint32_t occ = fx->E() / (lanes * 8u) + 1u;
       if (occ < SEG) SEG = occ;
     }
     if (SEG < seg_min) SEG = seg_min;
@@ -1444,6 +1552,7 @@ template <class G> class MsmEngine {
     const size_t o_bases = take(fx ? 0 : (size_t)n * IO::AFF_WORDS * 4);
     const size_t o_sc2 = take(glv ? (size_t)n * 16 : 0);
     const size_t o_digits = take((size_t)n * nw_all * 2);
+    const size_t o_remap = take(fx_Ep ? (size_t)n * nw_all * 4 : 0);
     const size_t o_sorted = take((size_t)n * nw * 4);
     // two-level sort: NBIN bins per window by the low HIB bucket bits, KB2 blocks per window in the partition pass
     const uint32_t HIB = LB < 8 ? 0u : (uint32_t)LB - 8u, NBIN = 1u << HIB;     // bins by the low HIB bucket bits, <= 8 key bits above
@@ -1514,7 +1623,14 @@ template <class G> class MsmEngine {
     else hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_ark_bases, d_bases, (size_t)n);
     HIP_OK(hipEventRecord(ev[1], stream));
     // ---- sort
-    if (fx) hipLaunchKernelGGL((k_fixed_digits<SW, G::SCALAR_BITS>), dim3((fx->n + 255) / 256), dim3(256), 0, stream, d_scalars, fx->tinf, d_digits_all, fx->n, (uint32_t)n_,
+    uint32_t* d_remap = fx_Ep ? (uint32_t*)(A + o_remap) : nullptr;
+    if (fx && fx_Ep) {
+      HIP_OK(hipMemsetAsync(d_digits_all, 0xFF, (size_t)n * nw_all * 2, stream));             // every slot "no digit" until a record lands in it
+      HIP_OK(hipMemsetAsync(d_fx_cnt + 128, 0, 128 * 4, stream));                               // the rows' cursors
+      const uint32_t E32 = (uint32_t)fx->E();
+      hipLaunchKernelGGL((k_fixed_place<G>), dim3((E32 + 1023) / 1024 < 4096 ? (E32 + 1023) / 1024 : 4096), dim3(1024), 0, stream, d_fx_v8, d_fx_dg, d_fx_cnt + 128, d_digits_all,
+                         d_remap, E32, n, fx->NV);
+    } else if (fx) hipLaunchKernelGGL((k_fixed_digits<SW, G::SCALAR_BITS>), dim3((fx->n + 255) / 256), dim3(256), 0, stream, d_scalars, fx->tinf, d_digits_all, fx->n, (uint32_t)n_,
                                fx->cf, fx->W, fx->NV, fx->M);
     else if (glv) { if (launch_digits<4, GlvExpand<G>::BITS>(c, (const uint32_t*)(A + o_sc2), nullptr, d_digits_all, n, stream)) return 3; }
     else if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream)) return 3;
@@ -1525,7 +1641,7 @@ template <class G> class MsmEngine {
     const uint32_t TILE = TILE_EPT * ts_threads, max_tiles = NBIN + n / TILE + 1;
     hipLaunchKernelGGL((k_part_hist<G>), dim3(KB2, nw), dim3(1024), 0, stream, d_digits, d_blockcnt, n, chunk2, NBIN);
     hipLaunchKernelGGL((k_part_scan<G>), dim3(nw), dim3(1024), 0, stream, d_blockcnt, d_binstart, d_tileprefix, NBIN, KB2, TILE);
-    hipLaunchKernelGGL((k_part_scatter<G>), dim3(KB2, nw), dim3(1024), 0, stream, d_digits, d_blockcnt, d_recidx, d_reckey, n, chunk2, HIB, NBIN);
+    hipLaunchKernelGGL((k_part_scatter<G>), dim3(KB2, nw), dim3(1024), 0, stream, d_digits, d_blockcnt, d_recidx, d_reckey, n, chunk2, HIB, NBIN, (const uint32_t*)d_remap);
     hipLaunchKernelGGL((k_tile_count<G>), dim3(max_tiles, nw), dim3(ts_threads), 0, stream, d_reckey, d_binstart, d_tileprefix, d_counts, n, B, HIB, NBIN);
     hipLaunchKernelGGL((k_tile_sort<G>), dim3(max_tiles, nw), dim3(ts_threads), 0, stream, d_recidx, d_reckey, d_binstart, d_tileprefix, d_counts,
                        d_starts, d_sorted, d_pfirst, d_pstart, d_plen, d_big, d_nbig, d_mid, d_nmid, n, B, HIB, NBIN, SEG, PW);
@@ -2024,6 +2140,8 @@ template <class G> class MsmEngine {
   uint32_t* h_out = nullptr;
   uint64_t* d_fx_scalars = nullptr;    // staged scalars of the fixed-base form (run_fixed)
   size_t cap_fx = 0;
+  uint8_t* fxs = nullptr;              // fixed base: the per-entry (window id, digit) records and the windows' counts, taken before the arena is laid out
+  size_t fxs_bytes = 0;
   uint64_t* d_side_out = nullptr;      // results of a chained batch call that went through the big pipeline (run_batch)
   size_t side_out_bytes = 0;
   bool side_path = false;

@@ -1763,11 +1763,27 @@ template <class G> class MsmEngine {
     // quarter of a call below 2^16 terms.  The 6-limb prime field stays on one thread (0.15 ms: the joins would cost what the split saves).
     constexpr int HT = (sizeof(HF) > 6 * 8) ? HOST_HORNER_THREADS : 1;
     HXyzz<HF> total_pt;
-    if (HT > 1 && nw >= 2 * HT && host_threads && !fx) {
-      const int per_window = (int)horner_steps.size() / nw;       // uniform except for the narrow top windows: cut by counting steps
-      (void)per_window;
+    if (HT > 1 && host_threads && (fx ? horner_steps.size() >= 64 : nw >= 2 * HT)) {
       int start[HT + 1], dbls[HT];
-      {   // window boundaries in the step list: a window's steps end with its NODBL entry
+      if (fx) {
+        // fixed base (late round 4): the chain over the bit positions is linear in them too - a group of consecutive positions run from
+        // the identity gives P_j and the join is the same.  Cut BEFORE a doubling step, balancing the additions (the 15 positions that
+        // take every virtual window's level sums carry most of them): 0.8 -> 0.4 ms of BW6-761 host work per call at cf = 20.
+        int adds_total = 0;
+        for (int k = 0; k < (int)horner_steps.size(); k++) adds_total += horner_steps[k] >= 0 ? 1 : 0;
+        int g = 0, adds = 0;
+        start[0] = 0;
+        for (int k = 0; k < (int)horner_steps.size(); k++) {
+          if (horner_steps[k] < 0 && g + 1 < HT && k > start[g] && adds * HT >= (g + 1) * adds_total) start[++g] = k;
+          adds += horner_steps[k] >= 0 ? 1 : 0;
+        }
+        while (g + 1 < HT) start[++g] = (int)horner_steps.size();       // (fewer cuts than threads: empty groups, the identity)
+        start[HT] = (int)horner_steps.size();
+        for (int j = 0; j < HT; j++) {
+          dbls[j] = 0;
+          for (int k = start[j]; k < start[j + 1]; k++) if (horner_steps[k] < 0 || !(horner_steps[k] & HORNER_NODBL)) dbls[j]++;
+        }
+      } else {   // window boundaries in the step list: a window's steps end with its NODBL entry
         int wdone = 0, g = 0;
         start[0] = 0;
         for (int k = 0; k < (int)horner_steps.size(); k++) {
@@ -1868,8 +1884,11 @@ template <class G> class MsmEngine {
   static int fixed_window_bits(size_t n) {
     int lg = 0;
     while ((size_t(1) << lg) < n * ((G::SCALAR_BITS + 16) / 16)) lg++;
-    int cf = lg - 4;      // 2^21 BW6-761 terms: 20 (27.9 ms against 33.7 variable-base); 2^20 G1 terms: 20 (level with variable-base: cheap additions)
-    return cf < 16 ? 16 : cf > 20 ? 20 : cf;
+    int cf = lg - 4;      // 2^21 BW6-761 terms: 21 (26.3 ms against 33.3 variable-base; 26.8 at 20); 2^20 G1 terms: 20 (3.08 against 3.3 ms; 4.75 at 21)
+    // (21 only where the additions are expensive enough to pay for twice the buckets: the 28-limb fields; measured with the digits compacted
+    // by virtual window - before that 20 was the optimum everywhere, profiles/r4_fixed_sweep.txt)
+    const int top = sizeof(F) > 14 * sizeof(uint32_t) ? 21 : 20;
+    return cf < 16 ? 16 : cf > top ? top : cf;
   }
   // builds T (device memory of the calling thread's device) from n affine bases in arkworks layout; d_* are DEVICE pointers
   static int fixed_build(const uint64_t* d_ark_bases, const uint8_t* d_inf, size_t n_, int cf, FixedTable* T, hipStream_t stream) {

@@ -1316,12 +1316,20 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   uint64_t one2[12], one1[6];
   Fq2_::one().to_ark(one2);
   Fq_::one().to_ark(one1);
-  std::atomic<size_t> up_n[2];
-  std::atomic<unsigned> pass_done[2];
+  // Each pass runs in PHASES phases over the batch range that all workers share, and a phase stages its new rows in a region of its own
+  // (the rows of the positions before it are the worst case before it): the calling thread ships a finished phase's rows while the
+  // workers stage the next - what matters when many handles are new to the device (every signature of a block is; the first call of a
+  // process brings 10^6 keys too)
+  constexpr size_t PHASES = 4;
+  std::atomic<size_t> up_n[2][PHASES];
+  std::atomic<unsigned> phase_done[2][PHASES];
   std::atomic<bool> bad_handle(false);
-  for (int q = 0; q < 2; q++) { up_n[q].store(0); pass_done[q].store(0); }
+  for (int q = 0; q < 2; q++) for (size_t f = 0; f < PHASES; f++) { up_n[q][f].store(0); phase_done[q][f].store(0); }
+  auto phase_lo = [&](size_t f) { return m * f / PHASES; };
   auto work = [&](unsigned t, int pass) {
-    const size_t b_lo = m * t / nt, b_hi = m * (t + 1) / nt;
+   for (size_t f = 0; f < PHASES; f++) {
+    const size_t p_lo = phase_lo(f), p_hi = phase_lo(f + 1);
+    const size_t b_lo = p_lo + (p_hi - p_lo) * t / nt, b_hi = p_lo + (p_hi - p_lo) * (t + 1) / nt;
     const bool is_pk = pass == 0;
     Mirror& M = is_pk ? MK : MS;
     std::vector<const uint64_t*> todo;          // xyz of the handles this thread uploads (slot: behind the limbs, read again below)
@@ -1342,7 +1350,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     }
     if (!todo.empty()) {
       const int A3 = is_pk ? 36 : 18, A2 = is_pk ? 24 : 12;
-      const size_t base = up_n[pass].fetch_add(todo.size());
+      const size_t base = offs[p_lo] + up_n[pass][f].fetch_add(todo.size());     // the phase's region starts at its first position
       uint64_t* up_xy = is_pk ? up_pk_xy : up_sg_xy;
       uint32_t* up_slot = is_pk ? up_pk_slot : up_sg_slot;
       uint8_t* up_inf = is_pk ? up_pk_inf : up_sg_inf;
@@ -1364,33 +1372,41 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
         }
       }
     }
-    pass_done[pass].fetch_add(1);
+    phase_done[pass][f].fetch_add(1);
+   }
   };
   // calling thread: when a pass is through, the new rows go to their mirror slots, the slot numbers (and, with the keys, the exponents)
   // cross PCIe, the GPU gathers the dense arrays, and that leg's batch MSM starts - the G2 leg (the longest of the chain) first, the
   // signatures' host pass runs under it
   bool copy_failed = false;
+  // a finished phase's new rows: staging -> device -> their mirror slots (enqueued on the copy stream; the device buffer is reused
+  // phase after phase in stream order)
+  auto ship_phase = [&](int pass, size_t f) -> bool {
+    const bool is_pk = pass == 0;
+    Mirror& M = is_pk ? MK : MS;
+    const int W = is_pk ? 24 : 12;
+    const size_t k = up_n[pass][f].load(), base = offs[phase_lo(f)];
+    if (!k) return true;
+    const size_t row = (size_t)W * 8, upb = k * (row + 5) + 256;
+    if (upb > DS.d_up_cap) {
+      if (hipStreamSynchronize(copy_stream) != hipSuccess) return false;        // an earlier phase may still be reading the old buffer
+      if (DS.d_up) (void)hipFree(DS.d_up);
+      DS.d_up = nullptr; DS.d_up_cap = 0;
+      if (hipMalloc((void**)&DS.d_up, upb + upb / 4) != hipSuccess) return false;
+      DS.d_up_cap = upb + upb / 4;
+    }
+    uint64_t* du_xy = (uint64_t*)DS.d_up;
+    uint32_t* du_slot = (uint32_t*)(du_xy + k * W);
+    uint8_t* du_inf = (uint8_t*)(du_slot + k);
+    return hipMemcpyAsync(du_xy, (is_pk ? up_pk_xy : up_sg_xy) + base * W, k * row, hipMemcpyHostToDevice, copy_stream) == hipSuccess &&
+           hipMemcpyAsync(du_slot, (is_pk ? up_pk_slot : up_sg_slot) + base, k * 4, hipMemcpyHostToDevice, copy_stream) == hipSuccess &&
+           hipMemcpyAsync(du_inf, (is_pk ? up_pk_inf : up_sg_inf) + base, k, hipMemcpyHostToDevice, copy_stream) == hipSuccess &&
+           bv_mirror_scatter(W, du_xy, du_inf, du_slot, M.d_xy, M.d_inf, k, copy_stream) == 0;
+  };
   auto stage_pass = [&](int pass) -> bool {
     const bool is_pk = pass == 0;
     Mirror& M = is_pk ? MK : MS;
     const int W = is_pk ? 24 : 12;
-    const size_t k = up_n[pass].load();
-    if (k) {
-      const size_t row = (size_t)W * 8, upb = k * (row + 5) + 256;
-      if (upb > DS.d_up_cap) {
-        if (DS.d_up) (void)hipFree(DS.d_up);
-        DS.d_up = nullptr; DS.d_up_cap = 0;
-        if (hipMalloc((void**)&DS.d_up, upb + upb / 4) != hipSuccess) return false;
-        DS.d_up_cap = upb + upb / 4;
-      }
-      uint64_t* du_xy = (uint64_t*)DS.d_up;
-      uint32_t* du_slot = (uint32_t*)(du_xy + k * W);
-      uint8_t* du_inf = (uint8_t*)(du_slot + k);
-      if (hipMemcpyAsync(du_xy, is_pk ? up_pk_xy : up_sg_xy, k * row, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
-          hipMemcpyAsync(du_slot, is_pk ? up_pk_slot : up_sg_slot, k * 4, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
-          hipMemcpyAsync(du_inf, is_pk ? up_pk_inf : up_sg_inf, k, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
-          bv_mirror_scatter(W, du_xy, du_inf, du_slot, M.d_xy, M.d_inf, k, copy_stream) != 0) return false;
-    }
     if (tot) {
       if (hipMemcpyAsync(is_pk ? d_idx_pk : d_idx_sg, is_pk ? idx_pk : idx_sg, tot * 4, hipMemcpyHostToDevice, copy_stream) != hipSuccess) return false;
       if (is_pk && (hipMemcpyAsync(d_offs, offs.data(), (m + 1) * 4, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
@@ -1414,8 +1430,12 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
         catch (...) { for (unsigned t = (unsigned)th.size(); t < nt; t++) { work(t, 0); work(t, 1); } }   // no more threads: the rest of the ranges here
       } else { work(0, 0); work(0, 1); }
     }
-    for (int pass = 0; pass < 2; pass++) {
-      while (pass_done[pass].load() < nt) std::this_thread::yield();
+    for (int pass = 0; pass < 2 && !copy_failed; pass++) {
+      for (size_t f = 0; f < PHASES; f++) {
+        while (phase_done[pass][f].load() < nt) std::this_thread::yield();
+        if (bad_handle || !ship_phase(pass, f)) { copy_failed = true; break; }
+      }
+      if (copy_failed) break;
       ph.mark(pass == 0 ? "  host pass over the key handles" : "  host pass over the signature handles");
       if (bad_handle || !stage_pass(pass)) { copy_failed = true; break; }
       ph.mark("  rows / slots across, gathered on the device");

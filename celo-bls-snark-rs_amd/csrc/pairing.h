@@ -304,6 +304,9 @@ struct PP761 {
     static void prepare_lines(const uint64_t* q0, uint32_t* lines, hipStream_t s);                                                 \
     static void miller_prepared(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* off, \
                                 const uint32_t* lines, uint32_t* prod, uint32_t m, hipStream_t s);                                 \
+    static bool has_split();        /* a few thousand verify-shaped products: each cut in two by iteration range */                \
+    static void miller_prepared_split(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2,                 \
+                                      const uint32_t* lines, uint32_t* f, uint32_t m, hipStream_t s);                               \
     static void gt_product(const uint32_t* f, const uint32_t* off, uint32_t* prod, uint32_t m, hipStream_t s);                     \
     static void gt_tree(const uint32_t* in, uint32_t* out, uint32_t n_in, hipStream_t s);                                          \
     static void final_exp(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint32_t m, int do_fe, hipStream_t s);              \
@@ -429,8 +432,13 @@ template <class PP> class PairingEngine {
     uint32_t most = 0;
     for (size_t p = 0; p < m && shared; p++) { const uint32_t c = offsets[p + 1] - offsets[p]; shared = c <= 4; most = c > most ? c : most; }
     typedef typename PP::LL LL;
-    bool prepared = false;
-    if (shared && most <= 2 && LL::has_prepared() && k) {
+    bool prepared = false, split_done = false;
+    // a few thousand products of exactly two pairs (Batch::verify's verdicts): too few to fill the chip with one group per product, and one
+    // group per PAIR spends ~900 product rounds per pair; if the first pairs share their G2 point, every product is cut in two by iteration
+    // range instead (k_miller_prepared_split_slots: two groups per product, ~710 rounds each)
+    bool split_ok = !shared && LL::has_split() && m > WideProduct<PP>::MAX_PRODUCTS && m <= SPLIT_MAX_PRODUCTS && k == 2 * m && miller_split_enabled();
+    for (size_t p = 0; p < m && split_ok; p++) split_ok = offsets[p + 1] - offsets[p] == 2;
+    if (((shared && most <= 2) || split_ok) && LL::has_prepared() && k) {
       // verify shapes: every product's first pair on the same G2 point (-g2)?  Then its line coefficients are computed once.
       uint32_t* d_flag = (uint32_t*)(A + lay.o_flag);
       uint32_t* d_lines = (uint32_t*)(A + lay.o_lines);
@@ -451,11 +459,16 @@ template <class PP> class PairingEngine {
           lines_at = (const void*)d_lines;
           lines_valid = true;
         }
-        LL::miller_prepared(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_lines, d_prod, (uint32_t)m, stream);
-        prepared = true;
+        if (shared) {
+          LL::miller_prepared(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_lines, d_prod, (uint32_t)m, stream);
+          prepared = true;
+        } else {
+          LL::miller_prepared_split(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_lines, d_f, (uint32_t)m, stream);
+          split_done = true;      // two values per product at d_f[2 p], d_f[2 p + 1]: the product kernel below multiplies them (offsets are 0, 2, 4, ...)
+        }
       }
     }
-    if (prepared) {
+    if (prepared || split_done) {
     } else if (shared && most <= 2) LL::miller_product2(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
     else if (shared) LL::miller_product(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_off, d_prod, (uint32_t)m, stream);
     else if (k) LL::miller(d_g1, has_inf1 ? d_i1 : nullptr, d_g2, has_inf2 ? d_i2 : nullptr, d_f, k, stream);
@@ -488,6 +501,8 @@ template <class PP> class PairingEngine {
     return 0;
   }
   static constexpr size_t SHARED_MIN_PRODUCTS = 16384;
+  static constexpr size_t SPLIT_MAX_PRODUCTS = 5120;       // two groups per product, ten per wave: at most one wave per SIMD
+  static bool miller_split_enabled() { static const bool on = getenv("CELO_NO_MILLER_SPLIT") == nullptr; return on; }      // A/B switch
 
  private:
   uint64_t lines_q0[PP::G2_ARK64] = {};     // the G2 point whose prepared lines the arena holds at lines_at (run_staged)

@@ -611,6 +611,66 @@ __global__ void __launch_bounds__(64) LANES_OCC k_miller_prepared_slots(const ui
 #endif
   if (live) LP::store12(prod + (size_t)gi * lanes_gt_words<LP>(), S::ld12(0));
 }
+// ---- the same product CUT IN TWO BY ITERATION RANGE, for a few thousand verify-shaped products (late round 4: config 3's 4096 verdicts,
+// the exposed tail of Batch::verify).  With F_h the value after h iterations, F_63 = F_h^(2^(63 - h)) * G, G the same recurrence over the
+// iterations h .. 62 started from 1 with the running point R_h.  Block 2 q computes F_h and squares on (role 0: 17 rounds per iteration,
+// then 4); block 2 q + 1 walks the point to R_h without touching an accumulator and then runs G (role 1: 3.7 rounds, then 17): with
+// h = 30 both are ~710 product rounds where one group per PAIR - what the engine runs below 16384 products - is ~900 per pair.  Ten
+// products per block pair, two GT-shaped values per product at f_out[2 p], f_out[2 p + 1]: k_gt_product_lanes multiplies them.  Products of
+// exactly two pairs each (the caller checks), first pair on the prepared lines.
+template <class LP>
+__global__ void __launch_bounds__(64) LANES_OCC k_miller_prepared_split_slots(const uint64_t* __restrict__ g1, const uint8_t* __restrict__ inf1,
+                                                                              const uint64_t* __restrict__ g2, const uint8_t* __restrict__ inf2,
+                                                                              const uint32_t* __restrict__ lines, uint32_t* __restrict__ f_out, uint32_t m, int H) {
+  typedef Slots<LP> S;
+  typedef typename LP::Tow Tow;
+  typedef typename LP::QB QB;
+  typedef typename LP::Pair Pair;
+  typedef typename QB::V V;
+  constexpr int NS = S::product_slots(2);
+  const int role = (int)(blockIdx.x & 1);
+  const int g = QB::group();
+  const int gi = g >= LP::GROUPS ? -1 : (int)(blockIdx.x >> 1) * LP::GROUPS + g;
+  const bool live = gi >= 0 && (uint32_t)gi < m;
+  const uint32_t ia = live ? 2u * (uint32_t)gi : 0u, ib = ia + 1;                  // dead groups walk product 0 and store nothing
+  const bool live_a = !((inf1 && inf1[ia]) || (inf2 && inf2[ia])), live_b = !((inf1 && inf1[ib]) || (inf2 && inf2[ib]));
+  S::template st_p<NS>(0, 0, LP::load_p(g1 + (size_t)ia * LP::G1W, 0));
+  S::template st_p<NS>(0, 1, LP::load_p(g1 + (size_t)ia * LP::G1W, 1));
+  S::template st_p<NS>(1, 0, LP::load_p(g1 + (size_t)ib * LP::G1W, 0));
+  S::template st_p<NS>(1, 1, LP::load_p(g1 + (size_t)ib * LP::G1W, 1));
+  S::stv(1, 0, QB::template sel<2>(QB::one(), LP::load_q(g2 + (size_t)ib * LP::G2W)));
+  S::st12(0, Tow::one12());
+  const int h = QB::hsel();
+  int step = 0;
+  auto line_at = [&](int st) {
+    const uint32_t* o = lines + (size_t)st * PREPARED_LINE_WORDS + h * 16;
+    typename Pair::Line l;
+    l.c0 = V::load(o); l.c1 = V::load(o + 32); l.c2 = V::load(o + 64);
+    return l;
+  };
+  auto ldp_a = [](int c) { return S::template ld_p<NS>(0, c); };
+  auto ldp_b = [](int c) { return S::template ld_p<NS>(1, c); };
+#pragma unroll 1
+  for (int it = 0; it < 63; it++) {
+    const int b = 62 - it;
+    const bool mine = role == 0 ? it < H : it >= H;          // this role multiplies lines into its accumulator in this iteration
+    if (role == 1 || it < H) {                               // role 0 needs no point after its range; role 1 walks it from the start
+      if (mine || role == 0) S::sqr12(0);
+      typename Pair::Line lb;
+      { V Rb = S::ldv(1, 0); Pair::double_step(Rb, lb); S::stv(1, 0, Rb); }
+      if (mine) { const int st = step; S::ell2_slot(0, 1, 1, [&]() { return line_at(st); }, ldp_a, live_a, lb, ldp_b, live_b); }
+      step++;
+      if ((T377::X >> b) & 1) {
+        { const V Qc = LP::load_q(g2 + (size_t)ib * LP::G2W); V Rb = S::ldv(1, 0); Pair::add_step(Rb, Qc, lb); S::stv(1, 0, Rb); }
+        if (mine) { const int st = step; S::ell2_slot(0, 1, 1, [&]() { return line_at(st); }, ldp_a, live_a, lb, ldp_b, live_b); }
+        step++;
+      }
+    } else {
+      S::sqr12(0);                                           // role 0 beyond its range: F_h^(2^(63 - h))
+    }
+  }
+  if (live) LP::store12(f_out + ((size_t)2 * gi + role) * lanes_gt_words<LP>(), S::ld12(0));
+}
 template <class LP>
 __global__ void __launch_bounds__(64) LANES_OCC k_final_exp_slots(const uint32_t* __restrict__ prod, uint8_t* __restrict__ is_one,
                                                                   uint64_t* __restrict__ gt_ark, uint32_t m, int do_final_exp) {
@@ -647,6 +707,8 @@ __global__ void __launch_bounds__(64) LANES_OCC k_final_exp_slots(const uint32_t
   void LL::gt_product(const uint32_t* f, const uint32_t* off, uint32_t* prod, uint32_t m, hipStream_t s) {                               \
     hipLaunchKernelGGL((k_gt_product_lanes<LP>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64), 0, s, f, off, prod, m);           \
   }                                                                                                                                       \
+  bool LL::has_split() { return false; }                                                                                                  \
+  void LL::miller_prepared_split(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, uint32_t*, uint32_t, hipStream_t) {} \
   void LL::gt_tree(const uint32_t* in, uint32_t* out, uint32_t n_in, hipStream_t s) {                                                     \
     const uint32_t n_out = (n_in + 1) / 2;                                                                                                \
     hipLaunchKernelGGL((k_gt_tree_lanes<LP>), dim3((n_out + LP::GROUPS - 1) / LP::GROUPS), dim3(64), 0, s, in, out, n_in);            \
@@ -680,6 +742,13 @@ __global__ void __launch_bounds__(64) LANES_OCC k_final_exp_slots(const uint32_t
   }                                                                                                                                       \
   void LL::gt_product(const uint32_t* f, const uint32_t* off, uint32_t* prod, uint32_t m, hipStream_t s) {                               \
     hipLaunchKernelGGL((k_gt_product_lanes<LP>), dim3((m + LP::GROUPS - 1) / LP::GROUPS), dim3(64), 0, s, f, off, prod, m);               \
+  }                                                                                                                                       \
+  bool LL::has_split() { return true; }                                                                                                   \
+  void LL::miller_prepared_split(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* lines,     \
+                                 uint32_t* f, uint32_t m, hipStream_t s) {                                                                \
+    static const int cut = getenv("CELO_MILLER_SPLIT_H") ? atoi(getenv("CELO_MILLER_SPLIT_H")) : 30;   /* the cut h (tuning hook) */       \
+    hipLaunchKernelGGL((k_miller_prepared_split_slots<LP>), dim3(2 * ((m + LP::GROUPS - 1) / LP::GROUPS)), dim3(64),                      \
+                       Slots<LP>::product_lds_bytes(2), s, g1, i1, g2, i2, lines, f, m, cut < 1 ? 1 : cut > 62 ? 62 : cut);               \
   }                                                                                                                                       \
   void LL::gt_tree(const uint32_t* in, uint32_t* out, uint32_t n_in, hipStream_t s) {                                                     \
     const uint32_t n_out = (n_in + 1) / 2;                                                                                                \

@@ -239,11 +239,85 @@ __global__ void __launch_bounds__(64) LANES_OCC k377_w3_final_products(const uin
   if (is_one && LP::writer()) is_one[p] = one ? 1 : 0;
   if (gt_ark) LP::to_ark12(f, gt_ark + (size_t)p * 72);
 }
+// ---- the same with TWO lane groups per product, five products per wave (late round 4): 3073 ... 5120 products, where three groups per
+// product would give SIMDs a second wave.  A cyclotomic squaring's two Fq2 product rounds still run side by side (1 round: they are 70 % of
+// the chain's rounds), an Fq12 product takes two Fq6 steps instead of three (groups 0 | 1: x.a y.a | x.b y.b, then both the Karatsuba term).
+__device__ __forceinline__ int sub2() { return QB::group() & 1; }
+template <int R> __device__ __forceinline__ V from_sub2(const V& x) { return QB::from_addr(x, ((int)__lane_id() + 6 * (R - sub2())) << 2); }
+__device__ __forceinline__ V pick2(const V& a0, const V& a1) { return QB::choose(sub2() == 0, a0, a1); }
+__device__ __forceinline__ E12 mul12_w2(const E12& x, const E12& y) {
+  const V p = Tow::mul6(pick2(x.a, x.b), pick2(y.a, y.b));
+  const V t = Tow::mul6(QB::add(x.a, x.b), QB::add(y.a, y.b));
+  const V v0 = from_sub2<0>(p), v1 = from_sub2<1>(p);
+  E12 r;
+  r.b = QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(t, v0), v1));
+  r.a = QB::wred(QB::add_l(v0, Tow::template mul_by_gen_k_l<4>(v1)));
+  return r;
+}
+__device__ __forceinline__ E12 cyclo_w2(const E12& f) {
+  const V x = QB::template sel<1>(QB::template perm<QP(0, 0, 1)>(f.b), QB::template perm<QP(0, 0, 1)>(f.a));
+  const V y = QB::template sel<1>(QB::template perm<QP(1, 2, 2)>(f.a), QB::template perm<QP(1, 1, 2)>(f.b));
+  const V p = QB::mul(pick2(x, QB::add(x, y)), pick2(y, QB::add(QB::template mul_nr_k_l<4>(y), x)));
+  const V tmp = from_sub2<0>(p), m = from_sub2<1>(p);
+  const V o0 = QB::lred(QB::template sub_l<64>(QB::template sub_l<4>(m, tmp), QB::template mul_nr_k<4>(tmp)));
+  const V ut = QB::template perm<QP(2, 0, 1)>(tmp);
+  const V u = QB::dbl_l(QB::template sel<0>(QB::template mul_nr_k<4>(ut), ut));
+  E12 z;
+  z.a = QB::wred(QB::add_l(QB::dbl_l(QB::template sub_l<4>(o0, f.a)), o0));
+  z.b = QB::wred(QB::add_l(QB::dbl_l(QB::add_l(u, f.b)), u));
+  return z;
+}
+__device__ __attribute__((noinline)) E12 exp_by_x_w2(const E12& f) {
+  E12 acc = f;
+#pragma unroll 1
+  for (int i = 62; i >= 0; i--) {
+    acc = cyclo_w2(acc);
+    if ((T377::X >> i) & 1) acc = mul12_w2(acc, f);
+  }
+  return acc;
+}
+__device__ __forceinline__ E12 final_exp_w2(const E12& f_in) {
+  E12 f2 = Tow::inv12(f_in);
+  E12 r = mul12_w2(Tow::conj12(f_in), f2);
+  f2 = r;
+  r = mul12_w2(Pair::template frob12<2>(r), f2);
+  E12 y0 = Tow::conj12(cyclo_w2(r));
+  E12 y5 = exp_by_x_w2(r);
+  E12 y1 = cyclo_w2(y5);
+  E12 y3 = mul12_w2(y0, y5);
+  y0 = exp_by_x_w2(y3);
+  E12 y2 = exp_by_x_w2(y0);
+  E12 y4 = mul12_w2(exp_by_x_w2(y2), y1);
+  y1 = exp_by_x_w2(y4);
+  y3 = Tow::conj12(y3);
+  y1 = mul12_w2(mul12_w2(y1, y3), r);
+  y3 = Tow::conj12(r);
+  y0 = Pair::template frob12<3>(mul12_w2(y0, r));
+  y4 = Pair::template frob12<1>(mul12_w2(y4, y3));
+  y5 = Pair::template frob12<2>(mul12_w2(y5, y2));
+  y5 = mul12_w2(mul12_w2(y5, y0), y4);
+  return mul12_w2(y5, y1);
+}
+__global__ void __launch_bounds__(64) LANES_OCC k377_w2_final_products(const uint32_t* __restrict__ prod, uint8_t* __restrict__ is_one, uint64_t* __restrict__ gt_ark,
+                                                                       uint32_t m) {
+  const int g = QB::group();
+  if (g >= 10) return;
+  const uint32_t p = blockIdx.x * 5u + (uint32_t)(g >> 1);
+  const bool live = p < m;
+  const E12 f = final_exp_w2(LP::load12(prod + (size_t)(live ? p : 0) * W377));
+  const bool one = Tow::is_one12(f);
+  if (!live || sub2() != 0) return;
+  if (is_one && LP::writer()) is_one[p] = one ? 1 : 0;
+  if (gt_ark) LP::to_ark12(f, gt_ark + (size_t)p * 72);
+}
 }  // namespace
 
 // m products (GT-shaped Miller values at prod, six-lane device form) -> verdicts and / or GT values; enqueued on `s`
 void final_exp_w3_377(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint32_t m, hipStream_t s) {
   hipLaunchKernelGGL(k377_w3_final_products, dim3((m + SUPER - 1) / SUPER), dim3(64), 0, s, prod, is_one, gt, m);
+}
+void final_exp_w2_377(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint32_t m, hipStream_t s) {
+  hipLaunchKernelGGL(k377_w2_final_products, dim3((m + 4) / 5), dim3(64), 0, s, prod, is_one, gt, m);
 }
 
 size_t wide_lines_words_377(uint32_t kt) { return (size_t)LINE_STEPS * kt * LINE_WORDS; }

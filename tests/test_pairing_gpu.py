@@ -316,15 +316,15 @@ def test_medium_batches_final_exponentiation_side_by_side(gpu):
     assert np.array_equal(gt[500], one)
 
 
-def test_medium_batches_split_by_iteration_range(gpu):
+@pytest.mark.parametrize("m", [1003, 3101])
+def test_medium_batches_split_by_iteration_range(gpu, m):
     """769 ... 5120 verify-shaped products of exactly two pairs take k_miller_prepared_split_slots (late round 4): every product cut in
     two by iteration range, F_63 = F_h^(2^(63 - h)) * G.  Verdicts as constructed, Miller AND GT values bit for bit against the oracle on
     a sample, with a pair flagged as the identity in some products (that pair's line is 1) and a product count that is not a multiple
-    of the ten groups of a wave."""
+    of the ten groups of a wave.  m = 1003: final exponentiation with three groups per product; m = 3101: with two (k377_w2_final_products)."""
     base = 30
     rng = ecc.SplitMix64(5120)
     pairs = [_signed_pairs(rng, 2, bad=(0 if p % 6 == 2 else None)) for p in range(base)]
-    m = 1003
     g1l, g2l, want = [], [], []
     for p in range(m):
         a, b = pairs[p % base]
@@ -341,7 +341,7 @@ def test_medium_batches_split_by_iteration_range(gpu):
     i1b[2 * 500] = 1
     gt = gpu.pairing_gt(g1, i1b, g2, i2b, offs)
     ml = gpu.pairing_gt(g1, i1b, g2, i2b, offs, miller_only=True)
-    for p in (0, 2, 7, 499, 500, 1002):
+    for p in (0, 2, 7, 499, 500, m - 1):
         lo, hi = 2 * p, 2 * p + 2
         assert np.array_equal(ml[p], co.miller_loop_377(g1[lo:hi], i1b[lo:hi], g2[lo:hi], i2b[lo:hi])), p
         assert np.array_equal(gt[p], co.pairing_product_377(g1[lo:hi], i1b[lo:hi], g2[lo:hi], i2b[lo:hi])[0]), p

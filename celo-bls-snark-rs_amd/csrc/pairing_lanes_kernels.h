@@ -302,14 +302,34 @@ template <class LP> struct Slots {
     stv(dst, 1, QB::wred(QB::template sub_l<4>(QB::template sub_l<4>(t, v0), v1)));
     stv(dst, 0, QB::wred(QB::add_l(v0, Tow::template mul_by_gen_k_l<4>(v1))));
   }
+  // word i of half `which` of slot `slot` as lane t holds it - any lane of the wave may read it (the slot is memory)
+  __device__ __forceinline__ static V ldv_at(int slot, int which, int t) {
+    extern __shared__ uint32_t lanes_lds[];
+    const uint32_t* p = lanes_lds + slot * SLOT_WORDS + which * NW * 64 + t;
+    V r;
+#pragma unroll
+    for (int i = 0; i < NW; i++) r.l[i] = p[i * 64];
+    return r;
+  }
   __device__ __forceinline__ static void cyclo(int s) {        // Tow::cyclotomic_sqr_inl with f re-read for the last step
     typedef typename LP::QB QB;
     V x, y;
+#if defined(CELO_CYCLO_PERM)   // A/B switch: the round-3 form - both halves loaded as the lane owns them, four lane permutes to pair them up
     {
       const V fa = ldv(s, 0), fb = ldv(s, 1);
       x = QB::template sel<1>(QB::template perm<QP(0, 0, 1)>(fb), QB::template perm<QP(0, 0, 1)>(fa));
       y = QB::template sel<1>(QB::template perm<QP(1, 2, 2)>(fa), QB::template perm<QP(1, 1, 2)>(fb));
     }
+#else
+    {
+      // late round 4: the Fq4 pairs (a0, b1), (b0, a2), (a1, b2) are read straight from the slot at the lane that holds them - the slot is
+      // LDS, any lane's words are an address away: 28 ds_read instead of 28 ds_read + 56 ds_bpermute + 28 selects
+      const int j = QB::lane();
+      const int t0 = QB::group() >= LP::GROUPS ? QB::hsel() : (int)threadIdx.x - QB::sub() + QB::hsel();   // this group's tower lane 0, same half (the idle lanes 60 .. 63 read group 0's: in bounds)
+      x = ldv_at(s, j == 1 ? 1 : 0, t0 + (j == 2 ? 2 : 0));                          // a0 | b0 | a1
+      y = ldv_at(s, j == 1 ? 0 : 1, t0 + (j == 0 ? 2 : 4));                          // b1 | a2 | b2
+    }
+#endif
     fence();
     const V tmp = QB::mul(x, y);
     const V m = QB::mul(QB::add(x, y), QB::add(QB::template mul_nr_k_l<4>(y), x));

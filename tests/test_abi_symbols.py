@@ -68,6 +68,9 @@ def test_no_device_fails_loudly():
         ffi.groth16_prove(np.zeros((2, 24), dtype=np.uint64), np.zeros((2, 24), dtype=np.uint64), np.zeros((1, 24), dtype=np.uint64),
                           np.zeros((1, 24), dtype=np.uint64), np.zeros(24, dtype=np.uint64), np.zeros(24, dtype=np.uint64),
                           np.ones((1, 6), dtype=np.uint64), 1, np.ones((1, 6), dtype=np.uint64))
+    # round 4: the exponent generator of batch_verify_strict is a device kernel
+    with pytest.raises(RuntimeError):
+        ffi.draw_batch_exponents(np.arange(8, dtype=np.uint32), np.array([0, 3], dtype=np.uint32))
     with pytest.raises(RuntimeError):
         ffi.use_device(0)
     with pytest.raises(RuntimeError):

@@ -401,6 +401,11 @@ int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]) {
     default: return 1;
   }
 }
+int celo_amd_msm_set_host_chunks(int chunks) {
+  if (chunks < -1 || chunks > 64) return 1;
+  celo::host_chunks_override().store(chunks);
+  return 0;
+}
 int celo_amd_msm_set_window_bits(int group, int c) {
   if (c != 0 && (c < 4 || c > 16)) return 1;
   switch (group) {

@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <atomic>
 #include <thread>
 #include <system_error>
 #include "curve.h"
@@ -122,11 +123,23 @@ __global__ void __launch_bounds__(256) k_flag_ark_zero(const uint64_t* __restric
 // window full.  A narrow window uses the lower half of its bucket table; its top tree level is empty, so the host's Horner pass
 // leaves that level and its doubling out.  The extra bit is the headroom of the signed recoding: bits from SCALAR_BITS up are
 // ignored (as ark-ec's VariableBaseMSM ignores them), so the top digit plus its carry never exceeds 2^(width - 1).
+// CHUNKED layout (round 5, the host-pointer pipeline: run_device_windows' HostIn): the n scalars are cut into index chunks of m and the
+// digits of chunk k, window w form the row (k NW + w) of length m - every (chunk, window) pair is a "virtual window" of the sort below.
+// The lanes from n up to npad (the last chunk's tail) write "no digit".  m = npad = n is the plain layout.
 template <int SW, int CB, int NW, int KN, int BITS>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
-                                                uint16_t* __restrict__ digits, uint32_t n) {
+                                                uint16_t* __restrict__ digits, uint32_t n, uint32_t m, uint32_t npad) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= npad) return;
+  if (m != n) {
+    const uint32_t ch = i / m;
+    digits += (size_t)ch * NW * m + (i - ch * m);
+    if (i >= n) {
+#pragma unroll
+      for (int w = 0; w < NW; w++) digits[(size_t)w * m] = (uint16_t)0xFFFF;
+      return;
+    }
+  } else digits += i;
   uint32_t s[SW + 1];
   const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * SW);
 #pragma unroll
@@ -159,7 +172,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
     uint32_t neg = d > B ? 1u : 0u;
     uint32_t mag = neg ? ((1u << width) - d) : d;
     carry = neg;
-    digits[(size_t)w * n + i] = (mag == 0 || skip) ? (uint16_t)0xFFFF : (uint16_t)((mag - 1) | (neg << 15));
+    digits[(size_t)w * m] = (mag == 0 || skip) ? (uint16_t)0xFFFF : (uint16_t)((mag - 1) | (neg << 15));
   }
 }
 
@@ -261,7 +274,9 @@ __global__ void __launch_bounds__(1024) k_part_scan(uint32_t* __restrict__ block
 template <class G>
 __global__ void __launch_bounds__(1024) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ blockoff,
                                                        uint32_t* __restrict__ rec_idx, uint8_t* __restrict__ rec_key, uint32_t n,
-                                                       uint32_t chunk, uint32_t HIB, uint32_t NBIN, const uint32_t* __restrict__ remap = nullptr) {
+                                                       uint32_t chunk, uint32_t HIB, uint32_t NBIN, const uint32_t* __restrict__ remap = nullptr,
+                                                       uint32_t vw = 0) {
+  // vw > 0: the windows are virtual (chunked layout, k_digits): window w holds index chunk w / vw, whose entries are the points from (w / vw) n on
   constexpr uint32_t SB = 8 * 1024;   // entries per batch
   __shared__ uint32_t cur[128], lcnt[128], loff[128], wt[2];
   __shared__ uint32_t st_idx[SB];
@@ -273,6 +288,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const uint16_t* __restric
   uint32_t* oi = rec_idx + (size_t)w * n;
   uint8_t* ok = rec_key + (size_t)w * n;
   const int lane = t & 63, wv = t >> 6;
+  const uint32_t ioff = vw ? (w / vw) * n : 0u;
   for (uint32_t i0 = lo; i0 < hi; i0 += SB) {
     uint32_t d[8], r[8];
 #pragma unroll
@@ -303,7 +319,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const uint16_t* __restric
         const uint32_t b = d[k] & 0x7FFFu, bin = b & (NBIN - 1);
         const uint32_t s_ = loff[bin] + r[k];
         const uint32_t e_ = i0 + k * 1024 + t;        // remap (fixed base, compacted virtual windows): slot e_ of window w holds table entry remap[w n + e_]
-        st_idx[s_] = (remap ? remap[(size_t)w * n + e_] : e_) | ((d[k] >> 15) << 31);
+        st_idx[s_] = (remap ? remap[(size_t)w * n + e_] : e_ + ioff) | ((d[k] >> 15) << 31);
         st_key[s_] = (uint8_t)(b >> HIB);
         st_bin[s_] = (uint8_t)bin;
       }
@@ -369,7 +385,10 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint32_t* __restrict__
                                                     uint32_t* __restrict__ sorted, uint32_t* __restrict__ pfirst,
                                                     uint32_t* __restrict__ pstart, uint32_t* __restrict__ plen, uint32_t* __restrict__ big,
                                                     uint32_t* __restrict__ nbig, uint32_t* __restrict__ mid, uint32_t* __restrict__ nmid,
-                                                    uint32_t n, uint32_t B, uint32_t HIB, uint32_t NBIN, uint32_t SEG, uint32_t PW) {
+                                                    uint32_t n, uint32_t B, uint32_t HIB, uint32_t NBIN, uint32_t SEG, uint32_t PW,
+                                                    uint32_t* __restrict__ pbucket = nullptr, uint32_t vw = 0) {
+  // pbucket (chunked layout): the FIRST piece of a bucket of virtual window w carries the sum of bucket (w mod vw, b) across the chunks
+  // (k_accumulate_chunk): pbucket[piece] = (w mod vw) B + b for it, ~0 for the others
   __shared__ uint32_t cnt[256], cur[256], loff[256], wt[4], wt2[4], wt3[4], lists[4];
   __shared__ uint32_t st_idx[TILE_EPT * 1024];
   __shared__ uint8_t st_key[TILE_EPT * 1024];
@@ -427,6 +446,7 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint32_t* __restrict__
           for (uint32_t k = 0; k < p; k++) {
             pstart[pf + k] = s_ + k * SEG;
             plen[pf + k] = (v - k * SEG < SEG) ? v - k * SEG : SEG;
+            if (pbucket) pbucket[pf + k] = k ? 0xFFFFFFFFu : (w % vw) * B + ((t << HIB) | bin);
           }
           // multi-piece buckets go on the fold lists: ranks from LDS, ONE global atomic per workgroup and list (every bucket of
           // a short top window is on the mid list - 4096 atomics on one address took 40 us)
@@ -592,16 +612,93 @@ __global__ void __launch_bounds__(256) ACC_OCC k_accumulate(const uint32_t* __re
   IO::store_xyzz(partials + (size_t)pid * IO::XYZZ_WORDS, acc);
 }
 
+// The accumulation of ONE INDEX CHUNK of the host-pointer pipeline (round 5; run_device_windows' HostIn): the bases arrive over PCIe chunk
+// by chunk and every chunk is accumulated while the next one is in flight.  The sort ran over (chunk, window) virtual windows, so a
+// bucket's points of chunk k are a run of their own, cut into pieces as usual; the lane of a bucket's FIRST piece starts from the
+// bucket's carried sum - the value the same bucket reached in the earlier chunks (carrier[(w, b)], zeroes = the identity before chunk 0) -
+// and stores it back, so the chunks cost no additions that one pass over all n points would not have spent.  Further pieces of a bucket
+// (runs longer than SEG: skewed scalars) go to `partials` as in k_accumulate and are folded into the carrier after the last chunk
+// (k_combine_* with first = 1, k_merge_carried).  Chunk launches are stream-ordered: no two lanes ever hold the same carrier.
+template <class G>
+__global__ void __launch_bounds__(256) ACC_OCC k_accumulate_chunk(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                    const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ plen,
+                                                    const uint32_t* __restrict__ order, const uint32_t* __restrict__ nwork,
+                                                    uint32_t* __restrict__ partials, const uint32_t* __restrict__ pbucket,
+                                                    uint32_t* __restrict__ carrier, uint32_t cont) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= *nwork) return;
+  uint32_t pid = order[tid];
+  const uint32_t* run = sorted + pstart[pid];
+  uint32_t len = plen[pid];
+  const uint32_t pb = pbucket[pid];
+  uint32_t* dst = pb != 0xFFFFFFFFu ? carrier + (size_t)pb * IO::XYZZ_WORDS : partials + (size_t)pid * IO::XYZZ_WORDS;
+  const bool carried = cont && pb != 0xFFFFFFFFu;
+  Xyzz<F> acc = Xyzz<F>::identity();
+  if (carried) acc = IO::load_xyzz(dst);
+  if constexpr (sizeof(F) <= 14 * sizeof(uint32_t)) {
+    auto point = [&](uint32_t k) {
+      const uint32_t v = run[k];
+      Affine<F> p = IO::load_affine(bases + (size_t)(v & 0x7fffffffu) * IO::AFF_WORDS);
+      if (v >> 31) p = affine_neg(p);
+      return p;
+    };
+    uint32_t k0 = 0;
+    if (!carried && len >= 2) { acc = xyzz_add_affine(point(0), point(1)); k0 = 2; }
+    for (uint32_t k = k0; k < len; k++) xyzz_madd(acc, point(k));
+  } else {
+    if (len) {
+      uint32_t v = run[0];
+      Affine<F> p = IO::load_affine(bases + (size_t)(v & 0x7fffffffu) * IO::AFF_WORDS);
+      for (uint32_t k = 0; k < len; k++) {
+        const uint32_t vn = run[k + 1 < len ? k + 1 : k];
+        const Affine<F> pn = IO::load_affine(bases + (size_t)(vn & 0x7fffffffu) * IO::AFF_WORDS);
+        if (v >> 31) p = affine_neg(p);
+        xyzz_madd(acc, p);
+        p = pn;
+        v = vn;
+      }
+    }
+  }
+  IO::store_xyzz(dst, acc);
+}
+// after the last chunk: carrier(w, b) += the folded further pieces of bucket (w, b) of every chunk (piece pfirst + 1 of virtual window
+// k vw + w, where its run was longer than SEG).  One lane per bucket; for uniform scalars almost no lane has anything to add.
+template <class G>
+__global__ void __launch_bounds__(128) k_merge_carried(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ pfirst,
+                                                       const uint32_t* __restrict__ partials, uint32_t* __restrict__ carrier,
+                                                       uint32_t real_total, uint32_t chunks, uint32_t SEG) {
+  typedef typename G::F F;
+  typedef PointIO<F> IO;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= real_total) return;
+  bool any = false;
+  for (uint32_t k = 0; k < chunks; k++) any |= counts[(size_t)k * real_total + t] > SEG;
+  if (!any) return;
+  Xyzz<F> acc = IO::load_xyzz(carrier + (size_t)t * IO::XYZZ_WORDS);
+  for (uint32_t k = 0; k < chunks; k++) {
+    const size_t g = (size_t)k * real_total + t;
+    if (counts[g] > SEG) {
+      const Xyzz<F> v = IO::load_xyzz(partials + (size_t)(pfirst[g] + 1) * IO::XYZZ_WORDS);
+      xyzz_add_fn(acc, v);
+    }
+  }
+  IO::store_xyzz(carrier + (size_t)t * IO::XYZZ_WORDS, acc);
+}
+
 // ---- 5a. buckets cut into 2..16 pieces (e.g. every bucket of a short top window): one lane folds the pieces
+// (`first` = 1, chunked pipeline: the first piece is the bucket's carrier and stays out of the fold - the pieces from the second on are
+// folded into the second)
 template <class G>
 __global__ void __launch_bounds__(128) k_combine_mid(const uint32_t* __restrict__ mid, const uint32_t* __restrict__ nmid,
                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ pfirst,
-                                                     uint32_t* __restrict__ partials, uint32_t* __restrict__ pieces_of, uint32_t SEG) {
+                                                     uint32_t* __restrict__ partials, uint32_t* __restrict__ pieces_of, uint32_t SEG, uint32_t first = 0) {
   typedef typename G::F F;
   typedef PointIO<F> IO;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < *nmid; q += gridDim.x * blockDim.x) {
     uint32_t t = mid[q];
-    uint32_t pc = (counts[t] + SEG - 1) / SEG, pf = pfirst[t];
+    uint32_t pc = (counts[t] + SEG - 1) / SEG - first, pf = pfirst[t] + first;
     Xyzz<F> acc = IO::load_xyzz(partials + (size_t)pf * IO::XYZZ_WORDS);
     for (uint32_t k = 1; k < pc; k++) {
       Xyzz<F> v = IO::load_xyzz(partials + (size_t)(pf + k) * IO::XYZZ_WORDS);
@@ -616,7 +713,7 @@ __global__ void __launch_bounds__(128) k_combine_mid(const uint32_t* __restrict_
 template <class G>
 __global__ void __launch_bounds__(64) k_combine_mid_lanes(const uint32_t* __restrict__ mid, const uint32_t* __restrict__ nmid,
                                                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ pfirst,
-                                                          uint32_t* __restrict__ partials, uint32_t* __restrict__ pieces_of, uint32_t SEG) {
+                                                          uint32_t* __restrict__ partials, uint32_t* __restrict__ pieces_of, uint32_t SEG, uint32_t first = 0) {
   typedef typename G::F F;
   typedef PointIO<F> IO;
   typedef QTriT<FieldBase<F>> QB;
@@ -625,7 +722,7 @@ __global__ void __launch_bounds__(64) k_combine_mid_lanes(const uint32_t* __rest
   if (g >= 21) return;
   for (uint32_t q = blockIdx.x * 21u + (uint32_t)g; q < *nmid; q += gridDim.x * 21u) {
     const uint32_t t = mid[q];
-    const uint32_t pc = (counts[t] + SEG - 1) / SEG, pf = pfirst[t];
+    const uint32_t pc = (counts[t] + SEG - 1) / SEG - first, pf = pfirst[t] + first;
     const Xyzz<F> a = IO::load_xyzz(partials + (size_t)pf * IO::XYZZ_WORDS);
     typename LP::Pt acc = {{a.X, a.Y, a.ZZ, a.ZZZ}, a.is_identity()};
     for (uint32_t k = 1; k < pc; k++) {
@@ -645,13 +742,13 @@ __global__ void __launch_bounds__(64) k_combine_mid_lanes(const uint32_t* __rest
 template <class G>
 __global__ void __launch_bounds__(256) k_combine_big(const uint32_t* __restrict__ big, const uint32_t* __restrict__ nbig,
                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ pfirst,
-                                                     uint32_t* __restrict__ partials, uint32_t* __restrict__ pieces_of, uint32_t SEG) {
+                                                     uint32_t* __restrict__ partials, uint32_t* __restrict__ pieces_of, uint32_t SEG, uint32_t first = 0) {
   typedef typename G::F F;
   typedef PointIO<F> IO;
   __shared__ uint32_t stage[64 * IO::XYZZ_WORDS];
   for (uint32_t q = blockIdx.x; q < *nbig; q += gridDim.x) {
     uint32_t t = big[q];
-    uint32_t pc = (counts[t] + SEG - 1) / SEG, pf = pfirst[t];
+    uint32_t pc = (counts[t] + SEG - 1) / SEG - first, pf = pfirst[t] + first;
     Xyzz<F> acc = Xyzz<F>::identity();
     for (uint32_t k = threadIdx.x; k < pc; k += 256) {
       Xyzz<F> v = IO::load_xyzz(partials + (size_t)(pf + k) * IO::XYZZ_WORDS);
@@ -677,6 +774,7 @@ template <class G> HD Xyzz<typename G::F> load_bucket(const uint32_t* partials, 
                                                        const uint32_t* pieces_of, uint32_t t, uint32_t SEG) {
   typedef typename G::F F;
   typedef PointIO<F> IO;
+  if (!counts) return IO::load_xyzz(partials + (size_t)t * IO::XYZZ_WORDS);    // chunked pipeline: `partials` is the carrier table, one slot per bucket
   uint32_t c = counts[t];
   if (c == 0) return Xyzz<F>::identity();
   (void)pieces_of; (void)SEG;  // k_combine_mid / k_combine_big have folded multi-piece buckets into their first piece
@@ -1350,6 +1448,7 @@ struct MsmTuning {
   uint32_t seg_min, seg_min_shard, bitsum_lanes_max_shard;
   int seg_halves;          // piece length in half mean-bucket lengths (4 = twice the mean); 0 = not set: the path's own default
   uint32_t bitsum_lanes_max;
+  uint32_t host_chunks;    // host-pointer entry: index chunks of the pipelined transfer (CELO_HOST_CHUNKS; 0 or 1 = the plain form)
   static const MsmTuning& get() {
     static const MsmTuning t = [] {
       MsmTuning v;
@@ -1362,6 +1461,7 @@ struct MsmTuning {
       v.gls_force = false;       // the release library never applies psi to the plain entry points' arbitrary curve points
 #endif
       v.lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;
+      v.host_chunks = getenv("CELO_HOST_CHUNKS") ? (uint32_t)atoi(getenv("CELO_HOST_CHUNKS")) : 4u;
       v.fx_compact = getenv("CELO_FX_NO_COMPACT") == nullptr;        // A/B switch: fixed base, digits compacted by virtual window
       v.host_threads = getenv("CELO_NO_HOST_THREADS") == nullptr;
       v.seg_halves = getenv("CELO_SEG_HALVES") ? atoi(getenv("CELO_SEG_HALVES")) : 0;
@@ -1395,6 +1495,8 @@ template <class G> class MsmEngine {
     if (d_fx_scalars) { (void)hipFree(d_fx_scalars); d_fx_scalars = nullptr; cap_fx = 0; }
     for (int i = 0; i < 6; i++) if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
     for (int i = 0; i < 2; i++) if (ev_side[i]) { (void)hipEventDestroy(ev_side[i]); ev_side[i] = nullptr; }
+    for (hipEvent_t e : ev_copy) if (e) (void)hipEventDestroy(e);
+    ev_copy.clear();
   }
   // Measured on the MI355X (sweep over c at n = 2^8 .. 2^20, uniform scalars, all groups): with the log-depth bucket reduction
   // the buckets are cheap and the accumulate lanes are not - few long bucket runs are pure latency - so small and mid-size
@@ -1470,8 +1572,14 @@ template <class G> class MsmEngine {
   // epilogue's own coordinates, so that the join needs no conversion.
   // fx != nullptr: the FIXED-BASE form (FixedTable above): d_ark_bases / d_inf are unused, n_ = the number of scalars (<= fx->n), the
   // pipeline runs over the table's E entries in NV virtual windows of 2^15 buckets.
+  // hin != nullptr: the HOST-POINTER pipeline (round 5; VERDICT r4 item 1 - the call a drop-in caller makes: signature.rs:82-85,
+  // public.rs:58-61 hand host slices to multi_scalar_mul).  d_ark_bases / d_inf / d_scalars are then the engine's staging buffers, still
+  // EMPTY: the scalars (and flags) are sent first, the digits and the whole sort run over (chunk, window) virtual windows while the bases
+  // follow in hin->chunks index chunks on a second stream, and every chunk is converted and accumulated (k_accumulate_chunk) as soon as
+  // it has landed - the PCIe time of the bases hides under the accumulation instead of preceding it.
+  struct HostIn { const uint64_t* bases; const uint8_t* inf; const uint64_t* scalars; uint32_t chunks; };
   int run_device_windows(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, int win_lo, int win_cnt,
-                         uint64_t* out_jac, uint64_t* out_xyzz, hipStream_t stream, const FixedTable* fx = nullptr) {
+                         uint64_t* out_jac, uint64_t* out_xyzz, hipStream_t stream, const FixedTable* fx = nullptr, const HostIn* hin = nullptr) {
     if (n_ == 0) {
       if (out_jac) write_identity(out_jac);
       if (out_xyzz) memset(out_xyzz, 0, 4 * IO::ARK64 * 8);
@@ -1506,6 +1614,7 @@ template <class G> class MsmEngine {
       if (ep >= 4096 && ep * 2 <= E) fx_Ep = (uint32_t)ep;       // (a window that holds most entries - tiny scalars - gains nothing: the uncompacted form)
     }
     if (fx) { pl.glv = false; pl.n = fx_Ep ? fx_Ep : fx->E(); pl.sbits = G::SCALAR_BITS; pl.c = 16; pl.nw = (int)fx->NV; pl.kn = 0; }
+    if (hin && (fx || pl.glv || win_cnt || hin->chunks < 1 || hin->chunks > 64 || !side_stream_.get())) return 2;
     const bool glv = pl.glv;
     const uint32_t n = pl.n;
     const int sbits = pl.sbits, c = pl.c, nw_all = pl.nw;
@@ -1515,11 +1624,22 @@ template <class G> class MsmEngine {
     if ((uint64_t)n * (uint64_t)nw_all >= (uint64_t(1) << 32)) return 2;  // run offsets are 32-bit (n*windows < 2^32: n <= 2^27 at c = 16)
     const uint32_t B = 1u << (c - 1);
     const uint32_t total = (uint32_t)nw * B;
+    // the sort's view: ns entries in each of nws windows - the call's own, or (host-pointer pipeline) the K index chunks of cm points
+    // times the windows, chunk-major: virtual window k nw + w
+    uint32_t K = 0, cm = n;
+    if (hin) {
+      cm = ((n + hin->chunks - 1) / hin->chunks + 1023u) & ~1023u;
+      K = (n + cm - 1) / cm;
+    }
+    const uint32_t ns = hin ? cm : n, nws = hin ? K * (uint32_t)nw : (uint32_t)nw, vw = hin ? (uint32_t)nw : 0u;
+    const uint32_t npad = hin ? K * cm : n;
+    if ((uint64_t)npad * (uint64_t)nw_all >= (uint64_t(1) << 32)) return 2;
+    const uint32_t total_s = nws * B;
     // piece length: twice the average bucket, within [32, SIZE_BINS-1]
     // (the split's buckets are twice as long - 64 points at 2^20 - and fewer: pieces of 1.5 mean buckets balance its last round better:
     // accumulate 2.64 -> 2.46 ms at 2^20; the plain path is flat between 1.5 and 3)
     const int seg_h = MsmTuning::get().seg_halves ? MsmTuning::get().seg_halves : (glv ? 3 : 4);
-    uint32_t SEG = (uint32_t)seg_h * ((fx && !fx_Ep ? n / (uint32_t)nw_all : n) / B + 1) / 2;      // (fixed base: a virtual window holds E / NV of the entries; compacted: its row)
+    uint32_t SEG = (uint32_t)seg_h * ((fx && !fx_Ep ? n / (uint32_t)nw_all : ns) / B + 1) / 2;      // (fixed base: a virtual window holds E / NV of the entries; compacted: its row)
     uint32_t seg_min = MsmTuning::get().seg_min;
     if (win_cnt && MsmTuning::get().seg_occupancy) {
       // a call that owns FEW windows (a window shard) has fewer additions than the chip has lanes x the usual piece length: a lane is
@@ -1540,8 +1660,8 @@ template <class G> class MsmEngine {
     }
     if (SEG < seg_min) SEG = seg_min;
     if (SEG > SIZE_BINS - 1) SEG = SIZE_BINS - 1;
-    const uint32_t PW = B + n / SEG + 1;       // static piece region per window
-    const uint32_t slots = (uint32_t)nw * PW;
+    const uint32_t PW = B + ns / SEG + 1;       // static piece region per window
+    const uint32_t slots = nws * PW;
     const int LB = c - 1;                                          // bucket-index bits (c >= 4)
     const uint32_t res_pts = (uint32_t)(LB + 1) * (uint32_t)nw;    // results: [0] = node(0,0), [l] = O_l, nw points each
     const uint32_t half_pts = (uint32_t)nw * (B / 2 + B / 4);      // most outputs of one launch (the first)
@@ -1551,31 +1671,34 @@ template <class G> class MsmEngine {
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
     const size_t o_bases = take(fx ? 0 : (size_t)n * IO::AFF_WORDS * 4);
     const size_t o_sc2 = take(glv ? (size_t)n * 16 : 0);
-    const size_t o_digits = take((size_t)n * nw_all * 2);
+    const size_t o_digits = take((size_t)npad * nw_all * 2);
     const size_t o_remap = take(fx_Ep ? (size_t)n * nw_all * 4 : 0);
-    const size_t o_sorted = take((size_t)n * nw * 4);
+    const size_t o_sorted = take((size_t)ns * nws * 4);
     // two-level sort: NBIN bins per window by the low HIB bucket bits, KB2 blocks per window in the partition pass
     const uint32_t HIB = LB < 8 ? 0u : (uint32_t)LB - 8u, NBIN = 1u << HIB;     // bins by the low HIB bucket bits, <= 8 key bits above
-    uint32_t KB2 = n / (64 * NBIN > 4096 ? 64 * NBIN : 4096);
+    uint32_t KB2 = ns / (64 * NBIN > 4096 ? 64 * NBIN : 4096);
     if (KB2 < 1) KB2 = 1;
     if (KB2 > 64) KB2 = 64;
-    const uint32_t chunk2 = (n + KB2 - 1) / KB2;
-    const size_t o_blockcnt = take((size_t)nw * NBIN * KB2 * 4);
-    const size_t o_binstart = take((size_t)nw * (NBIN + 1) * 4);
-    const size_t o_tileprefix = take((size_t)nw * (NBIN + 1) * 4);
-    const size_t o_recidx = take((size_t)n * nw * 4);
-    const size_t o_reckey = take((size_t)n * nw);
+    const uint32_t chunk2 = (ns + KB2 - 1) / KB2;
+    const size_t o_blockcnt = take((size_t)nws * NBIN * KB2 * 4);
+    const size_t o_binstart = take((size_t)nws * (NBIN + 1) * 4);
+    const size_t o_tileprefix = take((size_t)nws * (NBIN + 1) * 4);
+    const size_t o_recidx = take((size_t)ns * nws * 4);
+    const size_t o_reckey = take((size_t)ns * nws);
     // zeroed per call, adjacent so that ONE fill covers them: bucket counts, the tiles' run cursors (`starts`), the folded-bucket
     // flags, the piece lengths (unused slots stay 0) and the size bins with their counters
-    const size_t o_counts = take((size_t)total * 4);
-    const size_t o_starts = take((size_t)total * 4);
-    const size_t o_piecesof = take((size_t)total * 4);
+    const size_t o_counts = take((size_t)total_s * 4);
+    const size_t o_starts = take((size_t)total_s * 4);
+    const size_t o_piecesof = take((size_t)total_s * 4);
     const size_t o_plen = take((size_t)slots * 4);
-    const size_t o_bins = take((size_t)SIZE_BINS * 4 + 256);  // + nwork, nbig, nmid
+    constexpr size_t BINS_STRIDE = SIZE_BINS + 64;            // words: the size bins + nwork, nbig, nmid; one set per chunk (host-pointer pipeline)
+    const size_t o_bins = take(BINS_STRIDE * 4 * (hin ? K : 1u));
     const size_t o_zero_end = off;
-    const size_t o_pfirst = take((size_t)total * 4);
-    const size_t o_big = take((size_t)total * 4);
-    const size_t o_mid = take((size_t)total * 4);
+    const size_t o_pfirst = take((size_t)total_s * 4);
+    const size_t o_big = take((size_t)total_s * 4);
+    const size_t o_mid = take((size_t)total_s * 4);
+    const size_t o_pbucket = take(hin ? (size_t)slots * 4 : 0);
+    const size_t o_carrier = take(hin ? (size_t)total * IO::XYZZ_WORDS * 4 : 0);
     const size_t o_pstart = take((size_t)slots * 4);
     const size_t o_order = take((size_t)slots * 4);
     const size_t o_partials = take((size_t)slots * IO::XYZZ_WORDS * 4);
@@ -1608,12 +1731,28 @@ template <class G> class MsmEngine {
     uint32_t* d_partials = (uint32_t*)(A + o_partials);
     uint32_t* d_work = (uint32_t*)(A + o_work);
 
+    uint32_t* d_pbucket = hin ? (uint32_t*)(A + o_pbucket) : nullptr;
+    uint32_t* d_carrier = hin ? (uint32_t*)(A + o_carrier) : nullptr;
     HIP_OK(hipEventRecord(ev[0], stream));
+    if (hin) {
+      // the per-call fills run under the scalars' transfer; the scalars (and flags) go first: the digits need all of them
+      HIP_OK(hipMemsetAsync(d_carrier, 0, (size_t)total * IO::XYZZ_WORDS * 4, stream));
+      hipStream_t cs = side_stream_.get();
+      if (ev_copy.size() < (size_t)K + 1) {
+        const size_t have = ev_copy.size();
+        ev_copy.resize((size_t)K + 1, nullptr);
+        for (size_t i = have; i < ev_copy.size(); i++) HIP_OK(hipEventCreateWithFlags(&ev_copy[i], hipEventDisableTiming));
+      }
+      HIP_OK(hipMemcpyAsync((void*)d_scalars, hin->scalars, (size_t)n * SW * 4, hipMemcpyHostToDevice, cs));
+      if (hin->inf) HIP_OK(hipMemcpyAsync((void*)d_inf, hin->inf, (size_t)n, hipMemcpyHostToDevice, cs));
+      HIP_OK(hipEventRecord(ev_copy[0], cs));
+      HIP_OK(hipStreamWaitEvent(stream, ev_copy[0], 0));
+    }
     // window shards (A/B hook CELO_SIDE_CONVERT): the conversion of ALL n bases is replicated on every shard while its sort shrinks to a
     // handful of latency-bound launches - the two are independent until the accumulation, so the conversion may run on a second stream
     const bool side = win_cnt && !glv && MsmTuning::get().side_convert && side_stream_.get() && ev_side[0];
-    if (fx) {
-      // nothing to convert: the table is in device form
+    if (fx || hin) {
+      // nothing to convert: the table is in device form / the bases are converted chunk by chunk as they land
     } else if (side) {
       HIP_OK(hipEventRecord(ev_side[0], stream));
       HIP_OK(hipStreamWaitEvent(side_stream_.get(), ev_side[0], 0));
@@ -1621,7 +1760,7 @@ template <class G> class MsmEngine {
       HIP_OK(hipEventRecord(ev_side[1], side_stream_.get()));
     } else if (glv) GlvExpand<G>::launch(d_ark_bases, d_inf, d_scalars, (uint32_t)n_, d_bases, (uint32_t*)(A + o_sc2), stream);
     else hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_ark_bases, d_bases, (size_t)n);
-    HIP_OK(hipEventRecord(ev[1], stream));
+    if (!hin) HIP_OK(hipEventRecord(ev[1], stream));
     // ---- sort
     uint32_t* d_remap = fx_Ep ? (uint32_t*)(A + o_remap) : nullptr;
     if (fx && fx_Ep) {
@@ -1633,19 +1772,44 @@ template <class G> class MsmEngine {
     } else if (fx) hipLaunchKernelGGL((k_fixed_digits<SW, G::SCALAR_BITS>), dim3((fx->n + 255) / 256), dim3(256), 0, stream, d_scalars, fx->tinf, d_digits_all, fx->n, (uint32_t)n_,
                                fx->cf, fx->W, fx->NV, fx->M);
     else if (glv) { if (launch_digits<4, GlvExpand<G>::BITS>(c, (const uint32_t*)(A + o_sc2), nullptr, d_digits_all, n, stream)) return 3; }
-    else if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream)) return 3;
+    else if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream, hin ? cm : 0u, npad)) return 3;
+    if (hin) HIP_OK(hipEventRecord(ev[1], stream));      // (host-pointer pipeline: "convert" = the scalars' transfer and the digits)
     HIP_OK(hipMemsetAsync(d_counts, 0, o_zero_end - o_counts, stream));
-    // mean region n / NBIN: the smallest workgroup whose tile capacity (TILE_EPT entries per lane) holds it with 20 % to spare
-    const uint32_t region = n / NBIN;
+    // mean region ns / NBIN: the smallest workgroup whose tile capacity (TILE_EPT entries per lane) holds it with 20 % to spare
+    const uint32_t region = ns / NBIN;
     const uint32_t ts_threads = region <= 2048 ? 256u : region <= 4096 ? 512u : 1024u;
-    const uint32_t TILE = TILE_EPT * ts_threads, max_tiles = NBIN + n / TILE + 1;
-    hipLaunchKernelGGL((k_part_hist<G>), dim3(KB2, nw), dim3(1024), 0, stream, d_digits, d_blockcnt, n, chunk2, NBIN);
-    hipLaunchKernelGGL((k_part_scan<G>), dim3(nw), dim3(1024), 0, stream, d_blockcnt, d_binstart, d_tileprefix, NBIN, KB2, TILE);
-    hipLaunchKernelGGL((k_part_scatter<G>), dim3(KB2, nw), dim3(1024), 0, stream, d_digits, d_blockcnt, d_recidx, d_reckey, n, chunk2, HIB, NBIN, (const uint32_t*)d_remap);
-    hipLaunchKernelGGL((k_tile_count<G>), dim3(max_tiles, nw), dim3(ts_threads), 0, stream, d_reckey, d_binstart, d_tileprefix, d_counts, n, B, HIB, NBIN);
-    hipLaunchKernelGGL((k_tile_sort<G>), dim3(max_tiles, nw), dim3(ts_threads), 0, stream, d_recidx, d_reckey, d_binstart, d_tileprefix, d_counts,
-                       d_starts, d_sorted, d_pfirst, d_pstart, d_plen, d_big, d_nbig, d_mid, d_nmid, n, B, HIB, NBIN, SEG, PW);
+    const uint32_t TILE = TILE_EPT * ts_threads, max_tiles = NBIN + ns / TILE + 1;
+    hipLaunchKernelGGL((k_part_hist<G>), dim3(KB2, nws), dim3(1024), 0, stream, d_digits, d_blockcnt, ns, chunk2, NBIN);
+    hipLaunchKernelGGL((k_part_scan<G>), dim3(nws), dim3(1024), 0, stream, d_blockcnt, d_binstart, d_tileprefix, NBIN, KB2, TILE);
+    hipLaunchKernelGGL((k_part_scatter<G>), dim3(KB2, nws), dim3(1024), 0, stream, d_digits, d_blockcnt, d_recidx, d_reckey, ns, chunk2, HIB, NBIN, (const uint32_t*)d_remap, vw);
+    hipLaunchKernelGGL((k_tile_count<G>), dim3(max_tiles, nws), dim3(ts_threads), 0, stream, d_reckey, d_binstart, d_tileprefix, d_counts, ns, B, HIB, NBIN);
+    hipLaunchKernelGGL((k_tile_sort<G>), dim3(max_tiles, nws), dim3(ts_threads), 0, stream, d_recidx, d_reckey, d_binstart, d_tileprefix, d_counts,
+                       d_starts, d_sorted, d_pfirst, d_pstart, d_plen, d_big, d_nbig, d_mid, d_nmid, ns, B, HIB, NBIN, SEG, PW, d_pbucket, vw);
     // ---- work items, longest first
+    if (hin) {
+      // one schedule per chunk over its own slots (a chunk's virtual windows are adjacent); the fold lists' counters are chunk 0's
+      const uint32_t cslots = (uint32_t)nw * PW;
+      for (uint32_t k = 0; k < K; k++) {
+        uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;
+        hipLaunchKernelGGL((k_size_hist<G>), dim3(cslots / 256 < 512 ? (cslots + 255) / 256 : 512), dim3(256), 0, stream, d_plen + (size_t)k * cslots, bins_k, cslots);
+        hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, bins_k, bins_k + SIZE_BINS);
+        hipLaunchKernelGGL((k_size_scatter<G>), dim3((cslots + 4095) / 4096), dim3(1024), 0, stream, d_plen + (size_t)k * cslots, bins_k, d_order + (size_t)k * cslots, cslots);
+      }
+      HIP_OK(hipEventRecord(ev[2], stream));
+      // ---- the bases, chunk by chunk: transfer on the side stream, conversion and accumulation behind it on the call's stream
+      hipStream_t cs = side_stream_.get();
+      constexpr size_t PT_BYTES = 2 * (size_t)IO::ARK64 * 8;
+      for (uint32_t k = 0; k < K; k++) {
+        const size_t lo = (size_t)k * cm, cnt = (lo + cm <= n ? (size_t)cm : (size_t)n - lo);
+        HIP_OK(hipMemcpyAsync((char*)d_ark_bases + lo * PT_BYTES, (const char*)hin->bases + lo * PT_BYTES, cnt * PT_BYTES, hipMemcpyHostToDevice, cs));
+        HIP_OK(hipEventRecord(ev_copy[1 + k], cs));
+        HIP_OK(hipStreamWaitEvent(stream, ev_copy[1 + k], 0));
+        hipLaunchKernelGGL((k_convert_bases<G>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, d_ark_bases + lo * 2 * IO::ARK64, d_bases + lo * IO::AFF_WORDS, cnt);
+        const uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;
+        hipLaunchKernelGGL((k_accumulate_chunk<G>), dim3((cslots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart + (size_t)k * cslots, d_plen + (size_t)k * cslots,
+                           d_order + (size_t)k * cslots, bins_k + SIZE_BINS, d_partials + (size_t)k * cslots * IO::XYZZ_WORDS, d_pbucket + (size_t)k * cslots, d_carrier, k ? 1u : 0u);
+      }
+    } else {
     hipLaunchKernelGGL((k_size_hist<G>), dim3(slots / 256 < 512 ? (slots + 255) / 256 : 512), dim3(256), 0, stream, d_plen, d_bins, slots);
     hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
     hipLaunchKernelGGL((k_size_scatter<G>), dim3((slots + 4095) / 4096), dim3(1024), 0, stream, d_plen, d_bins, d_order, slots);
@@ -1654,13 +1818,22 @@ template <class G> class MsmEngine {
     // ---- accumulate (grid covers every slot; lanes beyond the number of non-empty pieces exit)
     hipLaunchKernelGGL((k_accumulate<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order,
                        d_nwork, d_partials);
+    }
     HIP_OK(hipEventRecord(ev[3], stream));
     // ---- bucket reduction
     // (a window shard cuts EVERY bucket in two or three: one group of lanes per bucket of the call, not 21504 groups striding over them)
     const uint32_t mid_blocks = win_cnt ? (total + 20) / 21 < 16384 ? (total + 20) / 21 : 16384 : 1024;
-    if (lane_bitsum) hipLaunchKernelGGL((k_combine_mid_lanes<G>), dim3(mid_blocks), dim3(64), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
-    else hipLaunchKernelGGL((k_combine_mid<G>), dim3(256), dim3(128), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
-    hipLaunchKernelGGL((k_combine_big<G>), dim3(256), dim3(256), 0, stream, d_big, d_nbig, d_counts, d_pfirst, d_partials, d_piecesof, SEG);
+    const uint32_t cfirst = hin ? 1u : 0u;      // host-pointer pipeline: a bucket's first piece is its carrier and stays out of the folds
+    if (lane_bitsum) hipLaunchKernelGGL((k_combine_mid_lanes<G>), dim3(mid_blocks), dim3(64), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG, cfirst);
+    else hipLaunchKernelGGL((k_combine_mid<G>), dim3(256), dim3(128), 0, stream, d_mid, d_nmid, d_counts, d_pfirst, d_partials, d_piecesof, SEG, cfirst);
+    hipLaunchKernelGGL((k_combine_big<G>), dim3(256), dim3(256), 0, stream, d_big, d_nbig, d_counts, d_pfirst, d_partials, d_piecesof, SEG, cfirst);
+    // the leaves of the reduction: the buckets' pieces, or (host-pointer pipeline) the carrier table, one slot per bucket
+    const uint32_t* d_leaf = d_partials;
+    const uint32_t* d_leaf_counts = d_counts;
+    if (hin) {
+      hipLaunchKernelGGL((k_merge_carried<G>), dim3((total + 127) / 128), dim3(128), 0, stream, d_counts, d_pfirst, d_partials, d_carrier, total, K, SEG);
+      d_leaf = d_carrier; d_leaf_counts = nullptr;
+    }
     {
       // work area (in points): [0, res_pts) results, then two launch-alternating halves of half_pts
       struct Arr { uint32_t at, per_window; bool born; int level; };  // `born`: odd list not yet halved (read strided from its level)
@@ -1702,9 +1875,9 @@ template <class G> class MsmEngine {
         }
         lists.swap(next_lists);
         if (lane_bitsum && total_out <= (win_cnt ? MsmTuning::get().bitsum_lanes_max_shard : BITSUM_LANES_MAX))
-          hipLaunchKernelGGL((k_bitsum_lanes<G>), dim3((total_out + 20) / 21), dim3(64), 0, stream, d_partials, d_counts, d_pfirst, d_piecesof, SEG, d_work, jobs);
+          hipLaunchKernelGGL((k_bitsum_lanes<G>), dim3((total_out + 20) / 21), dim3(64), 0, stream, d_leaf, d_leaf_counts, d_pfirst, d_piecesof, SEG, d_work, jobs);
         else
-          hipLaunchKernelGGL((k_bitsum<G>), dim3((total_out + 127) / 128), dim3(128), 0, stream, d_partials, d_counts, d_pfirst, d_piecesof, SEG,
+          hipLaunchKernelGGL((k_bitsum<G>), dim3((total_out + 127) / 128), dim3(128), 0, stream, d_leaf, d_leaf_counts, d_pfirst, d_piecesof, SEG,
                              d_work, jobs);
       }
       hipLaunchKernelGGL((k_results_to_ark<G>), dim3((4 * res_pts + 63) / 64), dim3(64), 0, stream, d_work, res_pts);
@@ -1850,6 +2023,17 @@ template <class G> class MsmEngine {
       HIP_OK(hipMalloc(&d_in_scalars, n * SW * 4));
       HIP_OK(hipMalloc(&d_in_inf, n));
       cap_in = n;
+    }
+    // the pipelined form (run_device_windows' HostIn) from 2^17 terms up, in chunks of at least 2^16 points; the prover's entry points
+    // (ark_zero_identity: the flags come from the bases), the GLV split (its expansion reads bases and scalars together) and window
+    // shards keep the plain form below: three transfers, then the resident pipeline
+    const int ovr = host_chunks_override().load();
+    uint32_t chunks = ovr >= 0 ? (uint32_t)ovr : MsmTuning::get().host_chunks;
+    if (chunks > 64) chunks = 64;
+    if (chunks > (n >> 16)) chunks = (uint32_t)(n >> 16);
+    if (chunks >= 2 && !ark_zero_identity && !win_cnt && !plan(n).glv && n < (size_t(1) << 30)) {
+      const HostIn hin = {bases, inf, scalars, chunks};
+      return run_device_windows(d_in_bases, inf ? d_in_inf : nullptr, (const uint32_t*)d_in_scalars, n, 0, 0, out_jac, out_xyzz, stream, nullptr, &hin);
     }
     HIP_OK(hipMemcpyAsync(d_in_bases, bases, n * 2 * IO::ARK64 * 8, hipMemcpyHostToDevice, stream));
     HIP_OK(hipMemcpyAsync(d_in_scalars, scalars, n * SW * 4, hipMemcpyHostToDevice, stream));
@@ -2168,6 +2352,7 @@ template <class G> class MsmEngine {
   OwnedStream stream_;
   OwnedStream side_stream_;            // window shards: the base conversion beside the sort (CELO_SIDE_CONVERT)
   hipEvent_t ev_side[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ev_copy;     // host-pointer pipeline: one per transfer (the scalars, then each chunk of bases)
   std::vector<int32_t> horner_steps;   // the host epilogue's step list (host64.h), rebuilt per call
   std::vector<uint32_t> gls_off;       // instance offsets of the expanded (GLS) batch
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -2212,30 +2397,32 @@ template <class G> class MsmEngine {
       default: return 1;
     }
   }
-  template <int SWX, int BITS, int CB> int launch_digits_c(const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {
+  template <int SWX, int BITS, int CB> int launch_digits_c(const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st, uint32_t m, uint32_t npad) {
     constexpr int NW = (BITS + CB) / CB;
     constexpr int KN = NW * CB - (BITS + 1);     // 0 <= KN < CB <= NW for every window size in use
     if constexpr (KN > 0 && KN < NW) {
-      if (narrow_top(CB)) { hipLaunchKernelGGL((k_digits<SWX, CB, NW, KN, BITS>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n); return 0; }
+      if (narrow_top(CB)) { hipLaunchKernelGGL((k_digits<SWX, CB, NW, KN, BITS>), dim3((npad + 255) / 256), dim3(256), 0, st, sc, inf, digits, n, m, npad); return 0; }
     }
-    hipLaunchKernelGGL((k_digits<SWX, CB, NW, 0, BITS>), dim3((n + 255) / 256), dim3(256), 0, st, sc, inf, digits, n);
+    hipLaunchKernelGGL((k_digits<SWX, CB, NW, 0, BITS>), dim3((npad + 255) / 256), dim3(256), 0, st, sc, inf, digits, n, m, npad);
     return 0;
   }
-  template <int SWX, int BITS> int launch_digits(int c, const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st) {
+  // m, npad: the chunked layout (k_digits); 0 = plain
+  template <int SWX, int BITS> int launch_digits(int c, const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st, uint32_t m = 0, uint32_t npad = 0) {
+    if (!m) { m = n; npad = n; }
     switch (c) {
-      case 4: return launch_digits_c<SWX, BITS, 4>(sc, inf, digits, n, st);
-      case 5: return launch_digits_c<SWX, BITS, 5>(sc, inf, digits, n, st);
-      case 6: return launch_digits_c<SWX, BITS, 6>(sc, inf, digits, n, st);
-      case 7: return launch_digits_c<SWX, BITS, 7>(sc, inf, digits, n, st);
-      case 8: return launch_digits_c<SWX, BITS, 8>(sc, inf, digits, n, st);
-      case 9: return launch_digits_c<SWX, BITS, 9>(sc, inf, digits, n, st);
-      case 10: return launch_digits_c<SWX, BITS, 10>(sc, inf, digits, n, st);
-      case 11: return launch_digits_c<SWX, BITS, 11>(sc, inf, digits, n, st);
-      case 12: return launch_digits_c<SWX, BITS, 12>(sc, inf, digits, n, st);
-      case 13: return launch_digits_c<SWX, BITS, 13>(sc, inf, digits, n, st);
-      case 14: return launch_digits_c<SWX, BITS, 14>(sc, inf, digits, n, st);
-      case 15: return launch_digits_c<SWX, BITS, 15>(sc, inf, digits, n, st);
-      case 16: return launch_digits_c<SWX, BITS, 16>(sc, inf, digits, n, st);
+      case 4: return launch_digits_c<SWX, BITS, 4>(sc, inf, digits, n, st, m, npad);
+      case 5: return launch_digits_c<SWX, BITS, 5>(sc, inf, digits, n, st, m, npad);
+      case 6: return launch_digits_c<SWX, BITS, 6>(sc, inf, digits, n, st, m, npad);
+      case 7: return launch_digits_c<SWX, BITS, 7>(sc, inf, digits, n, st, m, npad);
+      case 8: return launch_digits_c<SWX, BITS, 8>(sc, inf, digits, n, st, m, npad);
+      case 9: return launch_digits_c<SWX, BITS, 9>(sc, inf, digits, n, st, m, npad);
+      case 10: return launch_digits_c<SWX, BITS, 10>(sc, inf, digits, n, st, m, npad);
+      case 11: return launch_digits_c<SWX, BITS, 11>(sc, inf, digits, n, st, m, npad);
+      case 12: return launch_digits_c<SWX, BITS, 12>(sc, inf, digits, n, st, m, npad);
+      case 13: return launch_digits_c<SWX, BITS, 13>(sc, inf, digits, n, st, m, npad);
+      case 14: return launch_digits_c<SWX, BITS, 14>(sc, inf, digits, n, st, m, npad);
+      case 15: return launch_digits_c<SWX, BITS, 15>(sc, inf, digits, n, st, m, npad);
+      case 16: return launch_digits_c<SWX, BITS, 16>(sc, inf, digits, n, st, m, npad);
       default: return 1;
     }
   }

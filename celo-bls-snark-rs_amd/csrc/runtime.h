@@ -12,6 +12,7 @@
 // celo_amd_use_device() binds a host thread to a device, the msm_*_multi entry points do that internally (one thread per device).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -71,6 +72,10 @@ template <class E> class EnginePool {
     cv.notify_one();
   }
 };
+
+// celo_amd_msm_set_host_chunks (tests, bench.py's sweep): >= 0 overrides CELO_HOST_CHUNKS for the host-pointer MSM calls that follow
+// (msm.h run_host_windows); -1 = the default
+inline std::atomic<int>& host_chunks_override() { static std::atomic<int> v{-1}; return v; }
 
 // an engine-owned stream: non-blocking, so that engines of different calls do not serialise through the null stream
 struct OwnedStream {

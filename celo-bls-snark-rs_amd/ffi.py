@@ -35,7 +35,7 @@ EXPORTS = [
     "pairing_product_is_one_bls12_377", "pairing_product_is_one_batch_bls12_377", "celo_amd_pairing_gt_bls12_377",
     "celo_amd_pairing_last_timings", "pairing_product_is_one_bw6_761", "celo_amd_pairing_gt_bw6_761",
     "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
-    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits",
+    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
     "celo_amd_gen_points_grouped_bls12_377_g1_dev", "celo_amd_gen_points_grouped_bls12_377_g2_dev",
     "batch_verify_bls12_377", "batch_verify_bls12_377_dev", "celo_amd_draw_batch_exponents",
@@ -267,6 +267,13 @@ def msm_timings(group):
     assert rc == 0
     return {"convert_ms": ms[0], "sort_ms": ms[1], "accumulate_ms": ms[2], "reduce_ms": ms[3], "total_ms": ms[4],
             "window_bits": cfg[0], "windows": cfg[1], "buckets": cfg[2]}
+
+
+def set_host_chunks(chunks):
+    """Host-pointer msm(): index chunks of the pipelined transfer (0 / 1 = unpipelined, -1 = default).  Process-wide."""
+    rc = lib().celo_amd_msm_set_host_chunks(C.c_int(chunks))
+    if rc != 0:
+        raise ValueError(f"host chunks {chunks} not supported")
 
 
 def set_window_bits(group, c):

@@ -1,0 +1,161 @@
+"""GPU (-m gpu): the HOST-POINTER MSM entry points - the call a drop-in caller makes (crates/bls-crypto/src/bls/signature.rs:82-85,
+public.rs:58-61 hand host slices to VariableBaseMSM::multi_scalar_mul; INTEGRATION.md's Rust wrapper) - in their pipelined form
+(csrc/msm.h run_device_windows' HostIn, round 5): scalars first, the sort over (chunk, window) virtual windows, the bases in index
+chunks that are accumulated while the next one crosses PCIe, every bucket's sum carried from chunk to chunk (k_accumulate_chunk).
+
+Parity = equality of the affine-normalised group element against the oracle, for every chunk count incl. the unpipelined form, at
+ragged sizes (a short last chunk), with infinity flags, with bucket runs longer than a piece (skew: further pieces + k_merge_carried)
+and with carried sums that pass through the doubling and the cancellation branches at a chunk boundary."""
+import numpy as np
+import pytest
+import torch
+from oracle.py import ecc
+from oracle import cpu_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+THREADS = None
+
+
+def _threads():
+    global THREADS
+    if THREADS is None:
+        THREADS = max(1, min(32, co.lib().orc_hardware_threads()))
+    return THREADS
+
+
+def _gen(gpu, group, n, seed, gen_limbs, words):
+    t = torch.empty(n * words, dtype=torch.int64, device="cuda")
+    gpu.gen_points_dev(group, t.data_ptr(), n, seed, gen_limbs)
+    torch.cuda.synchronize()
+    return t.cpu().numpy().view(np.uint64).reshape(n, words)
+
+
+def _uniform(n, limbs, top_bits, seed):
+    rng = np.random.default_rng(seed)
+    sc = rng.integers(0, 1 << 63, size=(n, limbs), dtype=np.int64).astype(np.uint64)
+    sc ^= rng.integers(0, 1 << 63, size=(n, limbs), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    sc[:, limbs - 1] &= np.uint64((1 << top_bits) - 1)
+    return sc
+
+
+@pytest.fixture
+def chunks(gpu):
+    """Sets the chunk count for a test and restores the default afterwards."""
+    yield gpu.set_host_chunks
+    gpu.set_host_chunks(-1)
+
+
+def test_g1_ragged_sizes_every_chunk_count(gpu, chunks):
+    """2^17 + 4321 and 2^18 + 1 terms (short last chunk, chunk length rounded to 1024), infinity flags, a repeated (point, scalar) pair
+    and a cancelling pair that straddle a chunk boundary; chunk counts 0 (unpipelined), 2, 3, 4, 7 must all give the oracle's point."""
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    for n, seed in (((1 << 17) + 4321, 501), ((1 << 18) + 1, 502)):
+        xy = _gen(gpu, "bls12_377_g1", n, seed, gen.reshape(-1), 12)
+        sc = _uniform(n, 4, 60, seed + 10)
+        inf = np.zeros(n, dtype=np.uint8)
+        inf[[0, 5, n // 2, n - 1]] = 1
+        # equal pairs and opposite pairs with equal scalars, one member in the first chunk and one in the last
+        xy[n - 7] = xy[3]; sc[n - 7] = sc[3]
+        neg = co.pack_g1_377([ecc.E1_377.neg(tuple(co.from_mont(xy[9].reshape(2, 6), ecc.Q377)))])[0][0]
+        xy[n - 9] = neg; sc[n - 9] = sc[9]
+        exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, inf, sc, threads=_threads()), "g1_377")
+        for k in (0, 2, 3, 4, 7):
+            chunks(k)
+            got = co.jac_to_affine(gpu.msm("bls12_377_g1", xy, inf, sc), "g1_377")
+            assert got == exp, (n, k)
+        chunks(-1)
+        assert co.jac_to_affine(gpu.msm("bls12_377_g1", xy, None, sc), "g1_377") == \
+            co.jac_to_affine(co.msm("bls12_377_g1", xy, None, sc, threads=_threads()), "g1_377")
+
+
+def test_g1_skew_runs_longer_than_a_piece(gpu, chunks):
+    """Every scalar equal: one bucket per window holds a whole chunk (carrier + thousands of further pieces: k_combine_big with the
+    first piece left out, k_merge_carried); and witness-like scalars (40 % zero, 30 % one: SURVEY.md section 3.4)."""
+    n = 1 << 18
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    xy = _gen(gpu, "bls12_377_g1", n, 0xABCE, gen.reshape(-1), 12)
+    k = 0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789AB % ecc.R377
+    sc = np.tile(co.ints_to_limbs([k], 4), (n, 1))
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, None, sc, threads=_threads()), "g1_377")
+    for kk in (2, 4):
+        chunks(kk)
+        assert co.jac_to_affine(gpu.msm("bls12_377_g1", xy, None, sc), "g1_377") == exp, kk
+    rng = np.random.default_rng(18)
+    sc = _uniform(n, 4, 60, 19)
+    kind = rng.integers(0, 10, size=n)
+    sc[kind < 4] = 0
+    sc[(kind >= 4) & (kind < 7)] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, None, sc, threads=_threads()), "g1_377")
+    for kk in (0, 4):
+        chunks(kk)
+        assert co.jac_to_affine(gpu.msm("bls12_377_g1", xy, None, sc), "g1_377") == exp, kk
+
+
+def test_g1_carried_sum_through_doubling_and_cancellation(gpu, chunks):
+    """All scalars equal and the bases chosen so that a bucket's carried sum meets its own value and its negative in the next chunk:
+    chunk 0 holds copies of P only, chunk 1 copies of -P only (the carrier walks down to the identity and every further piece
+    cancels), then the same with 2P-sums meeting P (doubling branch of the mixed addition on a carried accumulator)."""
+    n = 1 << 17
+    rng = ecc.SplitMix64(77)
+    P = ecc.E1_377.mul(ecc.G1_377, rng.next())
+    Q = ecc.E1_377.mul(ecc.G1_377, rng.next())
+    pxy = co.pack_g1_377([P, ecc.E1_377.neg(P), Q, ecc.E1_377.add(P, P)])[0]
+    k = 0x0F1E2D3C4B5A69788796A5B4C3D2E1F00F1E2D3C4B5A69788796A5B4C3D2E1 % ecc.R377
+    sc = np.tile(co.ints_to_limbs([k], 4), (n, 1))
+    half = n // 2
+    layouts = []
+    a = np.empty((n, 12), dtype=np.uint64); a[:half] = pxy[0]; a[half:] = pxy[1]; layouts.append(a)                 # sum = identity
+    b = a.copy(); b[n - 1] = pxy[2]; layouts.append(b)                                                             # = -P + Q ... via identity
+    c = np.empty((n, 12), dtype=np.uint64); c[:half] = pxy[0]; c[half:] = pxy[0]; c[half + 1] = pxy[3]; layouts.append(c)
+    d = np.empty((n, 12), dtype=np.uint64); d[:] = pxy[2]; d[0] = pxy[0]; d[1] = pxy[0]; d[half] = pxy[3]; d[half + 1] = pxy[1]; layouts.append(d)
+    for i, xy in enumerate(layouts):
+        exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, None, sc, threads=_threads()), "g1_377")
+        for kk in (0, 2):
+            chunks(kk)
+            assert co.jac_to_affine(gpu.msm("bls12_377_g1", xy, None, sc), "g1_377") == exp, (i, kk)
+    # one scalar per point, two points: the pieces are single points and the carrier is the only piece of its bucket
+    chunks(2)
+    sc2 = _uniform(n, 4, 60, 5)
+    sc2[half] = sc2[0]; sc2[half + 1] = sc2[1]
+    e = np.empty((n, 12), dtype=np.uint64); e[:] = pxy[2]; e[0] = pxy[0]; e[half] = pxy[0]; e[1] = pxy[0]; e[half + 1] = pxy[1]
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", e, None, sc2, threads=_threads()), "g1_377")
+    assert co.jac_to_affine(gpu.msm("bls12_377_g1", e, None, sc2), "g1_377") == exp
+
+
+def test_g1_two_to_20_pipelined_equals_resident(gpu, chunks):
+    """BASELINE config 2 size through the host-pointer entry, default chunk count and 8: same point as the oracle and as the resident
+    entry on the same buffers."""
+    n = 1 << 20
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    xy = _gen(gpu, "bls12_377_g1", n, 0x5EED0002, gen.reshape(-1), 12)
+    sc = _uniform(n, 4, 60, 0x5EED0001)
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, None, sc, threads=_threads()), "g1_377")
+    for kk in (-1, 8):
+        chunks(kk)
+        assert co.jac_to_affine(gpu.msm("bls12_377_g1", xy, None, sc), "g1_377") == exp, kk
+    d_xy = torch.from_numpy(xy.view(np.int64)).cuda()
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    assert co.jac_to_affine(gpu.msm_dev("bls12_377_g1", d_xy.data_ptr(), 0, d_sc.data_ptr(), n), "g1_377") == exp
+
+
+def test_g2_and_bw6_pipelined(gpu, chunks, golden):
+    """The one-wave-per-SIMD instantiations of k_accumulate_chunk (G2 of BLS12-377, BW6-761) at 2^17 + 77 terms, chunk counts 0 / 2."""
+    from oracle.py import epoch as ep
+    n = (1 << 17) + 77
+    g2, _ = co.pack_g2_377([ecc.G2_377])
+    xy = _gen(gpu, "bls12_377_g2", n, 0x62, g2.reshape(-1), 24)
+    sc = _uniform(n, 4, 60, 63)
+    inf = np.zeros(n, dtype=np.uint8); inf[[1, n - 2]] = 1
+    exp = co.jac_to_affine(co.msm("bls12_377_g2", xy, inf, sc, threads=_threads()), "g2_377")
+    for kk in (0, 2):
+        chunks(kk)
+        assert co.jac_to_affine(gpu.msm("bls12_377_g2", xy, inf, sc), "g2_377") == exp, kk
+    vk = ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))
+    g, _ = co.pack_761([vk["alpha_g1"]])
+    xy = _gen(gpu, "bw6_761_g1", n, 0x761, g.reshape(-1), 24)
+    sc = _uniform(n, 6, 56, 64)
+    exp = co.jac_to_affine(co.msm("bw6_761_g1", xy, None, sc, threads=_threads()), "761")
+    for kk in (0, 2):
+        chunks(kk)
+        assert co.jac_to_affine(gpu.msm("bw6_761_g1", xy, None, sc), "761") == exp, kk

@@ -128,8 +128,8 @@ __global__ void __launch_bounds__(256) k_flag_ark_zero(const uint64_t* __restric
 // The lanes from n up to npad (the last chunk's tail) write "no digit".  m = npad = n is the plain layout.
 template <int SW, int CB, int NW, int KN, int BITS>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf,
-                                                uint16_t* __restrict__ digits, uint32_t n, uint32_t m, uint32_t npad) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                uint16_t* __restrict__ digits, uint32_t n, uint32_t m, uint32_t npad, uint32_t ibase = 0) {
+  uint32_t i = ibase + blockIdx.x * blockDim.x + threadIdx.x;     // (ibase .. npad: the range of one launch - the host-pointer pipeline takes chunk 0 first)
   if (i >= npad) return;
   if (m != n) {
     const uint32_t ch = i / m;
@@ -192,9 +192,10 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 // index - nothing downstream assumes an order (pieces carry their own start).
 template <class G>
 __global__ void __launch_bounds__(1024) k_part_hist(const uint16_t* __restrict__ digits, uint32_t* __restrict__ blockcnt, uint32_t n,
-                                                    uint32_t chunk, uint32_t NBIN) {
+                                                    uint32_t chunk, uint32_t NBIN, uint32_t wbase = 0) {
+  // (wbase, here and in the four kernels below: the first window of the launch - the host-pointer pipeline sorts chunk 0's windows first)
   __shared__ uint32_t h[128];
-  const uint32_t j = blockIdx.x, w = blockIdx.y, KB = gridDim.x;
+  const uint32_t j = blockIdx.x, w = blockIdx.y + wbase, KB = gridDim.x;
   if (threadIdx.x < 128) h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lo = j * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
@@ -214,9 +215,9 @@ __global__ void __launch_bounds__(1024) k_part_hist(const uint16_t* __restrict__
 // window-relative), the NBIN + 1 region boundaries and the prefix of the regions' tile counts; one workgroup per window
 template <class G>
 __global__ void __launch_bounds__(1024) k_part_scan(uint32_t* __restrict__ blockcnt, uint32_t* __restrict__ binstart,
-                                                    uint32_t* __restrict__ tileprefix, uint32_t NBIN, uint32_t KB, uint32_t TILE) {
+                                                    uint32_t* __restrict__ tileprefix, uint32_t NBIN, uint32_t KB, uint32_t TILE, uint32_t wbase = 0) {
   __shared__ uint32_t wave_tot[16], bs[129], tw[2];
-  const uint32_t E = NBIN * KB, w = blockIdx.x;
+  const uint32_t E = NBIN * KB, w = blockIdx.x + wbase;
   uint32_t* c = blockcnt + (size_t)w * E;
   const uint32_t PER = (E + 1023) / 1024;   // <= 8
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -275,13 +276,13 @@ template <class G>
 __global__ void __launch_bounds__(1024) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ blockoff,
                                                        uint32_t* __restrict__ rec_idx, uint8_t* __restrict__ rec_key, uint32_t n,
                                                        uint32_t chunk, uint32_t HIB, uint32_t NBIN, const uint32_t* __restrict__ remap = nullptr,
-                                                       uint32_t vw = 0) {
+                                                       uint32_t vw = 0, uint32_t wbase = 0) {
   // vw > 0: the windows are virtual (chunked layout, k_digits): window w holds index chunk w / vw, whose entries are the points from (w / vw) n on
   constexpr uint32_t SB = 8 * 1024;   // entries per batch
   __shared__ uint32_t cur[128], lcnt[128], loff[128], wt[2];
   __shared__ uint32_t st_idx[SB];
   __shared__ uint8_t st_key[SB], st_bin[SB];
-  const uint32_t j = blockIdx.x, w = blockIdx.y, KB = gridDim.x, t = threadIdx.x;
+  const uint32_t j = blockIdx.x, w = blockIdx.y + wbase, KB = gridDim.x, t = threadIdx.x;
   if (t < 128) cur[t] = t < NBIN ? blockoff[((size_t)w * NBIN + t) * KB + j] : 0u;
   const uint32_t lo = j * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
   const uint16_t* dg = digits + (size_t)w * n;
@@ -358,9 +359,9 @@ __device__ __forceinline__ void tile_range(uint32_t rs, uint32_t re, uint32_t z,
 template <class G>
 __global__ void __launch_bounds__(1024) k_tile_count(const uint8_t* __restrict__ rec_key, const uint32_t* __restrict__ binstart,
                                                      const uint32_t* __restrict__ tileprefix, uint32_t* __restrict__ counts, uint32_t n,
-                                                     uint32_t B, uint32_t HIB, uint32_t NBIN) {
+                                                     uint32_t B, uint32_t HIB, uint32_t NBIN, uint32_t wbase = 0) {
   __shared__ uint32_t cnt[256];
-  const uint32_t w = blockIdx.y, t = threadIdx.x, bd = blockDim.x;
+  const uint32_t w = blockIdx.y + wbase, t = threadIdx.x, bd = blockDim.x;
   uint32_t bin, z, tiles, tile_lo, tile_n;
   if (!tile_locate(tileprefix + w * (NBIN + 1), NBIN, blockIdx.x, bin, z, tiles)) return;
   if (tiles == 1) return;      // a one-tile region (the usual case) is counted by its k_tile_sort workgroup itself
@@ -386,13 +387,13 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint32_t* __restrict__
                                                     uint32_t* __restrict__ pstart, uint32_t* __restrict__ plen, uint32_t* __restrict__ big,
                                                     uint32_t* __restrict__ nbig, uint32_t* __restrict__ mid, uint32_t* __restrict__ nmid,
                                                     uint32_t n, uint32_t B, uint32_t HIB, uint32_t NBIN, uint32_t SEG, uint32_t PW,
-                                                    uint32_t* __restrict__ pbucket = nullptr, uint32_t vw = 0) {
+                                                    uint32_t* __restrict__ pbucket = nullptr, uint32_t vw = 0, uint32_t wbase = 0) {
   // pbucket (chunked layout): the FIRST piece of a bucket of virtual window w carries the sum of bucket (w mod vw, b) across the chunks
   // (k_accumulate_chunk): pbucket[piece] = (w mod vw) B + b for it, ~0 for the others
   __shared__ uint32_t cnt[256], cur[256], loff[256], wt[4], wt2[4], wt3[4], lists[4];
   __shared__ uint32_t st_idx[TILE_EPT * 1024];
   __shared__ uint8_t st_key[TILE_EPT * 1024];
-  const uint32_t w = blockIdx.y, t = threadIdx.x, bd = blockDim.x, NLO = B >> HIB;
+  const uint32_t w = blockIdx.y + wbase, t = threadIdx.x, bd = blockDim.x, NLO = B >> HIB;
   uint32_t bin, z, tiles, tile_lo, tile_n;
   if (!tile_locate(tileprefix + w * (NBIN + 1), NBIN, blockIdx.x, bin, z, tiles)) return;
   const uint32_t rs = binstart[w * (NBIN + 1) + bin];
@@ -1461,7 +1462,7 @@ struct MsmTuning {
       v.gls_force = false;       // the release library never applies psi to the plain entry points' arbitrary curve points
 #endif
       v.lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;
-      v.host_chunks = getenv("CELO_HOST_CHUNKS") ? (uint32_t)atoi(getenv("CELO_HOST_CHUNKS")) : 4u;
+      v.host_chunks = getenv("CELO_HOST_CHUNKS") ? (uint32_t)atoi(getenv("CELO_HOST_CHUNKS")) : 0xFFFFFFFFu;   // not set: the group's own default
       v.fx_compact = getenv("CELO_FX_NO_COMPACT") == nullptr;        // A/B switch: fixed base, digits compacted by virtual window
       v.host_threads = getenv("CELO_NO_HOST_THREADS") == nullptr;
       v.seg_halves = getenv("CELO_SEG_HALVES") ? atoi(getenv("CELO_SEG_HALVES")) : 0;
@@ -1734,25 +1735,83 @@ template <class G> class MsmEngine {
     uint32_t* d_pbucket = hin ? (uint32_t*)(A + o_pbucket) : nullptr;
     uint32_t* d_carrier = hin ? (uint32_t*)(A + o_carrier) : nullptr;
     HIP_OK(hipEventRecord(ev[0], stream));
+    // mean region ns / NBIN: the smallest workgroup whose tile capacity (TILE_EPT entries per lane) holds it with 20 % to spare
+    const uint32_t region = ns / NBIN;
+    const uint32_t ts_threads = region <= 2048 ? 256u : region <= 4096 ? 512u : 1024u;
+    const uint32_t TILE = TILE_EPT * ts_threads, max_tiles = NBIN + ns / TILE + 1;
+    uint32_t* d_remap = fx_Ep ? (uint32_t*)(A + o_remap) : nullptr;
+    // the two-level sort of the windows [wb, wb + wn) (all of them, or one pass of the host-pointer pipeline)
+    auto sort_windows = [&](uint32_t wb, uint32_t wn) {
+      hipLaunchKernelGGL((k_part_hist<G>), dim3(KB2, wn), dim3(1024), 0, stream, d_digits, d_blockcnt, ns, chunk2, NBIN, wb);
+      hipLaunchKernelGGL((k_part_scan<G>), dim3(wn), dim3(1024), 0, stream, d_blockcnt, d_binstart, d_tileprefix, NBIN, KB2, TILE, wb);
+      hipLaunchKernelGGL((k_part_scatter<G>), dim3(KB2, wn), dim3(1024), 0, stream, d_digits, d_blockcnt, d_recidx, d_reckey, ns, chunk2, HIB, NBIN, (const uint32_t*)d_remap, vw, wb);
+      hipLaunchKernelGGL((k_tile_count<G>), dim3(max_tiles, wn), dim3(ts_threads), 0, stream, d_reckey, d_binstart, d_tileprefix, d_counts, ns, B, HIB, NBIN, wb);
+      hipLaunchKernelGGL((k_tile_sort<G>), dim3(max_tiles, wn), dim3(ts_threads), 0, stream, d_recidx, d_reckey, d_binstart, d_tileprefix, d_counts,
+                         d_starts, d_sorted, d_pfirst, d_pstart, d_plen, d_big, d_nbig, d_mid, d_nmid, ns, B, HIB, NBIN, SEG, PW, d_pbucket, vw, wb);
+    };
     if (hin) {
-      // the per-call fills run under the scalars' transfer; the scalars (and flags) go first: the digits need all of them
-      HIP_OK(hipMemsetAsync(d_carrier, 0, (size_t)total * IO::XYZZ_WORDS * 4, stream));
+      // ---- host-pointer pipeline.  Transfers, in this order on the side stream (a pageable hipMemcpyAsync holds the calling thread until
+      // its bytes have left, so every launch below is issued before the NEXT transfer starts):
+      //   scalars (+ flags) of chunk 0 | bases of chunk 0 | the remaining scalars (+ flags) | bases of chunk 1 | ... | bases of chunk K - 1
+      // and behind them on the call's stream: digits + sort + schedule of chunk 0's windows, conversion + accumulation of chunk 0 (running
+      // while the remaining scalars and chunk 1 cross), digits + sort + schedules of the other chunks' windows in ONE pass, then conversion
+      // + accumulation chunk by chunk.  The accumulation is the longer side of every stage from chunk 0 on (2^20 G1 terms: 2.4 ms of
+      // accumulation against 1.8 ms of transfers), so what the call pays on top of the resident pipeline is the first chunk's transfer.
       hipStream_t cs = side_stream_.get();
-      if (ev_copy.size() < (size_t)K + 1) {
+      if (ev_copy.size() < (size_t)K + 2) {
         const size_t have = ev_copy.size();
-        ev_copy.resize((size_t)K + 1, nullptr);
+        ev_copy.resize((size_t)K + 2, nullptr);
         for (size_t i = have; i < ev_copy.size(); i++) HIP_OK(hipEventCreateWithFlags(&ev_copy[i], hipEventDisableTiming));
       }
-      HIP_OK(hipMemcpyAsync((void*)d_scalars, hin->scalars, (size_t)n * SW * 4, hipMemcpyHostToDevice, cs));
-      if (hin->inf) HIP_OK(hipMemcpyAsync((void*)d_inf, hin->inf, (size_t)n, hipMemcpyHostToDevice, cs));
-      HIP_OK(hipEventRecord(ev_copy[0], cs));
-      HIP_OK(hipStreamWaitEvent(stream, ev_copy[0], 0));
-    }
+      HIP_OK(hipMemsetAsync(d_counts, 0, o_zero_end - o_counts, stream));       // (the per-call fills run under the first transfer)
+      HIP_OK(hipMemsetAsync(d_carrier, 0, (size_t)total * IO::XYZZ_WORDS * 4, stream));
+      constexpr size_t PT_BYTES = 2 * (size_t)IO::ARK64 * 8;
+      const uint32_t cslots = (uint32_t)nw * PW;
+      auto send_scalars = [&](size_t lo, size_t hi, hipEvent_t done) -> int {
+        HIP_OK(hipMemcpyAsync((char*)d_scalars + lo * SW * 4, (const char*)hin->scalars + lo * SW * 4, (hi - lo) * SW * 4, hipMemcpyHostToDevice, cs));
+        if (hin->inf) HIP_OK(hipMemcpyAsync((char*)d_inf + lo, hin->inf + lo, hi - lo, hipMemcpyHostToDevice, cs));
+        HIP_OK(hipEventRecord(done, cs));
+        HIP_OK(hipStreamWaitEvent(stream, done, 0));
+        return 0;
+      };
+      auto schedule_chunk = [&](uint32_t k) {      // longest-first schedule over the chunk's own slots (its virtual windows are adjacent)
+        uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;
+        hipLaunchKernelGGL((k_size_hist<G>), dim3(cslots / 256 < 512 ? (cslots + 255) / 256 : 512), dim3(256), 0, stream, d_plen + (size_t)k * cslots, bins_k, cslots);
+        hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, bins_k, bins_k + SIZE_BINS);
+        hipLaunchKernelGGL((k_size_scatter<G>), dim3((cslots + 4095) / 4096), dim3(1024), 0, stream, d_plen + (size_t)k * cslots, bins_k, d_order + (size_t)k * cslots, cslots);
+      };
+      auto send_and_accumulate = [&](uint32_t k) -> int {
+        const size_t lo = (size_t)k * cm, cnt = (lo + cm <= n ? (size_t)cm : (size_t)n - lo);
+        HIP_OK(hipMemcpyAsync((char*)d_ark_bases + lo * PT_BYTES, (const char*)hin->bases + lo * PT_BYTES, cnt * PT_BYTES, hipMemcpyHostToDevice, cs));
+        HIP_OK(hipEventRecord(ev_copy[2 + k], cs));
+        HIP_OK(hipStreamWaitEvent(stream, ev_copy[2 + k], 0));
+        hipLaunchKernelGGL((k_convert_bases<G>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, d_ark_bases + lo * 2 * IO::ARK64, d_bases + lo * IO::AFF_WORDS, cnt);
+        const uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;
+        hipLaunchKernelGGL((k_accumulate_chunk<G>), dim3((cslots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart + (size_t)k * cslots, d_plen + (size_t)k * cslots,
+                           d_order + (size_t)k * cslots, bins_k + SIZE_BINS, d_partials + (size_t)k * cslots * IO::XYZZ_WORDS, d_pbucket + (size_t)k * cslots, d_carrier, k ? 1u : 0u);
+        return 0;
+      };
+      const size_t first = K > 1 ? (size_t)cm : (size_t)n;
+      if (send_scalars(0, first, ev_copy[0])) return 1;
+      if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream, cm, K > 1 ? cm : npad, 0)) return 3;
+      HIP_OK(hipEventRecord(ev[1], stream));      // ("convert" = the first scalars' transfer and their digits)
+      sort_windows(0, (uint32_t)nw);
+      schedule_chunk(0);
+      HIP_OK(hipEventRecord(ev[2], stream));      // ("sort" = chunk 0's; "accumulate" = everything from here to the last chunk's end)
+      if (send_and_accumulate(0)) return 1;
+      if (K > 1) {
+        if (send_scalars(first, n, ev_copy[1])) return 1;
+        if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream, cm, npad, cm)) return 3;
+        sort_windows((uint32_t)nw, (K - 1) * (uint32_t)nw);
+        for (uint32_t k = 1; k < K; k++) schedule_chunk(k);
+        for (uint32_t k = 1; k < K; k++) if (send_and_accumulate(k)) return 1;
+      }
+    } else {
     // window shards (A/B hook CELO_SIDE_CONVERT): the conversion of ALL n bases is replicated on every shard while its sort shrinks to a
     // handful of latency-bound launches - the two are independent until the accumulation, so the conversion may run on a second stream
     const bool side = win_cnt && !glv && MsmTuning::get().side_convert && side_stream_.get() && ev_side[0];
-    if (fx || hin) {
-      // nothing to convert: the table is in device form / the bases are converted chunk by chunk as they land
+    if (fx) {
+      // nothing to convert: the table is in device form
     } else if (side) {
       HIP_OK(hipEventRecord(ev_side[0], stream));
       HIP_OK(hipStreamWaitEvent(side_stream_.get(), ev_side[0], 0));
@@ -1760,9 +1819,8 @@ template <class G> class MsmEngine {
       HIP_OK(hipEventRecord(ev_side[1], side_stream_.get()));
     } else if (glv) GlvExpand<G>::launch(d_ark_bases, d_inf, d_scalars, (uint32_t)n_, d_bases, (uint32_t*)(A + o_sc2), stream);
     else hipLaunchKernelGGL((k_convert_bases<G>), dim3((n + 255) / 256), dim3(256), 0, stream, d_ark_bases, d_bases, (size_t)n);
-    if (!hin) HIP_OK(hipEventRecord(ev[1], stream));
+    HIP_OK(hipEventRecord(ev[1], stream));
     // ---- sort
-    uint32_t* d_remap = fx_Ep ? (uint32_t*)(A + o_remap) : nullptr;
     if (fx && fx_Ep) {
       HIP_OK(hipMemsetAsync(d_digits_all, 0xFF, (size_t)n * nw_all * 2, stream));             // every slot "no digit" until a record lands in it
       HIP_OK(hipMemsetAsync(d_fx_cnt + 128, 0, 128 * 4, stream));                               // the rows' cursors
@@ -1772,44 +1830,10 @@ template <class G> class MsmEngine {
     } else if (fx) hipLaunchKernelGGL((k_fixed_digits<SW, G::SCALAR_BITS>), dim3((fx->n + 255) / 256), dim3(256), 0, stream, d_scalars, fx->tinf, d_digits_all, fx->n, (uint32_t)n_,
                                fx->cf, fx->W, fx->NV, fx->M);
     else if (glv) { if (launch_digits<4, GlvExpand<G>::BITS>(c, (const uint32_t*)(A + o_sc2), nullptr, d_digits_all, n, stream)) return 3; }
-    else if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream, hin ? cm : 0u, npad)) return 3;
-    if (hin) HIP_OK(hipEventRecord(ev[1], stream));      // (host-pointer pipeline: "convert" = the scalars' transfer and the digits)
+    else if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream)) return 3;
     HIP_OK(hipMemsetAsync(d_counts, 0, o_zero_end - o_counts, stream));
-    // mean region ns / NBIN: the smallest workgroup whose tile capacity (TILE_EPT entries per lane) holds it with 20 % to spare
-    const uint32_t region = ns / NBIN;
-    const uint32_t ts_threads = region <= 2048 ? 256u : region <= 4096 ? 512u : 1024u;
-    const uint32_t TILE = TILE_EPT * ts_threads, max_tiles = NBIN + ns / TILE + 1;
-    hipLaunchKernelGGL((k_part_hist<G>), dim3(KB2, nws), dim3(1024), 0, stream, d_digits, d_blockcnt, ns, chunk2, NBIN);
-    hipLaunchKernelGGL((k_part_scan<G>), dim3(nws), dim3(1024), 0, stream, d_blockcnt, d_binstart, d_tileprefix, NBIN, KB2, TILE);
-    hipLaunchKernelGGL((k_part_scatter<G>), dim3(KB2, nws), dim3(1024), 0, stream, d_digits, d_blockcnt, d_recidx, d_reckey, ns, chunk2, HIB, NBIN, (const uint32_t*)d_remap, vw);
-    hipLaunchKernelGGL((k_tile_count<G>), dim3(max_tiles, nws), dim3(ts_threads), 0, stream, d_reckey, d_binstart, d_tileprefix, d_counts, ns, B, HIB, NBIN);
-    hipLaunchKernelGGL((k_tile_sort<G>), dim3(max_tiles, nws), dim3(ts_threads), 0, stream, d_recidx, d_reckey, d_binstart, d_tileprefix, d_counts,
-                       d_starts, d_sorted, d_pfirst, d_pstart, d_plen, d_big, d_nbig, d_mid, d_nmid, ns, B, HIB, NBIN, SEG, PW, d_pbucket, vw);
+    sort_windows(0, (uint32_t)nw);
     // ---- work items, longest first
-    if (hin) {
-      // one schedule per chunk over its own slots (a chunk's virtual windows are adjacent); the fold lists' counters are chunk 0's
-      const uint32_t cslots = (uint32_t)nw * PW;
-      for (uint32_t k = 0; k < K; k++) {
-        uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;
-        hipLaunchKernelGGL((k_size_hist<G>), dim3(cslots / 256 < 512 ? (cslots + 255) / 256 : 512), dim3(256), 0, stream, d_plen + (size_t)k * cslots, bins_k, cslots);
-        hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, bins_k, bins_k + SIZE_BINS);
-        hipLaunchKernelGGL((k_size_scatter<G>), dim3((cslots + 4095) / 4096), dim3(1024), 0, stream, d_plen + (size_t)k * cslots, bins_k, d_order + (size_t)k * cslots, cslots);
-      }
-      HIP_OK(hipEventRecord(ev[2], stream));
-      // ---- the bases, chunk by chunk: transfer on the side stream, conversion and accumulation behind it on the call's stream
-      hipStream_t cs = side_stream_.get();
-      constexpr size_t PT_BYTES = 2 * (size_t)IO::ARK64 * 8;
-      for (uint32_t k = 0; k < K; k++) {
-        const size_t lo = (size_t)k * cm, cnt = (lo + cm <= n ? (size_t)cm : (size_t)n - lo);
-        HIP_OK(hipMemcpyAsync((char*)d_ark_bases + lo * PT_BYTES, (const char*)hin->bases + lo * PT_BYTES, cnt * PT_BYTES, hipMemcpyHostToDevice, cs));
-        HIP_OK(hipEventRecord(ev_copy[1 + k], cs));
-        HIP_OK(hipStreamWaitEvent(stream, ev_copy[1 + k], 0));
-        hipLaunchKernelGGL((k_convert_bases<G>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, d_ark_bases + lo * 2 * IO::ARK64, d_bases + lo * IO::AFF_WORDS, cnt);
-        const uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;
-        hipLaunchKernelGGL((k_accumulate_chunk<G>), dim3((cslots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart + (size_t)k * cslots, d_plen + (size_t)k * cslots,
-                           d_order + (size_t)k * cslots, bins_k + SIZE_BINS, d_partials + (size_t)k * cslots * IO::XYZZ_WORDS, d_pbucket + (size_t)k * cslots, d_carrier, k ? 1u : 0u);
-      }
-    } else {
     hipLaunchKernelGGL((k_size_hist<G>), dim3(slots / 256 < 512 ? (slots + 255) / 256 : 512), dim3(256), 0, stream, d_plen, d_bins, slots);
     hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
     hipLaunchKernelGGL((k_size_scatter<G>), dim3((slots + 4095) / 4096), dim3(1024), 0, stream, d_plen, d_bins, d_order, slots);
@@ -2028,7 +2052,10 @@ template <class G> class MsmEngine {
     // (ark_zero_identity: the flags come from the bases), the GLV split (its expansion reads bases and scalars together) and window
     // shards keep the plain form below: three transfers, then the resident pipeline
     const int ovr = host_chunks_override().load();
-    uint32_t chunks = ovr >= 0 ? (uint32_t)ovr : MsmTuning::get().host_chunks;
+    // measured on the MI355X box (profiles/r5_host_pointer_*.json): 4 chunks for the 253-bit groups (2^20 G1 terms: 5.87 ms unpipelined, 4.68 /
+    // 4.35 / 4.26 / 4.37 / 4.35 / 4.38 ms with 2 / 3 / 4 / 5 / 6 / 8 chunks against 3.24 ms resident), 8 for BW6-761 (2^21 terms: 43.0, 37.4, 36.2 ms
+    // with 0 / 4 / 8 against 32.8 resident)
+    uint32_t chunks = ovr >= 0 ? (uint32_t)ovr : MsmTuning::get().host_chunks != 0xFFFFFFFFu ? MsmTuning::get().host_chunks : (G::SCALAR_BITS > 256 ? 8u : 4u);
     if (chunks > 64) chunks = 64;
     if (chunks > (n >> 16)) chunks = (uint32_t)(n >> 16);
     if (chunks >= 2 && !ark_zero_identity && !win_cnt && !plan(n).glv && n < (size_t(1) << 30)) {
@@ -2397,32 +2424,32 @@ template <class G> class MsmEngine {
       default: return 1;
     }
   }
-  template <int SWX, int BITS, int CB> int launch_digits_c(const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st, uint32_t m, uint32_t npad) {
+  template <int SWX, int BITS, int CB> int launch_digits_c(const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st, uint32_t m, uint32_t npad, uint32_t ibase) {
     constexpr int NW = (BITS + CB) / CB;
     constexpr int KN = NW * CB - (BITS + 1);     // 0 <= KN < CB <= NW for every window size in use
     if constexpr (KN > 0 && KN < NW) {
-      if (narrow_top(CB)) { hipLaunchKernelGGL((k_digits<SWX, CB, NW, KN, BITS>), dim3((npad + 255) / 256), dim3(256), 0, st, sc, inf, digits, n, m, npad); return 0; }
+      if (narrow_top(CB)) { hipLaunchKernelGGL((k_digits<SWX, CB, NW, KN, BITS>), dim3((npad - ibase + 255) / 256), dim3(256), 0, st, sc, inf, digits, n, m, npad, ibase); return 0; }
     }
-    hipLaunchKernelGGL((k_digits<SWX, CB, NW, 0, BITS>), dim3((npad + 255) / 256), dim3(256), 0, st, sc, inf, digits, n, m, npad);
+    hipLaunchKernelGGL((k_digits<SWX, CB, NW, 0, BITS>), dim3((npad - ibase + 255) / 256), dim3(256), 0, st, sc, inf, digits, n, m, npad, ibase);
     return 0;
   }
   // m, npad: the chunked layout (k_digits); 0 = plain
-  template <int SWX, int BITS> int launch_digits(int c, const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st, uint32_t m = 0, uint32_t npad = 0) {
+  template <int SWX, int BITS> int launch_digits(int c, const uint32_t* sc, const uint8_t* inf, uint16_t* digits, uint32_t n, hipStream_t st, uint32_t m = 0, uint32_t npad = 0, uint32_t ibase = 0) {
     if (!m) { m = n; npad = n; }
     switch (c) {
-      case 4: return launch_digits_c<SWX, BITS, 4>(sc, inf, digits, n, st, m, npad);
-      case 5: return launch_digits_c<SWX, BITS, 5>(sc, inf, digits, n, st, m, npad);
-      case 6: return launch_digits_c<SWX, BITS, 6>(sc, inf, digits, n, st, m, npad);
-      case 7: return launch_digits_c<SWX, BITS, 7>(sc, inf, digits, n, st, m, npad);
-      case 8: return launch_digits_c<SWX, BITS, 8>(sc, inf, digits, n, st, m, npad);
-      case 9: return launch_digits_c<SWX, BITS, 9>(sc, inf, digits, n, st, m, npad);
-      case 10: return launch_digits_c<SWX, BITS, 10>(sc, inf, digits, n, st, m, npad);
-      case 11: return launch_digits_c<SWX, BITS, 11>(sc, inf, digits, n, st, m, npad);
-      case 12: return launch_digits_c<SWX, BITS, 12>(sc, inf, digits, n, st, m, npad);
-      case 13: return launch_digits_c<SWX, BITS, 13>(sc, inf, digits, n, st, m, npad);
-      case 14: return launch_digits_c<SWX, BITS, 14>(sc, inf, digits, n, st, m, npad);
-      case 15: return launch_digits_c<SWX, BITS, 15>(sc, inf, digits, n, st, m, npad);
-      case 16: return launch_digits_c<SWX, BITS, 16>(sc, inf, digits, n, st, m, npad);
+      case 4: return launch_digits_c<SWX, BITS, 4>(sc, inf, digits, n, st, m, npad, ibase);
+      case 5: return launch_digits_c<SWX, BITS, 5>(sc, inf, digits, n, st, m, npad, ibase);
+      case 6: return launch_digits_c<SWX, BITS, 6>(sc, inf, digits, n, st, m, npad, ibase);
+      case 7: return launch_digits_c<SWX, BITS, 7>(sc, inf, digits, n, st, m, npad, ibase);
+      case 8: return launch_digits_c<SWX, BITS, 8>(sc, inf, digits, n, st, m, npad, ibase);
+      case 9: return launch_digits_c<SWX, BITS, 9>(sc, inf, digits, n, st, m, npad, ibase);
+      case 10: return launch_digits_c<SWX, BITS, 10>(sc, inf, digits, n, st, m, npad, ibase);
+      case 11: return launch_digits_c<SWX, BITS, 11>(sc, inf, digits, n, st, m, npad, ibase);
+      case 12: return launch_digits_c<SWX, BITS, 12>(sc, inf, digits, n, st, m, npad, ibase);
+      case 13: return launch_digits_c<SWX, BITS, 13>(sc, inf, digits, n, st, m, npad, ibase);
+      case 14: return launch_digits_c<SWX, BITS, 14>(sc, inf, digits, n, st, m, npad, ibase);
+      case 15: return launch_digits_c<SWX, BITS, 15>(sc, inf, digits, n, st, m, npad, ibase);
+      case 16: return launch_digits_c<SWX, BITS, 16>(sc, inf, digits, n, st, m, npad, ibase);
       default: return 1;
     }
   }

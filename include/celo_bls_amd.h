@@ -372,7 +372,8 @@ int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]);
 int celo_amd_msm_set_window_bits(int group, int c);
 /* Host-pointer entry points (msm_<group>, from 2^17 terms): the number of index chunks in which the bases cross PCIe while the
  * chunks already on the device are accumulated (csrc/msm.h HostIn).  0 or 1 = the unpipelined form (three transfers, then the
- * resident pipeline), -1 = the default (CELO_HOST_CHUNKS, else 4).  Process-wide — tuning and test hook. */
+ * resident pipeline), -1 = the default (CELO_HOST_CHUNKS, else 4 for the BLS12-377 groups and 8 for BW6-761).  Process-wide — tuning and
+ * test hook. */
 int celo_amd_msm_set_host_chunks(int chunks);
 
 /* ---- synthetic-workload generators (bench / tests only): writes n affine points

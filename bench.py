@@ -66,6 +66,25 @@ PROFILED = {"k_accumulate<G1_377>": {20: "r4", 22: "r4_cfg5", "cfg3": "r4_cfg3"}
 
 
 _BUILD_SIG = None
+_PEAKS = None
+
+
+def valu_peaks():
+    """The multiplier roofline of this run: the library's own field-product loops timed on THIS device in THIS process, right after the
+    timed steps (celo_amd_ubench_fp, csrc/unit_ubench.hip; ~0.3 s).  mix(group) = the rate of an XYZZ mixed addition's 8 M + 2 S in units of
+    that group's coordinate-field products: Fq(BLS12-377) for G1, Fq(BW6-761) for BW6-761; an Fq2 product of G2 is priced as four Fq(BLS12-377)
+    limb-product sweeps, as rounds 1-4 did."""
+    global _PEAKS
+    if _PEAKS is None:
+        from celo_bls_snark_rs_amd import ffi
+        u = ffi.ubench_fp()
+        mix377 = 10.0 / (8.0 / u["fq377_mul_G"] + 2.0 / u["fq377_sqr_G"])
+        mix761 = 10.0 / (8.0 / u["fq761_mul_G"] + 2.0 / u["fq761_sqr_G"])
+        _PEAKS = {"measured": u, "mix": {"bls12_377_g1": mix377, "bls12_377_g2": mix377 / 4.0, "bw6_761_g1": mix761, "bw6_761_g2": mix761},
+                  "note": "peak measured in this run on this device by celo_amd_ubench_fp (register-resident loops of the library's own product bodies): "
+                          "Fq377 mul %.1f / sqr %.1f, Fq761 mul %.1f / sqr %.1f G products/s, shader clock during the first loop %.0f MHz"
+                          % (u["fq377_mul_G"], u["fq377_sqr_G"], u["fq761_mul_G"], u["fq761_sqr_G"], u["clock_mhz"])}
+    return _PEAKS
 
 
 def build_signature():
@@ -252,11 +271,12 @@ class MsmConfig:
         # the honest roofline: integer-VALU issue.  One XYZZ mixed add per (scalar, window) = 8 M + 2 S; peak = the chip-wide rate of the same
         # multiply / square bodies in a register-resident loop (tools/ubench_fp.hip on this GPU; BW6-761 products are 4x the limb products)
         fq_ops = self.n * tm["windows"] * 10
-        scale = 1.0 if self.group == "bls12_377_g1" else 4.0
-        valu_peak = 10.0 / (8.0 / 78.0 + 2.0 / 94.0) / scale
+        pk = valu_peaks()
+        valu_peak = pk["mix"][self.group]
         line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": ACC_KERNEL[self.group], "achieved": fq_ops / (acc * 1e-3) / 1e9,
                                  "peak": valu_peak, "unit": "G field-mul-or-sqr/s", "frac": fq_ops / (acc * 1e-3) / 1e9 / valu_peak,
-                                 "note": "peak from tools/ubench_fp.hip (register-resident multiply loops, 8 waves/SIMD); achieved = n*windows mixed adds * (8M+2S) / accumulate time"}
+                                 "peak_measured_in_run": pk["measured"],
+                                 "note": pk["note"] + "; achieved = n*windows mixed adds * (8M+2S) / accumulate time"}
         if self.fixed is not None:
             fi = self.fixed.info()
             line["config"]["entry_point"] = "msm_%s_fixed_dev: per-key tables T[j][i] = 2^(c j) P_i built once by msm_%s_precompute_dev (the prover's queries stay, the assignment changes)" % (self.group, self.group)
@@ -593,6 +613,17 @@ class BatchVerifyConfig:
                             "note": "integer-VALU bound; algorithmic bytes = signers*224 B per launch; median HIP-event ms: G2 MSM %.2f (accumulate %.2f), G1 MSM %.2f, "
                                     "pairings %.2f (Miller %.2f, final exp %.2f) - the two MSMs overlap on the GPU, so their event times include each other's work"
                                     % (d[0], d[1], d[2], d[3], d[4], d[5])}
+        from celo_bls_snark_rs_amd import ffi
+        g2t = ffi.msm_timings("bls12_377_g2")
+        pk = valu_peaks()
+        # the batched G2 accumulation: every (term, window) of the (GLS-expanded) instances is one mixed addition over Fq2
+        terms = tot * (3 if g2t["windows"] * g2t["window_bits"] < 100 else 1)     # psi-split (csrc/msm.h gls_digits): three 64-bit digits per 136-bit exponent
+        fq2_ops = terms * g2t["windows"] * 10
+        line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": "k_accumulate<G2_377> (batched path)", "achieved": fq2_ops / (d[1] * 1e-3) / 1e9,
+                                 "peak": pk["mix"]["bls12_377_g2"], "unit": "G Fq2-mul-or-sqr/s", "frac": fq2_ops / (d[1] * 1e-3) / 1e9 / pk["mix"]["bls12_377_g2"],
+                                 "peak_measured_in_run": pk["measured"], "windows": g2t["windows"], "window_bits": g2t["window_bits"], "expanded_terms": terms,
+                                 "note": pk["note"] + "; achieved = expanded terms * windows mixed adds * (8M+2S over Fq2) / accumulate ms; an Fq2 product priced as 4 Fq sweeps; "
+                                         "the G1 leg overlaps on the GPU, so the accumulate time includes some of its work"}
         line["config"]["signatures_per_s"] = line["value"] * self.n
         line["parity"] = {"checked": True, "against": "this rank's accept vector of the timed step == the one built into the workload (1 % of the batches corrupted)"}
         if not cx.args.no_cpu_baseline and cx.rank == 0:
@@ -783,7 +814,22 @@ def pairing_leg(ffi, check_oracle=True):
     # every product's first pair is (sig, -g2): the engine evaluates prepared line coefficients for it (pairing.h run_staged)
     kernels = ["k_prepare_lines<LPH377>", "k_miller_prepared_slots<LPH377>", "k_final_exp_slots<LPH377>"]
     traffic, src = committed_traffic(kernels, m)
-    return {"metric": "BLS12-377 Miller loops/s (2-pair products, 1 final exponentiation per product)", "value": 2 * m / secs,
+    # multiplier roofline of the leg: the six-lane kernels work in PRODUCT ROUNDS - one half-Fq2 signed pass (2 limb-product sweeps + 1 reduction
+    # = 588 multiply-adds = 1.5 plain Fq products of 392) on each of a group's six lanes = 9 Fq-product equivalents; DESIGN.md section 5 counts
+    # 63 x 17.0 + 6 x 14.3 = 1157 rounds in the prepared-line Miller loop of a two-pair product and ~900 in its final exponentiation (315
+    # cyclotomic squarings of 2, ~45 Fq12 products of 6, the easy part)
+    pk = valu_peaks()
+    rounds = {"miller": 1157, "final_exp": 900}
+    peak = pk["measured"]["fq377_mul_G"]
+    vr = {"bound": "integer VALU (v_mad_u64_u32 / v_mad_i64_i32 issue)", "unit": "G Fq-product equivalents/s", "peak": peak, "peak_measured_in_run": pk["measured"],
+          "rounds_per_product": rounds, "fq_products_per_round": 9}
+    for k_, ms_ in (("miller", best["miller_ms"]), ("final_exp", best["final_exp_ms"])):
+        vr[k_] = {"achieved": m * rounds[k_] * 9 / (ms_ * 1e-3) / 1e9, "frac": m * rounds[k_] * 9 / (ms_ * 1e-3) / 1e9 / peak}
+    vr["achieved"] = m * (rounds["miller"] + rounds["final_exp"]) * 9 / ((best["miller_ms"] + best["final_exp_ms"]) * 1e-3) / 1e9
+    vr["frac"] = vr["achieved"] / peak
+    vr["note"] = pk["note"] + "; achieved = products x product rounds x 9 Fq-product equivalents / kernel ms (HIP events); the rounds exclude the tower's additions, carries, " \
+                              "selects and lane exchanges, which is what the fraction below 1 is made of"
+    return {"metric": "BLS12-377 Miller loops/s (2-pair products, 1 final exponentiation per product)", "value": 2 * m / secs, "valu_roofline": vr,
             "products": m, "device_ms": best["total_ms"], "wall_ms_incl_pcie": best["wall_ms"], "miller_ms": best["miller_ms"], "final_exp_ms": best["final_exp_ms"],
             "roofline": {"bound": "hbm", "kernel": " + ".join(kernels), "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src, "note": "algorithmic bytes = 288 B per Miller loop (SURVEY.md section 8d); integer-VALU bound"},

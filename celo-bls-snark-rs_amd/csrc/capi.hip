@@ -71,6 +71,7 @@ int pairing_timings_377(float*);
 int ntt_run(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const uint64_t*, int, void*);
 int ntt_run_253(uint64_t*, unsigned, const uint64_t*, const uint64_t*, int, const uint64_t*, int, void*);
 int ntt_timings(float*, int*);
+int ubench_fp_run(float*);                // unit_ubench.hip
 int witness_map_253_run(uint64_t*, uint64_t*, uint64_t*, unsigned, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, int, int, void*);
 int groth16_prove_377_run(const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, size_t, const uint64_t*, const uint64_t*,
                           const uint64_t*, size_t, size_t, const uint64_t*, size_t, uint64_t*, uint64_t*, uint64_t*);
@@ -400,6 +401,10 @@ int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]) {
     case 2: return msm_timings_761(ms, cfg);
     default: return 1;
   }
+}
+int celo_amd_ubench_fp(float out[9]) {
+  if (!out) return 2;
+  return celo::ubench_fp_run(out);
 }
 int celo_amd_msm_set_host_chunks(int chunks) {
   if (chunks < -1 || chunks > 64) return 1;

@@ -35,7 +35,7 @@ EXPORTS = [
     "pairing_product_is_one_bls12_377", "pairing_product_is_one_batch_bls12_377", "celo_amd_pairing_gt_bls12_377",
     "celo_amd_pairing_last_timings", "pairing_product_is_one_bw6_761", "celo_amd_pairing_gt_bw6_761",
     "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
-    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks",
+    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks", "celo_amd_ubench_fp",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
     "celo_amd_gen_points_grouped_bls12_377_g1_dev", "celo_amd_gen_points_grouped_bls12_377_g2_dev",
     "batch_verify_bls12_377", "batch_verify_bls12_377_dev", "celo_amd_draw_batch_exponents",
@@ -267,6 +267,16 @@ def msm_timings(group):
     assert rc == 0
     return {"convert_ms": ms[0], "sort_ms": ms[1], "accumulate_ms": ms[2], "reduce_ms": ms[3], "total_ms": ms[4],
             "window_bits": cfg[0], "windows": cfg[1], "buckets": cfg[2]}
+
+
+def ubench_fp():
+    """The multiplier peaks of this device, measured now (celo_amd_ubench_fp): G products/s for the 377- and 761-bit fields + the loop's clock."""
+    out = (C.c_float * 9)()
+    rc = lib().celo_amd_ubench_fp(out)
+    if rc != 0:
+        raise RuntimeError(f"celo_amd_ubench_fp failed rc={rc}")
+    return {"fq377_mul_G": out[0], "fq377_sqr_G": out[1], "fq761_mul_G": out[2], "fq761_sqr_G": out[3], "clock_mhz": out[4],
+            "kernel_ms": [out[5], out[6], out[7], out[8]]}
 
 
 def set_host_chunks(chunks):

@@ -368,6 +368,10 @@ int celo_amd_sum_jacobian_bw6_761(const uint64_t* jac /* k*36 */, size_t k, uint
  * ms[5] = {convert, sort, accumulate, reduce, total} of the last MSM on that engine, from HIP events recorded on the
  * MSM's own stream; cfg[3] = {window bits c, windows, buckets}. */
 int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]);
+/* The multiplier roofline of THIS device in THIS process (bench.py's valu_roofline.peak): chip-wide rate of the library's own field-product
+ * bodies in register-resident loops (csrc/unit_ubench.hip; ~0.3 s).  out[0..3] = 1e9 products/s: Fq(BLS12-377) mul, sqr, Fq(BW6-761) mul,
+ * sqr; out[4] = shader clock in MHz during the first loop (s_memtime against the 100 MHz s_memrealtime); out[5..8] = the loops' kernel ms. */
+int celo_amd_ubench_fp(float out[9]);
 /* Forces the Pippenger window size (0 = automatic) — tuning and test hook. */
 int celo_amd_msm_set_window_bits(int group, int c);
 /* Host-pointer entry points (msm_<group>, from 2^17 terms): the number of index chunks in which the bases cross PCIe while the

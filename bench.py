@@ -290,6 +290,8 @@ class MsmConfig:
             line["roofline"]["traffic"], line["roofline"]["traffic_source"] = None, "no committed PMC profile of this launch shape"
         if cx.args.subgroup_points:
             line["config"]["entry_point"] = "msm_bls12_377_g1_subgroup_dev: bases vouched to lie in G1 (what Signature::batch hands over), GLV split"
+        if cx.world > 1 and not cx.devices and self.fixed is None and not self.by_windows and cx.args.scaling == "weak" and not cx.args.subgroup_points and not cx.args.witness_like and not cx.args.balanced and self.n <= (1 << 21):
+            line["strong"] = self.strong_block()
         if cx.world == 1 and not cx.devices and self.fixed is None and not cx.args.subgroup_points:
             line["host_pointer"] = self.host_pointer(result, line["ms_per_step"])
         if cx.world == 1 and not cx.devices and self.fixed is None:
@@ -299,7 +301,7 @@ class MsmConfig:
         if not cx.args.no_cpu_baseline:
             line["cpu_baseline"] = self.cpu_baseline(result)
             pw = (line["cpu_baseline"] or {}).get("parity_with_gpu")
-            line["parity"] = {"checked": pw is True, "against": "the CPU port (oracle/cpu) on the whole job: every shard's inputs gathered on rank 0, affine results compared"
+            line["parity"] = {"checked": pw is True, "against": "the CPU port (oracle/cpu) on the whole job, affine results compared: " + str((line["cpu_baseline"] or {}).get("sample"))
                               if pw is True else str(pw)}
         else:
             line["parity"] = {"checked": False, "against": "--no-cpu-baseline"}
@@ -343,6 +345,52 @@ class MsmConfig:
         return {"value": 2 * reps * self.n / dt, "unit": "scalar-muls/s", "ms_per_msm": dt * 1e3 / (2 * reps),
                 "per_thread_median_call_ms": [float(np.median(x)) for x in lat], "per_thread_max_call_ms": [float(np.max(x)) for x in lat],
                 "note": "two host threads, %d MSMs each after a concurrent 3-call warm-up, engines and streams from the pool; results identical to the sequential call" % reps}
+
+    def strong_block(self):
+        """N > 1, weak line: the STRONG-scaling number beside it (one SCALE run yields both curves).  ONE job of this
+        config's size - rank 0's terms, replicated on every rank - cut by the window partition: every rank runs the windows it owns
+        (msm_*_window_shard_dev), one all_gather of the fixed-size records, the join on every rank (msm_*_join_windows).  Timed like the
+        headline: barrier + synchronize on both sides, max over ranks; the joined point is compared with rank 0's own full MSM of the job."""
+        from celo_bls_snark_rs_amd import ffi, synthetic as syn, codec
+        cx = self.cx
+        steps, warm = max(3, cx.args.steps), 2
+        if cx.rank == 0:
+            bases, d_sc = self.bases, self.d_sc
+        else:
+            bases = syn.device_points(self.group, self.n, 0x5EED0002)
+            d_sc = torch.from_numpy(syn.uniform_scalars(self.group, self.n, 0x5EED0001).view(np.int64)).cuda()
+        join = WindowJoiner(cx, self.group)
+
+        def one():
+            rec, bit = ffi.msm_window_shard_dev(self.group, bases.data_ptr(), 0, d_sc.data_ptr(), self.n, cx.rank, cx.world, cx.stream)
+            return join(rec, bit)
+
+        def barrier():
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        for _ in range(warm):
+            out = one()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = one()
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cx.xdev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        ms = float(el.item()) * 1e3 / steps
+        tm = ffi.msm_timings(self.group)
+        ok = True
+        if cx.rank == 0:
+            p = codec.Q377 if self.group.startswith("bls12_377") else codec.Q761
+            whole = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n)
+            ok = codec.jacobian_to_affine(out, p, 1) == codec.jacobian_to_affine(whole, p, 1)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cx.xdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            raise SystemExit("PARITY FAILURE: the window-partitioned job != the whole MSM on rank 0")
+        return {"value": self.n / (ms * 1e-3), "unit": "scalar-muls/s", "ms_per_step": ms, "steps": steps, "scaling": "strong", "partition": "windows",
+                "job": "ONE %s MSM of 2^%d terms (rank 0's), replicated on the %d ranks, windows partitioned" % (self.group, self.log_n, cx.world),
+                "windows_here": tm["windows"], "shard_kernel_ms_rank0": {k: tm[k] for k in ("convert_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")},
+                "parity": {"checked": True, "against": "rank 0's msm_%s_dev of the whole job (same affine point)" % self.group}}
 
     def host_pointer(self, resident_result, resident_ms):
         """Secondary number (not `value`; SURVEY.md section 8d "report also with H2D included"): the SAME job through the host-pointer entry
@@ -433,6 +481,9 @@ class MsmConfig:
             h_b = np.concatenate([b.view(self.n, A).cpu().numpy().view(np.uint64) for b in self.sh_bases])
             h_s = np.concatenate([s_.view(self.n, -1).cpu().numpy().view(np.uint64) for s_ in self.sh_sc])
         else:
+            n_all = cx.world * self.n
+            if cx.world > 1 and self.fixed is None and not (n_all <= (1 << 21) if self.group == "bls12_377_g1" else n_all <= (1 << 19)):
+                return self.cpu_baseline_distributed(gpu_result)
             h_b, h_s = gather_to_rank0(cx, self.bases.view(self.n, A)), gather_to_rank0(cx, self.d_sc.view(self.n, -1))
         if cx.rank != 0:
             return None
@@ -443,7 +494,7 @@ class MsmConfig:
         c = 3 if n_all < 32 else (lg * 69) // 100 + 2
         windows = (bits + c - 1) // c
         T = max(1, min(hw, windows))
-        full = n_all <= (1 << 21) if self.group == "bls12_377_g1" else n_all <= (1 << 19)
+        full = n_all <= (1 << 23) if self.group == "bls12_377_g1" else n_all <= (1 << 19)
         res = {}
         if full:
             t0 = time.perf_counter()
@@ -454,6 +505,30 @@ class MsmConfig:
                 raise SystemExit("PARITY FAILURE: GPU MSM result != CPU oracle result at full size")
             res = {"value": n_all / secs, "seconds": secs, "parity_with_gpu": True,
                    "sample": "the full %d-term job once (all %d shard(s)), arkworks windowing c=%d (%d windows), one thread per window like rayon" % (n_all, cx.nshards, c, windows)}
+        elif cx.world == 1 and not cx.devices and self.fixed is None and n_all >= (1 << 20):
+            # one GPU, a job too large for ONE oracle call in bounded time (cfg4 as named: 2^24 BW6-761 terms): the port over index ranges side by
+            # side on the host's cores, the partial points added with the big-integer group law - full-size parity in n / (cores' rate) seconds
+            from oracle.py import ecc
+            chunks = max(1, min(16, hw // T))
+            parts = [None] * chunks
+            def run_part(i):
+                lo, hi = n_all * i // chunks, n_all * (i + 1) // chunks
+                parts[i] = co.jac_to_affine(co.msm(self.group, h_b[lo:hi], None, h_s[lo:hi], threads=T), KIND[self.group])
+            th = [threading.Thread(target=run_part, args=(i,)) for i in range(chunks)]
+            t0 = time.perf_counter()
+            for t in th: t.start()
+            for t in th: t.join()
+            secs = time.perf_counter() - t0
+            E = ecc.E1_377 if self.group == "bls12_377_g1" else ecc.E1_761
+            tot = None
+            for P in parts:
+                tot = E.add(tot, P)
+            if tot != co.jac_to_affine(gpu_result, KIND[self.group]):
+                raise SystemExit("PARITY FAILURE: GPU MSM result != CPU oracle result at full size (sum over %d index ranges)" % chunks)
+            res = {"value": n_all / secs, "seconds": secs, "parity_with_gpu": True,
+                   "sample": "the full %d-term job cut into %d index ranges run side by side (%d threads each, arkworks windowing c=%d), partial points added with the "
+                             "big-integer group law" % (n_all, chunks, T, c)}
+            T = chunks * T
         else:                                                   # bounded: time a 2^18 sample; parity by linearity on the sample (a fresh GPU call)
             from celo_bls_snark_rs_amd import ffi
             k = 1 << 18
@@ -490,6 +565,64 @@ class MsmConfig:
             res["all_cores"] = {"value": n_all / (time.perf_counter() - t0), "threads": chunks * T,
                                 "sample": "the same job cut into %d index ranges run side by side (not how the reference calls arkworks)" % chunks}
         return res
+
+
+def _cpu_baseline_distributed(self, gpu_result):
+    """N > 1 ranks, index-range shards too large for one oracle run on rank 0: FULL-SIZE parity with the ranks' host cores side by side.
+    Every rank runs the CPU port on its OWN shard (hardware threads / ranks each) and compares it with its own GPU partial sum; the CPU
+    partials are all-gathered and rank 0 adds them with the oracle's big-integer group law and compares the sum with the timed, folded
+    GPU result.  Any mismatch on any rank ends every rank."""
+    from oracle import cpu_oracle as co
+    from oracle.py import ecc
+    from celo_bls_snark_rs_amd import ffi
+    cx = self.cx
+    A = self.bases.numel() // self.n
+    hw = co.lib().orc_hardware_threads()
+    bits = 253 if self.group == "bls12_377_g1" else 377
+    lg = (self.n - 1).bit_length()
+    c = 3 if self.n < 32 else (lg * 69) // 100 + 2
+    windows = (bits + c - 1) // c
+    T = max(1, min(windows, hw // cx.world))
+    h_b = self.bases.view(self.n, A).cpu().numpy().view(np.uint64)
+    h_s = self.d_sc.view(self.n, -1).cpu().numpy().view(np.uint64)
+    dist.barrier()
+    t0 = time.perf_counter()
+    mine = co.msm(self.group, h_b, None, h_s, threads=T)
+    secs = time.perf_counter() - t0
+    own = ffi.msm_dev(self.group, self.bases.data_ptr(), 0, self.d_sc.data_ptr(), self.n, cx.stream)
+    kind = KIND[self.group]
+    ok = co.jac_to_affine(mine, kind) == co.jac_to_affine(own, kind)
+    t_all = torch.tensor([secs], dtype=torch.float64, device=cx.xdev)
+    dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    part = torch.from_numpy(np.ascontiguousarray(mine).view(np.int64).reshape(-1)).to(cx.xdev)
+    allp = torch.empty(cx.world * part.numel(), dtype=torch.int64, device=cx.xdev)
+    dist.all_gather_into_tensor(allp, part)
+    if cx.rank == 0 and ok:
+        E = ecc.E1_377 if self.group == "bls12_377_g1" else ecc.E1_761
+        tot = None
+        for r in range(cx.world):
+            tot = E.add(tot, co.jac_to_affine(allp.cpu().numpy().view(np.uint64).reshape(cx.world, -1)[r], kind))
+        ok = tot == co.jac_to_affine(gpu_result, kind)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cx.xdev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        raise SystemExit("PARITY FAILURE: a rank's GPU partial sum != the CPU port on its shard, or the folded GPU result != the sum of the CPU partials")
+    if cx.rank != 0:
+        return None
+    secs = float(t_all.item())
+    res = {"value": cx.world * self.n / secs, "seconds": secs, "parity_with_gpu": True, "unit": "scalar-muls/s", "cores": T * cx.world, "kind": "port", "hardware_threads": hw,
+           "sample": "the full job: every rank ran the port on its own %d-term shard with %d threads at the same time (arkworks windowing c=%d, %d windows); each shard's "
+                     "partial sum compared with that rank's GPU partial, their big-integer sum with the folded result" % (self.n, T, c, windows),
+           "note": "C++ restatement of ark-ec VariableBaseMSM (not the Rust binary: no Rust toolchain); %d x %d threads is not how ONE arkworks call parallelises "
+                   "(rayon: one task per window) - it is the box's cores applied to the sharded job" % (cx.world, T)}
+    k1 = 1 << 15
+    t0 = time.perf_counter()
+    co.msm(self.group, h_b[:k1], None, h_s[:k1], threads=1)
+    res["one_thread"] = {"value": k1 / (time.perf_counter() - t0), "sample": "2^15 terms, 1 thread"}
+    return res
+
+
+MsmConfig.cpu_baseline_distributed = _cpu_baseline_distributed
 
 
 class Folder:

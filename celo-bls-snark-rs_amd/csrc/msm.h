@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint64_t* __restric
 // one_ark: y's arkworks limbs for 1 (Fq2: (1, 0)).
 template <int ARK64X> struct ArkCoord { uint64_t v[ARK64X]; };
 template <class G>
-__global__ void __launch_bounds__(256) k_flag_ark_zero(const uint64_t* __restrict__ ark, const uint8_t* __restrict__ inf_in, uint8_t* __restrict__ inf_out, size_t n,
+__global__ void __launch_bounds__(256) k_flag_ark_zero(const uint64_t* __restrict__ ark, const uint8_t* inf_in, uint8_t* inf_out, size_t n,     // (inf_in may BE inf_out: no __restrict__)
                                                        ArkCoord<PointIO<typename G::F>::ARK64> one_ark) {
   constexpr int A = PointIO<typename G::F>::ARK64;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1456,11 +1456,7 @@ struct MsmTuning {
       v.narrow_windows = getenv("CELO_NO_NARROW") == nullptr;
       v.use_glv = getenv("CELO_NO_GLV") == nullptr;
       v.use_gls = getenv("CELO_NO_GLS") == nullptr;
-#ifdef CELO_BENCH_HOOKS
-      v.gls_force = getenv("CELO_GLS_ALL") != nullptr;       // measurement hook (tools/bench_config3.py): split also for the plain msm_batch_* entry points
-#else
-      v.gls_force = false;       // the release library never applies psi to the plain entry points' arbitrary curve points
-#endif
+      v.gls_force = false;       // the library never applies psi to the plain entry points' arbitrary curve points (the round-3 measurement hook is gone)
       v.lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;
       v.host_chunks = getenv("CELO_HOST_CHUNKS") ? (uint32_t)atoi(getenv("CELO_HOST_CHUNKS")) : 0xFFFFFFFFu;   // not set: the group's own default
       v.fx_compact = getenv("CELO_FX_NO_COMPACT") == nullptr;        // A/B switch: fixed base, digits compacted by virtual window
@@ -2104,11 +2100,20 @@ template <class G> class MsmEngine {
   // builds T (device memory of the calling thread's device) from n affine bases in arkworks layout; d_* are DEVICE pointers
   static int fixed_build(const uint64_t* d_ark_bases, const uint8_t* d_inf, size_t n_, int cf, FixedTable* T, hipStream_t stream) {
     if (n_ == 0 || n_ >= (size_t(1) << 27)) return 2;
-    if (cf == 0) cf = fixed_window_bits(n_);
-    if (cf < 16 || cf > 22) return 2;
+    // the pipeline's 32-bit run offsets bound a table: n W < 2^31 entries and (uncompacted form: every entry in every virtual window)
+    // n W NV < 2^32.  With the automatic choice the window steps down until both hold (2^24 BW6-761 terms at the preferred cf = 21
+    // are W = 18, NV = 33: 10^10 slots - the key's size the header names for the prover; cf = 19 fits); an explicit cf that does not fit is refused.
+    auto fits = [&](int c_) {
+      const uint64_t W_ = (uint64_t)((G::SCALAR_BITS + c_) / c_), M_ = c_ == 16 ? 32768u : 32767u, NV_ = ((uint64_t(1) << (c_ - 1)) - 1u) / M_ + 1u;
+      return (uint64_t)n_ * W_ < (uint64_t(1) << 31) && (uint64_t)n_ * W_ * NV_ < (uint64_t(1) << 32);
+    };
+    if (cf == 0) {
+      cf = fixed_window_bits(n_);
+      while (cf > 16 && !fits(cf)) cf--;
+    }
+    if (cf < 16 || cf > 22 || !fits(cf)) return 2;
     const uint32_t n = (uint32_t)n_, W = (uint32_t)((G::SCALAR_BITS + cf) / cf);      // W cf >= SCALAR_BITS + 1: room for the signed recoding's carry
     const uint32_t M = cf == 16 ? 32768u : 32767u, NV = ((1u << (cf - 1)) - 1u) / M + 1u;
-    if ((uint64_t)n * W >= (uint64_t(1) << 31) || (uint64_t)n * W * NV >= (uint64_t(1) << 32)) return 2;
     const size_t E = (size_t)n * W;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));

@@ -1324,10 +1324,14 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   std::atomic<size_t> up_n[2][PHASES];
   std::atomic<unsigned> phase_done[2][PHASES];
   std::atomic<bool> bad_handle(false);
+  std::atomic<bool> work_failed(false);        // a range threw (out of memory in its vectors): the call fails, on whichever thread the range ran
   for (int q = 0; q < 2; q++) for (size_t f = 0; f < PHASES; f++) { up_n[q][f].store(0); phase_done[q][f].store(0); }
   auto phase_lo = [&](size_t f) { return m * f / PHASES; };
   auto work = [&](unsigned t, int pass) {
    for (size_t f = 0; f < PHASES; f++) {
+    // a range never lets an exception out - the pool's workers, the fallback threads and the inline calls all run it - and always
+    // counts its phase as done: the calling thread waits on that counter
+    try {
     const size_t p_lo = phase_lo(f), p_hi = phase_lo(f + 1);
     const size_t b_lo = p_lo + (p_hi - p_lo) * t / nt, b_hi = p_lo + (p_hi - p_lo) * (t + 1) / nt;
     const bool is_pk = pass == 0;
@@ -1372,6 +1376,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
         }
       }
     }
+    } catch (...) { work_failed = true; }
     phase_done[pass][f].fetch_add(1);
    }
   };
@@ -1433,7 +1438,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     for (int pass = 0; pass < 2 && !copy_failed; pass++) {
       for (size_t f = 0; f < PHASES; f++) {
         while (phase_done[pass][f].load() < nt) std::this_thread::yield();
-        if (bad_handle || !ship_phase(pass, f)) { copy_failed = true; break; }
+        if (bad_handle || work_failed || !ship_phase(pass, f)) { copy_failed = true; break; }
       }
       if (copy_failed) break;
       ph.mark(pass == 0 ? "  host pass over the key handles" : "  host pass over the signature handles");
@@ -1443,7 +1448,7 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
       else { rc_sigs = bv_begin_sigs(&job, d_sg_xy, d_sg_inf, d_sc, 1, offs.data(), m); ph.mark("signature slots across, G1 batch MSM started"); }
     }
   }
-  if (pool_failed) copy_failed = true;                                  // a worker's range threw (out of memory): rows may be missing
+  if (pool_failed || work_failed) copy_failed = true;                   // a range threw (out of memory): rows may be missing
   mirrors_ok = !copy_failed;
   if (bad_handle) log_err("batch_verify_strict: a destroyed or foreign handle in the batch lists");
   hasher.join();

@@ -134,6 +134,11 @@ int msm_bw6_761_join_windows(const uint64_t* xyzz /* nshards x 48 */, const int*
  * 377-bit scalar at c = 20).  Same result as msm_* (which stays VariableBaseMSM: nothing is cached behind its back).
  * A base may be flagged as the identity (inf); a base whose 2^(c j) multiple is the identity is handled.  The handle is bound to the
  * device it was built on (a call from a thread bound to another device returns 101) and may be used from several host threads at once.
+ * Size limits (the pipeline's 32-bit run offsets): n W < 2^31 and n W NV < 2^32 with NV = the 2^15-bucket virtual windows of a c-bit digit
+ * (1 at c = 16, then 3, 5, 9, 17, 33, 65 at c = 17 .. 22).  For the 377-bit scalars of BW6-761 that is n < 2^26.4 at c = 16, 2^25.9 at 17,
+ * 2^25.3 at 18, 2^24.5 at 19 (a 2^24-term key, the prover's size, fits), 2^23.7 at 20, 2^22.8 at 21, 2^21.8 at 22; for the 253-bit scalars
+ * of BLS12-377 about 1.5 times that.  window_bits = 0 starts from the measured optimum (20 / 21) and steps down until the limits hold;
+ * an explicit window_bits that does not fit returns 2.
  * celo_amd_msm_fixed_info: the table's shape, its size in bytes and its build time (HIP events). */
 int msm_bls12_377_g1_precompute(const uint64_t* bases_xy /* n*12 */, const uint8_t* inf, size_t n, int window_bits, void** out_handle);
 int msm_bls12_377_g2_precompute(const uint64_t* bases_xy /* n*24 */, const uint8_t* inf, size_t n, int window_bits, void** out_handle);

@@ -170,6 +170,41 @@ def test_cfg4_bw6_761_g1_shard_size_vs_oracle(gpu):
     assert got == co.jac_to_affine(co.msm("bw6_761_g1", h[:k], None, sw, threads=_threads()), "761")
 
 
+def test_cfg4_whole_job_2p24_on_one_gpu_vs_oracle_over_the_8_index_shards(gpu):
+    """BASELINE config 4 AS NAMED - the epoch-snark prover's BW6-761 G1 MSM of 2^24 terms (crates/epoch-snark/src/api/prover.rs:78) - run whole on
+    ONE GPU (3.2 GB of bases + 0.8 GB of scalars fit; it is also the only stand-in for the 8-GPU fold while no node exists): the device result
+    against the oracle run over the SAME 8 index shards the 8-GPU job would cut (one oracle call per shard, side by side on the host's cores, the
+    eight partial points added with the big-integer group law), for uniform and for witness-like scalars; and the 8-engine in-process fold of the
+    same shards (msm_bw6_761_g1_multi_dev on device 0) against both."""
+    import threading
+    from celo_bls_snark_rs_amd import synthetic as syn
+    n, shards = 1 << 24, 8
+    per = n // shards
+    bases = syn.device_points("bw6_761_g1", n, 0x5EED0424)
+    h = bases.cpu().numpy().view(np.uint64).reshape(n, 24)
+    T = max(1, min(24, co.lib().orc_hardware_threads() // shards))
+    for kind, sc in (("uniform", syn.uniform_scalars("bw6_761_g1", n, 0x5EED0425)), ("witness-like", syn.witness_like_scalars("bw6_761_g1", n, 0x5EED0426))):
+        d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+        got = co.jac_to_affine(gpu.msm_dev("bw6_761_g1", bases.data_ptr(), 0, d_sc.data_ptr(), n), "761")
+        parts = [None] * shards
+
+        def run(i):
+            parts[i] = co.jac_to_affine(co.msm("bw6_761_g1", h[i * per:(i + 1) * per], None, sc[i * per:(i + 1) * per], threads=T), "761")
+        th = [threading.Thread(target=run, args=(i,)) for i in range(shards)]
+        for t in th: t.start()
+        for t in th: t.join()
+        exp = None
+        for P in parts:
+            exp = ecc.E1_761.add(exp, P)
+        assert got == exp and got is not None, kind
+        if kind == "uniform":
+            bp = [bases.data_ptr() + i * per * 24 * 8 for i in range(shards)]
+            sp = [d_sc.data_ptr() + i * per * 6 * 8 for i in range(shards)]
+            multi = gpu.msm_multi_dev("bw6_761_g1", [0] * shards, bp, None, sp, [per] * shards)
+            assert co.jac_to_affine(multi, "761") == exp
+        del d_sc
+
+
 # ------------------------------------------------------------------------------------------------ cfg5
 def test_cfg5_mixed_g1_g2_msm_and_miller_loops_concurrently(gpu):
     from celo_bls_snark_rs_amd import synthetic as syn

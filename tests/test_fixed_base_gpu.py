@@ -112,3 +112,23 @@ def test_bad_arguments_are_refused(gpu):
     fb = gpu.FixedBase("bls12_377_g1", xy, inf)
     assert co.jac_to_affine(fb.msm(np.zeros((0, 4), dtype=np.uint64)), "g1_377") is None        # no scalars: the identity
     fb.release()
+
+
+def test_automatic_window_steps_down_for_a_large_key(gpu):
+    """with window_bits = 0 a key too large for the preferred window (BW6-761 at c = 21: n W NV >= 2^32 from ~2^22.8 terms) used to be
+    refused with rc = 2 at the sizes the header names for the prover.  The automatic choice now steps down until the table fits the pipeline's
+    32-bit offsets: 2^23 BW6-761 terms build at c = 20 and give the variable-base entry point's point (itself checked against the oracle up to
+    2^24 terms in tests/test_configs_gpu.py); an explicit c = 21 at that size is still refused."""
+    from celo_bls_snark_rs_amd import synthetic as syn
+    n = 1 << 23
+    pts = syn.device_points("bw6_761_g1", n, 0x5EED4523)
+    sc = syn.uniform_scalars("bw6_761_g1", n, 0x5EED4524)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    fb = gpu.FixedBase("bw6_761_g1", d_bases=pts.data_ptr(), n=n, window_bits=0)
+    info = fb.info()
+    assert info["window_bits"] == 20 and info["n"] == n
+    got = co.jac_to_affine(fb.msm_dev(d_sc.data_ptr(), n), "761")
+    fb.release()
+    assert got == co.jac_to_affine(gpu.msm_dev("bw6_761_g1", pts.data_ptr(), 0, d_sc.data_ptr(), n), "761") and got is not None
+    with pytest.raises(RuntimeError):
+        gpu.FixedBase("bw6_761_g1", d_bases=pts.data_ptr(), n=n, window_bits=21)

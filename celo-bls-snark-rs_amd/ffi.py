@@ -35,7 +35,7 @@ EXPORTS = [
     "pairing_product_is_one_bls12_377", "pairing_product_is_one_batch_bls12_377", "celo_amd_pairing_gt_bls12_377",
     "celo_amd_pairing_last_timings", "pairing_product_is_one_bw6_761", "celo_amd_pairing_gt_bw6_761",
     "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
-    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks", "celo_amd_ubench_fp",
+    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks", "celo_amd_ubench_fp", "celo_amd_selftest_accumulate",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
     "celo_amd_gen_points_grouped_bls12_377_g1_dev", "celo_amd_gen_points_grouped_bls12_377_g2_dev",
     "batch_verify_bls12_377", "batch_verify_bls12_377_dev", "celo_amd_draw_batch_exponents",
@@ -267,6 +267,18 @@ def msm_timings(group):
     assert rc == 0
     return {"convert_ms": ms[0], "sort_ms": ms[1], "accumulate_ms": ms[2], "reduce_ms": ms[3], "total_ms": ms[4],
             "window_bits": cfg[0], "windows": cfg[1], "buckets": cfg[2]}
+
+
+def selftest_accumulate(group, gen_xy, runs=16384, length=24, seed=1, check=2048, chunked=False):
+    """The library's own k_accumulate<group> / k_accumulate_chunk<group> against the host replay of the same templates; returns the number of
+    runs whose partial sum differs (celo_amd_selftest_accumulate)."""
+    gen_xy = np.ascontiguousarray(gen_xy, dtype=np.uint64)
+    d = C.c_uint32(0xFFFFFFFF)
+    rc = lib().celo_amd_selftest_accumulate(C.c_int(GROUP_ID[group]), _p(gen_xy), C.c_uint32(runs), C.c_uint32(length), C.c_uint32(seed), C.c_uint32(check),
+                                            C.c_int(1 if chunked else 0), C.byref(d))
+    if rc != 0:
+        raise RuntimeError(f"celo_amd_selftest_accumulate failed rc={rc}")
+    return d.value
 
 
 def ubench_fp():

@@ -373,6 +373,11 @@ int celo_amd_sum_jacobian_bw6_761(const uint64_t* jac /* k*36 */, size_t k, uint
  * ms[5] = {convert, sort, accumulate, reduce, total} of the last MSM on that engine, from HIP events recorded on the
  * MSM's own stream; cfg[3] = {window bits c, windows, buckets}. */
 int celo_amd_msm_last_timings(int group, float ms[5], int cfg[3]);
+/* Self-test of the bucket-accumulation kernels the library runs (tests/test_msm_gpu.py): `runs` runs of `len` random signed multiples of the
+ * affine generator gen_xy (HOST pointer, arkworks layout) through k_accumulate<group> (chunked = 0) or through the host-pointer pipeline's
+ * k_accumulate_chunk<group> twice, the second launch continuing the first's carried sums (chunked = 1); the first `check` partial sums are
+ * compared limb for limb with the same formulas run on the host.  *differ = the number of runs that disagree (0 expected). */
+int celo_amd_selftest_accumulate(int group, const uint64_t* gen_xy, uint32_t runs, uint32_t len, uint32_t seed, uint32_t check, int chunked, uint32_t* differ);
 /* The multiplier roofline of THIS device in THIS process (bench.py's valu_roofline.peak): chip-wide rate of the library's own field-product
  * bodies in register-resident loops (csrc/unit_ubench.hip; ~0.3 s).  out[0..3] = 1e9 products/s: Fq(BLS12-377) mul, sqr, Fq(BW6-761) mul,
  * sqr; out[4] = shader clock in MHz during the first loop (s_memtime against the 100 MHz s_memrealtime); out[5..8] = the loops' kernel ms. */

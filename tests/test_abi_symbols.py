@@ -91,3 +91,21 @@ def test_no_stray_c_symbols_exported():
         hdr += open(os.path.join(ROOT, "include", h)).read()
     stray = [n for n in plain if not n.startswith("celo_") and not re.search(r"\b%s\s*\(" % re.escape(n), hdr)]
     assert stray == [], stray
+
+
+def test_accumulate_kernels_are_out_of_the_sgpr_spill_regime():
+    """rounds 2-4 shipped k_accumulate with 107-211 spilled SGPRs (the K p tables of the cold canonical reduction, hoisted
+    into the prologue and parked in VGPR lanes) - the register shape next to which the round-3 signed-pass instantiation miscompiled.  Round 5
+    made those tables immediates (csrc/fp.h reduce / cond_sub_k): what the compiler still parks are the exec masks of nested divergent
+    regions, a handful.  The build's own resource remarks (-Rpass-analysis=kernel-resource-usage, written by the Makefile next to every
+    object) are the evidence: every instantiation of k_accumulate / k_accumulate_chunk reports at most 8 spilled SGPRs and no scratch."""
+    import glob
+    import re
+    build = os.path.join(ROOT, "celo-bls-snark-rs_amd", "build")
+    seen = 0
+    for f in glob.glob(os.path.join(build, "unit_*.remarks.txt")):
+        txt = open(f).read()
+        for m in re.finditer(r"Function Name: (\S*k_accumulate\S*).*?ScratchSize \[bytes/lane\]: (\d+).*?SGPRs Spill: (\d+)", txt, re.S):
+            seen += 1
+            assert int(m.group(3)) <= 8 and int(m.group(2)) == 0, (os.path.basename(f), m.group(1), m.group(2), m.group(3))
+    assert seen >= 6, "no resource remarks found: build with make -C celo-bls-snark-rs_amd/csrc"

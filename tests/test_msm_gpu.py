@@ -514,3 +514,23 @@ def test_shipped_g2_accumulate_kernel_equals_the_host_replay(gpu):
     host = [ln for ln in r.stdout.splitlines() if ln.startswith("host replay")]
     assert host and host[-1].endswith(": 0 differ"), r.stdout[-2000:] + r.stderr[-2000:]
     assert r.returncode in (0, 2)          # 2: the signed instantiation differs somewhere (the finding itself), 4 would be the shipped kernel
+
+
+@pytest.mark.parametrize("group", ["bls12_377_g1", "bls12_377_g2", "bw6_761_g1"])
+@pytest.mark.parametrize("chunked", [False, True])
+def test_library_accumulate_kernels_equal_the_host_replay(gpu, golden, group, chunked):
+    """The kernels the LIBRARY launches (not a tool's own compilation of the template): k_accumulate<G> and the host-pointer pipeline's
+    k_accumulate_chunk<G>, every group, 16384 runs of 24 (+ 24 carried-on) random signed points with equal / opposite pairs at the head of some
+    runs, the first 2048 partial sums against the host replay of the same formulas limb for limb (celo_amd_selftest_accumulate; round 5: the
+    guard of round 4 covered one group in a side build).  Also what the build says about these kernels' registers: no SGPR spills beyond
+    a handful of exec masks (tests/test_abi_symbols.py)."""
+    from oracle.py import epoch as ep
+    if group == "bls12_377_g1":
+        gen = co.pack_g1_377([ecc.G1_377])[0]
+    elif group == "bls12_377_g2":
+        gen = co.pack_g2_377([ecc.G2_377])[0]
+    else:
+        gen = co.pack_761([ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))["alpha_g1"]])[0]
+    for seed in (1, 2):
+        assert gpu.selftest_accumulate(group, gen.reshape(-1), runs=16384, length=24, seed=seed, check=2048, chunked=chunked) == 0
+    assert gpu.selftest_accumulate(group, gen.reshape(-1), runs=300, length=1, seed=3, check=300, chunked=chunked) == 0

@@ -344,8 +344,17 @@ template <class P> struct Fp {
     return r;
   }
   template <int K> HD static void cond_sub_k(Fp& r) {
-    constexpr KpTable T = kp_table<K>();
-    cond_sub(r, T.v);
+    if constexpr (L > 14) {
+      // the 28-limb field keeps the tables behind pointers: with immediates `k_combine_big<G_761>` (one workgroup folding a skewed bucket's
+      // pieces through LDS, its additions out of line) never returns on witness-like scalars - found by the -m gpu suite in round 5,
+      // reproduced with a function-local constexpr table and with a static one, gone with the pointer form (tools/dbg_witness.py; same
+      // sources otherwise, SLP vectorizer off in all three builds).  Not understood; the accumulate kernels of this field therefore keep their
+      // prologue loads and parked SGPRs (tests/test_abi_symbols.py allows them for G_761 only).
+      cond_sub(r, K == 64 ? P::NP64 : K == 32 ? P::NP32 : K == 16 ? P::NP16 : K == 8 ? P::NP8 : K == 4 ? P::NP4 : K == 2 ? P::NP2 : P::NP1);
+    } else {
+      constexpr KpTable T = kp_table<K>();
+      cond_sub(r, T.v);
+    }
   }
   HD static void cond_sub(Fp& r, const uint32_t* kp) {
     // r (normalised) >= kp ? r - kp : r

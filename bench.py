@@ -56,13 +56,13 @@ class Ctx:
 
 
 # launch shapes the committed PMC profiles were taken at, and the profile set (profiles/<tag>_traffic.json, written by
-# tools/summarise_profile.py from the separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/r4_sweep.sh) that holds each:
+# tools/summarise_profile.py from the separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/r5_profiles.sh) that holds each:
 # kernel -> {shape: tag}.  Shapes: log2 n of an MSM, the number of products of a pairing launch, "cfg3" = 4096 batches x 256 signers.
-PROFILED = {"k_accumulate<G1_377>": {20: "r4", 22: "r4_cfg5", "cfg3": "r4_cfg3"},
-            "k_accumulate<G2_377>": {20: "r4_groups", 22: "r4_cfg5", "cfg3": "r4_cfg3"},
-            "k_accumulate<G_761>": {20: "r4_groups", 21: "r4_cfg4"},
-            "k_miller_product_slots<LPH377, 2>": {81920: "r4_pairing"}, "k_miller_prepared_slots<LPH377>": {81920: "r4"},
-            "k_prepare_lines<LPH377>": {81920: "r4"}, "k_final_exp_slots<LPH377>": {81920: "r4"}}
+PROFILED = {"k_accumulate<G1_377>": {20: "r5", 22: "r5_cfg5", "cfg3": "r5_cfg3"},
+            "k_accumulate<G2_377>": {20: "r5_groups", 22: "r5_cfg5", "cfg3": "r5_cfg3"},
+            "k_accumulate<G_761>": {20: "r5_groups", 21: "r5_cfg4"},
+            "k_miller_product_slots<LPH377, 2>": {81920: "r5_pairing"}, "k_miller_prepared_slots<LPH377>": {81920: "r5"},
+            "k_prepare_lines<LPH377>": {81920: "r5"}, "k_final_exp_slots<LPH377>": {81920: "r5"}}
 
 
 _BUILD_SIG = None
@@ -505,7 +505,7 @@ class MsmConfig:
                 raise SystemExit("PARITY FAILURE: GPU MSM result != CPU oracle result at full size")
             res = {"value": n_all / secs, "seconds": secs, "parity_with_gpu": True,
                    "sample": "the full %d-term job once (all %d shard(s)), arkworks windowing c=%d (%d windows), one thread per window like rayon" % (n_all, cx.nshards, c, windows)}
-        elif cx.world == 1 and not cx.devices and self.fixed is None and n_all >= (1 << 20):
+        elif (cx.world == 1 or self.by_windows) and self.fixed is None and n_all >= (1 << 20):
             # one GPU, a job too large for ONE oracle call in bounded time (cfg4 as named: 2^24 BW6-761 terms): the port over index ranges side by
             # side on the host's cores, the partial points added with the big-integer group law - full-size parity in n / (cores' rate) seconds
             from oracle.py import ecc

@@ -69,21 +69,42 @@ _BUILD_SIG = None
 _PEAKS = None
 
 
+# Multiply-adds (v_mad_u64_u32 / v_mad_i64_i32 lane-operations) of the library's arithmetic, counted from csrc/fp.h, fp2.h, curve.h.
+# 14-limb field (p = 1 mod 2^28: the quotient's p0 term is free): product sweep 14^2 = 196, symmetric (squaring) sweep 105, reduction sweep
+# 14 * 13 = 182; 28-limb field: 784, 406, 784.
+MADS = {
+    "fq377_mul": 196 + 182, "fq377_sqr": 105 + 182, "fq761_mul": 784 + 784, "fq761_sqr": 406 + 784,
+    # one XYZZ mixed addition (madd-2008-s, curve.h xyzz_madd): U2, S2, PPP, Q, ZZ3, ZZZ3 products, PP and R^2 squarings, Y3 = R t - Y1 PPP in one pass
+    "madd": {"bls12_377_g1": 6 * (196 + 182) + 2 * (105 + 182) + (2 * 196 + 182),                                   # 3416
+             # Fq2: a product = two passes of (2 sweeps + 1 reduction); a squaring = sqr2m5 (2 x 105 + 182) + one Fq product; Y3 = two mul4k passes (4 sweeps + 1 reduction)
+             "bls12_377_g2": 6 * 2 * (2 * 196 + 182) + 2 * ((2 * 105 + 182) + (196 + 182)) + 2 * (4 * 196 + 182),     # 10360
+             "bw6_761_g1": 6 * (784 + 784) + 2 * (406 + 784) + (2 * 784 + 784),                                      # 14140
+             "bw6_761_g2": 6 * (784 + 784) + 2 * (406 + 784) + (2 * 784 + 784)},
+    # one product round of the six-lane pairing backend: a half-Fq2 signed pass (2 sweeps + 1 reduction) on each of a group's six lanes
+    "hex_round": 6 * (2 * 196 + 182),
+}
+
+
 def valu_peaks():
-    """The multiplier roofline of this run: the library's own field-product loops timed on THIS device in THIS process, right after the
-    timed steps (celo_amd_ubench_fp, csrc/unit_ubench.hip; ~0.3 s).  mix(group) = the rate of an XYZZ mixed addition's 8 M + 2 S in units of
-    that group's coordinate-field products: Fq(BLS12-377) for G1, Fq(BW6-761) for BW6-761; an Fq2 product of G2 is priced as four Fq(BLS12-377)
-    limb-product sweeps, as rounds 1-4 did."""
+    """The multiplier roofline of this run, in MULTIPLY-ADDS per second: the library's own field-product loops timed on THIS device in THIS
+    process, right after the timed steps (celo_amd_ubench_fp, csrc/unit_ubench.hip; ~0.1 s) - products/s x multiply-adds per product (MADS).
+    The mul and sqr loops of a field agree to 1 % in these units (14 limbs: 73.5 G x 378 = 27.8 T, 96.0 G x 287 = 27.6 T), which is what makes the
+    unit the right one: kernels are priced by the multiply-adds their formulas execute, not by a nominal count of field operations (rounds 2-4
+    priced an XYZZ mixed addition as 8 M + 2 S although its Y3 pass shares one reduction between two products, and an Fq2 product as four Fq
+    products although it takes three: 0.96-0.98 and > 1 where the counts below give 0.91 and 0.8)."""
     global _PEAKS
     if _PEAKS is None:
         from celo_bls_snark_rs_amd import ffi
         u = ffi.ubench_fp()
-        mix377 = 10.0 / (8.0 / u["fq377_mul_G"] + 2.0 / u["fq377_sqr_G"])
-        mix761 = 10.0 / (8.0 / u["fq761_mul_G"] + 2.0 / u["fq761_sqr_G"])
-        _PEAKS = {"measured": u, "mix": {"bls12_377_g1": mix377, "bls12_377_g2": mix377 / 4.0, "bw6_761_g1": mix761, "bw6_761_g2": mix761},
+        p377 = u["fq377_mul_G"] * MADS["fq377_mul"] / 1e3
+        p761 = u["fq761_mul_G"] * MADS["fq761_mul"] / 1e3
+        _PEAKS = {"measured": u, "tmads": {"bls12_377_g1": p377, "bls12_377_g2": p377, "bw6_761_g1": p761, "bw6_761_g2": p761},
+                  "sqr_loops_tmads": {"fq377": u["fq377_sqr_G"] * MADS["fq377_sqr"] / 1e3, "fq761": u["fq761_sqr_G"] * MADS["fq761_sqr"] / 1e3},
                   "note": "peak measured in this run on this device by celo_amd_ubench_fp (register-resident loops of the library's own product bodies): "
-                          "Fq377 mul %.1f / sqr %.1f, Fq761 mul %.1f / sqr %.1f G products/s, shader clock during the first loop %.0f MHz"
-                          % (u["fq377_mul_G"], u["fq377_sqr_G"], u["fq761_mul_G"], u["fq761_sqr_G"], u["clock_mhz"])}
+                          "Fq377 mul %.1f / sqr %.1f, Fq761 mul %.1f / sqr %.1f G products/s = %.1f / %.1f / %.1f / %.1f T multiply-adds/s (378 / 287 / 1568 / 1190 per product), "
+                          "shader clock during the first loop %.0f MHz"
+                          % (u["fq377_mul_G"], u["fq377_sqr_G"], u["fq761_mul_G"], u["fq761_sqr_G"], p377, u["fq377_sqr_G"] * MADS["fq377_sqr"] / 1e3, p761,
+                             u["fq761_sqr_G"] * MADS["fq761_sqr"] / 1e3, u["clock_mhz"])}
     return _PEAKS
 
 
@@ -268,23 +289,25 @@ class MsmConfig:
                             "note": "integer-VALU bound, not HBM bound (SURVEY.md section 8d); algorithmic bytes = n*%d B per launch; kernel ms (median over the timed "
                                     "steps) from HIP events on the MSM stream: accumulate=%.3f of total=%.3f (convert=%.3f sort=%.3f reduce=%.3f)"
                                     % (alg, acc, float(np.median(self.tot_ms)), tm["convert_ms"], tm["sort_ms"], tm["reduce_ms"])}
-        # the honest roofline: integer-VALU issue.  One XYZZ mixed add per (scalar, window) = 8 M + 2 S; peak = the chip-wide rate of the same
-        # multiply / square bodies in a register-resident loop (tools/ubench_fp.hip on this GPU; BW6-761 products are 4x the limb products)
-        fq_ops = self.n * tm["windows"] * 10
+        # the honest roofline: integer-VALU issue, in multiply-adds.  One XYZZ mixed addition per (scalar, window); peak = the chip-wide rate of the
+        # library's own product bodies in a register-resident loop, measured in this run (valu_peaks)
+        madd = MADS["madd"][self.group]
+        fq_ops = self.n * tm["windows"] * madd
         pk = valu_peaks()
-        valu_peak = pk["mix"][self.group]
-        line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": ACC_KERNEL[self.group], "achieved": fq_ops / (acc * 1e-3) / 1e9,
-                                 "peak": valu_peak, "unit": "G field-mul-or-sqr/s", "frac": fq_ops / (acc * 1e-3) / 1e9 / valu_peak,
-                                 "peak_measured_in_run": pk["measured"],
-                                 "note": pk["note"] + "; achieved = n*windows mixed adds * (8M+2S) / accumulate time"}
+        valu_peak = pk["tmads"][self.group]
+        line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": ACC_KERNEL[self.group], "achieved": fq_ops / (acc * 1e-3) / 1e12,
+                                 "peak": valu_peak, "unit": "T multiply-adds/s", "frac": fq_ops / (acc * 1e-3) / 1e12 / valu_peak,
+                                 "multiply_adds_per_mixed_addition": madd, "peak_measured_in_run": pk["measured"],
+                                 "note": pk["note"] + "; achieved = n*windows mixed additions x %d multiply-adds (6 products, 2 squarings, the one-pass Y3: bench.py MADS) / "
+                                                      "accumulate time" % madd}
         if self.fixed is not None:
             fi = self.fixed.info()
             line["config"]["entry_point"] = "msm_%s_fixed_dev: per-key tables T[j][i] = 2^(c j) P_i built once by msm_%s_precompute_dev (the prover's queries stay, the assignment changes)" % (self.group, self.group)
             line["config"]["fixed_base"] = {"window_bits": fi["window_bits"], "digits_per_scalar": fi["windows"], "virtual_windows": tm["windows"],
                                             "table_bytes": fi["table_bytes"], "table_build_ms": fi["build_ms"],
                                             "note": "the table build is outside the timed region: once per proving key (crates/epoch-snark/src/api/setup.rs:63-105)"}
-            fq_ops = self.n * fi["windows"] * 10
-            line["valu_roofline"]["achieved"] = fq_ops / (acc * 1e-3) / 1e9
+            fq_ops = self.n * fi["windows"] * madd
+            line["valu_roofline"]["achieved"] = fq_ops / (acc * 1e-3) / 1e12
             line["valu_roofline"]["frac"] = line["valu_roofline"]["achieved"] / valu_peak
             line["valu_roofline"]["note"] += "; fixed base: n * digits_per_scalar mixed adds"
             line["roofline"]["traffic"], line["roofline"]["traffic_source"] = None, "no committed PMC profile of this launch shape"
@@ -751,12 +774,13 @@ class BatchVerifyConfig:
         pk = valu_peaks()
         # the batched G2 accumulation: every (term, window) of the (GLS-expanded) instances is one mixed addition over Fq2
         terms = tot * (3 if g2t["windows"] * g2t["window_bits"] < 100 else 1)     # psi-split (csrc/msm.h gls_digits): three 64-bit digits per 136-bit exponent
-        fq2_ops = terms * g2t["windows"] * 10
-        line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": "k_accumulate<G2_377> (batched path)", "achieved": fq2_ops / (d[1] * 1e-3) / 1e9,
-                                 "peak": pk["mix"]["bls12_377_g2"], "unit": "G Fq2-mul-or-sqr/s", "frac": fq2_ops / (d[1] * 1e-3) / 1e9 / pk["mix"]["bls12_377_g2"],
+        fq2_ops = terms * g2t["windows"] * MADS["madd"]["bls12_377_g2"]
+        line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": "k_accumulate<G2_377> (batched path)", "achieved": fq2_ops / (d[1] * 1e-3) / 1e12,
+                                 "peak": pk["tmads"]["bls12_377_g2"], "unit": "T multiply-adds/s", "frac": fq2_ops / (d[1] * 1e-3) / 1e12 / pk["tmads"]["bls12_377_g2"],
+                                 "multiply_adds_per_mixed_addition": MADS["madd"]["bls12_377_g2"],
                                  "peak_measured_in_run": pk["measured"], "windows": g2t["windows"], "window_bits": g2t["window_bits"], "expanded_terms": terms,
-                                 "note": pk["note"] + "; achieved = expanded terms * windows mixed adds * (8M+2S over Fq2) / accumulate ms; an Fq2 product priced as 4 Fq sweeps; "
-                                         "the G1 leg overlaps on the GPU, so the accumulate time includes some of its work"}
+                                 "note": pk["note"] + "; achieved = expanded terms x windows mixed additions over Fq2 x %d multiply-adds / accumulate ms - an upper count (a zero digit "
+                                         "adds nothing: 1/64 of them at 6-bit windows) over a time that also holds part of the overlapping G1 leg's work" % MADS["madd"]["bls12_377_g2"]}
         line["config"]["signatures_per_s"] = line["value"] * self.n
         line["parity"] = {"checked": True, "against": "this rank's accept vector of the timed step == the one built into the workload (1 % of the batches corrupted)"}
         if not cx.args.no_cpu_baseline and cx.rank == 0:
@@ -948,19 +972,20 @@ def pairing_leg(ffi, check_oracle=True):
     kernels = ["k_prepare_lines<LPH377>", "k_miller_prepared_slots<LPH377>", "k_final_exp_slots<LPH377>"]
     traffic, src = committed_traffic(kernels, m)
     # multiplier roofline of the leg: the six-lane kernels work in PRODUCT ROUNDS - one half-Fq2 signed pass (2 limb-product sweeps + 1 reduction
-    # = 588 multiply-adds = 1.5 plain Fq products of 392) on each of a group's six lanes = 9 Fq-product equivalents; DESIGN.md section 5 counts
+    # = 574 multiply-adds) on each of a group's six lanes = 3444 multiply-adds; DESIGN.md section 5 counts
     # 63 x 17.0 + 6 x 14.3 = 1157 rounds in the prepared-line Miller loop of a two-pair product and ~900 in its final exponentiation (315
     # cyclotomic squarings of 2, ~45 Fq12 products of 6, the easy part)
     pk = valu_peaks()
     rounds = {"miller": 1157, "final_exp": 900}
-    peak = pk["measured"]["fq377_mul_G"]
-    vr = {"bound": "integer VALU (v_mad_u64_u32 / v_mad_i64_i32 issue)", "unit": "G Fq-product equivalents/s", "peak": peak, "peak_measured_in_run": pk["measured"],
-          "rounds_per_product": rounds, "fq_products_per_round": 9}
+    peak = pk["tmads"]["bls12_377_g1"]
+    hr = MADS["hex_round"]
+    vr = {"bound": "integer VALU (v_mad_u64_u32 / v_mad_i64_i32 issue)", "unit": "T multiply-adds/s", "peak": peak, "peak_measured_in_run": pk["measured"],
+          "rounds_per_product": rounds, "multiply_adds_per_round": hr}
     for k_, ms_ in (("miller", best["miller_ms"]), ("final_exp", best["final_exp_ms"])):
-        vr[k_] = {"achieved": m * rounds[k_] * 9 / (ms_ * 1e-3) / 1e9, "frac": m * rounds[k_] * 9 / (ms_ * 1e-3) / 1e9 / peak}
-    vr["achieved"] = m * (rounds["miller"] + rounds["final_exp"]) * 9 / ((best["miller_ms"] + best["final_exp_ms"]) * 1e-3) / 1e9
+        vr[k_] = {"achieved": m * rounds[k_] * hr / (ms_ * 1e-3) / 1e12, "frac": m * rounds[k_] * hr / (ms_ * 1e-3) / 1e12 / peak}
+    vr["achieved"] = m * (rounds["miller"] + rounds["final_exp"]) * hr / ((best["miller_ms"] + best["final_exp_ms"]) * 1e-3) / 1e12
     vr["frac"] = vr["achieved"] / peak
-    vr["note"] = pk["note"] + "; achieved = products x product rounds x 9 Fq-product equivalents / kernel ms (HIP events); the rounds exclude the tower's additions, carries, " \
+    vr["note"] = pk["note"] + "; achieved = products x product rounds x 3444 multiply-adds / kernel ms (HIP events); the rounds exclude the tower's additions, carries, " \
                               "selects and lane exchanges, which is what the fraction below 1 is made of"
     return {"metric": "BLS12-377 Miller loops/s (2-pair products, 1 final exponentiation per product)", "value": 2 * m / secs, "valu_roofline": vr,
             "products": m, "device_ms": best["total_ms"], "wall_ms_incl_pcie": best["wall_ms"], "miller_ms": best["miller_ms"], "final_exp_ms": best["final_exp_ms"],

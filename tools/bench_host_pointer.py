@@ -51,8 +51,17 @@ def main():
             o = ffi.msm(a.group, h_bases, None, h_sc)
             ts.append((time.perf_counter() - t0) * 1e3)
         tm = ffi.msm_timings(a.group)
-        ok = codec.jacobian_to_affine(o, p, ext) == want
+        # the same call on buffers the runtime has never seen (a caller that builds new Vecs per MSM): copies made outside the timing
+        fr = []
+        for _ in range(a.reps):
+            fb, fs = h_bases.copy(), h_sc.copy()
+            t0 = time.perf_counter()
+            o2 = ffi.msm(a.group, fb, None, fs)
+            fr.append((time.perf_counter() - t0) * 1e3)
+            del fb, fs
+        ok = codec.jacobian_to_affine(o, p, ext) == want and codec.jacobian_to_affine(o2, p, ext) == want
         out["chunks"][str(k)] = {"wall_ms": float(np.median(ts)), "min_ms": float(np.min(ts)), "ratio_to_resident": float(np.median(ts)) / res_ms, "parity": ok,
+                                 "fresh_buffers_wall_ms": float(np.median(fr)), "fresh_buffers_min_ms": float(np.min(fr)),
                                  "kernel_ms": {q: round(tm[q], 3) for q in ("convert_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")}}
         if not ok:
             raise SystemExit("PARITY FAILURE at chunks=%d" % k)

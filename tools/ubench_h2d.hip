@@ -39,6 +39,24 @@ int main(int argc, char** argv) {
     t0 = now_ms(); CK(hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); double t = now_ms() - t0;
     printf("pinned hipMemcpyAsync     %8.3f ms  %6.1f GB/s\n", t, bytes / t / 1e6);
   }
+  // a FRESH buffer per call (what a caller that builds new Vecs for every MSM hands over): allocation and first touch outside the timing
+  for (int r = 0; r < 5; r++) {
+    char* fresh = (char*)malloc(bytes);
+    for (size_t i = 0; i < bytes; i += 4096) fresh[i] = (char)(i + r);
+    t0 = now_ms(); CK(hipMemcpy(dev, fresh, bytes, hipMemcpyHostToDevice)); double t = now_ms() - t0;
+    printf("FRESH pageable buffer hipMemcpy   %8.3f ms  %6.1f GB/s\n", t, bytes / t / 1e6);
+    free(fresh);
+  }
+  for (int r = 0; r < 3; r++) {     // ... in four chunks on a stream, as the pipelined entry sends them
+    char* fresh = (char*)malloc(bytes);
+    for (size_t i = 0; i < bytes; i += 4096) fresh[i] = (char)(i + r);
+    t0 = now_ms();
+    for (int k = 0; k < 4; k++) CK(hipMemcpyAsync(dev + k * (bytes / 4), fresh + k * (bytes / 4), bytes / 4, hipMemcpyHostToDevice, s));
+    CK(hipStreamSynchronize(s));
+    double t = now_ms() - t0;
+    printf("FRESH pageable buffer, 4 async chunks %8.3f ms  %6.1f GB/s\n", t, bytes / t / 1e6);
+    free(fresh);
+  }
   for (size_t kb : {64, 256, 1024, 4096, 16384}) {
     const size_t blk = kb << 10;
     t0 = now_ms();

@@ -159,3 +159,32 @@ def test_g2_and_bw6_pipelined(gpu, chunks, golden):
     for kk in (0, 2):
         chunks(kk)
         assert co.jac_to_affine(gpu.msm("bw6_761_g1", xy, None, sc), "761") == exp, kk
+
+
+def test_concurrent_pipelined_calls_from_three_host_threads(gpu, chunks):
+    """Three host threads inside the pipelined entry at once (each call leases its own engine: arena, carrier table, copy stream and
+    events), different inputs and sizes, twice over so engines are re-leased with their carriers dirty: every result is the oracle's."""
+    import threading
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    jobs = []
+    for i, n in enumerate(((1 << 17) + 11, (1 << 17) + 4096, (1 << 18) - 5)):
+        xy = _gen(gpu, "bls12_377_g1", n, 900 + i, gen.reshape(-1), 12)
+        sc = _uniform(n, 4, 60, 910 + i)
+        jobs.append((xy, sc, co.jac_to_affine(co.msm("bls12_377_g1", xy, None, sc, threads=_threads()), "g1_377")))
+    chunks(3)
+    got, errs = {}, []
+
+    def run(i, rnd):
+        try:
+            xy, sc, _ = jobs[i]
+            got[(i, rnd)] = co.jac_to_affine(gpu.msm("bls12_377_g1", xy, None, sc), "g1_377")
+        except Exception as e:                               # noqa: BLE001
+            errs.append(repr(e))
+    for rnd in range(2):
+        th = [threading.Thread(target=run, args=(i, rnd)) for i in range(3)]
+        for t in th: t.start()
+        for t in th: t.join()
+    assert not errs, errs
+    for (i, rnd), v in got.items():
+        assert v == jobs[i][2], (i, rnd)
+    assert len(got) == 6

@@ -418,8 +418,8 @@ class MsmConfig:
     def host_pointer(self, resident_result, resident_ms):
         """Secondary number (not `value`; SURVEY.md section 8d "report also with H2D included"): the SAME job through the host-pointer entry
         point msm_<group> - the call INTEGRATION.md's Rust wrapper makes with the slices bls-crypto hands to multi_scalar_mul
-        (crates/bls-crypto/src/bls/signature.rs:82-85, public.rs:58-61) - on PAGEABLE numpy buffers: the scalars cross PCIe first, the bases
-        follow in index chunks that are accumulated while the next one is in flight (csrc/msm.h HostIn).  Reported beside the unpipelined
+        (crates/bls-crypto/src/bls/signature.rs:82-85, public.rs:58-61) - on PAGEABLE numpy buffers: scalars and bases cross PCIe in index
+        chunks, each sorted beside and accumulated behind the one before while the next is in flight (csrc/msm.h HostIn).  Reported beside the unpipelined
         form (three transfers, then the resident pipeline) and the bare transfer time of the same bytes."""
         from celo_bls_snark_rs_amd import ffi, codec
         reps = max(4, min(self.cx.args.steps, 20))
@@ -482,8 +482,8 @@ class MsmConfig:
                 "kernel_ms": {k: tm_p[k] for k in ("convert_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")},
                 "note": "entry point msm_%s on pageable numpy buffers, wall clock per call (median of %d after 2 warm calls; first_call_ms = the first call, "
                         "which also sizes the engine's staging buffers and takes the driver's first-touch of the pages; fresh_buffers_wall_ms = every call on newly "
-                        "allocated copies of the inputs, wall_ms = the same buffers call after call); kernel_ms.convert = scalars' transfer + "
-                        "digits, .accumulate = first chunk's launch to the last chunk's end (the bases' transfers hide here)" % (self.group, reps)}
+                        "allocated copies of the inputs, wall_ms = the same buffers call after call); kernel_ms.convert = the first chunk's scalars, "
+                        "digits and sort, .accumulate = from there to the last chunk's end (the transfers hide here)" % (self.group, reps)}
 
     def subgroup_entry(self, plain_result):
         """Secondary number (not `value`): the same job through msm_bls12_377_g1_subgroup_dev - the entry point for bases that are elements

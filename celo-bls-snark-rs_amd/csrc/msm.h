@@ -1571,9 +1571,9 @@ template <class G> class MsmEngine {
   // pipeline runs over the table's E entries in NV virtual windows of 2^15 buckets.
   // hin != nullptr: the HOST-POINTER pipeline (round 5; VERDICT r4 item 1 - the call a drop-in caller makes: signature.rs:82-85,
   // public.rs:58-61 hand host slices to multi_scalar_mul).  d_ark_bases / d_inf / d_scalars are then the engine's staging buffers, still
-  // EMPTY: the scalars (and flags) are sent first, the digits and the whole sort run over (chunk, window) virtual windows while the bases
-  // follow in hin->chunks index chunks on a second stream, and every chunk is converted and accumulated (k_accumulate_chunk) as soon as
-  // it has landed - the PCIe time of the bases hides under the accumulation instead of preceding it.
+  // EMPTY: scalars (and flags) and bases cross in hin->chunks index chunks on a copy stream; a chunk's digits and sort run over its
+  // (chunk, window) virtual windows on a sort stream beside the accumulation of the chunk before, and every chunk is converted and
+  // accumulated (k_accumulate_chunk) as soon as it has landed - the PCIe time hides under the accumulation instead of preceding it.
   struct HostIn { const uint64_t* bases; const uint8_t* inf; const uint64_t* scalars; uint32_t chunks; };
   int run_device_windows(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, int win_lo, int win_cnt,
                          uint64_t* out_jac, uint64_t* out_xyzz, hipStream_t stream, const FixedTable* fx = nullptr, const HostIn* hin = nullptr) {
@@ -1611,7 +1611,7 @@ template <class G> class MsmEngine {
       if (ep >= 4096 && ep * 2 <= E) fx_Ep = (uint32_t)ep;       // (a window that holds most entries - tiny scalars - gains nothing: the uncompacted form)
     }
     if (fx) { pl.glv = false; pl.n = fx_Ep ? fx_Ep : fx->E(); pl.sbits = G::SCALAR_BITS; pl.c = 16; pl.nw = (int)fx->NV; pl.kn = 0; }
-    if (hin && (fx || pl.glv || win_cnt || hin->chunks < 1 || hin->chunks > 64 || !side_stream_.get())) return 2;
+    if (hin && (fx || pl.glv || win_cnt || hin->chunks < 1 || hin->chunks > 64 || !side_stream_.get() || !sort_stream_.get())) return 2;
     const bool glv = pl.glv;
     const uint32_t n = pl.n;
     const int sbits = pl.sbits, c = pl.c, nw_all = pl.nw;
@@ -1737,70 +1737,65 @@ template <class G> class MsmEngine {
     const uint32_t TILE = TILE_EPT * ts_threads, max_tiles = NBIN + ns / TILE + 1;
     uint32_t* d_remap = fx_Ep ? (uint32_t*)(A + o_remap) : nullptr;
     // the two-level sort of the windows [wb, wb + wn) (all of them, or one pass of the host-pointer pipeline)
-    auto sort_windows = [&](uint32_t wb, uint32_t wn) {
-      hipLaunchKernelGGL((k_part_hist<G>), dim3(KB2, wn), dim3(1024), 0, stream, d_digits, d_blockcnt, ns, chunk2, NBIN, wb);
-      hipLaunchKernelGGL((k_part_scan<G>), dim3(wn), dim3(1024), 0, stream, d_blockcnt, d_binstart, d_tileprefix, NBIN, KB2, TILE, wb);
-      hipLaunchKernelGGL((k_part_scatter<G>), dim3(KB2, wn), dim3(1024), 0, stream, d_digits, d_blockcnt, d_recidx, d_reckey, ns, chunk2, HIB, NBIN, (const uint32_t*)d_remap, vw, wb);
-      hipLaunchKernelGGL((k_tile_count<G>), dim3(max_tiles, wn), dim3(ts_threads), 0, stream, d_reckey, d_binstart, d_tileprefix, d_counts, ns, B, HIB, NBIN, wb);
-      hipLaunchKernelGGL((k_tile_sort<G>), dim3(max_tiles, wn), dim3(ts_threads), 0, stream, d_recidx, d_reckey, d_binstart, d_tileprefix, d_counts,
+    auto sort_windows = [&](uint32_t wb, uint32_t wn, hipStream_t st) {
+      hipLaunchKernelGGL((k_part_hist<G>), dim3(KB2, wn), dim3(1024), 0, st, d_digits, d_blockcnt, ns, chunk2, NBIN, wb);
+      hipLaunchKernelGGL((k_part_scan<G>), dim3(wn), dim3(1024), 0, st, d_blockcnt, d_binstart, d_tileprefix, NBIN, KB2, TILE, wb);
+      hipLaunchKernelGGL((k_part_scatter<G>), dim3(KB2, wn), dim3(1024), 0, st, d_digits, d_blockcnt, d_recidx, d_reckey, ns, chunk2, HIB, NBIN, (const uint32_t*)d_remap, vw, wb);
+      hipLaunchKernelGGL((k_tile_count<G>), dim3(max_tiles, wn), dim3(ts_threads), 0, st, d_reckey, d_binstart, d_tileprefix, d_counts, ns, B, HIB, NBIN, wb);
+      hipLaunchKernelGGL((k_tile_sort<G>), dim3(max_tiles, wn), dim3(ts_threads), 0, st, d_recidx, d_reckey, d_binstart, d_tileprefix, d_counts,
                          d_starts, d_sorted, d_pfirst, d_pstart, d_plen, d_big, d_nbig, d_mid, d_nmid, ns, B, HIB, NBIN, SEG, PW, d_pbucket, vw, wb);
     };
     if (hin) {
-      // ---- host-pointer pipeline.  Transfers, in this order on the side stream (a pageable hipMemcpyAsync holds the calling thread until
-      // its bytes have left, so every launch below is issued before the NEXT transfer starts):
-      //   scalars (+ flags) of chunk 0 | bases of chunk 0 | the remaining scalars (+ flags) | bases of chunk 1 | ... | bases of chunk K - 1
-      // and behind them on the call's stream: digits + sort + schedule of chunk 0's windows, conversion + accumulation of chunk 0 (running
-      // while the remaining scalars and chunk 1 cross), digits + sort + schedules of the other chunks' windows in ONE pass, then conversion
-      // + accumulation chunk by chunk.  The accumulation is the longer side of every stage from chunk 0 on (2^20 G1 terms: 2.4 ms of
-      // accumulation against 1.8 ms of transfers), so what the call pays on top of the resident pipeline is the first chunk's transfer.
-      hipStream_t cs = side_stream_.get();
-      if (ev_copy.size() < (size_t)K + 2) {
+      // ---- host-pointer pipeline.  Three streams.  Transfers on the copy stream, in this order (a pageable hipMemcpyAsync holds the
+      // calling thread until its bytes have left, so every launch below is issued before the NEXT transfer starts):
+      //   scalars (+ flags) of chunk 0 | bases of chunk 0 | scalars of chunk 1 | bases of chunk 1 | ...
+      // behind each chunk's scalars, on the SORT stream: digits + two-level sort + longest-first schedule of the chunk's virtual windows
+      // (the sort's scratch is indexed by virtual window: passes of different chunks share nothing) - it runs beside the accumulation
+      // of the chunk before; behind each chunk's bases and its sort, on the call's stream: conversion + k_accumulate_chunk.  The
+      // accumulation is the longer side of every stage from chunk 0 on (2^20 G1 terms: 0.61 ms per quarter against 0.58 ms of
+      // transfers), so what the call pays on top of the resident pipeline is the first chunk's transfer.
+      hipStream_t cs = side_stream_.get(), ss = sort_stream_.get();
+      if (ev_copy.size() < 3 * (size_t)K + 1) {
         const size_t have = ev_copy.size();
-        ev_copy.resize((size_t)K + 2, nullptr);
+        ev_copy.resize(3 * (size_t)K + 1, nullptr);
         for (size_t i = have; i < ev_copy.size(); i++) HIP_OK(hipEventCreateWithFlags(&ev_copy[i], hipEventDisableTiming));
       }
+      hipEvent_t* ev_sc = ev_copy.data();             // [k]: chunk k's scalars are on the device
+      hipEvent_t* ev_bs = ev_copy.data() + K;         // [k]: chunk k's bases are
+      hipEvent_t* ev_so = ev_copy.data() + 2 * K;     // [k]: chunk k's runs, pieces and schedule are ready
       HIP_OK(hipMemsetAsync(d_counts, 0, o_zero_end - o_counts, stream));       // (the per-call fills run under the first transfer)
       HIP_OK(hipMemsetAsync(d_carrier, 0, (size_t)total * IO::XYZZ_WORDS * 4, stream));
+      HIP_OK(hipEventRecord(ev_copy[3 * K], stream));
+      HIP_OK(hipStreamWaitEvent(ss, ev_copy[3 * K], 0));
       constexpr size_t PT_BYTES = 2 * (size_t)IO::ARK64 * 8;
       const uint32_t cslots = (uint32_t)nw * PW;
-      auto send_scalars = [&](size_t lo, size_t hi, hipEvent_t done) -> int {
-        HIP_OK(hipMemcpyAsync((char*)d_scalars + lo * SW * 4, (const char*)hin->scalars + lo * SW * 4, (hi - lo) * SW * 4, hipMemcpyHostToDevice, cs));
-        if (hin->inf) HIP_OK(hipMemcpyAsync((char*)d_inf + lo, hin->inf + lo, hi - lo, hipMemcpyHostToDevice, cs));
-        HIP_OK(hipEventRecord(done, cs));
-        HIP_OK(hipStreamWaitEvent(stream, done, 0));
-        return 0;
-      };
-      auto schedule_chunk = [&](uint32_t k) {      // longest-first schedule over the chunk's own slots (its virtual windows are adjacent)
-        uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;
-        hipLaunchKernelGGL((k_size_hist<G>), dim3(cslots / 256 < 512 ? (cslots + 255) / 256 : 512), dim3(256), 0, stream, d_plen + (size_t)k * cslots, bins_k, cslots);
-        hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, bins_k, bins_k + SIZE_BINS);
-        hipLaunchKernelGGL((k_size_scatter<G>), dim3((cslots + 4095) / 4096), dim3(1024), 0, stream, d_plen + (size_t)k * cslots, bins_k, d_order + (size_t)k * cslots, cslots);
-      };
-      auto send_and_accumulate = [&](uint32_t k) -> int {
+      for (uint32_t k = 0; k < K; k++) {
         const size_t lo = (size_t)k * cm, cnt = (lo + cm <= n ? (size_t)cm : (size_t)n - lo);
+        // scalars -> digits, sort, schedule (sort stream)
+        HIP_OK(hipMemcpyAsync((char*)d_scalars + lo * SW * 4, (const char*)hin->scalars + lo * SW * 4, cnt * SW * 4, hipMemcpyHostToDevice, cs));
+        if (hin->inf) HIP_OK(hipMemcpyAsync((char*)d_inf + lo, hin->inf + lo, cnt, hipMemcpyHostToDevice, cs));
+        HIP_OK(hipEventRecord(ev_sc[k], cs));
+        HIP_OK(hipStreamWaitEvent(ss, ev_sc[k], 0));
+        if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, ss, cm, (k + 1) * cm, k * cm)) return 3;
+        sort_windows(k * (uint32_t)nw, (uint32_t)nw, ss);
+        uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;       // longest-first schedule over the chunk's own slots (its virtual windows are adjacent)
+        hipLaunchKernelGGL((k_size_hist<G>), dim3(cslots / 256 < 512 ? (cslots + 255) / 256 : 512), dim3(256), 0, ss, d_plen + (size_t)k * cslots, bins_k, cslots);
+        hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, ss, bins_k, bins_k + SIZE_BINS);
+        hipLaunchKernelGGL((k_size_scatter<G>), dim3((cslots + 4095) / 4096), dim3(1024), 0, ss, d_plen + (size_t)k * cslots, bins_k, d_order + (size_t)k * cslots, cslots);
+        HIP_OK(hipEventRecord(ev_so[k], ss));
+        if (k == 0) {
+          HIP_OK(hipStreamWaitEvent(stream, ev_so[0], 0));
+          HIP_OK(hipEventRecord(ev[1], stream));      // ("convert" = chunk 0's scalars, digits, sort and schedule; "sort" is empty on this path;
+          HIP_OK(hipEventRecord(ev[2], stream));      //  "accumulate" = everything from here to the last chunk's end)
+        }
+        // bases -> conversion, accumulation (the call's stream)
         HIP_OK(hipMemcpyAsync((char*)d_ark_bases + lo * PT_BYTES, (const char*)hin->bases + lo * PT_BYTES, cnt * PT_BYTES, hipMemcpyHostToDevice, cs));
-        HIP_OK(hipEventRecord(ev_copy[2 + k], cs));
-        HIP_OK(hipStreamWaitEvent(stream, ev_copy[2 + k], 0));
+        HIP_OK(hipEventRecord(ev_bs[k], cs));
+        HIP_OK(hipStreamWaitEvent(stream, ev_bs[k], 0));
+        if (k) HIP_OK(hipStreamWaitEvent(stream, ev_so[k], 0));
         hipLaunchKernelGGL((k_convert_bases<G>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, d_ark_bases + lo * 2 * IO::ARK64, d_bases + lo * IO::AFF_WORDS, cnt);
-        const uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;
         hipLaunchKernelGGL((k_accumulate_chunk<G>), dim3((cslots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart + (size_t)k * cslots, d_plen + (size_t)k * cslots,
                            d_order + (size_t)k * cslots, bins_k + SIZE_BINS, d_partials + (size_t)k * cslots * IO::XYZZ_WORDS, d_pbucket + (size_t)k * cslots, d_carrier, k ? 1u : 0u);
-        return 0;
-      };
-      const size_t first = K > 1 ? (size_t)cm : (size_t)n;
-      if (send_scalars(0, first, ev_copy[0])) return 1;
-      if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream, cm, K > 1 ? cm : npad, 0)) return 3;
-      HIP_OK(hipEventRecord(ev[1], stream));      // ("convert" = the first scalars' transfer and their digits)
-      sort_windows(0, (uint32_t)nw);
-      schedule_chunk(0);
-      HIP_OK(hipEventRecord(ev[2], stream));      // ("sort" = chunk 0's; "accumulate" = everything from here to the last chunk's end)
-      if (send_and_accumulate(0)) return 1;
-      if (K > 1) {
-        if (send_scalars(first, n, ev_copy[1])) return 1;
-        if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream, cm, npad, cm)) return 3;
-        sort_windows((uint32_t)nw, (K - 1) * (uint32_t)nw);
-        for (uint32_t k = 1; k < K; k++) schedule_chunk(k);
-        for (uint32_t k = 1; k < K; k++) if (send_and_accumulate(k)) return 1;
       }
     } else {
     // window shards (A/B hook CELO_SIDE_CONVERT): the conversion of ALL n bases is replicated on every shard while its sort shrinks to a
@@ -1828,7 +1823,7 @@ template <class G> class MsmEngine {
     else if (glv) { if (launch_digits<4, GlvExpand<G>::BITS>(c, (const uint32_t*)(A + o_sc2), nullptr, d_digits_all, n, stream)) return 3; }
     else if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, stream)) return 3;
     HIP_OK(hipMemsetAsync(d_counts, 0, o_zero_end - o_counts, stream));
-    sort_windows(0, (uint32_t)nw);
+    sort_windows(0, (uint32_t)nw, stream);
     // ---- work items, longest first
     hipLaunchKernelGGL((k_size_hist<G>), dim3(slots / 256 < 512 ? (slots + 255) / 256 : 512), dim3(256), 0, stream, d_plen, d_bins, slots);
     hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
@@ -2383,8 +2378,9 @@ template <class G> class MsmEngine {
   static constexpr size_t H_OUT_POINTS = 17 * 64;   // pinned result buffer: (LB + 1) * windows points; checked per call
   OwnedStream stream_;
   OwnedStream side_stream_;            // window shards: the base conversion beside the sort (CELO_SIDE_CONVERT)
+  OwnedStream sort_stream_;            // host-pointer pipeline: digits + sort + schedule of chunk k beside the accumulation of chunk k - 1
   hipEvent_t ev_side[2] = {nullptr, nullptr};
-  std::vector<hipEvent_t> ev_copy;     // host-pointer pipeline: one per transfer (the scalars, then each chunk of bases)
+  std::vector<hipEvent_t> ev_copy;     // host-pointer pipeline: per chunk - scalars sent, bases sent, sorted; + one for the per-call fills
   std::vector<int32_t> horner_steps;   // the host epilogue's step list (host64.h), rebuilt per call
   std::vector<uint32_t> gls_off;       // instance offsets of the expanded (GLS) batch
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -416,7 +416,7 @@ int celo_amd_ubench_fp(float out[9]) {
   return celo::ubench_fp_run(out);
 }
 int celo_amd_msm_set_host_chunks(int chunks) {
-  if (chunks < -1 || chunks > 64) return 1;
+  if (chunks < -1 || (chunks >= 0 && ((chunks & 0xFF) > 64 || ((chunks >> 8) & 15) > 9 || ((chunks >> 12) & 15) > 9 || (chunks >> 16)))) return 1;      // (chunks | (head_split + 1) << 8 | (tail_split + 1) << 12)
   celo::host_chunks_override().store(chunks);
   return 0;
 }

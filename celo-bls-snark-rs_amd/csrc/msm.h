@@ -1450,6 +1450,7 @@ struct MsmTuning {
   int seg_halves;          // piece length in half mean-bucket lengths (4 = twice the mean); 0 = not set: the path's own default
   uint32_t bitsum_lanes_max;
   uint32_t host_chunks;    // host-pointer entry: index chunks of the pipelined transfer (CELO_HOST_CHUNKS; 0 or 1 = the plain form)
+  uint32_t host_head_split, host_tail_split; // ... how often the first / the last of them is cut in halves (CELO_HOST_HEAD_SPLIT, CELO_HOST_TAIL_SPLIT)
   static const MsmTuning& get() {
     static const MsmTuning t = [] {
       MsmTuning v;
@@ -1459,6 +1460,8 @@ struct MsmTuning {
       v.gls_force = false;       // the library never applies psi to the plain entry points' arbitrary curve points (the round-3 measurement hook is gone)
       v.lane_bitsum = getenv("CELO_NO_LANE_BITSUM") == nullptr;
       v.host_chunks = getenv("CELO_HOST_CHUNKS") ? (uint32_t)atoi(getenv("CELO_HOST_CHUNKS")) : 0xFFFFFFFFu;   // not set: the group's own default
+      v.host_head_split = getenv("CELO_HOST_HEAD_SPLIT") ? (uint32_t)atoi(getenv("CELO_HOST_HEAD_SPLIT")) : 0xFFFFFFFFu;
+      v.host_tail_split = getenv("CELO_HOST_TAIL_SPLIT") ? (uint32_t)atoi(getenv("CELO_HOST_TAIL_SPLIT")) : 0xFFFFFFFFu;
       v.fx_compact = getenv("CELO_FX_NO_COMPACT") == nullptr;        // A/B switch: fixed base, digits compacted by virtual window
       v.host_threads = getenv("CELO_NO_HOST_THREADS") == nullptr;
       v.seg_halves = getenv("CELO_SEG_HALVES") ? atoi(getenv("CELO_SEG_HALVES")) : 0;
@@ -1574,7 +1577,35 @@ template <class G> class MsmEngine {
   // EMPTY: scalars (and flags) and bases cross in hin->chunks index chunks on a copy stream; a chunk's digits and sort run over its
   // (chunk, window) virtual windows on a sort stream beside the accumulation of the chunk before, and every chunk is converted and
   // accumulated (k_accumulate_chunk) as soon as it has landed - the PCIe time hides under the accumulation instead of preceding it.
-  struct HostIn { const uint64_t* bases; const uint8_t* inf; const uint64_t* scalars; uint32_t chunks; };
+  struct HostIn { const uint64_t* bases; const uint8_t* inf; const uint64_t* scalars; uint32_t chunks, head_split, tail_split; };
+  // The chunks of the host-pointer pipeline: `chunks` index chunks of cm points (a multiple of 1024), the FIRST of them cut in halves
+  // `head_split` times, smallest piece first - the pipeline is bound by the GPU's work from the moment the first chunk has landed
+  // (accumulating a chunk takes a little longer than sending the next), so what the call pays beyond the resident pipeline is the
+  // first chunk's transfer: it is short.  On the device chunk k lives at the virtual index k cm (the staging buffers have holes behind
+  // short chunks): nothing below the transfers knows chunk lengths.  Returns the number of chunks (<= 72).
+  static constexpr uint32_t HOST_CHUNKS_MAX = 72;
+  static constexpr uint32_t HOST_HEAD_SPLIT_DEFAULT = 1, HOST_TAIL_SPLIT_DEFAULT = 0;
+  static uint32_t host_chunk_plan(size_t n, uint32_t chunks, uint32_t head_split, uint32_t tail_split, uint32_t& cm, uint32_t* clen) {
+    cm = (uint32_t)(((n + chunks - 1) / chunks + 1023u) & ~size_t(1023));
+    const uint32_t base = (uint32_t)((n + cm - 1) / cm);       // >= 2 for every caller (chunks >= 2, chunks of >= 2^16 points)
+    uint32_t halves[8], nh = 0, piece = cm;
+    for (uint32_t t = 0; t < head_split && t < 8 && piece >= (1u << 16); t++) {
+      halves[nh] = ((piece + 1) / 2 + 1023u) & ~1023u;
+      piece -= halves[nh++];
+    }
+    uint32_t K = 0;
+    clen[K++] = piece;
+    while (nh) clen[K++] = halves[--nh];
+    for (uint32_t b = 1; b + 1 < base; b++) clen[K++] = cm;
+    piece = (uint32_t)(n - (size_t)(base - 1) * cm);           // the last base chunk, largest piece first
+    for (uint32_t t = 0; t < tail_split && t < 8 && piece >= (1u << 16); t++) {
+      const uint32_t half = ((piece + 1) / 2 + 1023u) & ~1023u;
+      clen[K++] = half;
+      piece -= half;
+    }
+    clen[K++] = piece;
+    return K;
+  }
   int run_device_windows(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, int win_lo, int win_cnt,
                          uint64_t* out_jac, uint64_t* out_xyzz, hipStream_t stream, const FixedTable* fx = nullptr, const HostIn* hin = nullptr) {
     if (n_ == 0) {
@@ -1624,10 +1655,8 @@ template <class G> class MsmEngine {
     // the sort's view: ns entries in each of nws windows - the call's own, or (host-pointer pipeline) the K index chunks of cm points
     // times the windows, chunk-major: virtual window k nw + w
     uint32_t K = 0, cm = n;
-    if (hin) {
-      cm = ((n + hin->chunks - 1) / hin->chunks + 1023u) & ~1023u;
-      K = (n + cm - 1) / cm;
-    }
+    uint32_t clen[HOST_CHUNKS_MAX];
+    if (hin) K = host_chunk_plan(n, hin->chunks, hin->head_split, hin->tail_split, cm, clen);
     const uint32_t ns = hin ? cm : n, nws = hin ? K * (uint32_t)nw : (uint32_t)nw, vw = hin ? (uint32_t)nw : 0u;
     const uint32_t npad = hin ? K * cm : n;
     if ((uint64_t)npad * (uint64_t)nw_all >= (uint64_t(1) << 32)) return 2;
@@ -1666,7 +1695,7 @@ template <class G> class MsmEngine {
     // ---- workspace arena
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
-    const size_t o_bases = take(fx ? 0 : (size_t)n * IO::AFF_WORDS * 4);
+    const size_t o_bases = take(fx ? 0 : (size_t)npad * IO::AFF_WORDS * 4);       // (npad > n: the host-pointer pipeline's virtual indices)
     const size_t o_sc2 = take(glv ? (size_t)n * 16 : 0);
     const size_t o_digits = take((size_t)npad * nw_all * 2);
     const size_t o_remap = take(fx_Ep ? (size_t)n * nw_all * 4 : 0);
@@ -1769,14 +1798,15 @@ template <class G> class MsmEngine {
       HIP_OK(hipStreamWaitEvent(ss, ev_copy[3 * K], 0));
       constexpr size_t PT_BYTES = 2 * (size_t)IO::ARK64 * 8;
       const uint32_t cslots = (uint32_t)nw * PW;
-      for (uint32_t k = 0; k < K; k++) {
-        const size_t lo = (size_t)k * cm, cnt = (lo + cm <= n ? (size_t)cm : (size_t)n - lo);
+      size_t hlo = 0;                                  // the chunk's first point in the caller's arrays
+      for (uint32_t k = 0; k < K; hlo += clen[k], k++) {
+        const size_t lo = (size_t)k * cm, cnt = clen[k];      // ... and on the device (virtual index)
         // scalars -> digits, sort, schedule (sort stream)
-        HIP_OK(hipMemcpyAsync((char*)d_scalars + lo * SW * 4, (const char*)hin->scalars + lo * SW * 4, cnt * SW * 4, hipMemcpyHostToDevice, cs));
-        if (hin->inf) HIP_OK(hipMemcpyAsync((char*)d_inf + lo, hin->inf + lo, cnt, hipMemcpyHostToDevice, cs));
+        HIP_OK(hipMemcpyAsync((char*)d_scalars + lo * SW * 4, (const char*)hin->scalars + hlo * SW * 4, cnt * SW * 4, hipMemcpyHostToDevice, cs));
+        if (hin->inf) HIP_OK(hipMemcpyAsync((char*)d_inf + lo, hin->inf + hlo, cnt, hipMemcpyHostToDevice, cs));
         HIP_OK(hipEventRecord(ev_sc[k], cs));
         HIP_OK(hipStreamWaitEvent(ss, ev_sc[k], 0));
-        if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, n, ss, cm, (k + 1) * cm, k * cm)) return 3;
+        if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, (uint32_t)(lo + cnt), ss, cm, (k + 1) * cm, k * cm)) return 3;    // (lanes behind the chunk's last point: "no digit")
         sort_windows(k * (uint32_t)nw, (uint32_t)nw, ss);
         uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;       // longest-first schedule over the chunk's own slots (its virtual windows are adjacent)
         hipLaunchKernelGGL((k_size_hist<G>), dim3(cslots / 256 < 512 ? (cslots + 255) / 256 : 512), dim3(256), 0, ss, d_plen + (size_t)k * cslots, bins_k, cslots);
@@ -1789,7 +1819,7 @@ template <class G> class MsmEngine {
           HIP_OK(hipEventRecord(ev[2], stream));      //  "accumulate" = everything from here to the last chunk's end)
         }
         // bases -> conversion, accumulation (the call's stream)
-        HIP_OK(hipMemcpyAsync((char*)d_ark_bases + lo * PT_BYTES, (const char*)hin->bases + lo * PT_BYTES, cnt * PT_BYTES, hipMemcpyHostToDevice, cs));
+        HIP_OK(hipMemcpyAsync((char*)d_ark_bases + lo * PT_BYTES, (const char*)hin->bases + hlo * PT_BYTES, cnt * PT_BYTES, hipMemcpyHostToDevice, cs));
         HIP_OK(hipEventRecord(ev_bs[k], cs));
         HIP_OK(hipStreamWaitEvent(stream, ev_bs[k], 0));
         if (k) HIP_OK(hipStreamWaitEvent(stream, ev_so[k], 0));
@@ -2029,6 +2059,25 @@ template <class G> class MsmEngine {
   int run_host_windows(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, size_t n, int win_lo, int win_cnt, uint64_t* out_jac,
                        uint64_t* out_xyzz, hipStream_t stream) {
     if (n == 0) return run_device_windows(nullptr, nullptr, nullptr, 0, win_lo, win_cnt, out_jac, out_xyzz, stream);
+    // the pipelined form (run_device_windows' HostIn) from 2^17 terms up, in chunks of at least 2^16 points; the prover's entry points
+    // (ark_zero_identity: the flags come from the bases), the GLV split (its expansion reads bases and scalars together) and window
+    // shards keep the plain form below: three transfers, then the resident pipeline
+    const int ovr = host_chunks_override().load();
+    // measured on the MI355X box (profiles/r5_host_pointer_*.json; DESIGN.md section 4 "Host-pointer pipeline"): 4 chunks for the 253-bit
+    // groups, 8 for BW6-761, the first one cut in halves once
+    uint32_t chunks = ovr >= 0 ? (uint32_t)(ovr & 0xFF) : MsmTuning::get().host_chunks != 0xFFFFFFFFu ? MsmTuning::get().host_chunks : (G::SCALAR_BITS > 256 ? 8u : 4u);
+    uint32_t head_split = ovr >= 0 && ((ovr >> 8) & 15) ? (uint32_t)((ovr >> 8) & 15) - 1u : MsmTuning::get().host_head_split != 0xFFFFFFFFu ? MsmTuning::get().host_head_split : HOST_HEAD_SPLIT_DEFAULT;
+    uint32_t tail_split = ovr >= 0 && ((ovr >> 12) & 15) ? (uint32_t)((ovr >> 12) & 15) - 1u : MsmTuning::get().host_tail_split != 0xFFFFFFFFu ? MsmTuning::get().host_tail_split : HOST_TAIL_SPLIT_DEFAULT;
+    if (chunks > 64) chunks = 64;
+    if (chunks > (n >> 16)) chunks = (uint32_t)(n >> 16);
+    const bool pipelined = chunks >= 2 && !ark_zero_identity && !win_cnt && !plan(n).glv && n < (size_t(1) << 30);
+    size_t need = n;                 // staging capacity in points: the pipelined form addresses chunk k at k cm
+    if (pipelined) {
+      uint32_t cm, clen[HOST_CHUNKS_MAX];
+      need = (size_t)host_chunk_plan(n, chunks, head_split, tail_split, cm, clen) * cm;
+    }
+    const size_t n_real = n;
+    n = need;
     if (n > cap_in) {
       if (d_in_bases) (void)hipFree(d_in_bases);
       if (d_in_scalars) (void)hipFree(d_in_scalars);
@@ -2039,18 +2088,9 @@ template <class G> class MsmEngine {
       HIP_OK(hipMalloc(&d_in_inf, n));
       cap_in = n;
     }
-    // the pipelined form (run_device_windows' HostIn) from 2^17 terms up, in chunks of at least 2^16 points; the prover's entry points
-    // (ark_zero_identity: the flags come from the bases), the GLV split (its expansion reads bases and scalars together) and window
-    // shards keep the plain form below: three transfers, then the resident pipeline
-    const int ovr = host_chunks_override().load();
-    // measured on the MI355X box (profiles/r5_host_pointer_*.json): 4 chunks for the 253-bit groups (2^20 G1 terms: 5.87 ms unpipelined, 4.68 /
-    // 4.35 / 4.26 / 4.37 / 4.35 / 4.38 ms with 2 / 3 / 4 / 5 / 6 / 8 chunks against 3.24 ms resident), 8 for BW6-761 (2^21 terms: 43.0, 37.4, 36.2 ms
-    // with 0 / 4 / 8 against 32.8 resident)
-    uint32_t chunks = ovr >= 0 ? (uint32_t)ovr : MsmTuning::get().host_chunks != 0xFFFFFFFFu ? MsmTuning::get().host_chunks : (G::SCALAR_BITS > 256 ? 8u : 4u);
-    if (chunks > 64) chunks = 64;
-    if (chunks > (n >> 16)) chunks = (uint32_t)(n >> 16);
-    if (chunks >= 2 && !ark_zero_identity && !win_cnt && !plan(n).glv && n < (size_t(1) << 30)) {
-      const HostIn hin = {bases, inf, scalars, chunks};
+    n = n_real;
+    if (pipelined) {
+      const HostIn hin = {bases, inf, scalars, chunks, head_split, tail_split};
       return run_device_windows(d_in_bases, inf ? d_in_inf : nullptr, (const uint32_t*)d_in_scalars, n, 0, 0, out_jac, out_xyzz, stream, nullptr, &hin);
     }
     HIP_OK(hipMemcpyAsync(d_in_bases, bases, n * 2 * IO::ARK64 * 8, hipMemcpyHostToDevice, stream));

@@ -291,8 +291,14 @@ def ubench_fp():
             "kernel_ms": [out[5], out[6], out[7], out[8]]}
 
 
-def set_host_chunks(chunks):
-    """Host-pointer msm(): index chunks of the pipelined transfer (0 / 1 = unpipelined, -1 = default).  Process-wide."""
+def set_host_chunks(chunks, head_split=None, tail_split=None):
+    """Host-pointer msm(): index chunks of the pipelined transfer (0 / 1 = unpipelined, -1 = default) and, optionally, how often the first /
+    the last chunk is cut in halves (default: the library's).  Process-wide."""
+    if chunks >= 0:
+        if head_split is not None:
+            chunks |= (head_split + 1) << 8
+        if tail_split is not None:
+            chunks |= (tail_split + 1) << 12
     rc = lib().celo_amd_msm_set_host_chunks(C.c_int(chunks))
     if rc != 0:
         raise ValueError(f"host chunks {chunks} not supported")

@@ -384,10 +384,11 @@ int celo_amd_selftest_accumulate(int group, const uint64_t* gen_xy, uint32_t run
 int celo_amd_ubench_fp(float out[9]);
 /* Forces the Pippenger window size (0 = automatic) — tuning and test hook. */
 int celo_amd_msm_set_window_bits(int group, int c);
-/* Host-pointer entry points (msm_<group>, from 2^17 terms): the number of index chunks in which the bases cross PCIe while the
- * chunks already on the device are accumulated (csrc/msm.h HostIn).  0 or 1 = the unpipelined form (three transfers, then the
- * resident pipeline), -1 = the default (CELO_HOST_CHUNKS, else 4 for the BLS12-377 groups and 8 for BW6-761).  Process-wide — tuning and
- * test hook. */
+/* Host-pointer entry points (msm_<group>, from 2^17 terms): the number of index chunks in which scalars and bases cross PCIe while the
+ * chunks already on the device are sorted and accumulated (csrc/msm.h HostIn).  0 or 1 = the unpipelined form (three transfers, then
+ * the resident pipeline), -1 = the default (CELO_HOST_CHUNKS, else 4 for the BLS12-377 groups and 8 for BW6-761).  The first chunk is cut
+ * in halves CELO_HOST_HEAD_SPLIT times (default 1), the last CELO_HOST_TAIL_SPLIT times (default 0); `chunks | (h + 1) << 8 | (t + 1) << 12`
+ * sets those counts to h and t (0 <= h, t <= 8) as well.  Process-wide — tuning and test hook. */
 int celo_amd_msm_set_host_chunks(int chunks);
 
 /* ---- synthetic-workload generators (bench / tests only): writes n affine points

@@ -1,7 +1,8 @@
 """GPU (-m gpu): the HOST-POINTER MSM entry points - the call a drop-in caller makes (crates/bls-crypto/src/bls/signature.rs:82-85,
 public.rs:58-61 hand host slices to VariableBaseMSM::multi_scalar_mul; INTEGRATION.md's Rust wrapper) - in their pipelined form
-(csrc/msm.h run_device_windows' HostIn, round 5): scalars first, the sort over (chunk, window) virtual windows, the bases in index
-chunks that are accumulated while the next one crosses PCIe, every bucket's sum carried from chunk to chunk (k_accumulate_chunk).
+(csrc/msm.h run_device_windows' HostIn, round 5): scalars and bases cross PCIe in index chunks (of unequal length: a short first one),
+each sorted over its (chunk, window) virtual windows beside the accumulation of the chunk before and accumulated while the next one
+crosses, every bucket's sum carried from chunk to chunk (k_accumulate_chunk).
 
 Parity = equality of the affine-normalised group element against the oracle, for every chunk count incl. the unpipelined form, at
 ragged sizes (a short last chunk), with infinity flags, with bucket runs longer than a piece (skew: further pieces + k_merge_carried)
@@ -64,6 +65,10 @@ def test_g1_ragged_sizes_every_chunk_count(gpu, chunks):
             chunks(k)
             got = co.jac_to_affine(gpu.msm("bls12_377_g1", xy, inf, sc), "g1_377")
             assert got == exp, (n, k)
+        # chunks of unequal length: the first cut in halves twice (smallest first), the last once; and neither
+        for k, hs, ts in ((2, 2, 1), (3, 0, 0), (3, 1, 2)):
+            chunks(k, hs, ts)
+            assert co.jac_to_affine(gpu.msm("bls12_377_g1", xy, inf, sc), "g1_377") == exp, (n, k, hs, ts)
         chunks(-1)
         assert co.jac_to_affine(gpu.msm("bls12_377_g1", xy, None, sc), "g1_377") == \
             co.jac_to_affine(co.msm("bls12_377_g1", xy, None, sc, threads=_threads()), "g1_377")

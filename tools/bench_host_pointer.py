@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--chunks", default="0,2,3,4,6,8,12,16")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--tail-split", default="", help="comma list: how often the last chunk is cut in halves (default: the library's)")
+    ap.add_argument("--head-split", default="", help="comma list: how often the first chunk is cut in halves (default: the library's)")
     a = ap.parse_args()
     from celo_bls_snark_rs_amd import ffi, synthetic as syn, codec
     ffi.init(0)
@@ -41,8 +43,10 @@ def main():
     res_ms = float(np.median(ts))
     want = codec.jacobian_to_affine(ref, p, ext)
     out = {"group": a.group, "log_n": a.log_n, "resident_wall_ms": res_ms, "resident_kernel_ms": ffi.msm_timings(a.group), "bytes": h_bases.nbytes + h_sc.nbytes, "chunks": {}}
-    for k in [int(x) for x in a.chunks.split(",")]:
-        ffi.set_host_chunks(k)
+    splits = [int(x) for x in a.head_split.split(",")] if a.head_split else [None]
+    tails = [int(x) for x in a.tail_split.split(",")] if a.tail_split else [None]
+    for k, sp, tl in [(int(x), sp, tl) for x in a.chunks.split(",") for sp in splits for tl in tails]:
+        ffi.set_host_chunks(k, sp, tl)
         for _ in range(2):
             o = ffi.msm(a.group, h_bases, None, h_sc)
         ts = []
@@ -60,7 +64,7 @@ def main():
             fr.append((time.perf_counter() - t0) * 1e3)
             del fb, fs
         ok = codec.jacobian_to_affine(o, p, ext) == want and codec.jacobian_to_affine(o2, p, ext) == want
-        out["chunks"][str(k)] = {"wall_ms": float(np.median(ts)), "min_ms": float(np.min(ts)), "ratio_to_resident": float(np.median(ts)) / res_ms, "parity": ok,
+        out["chunks"][str(k) if sp is None and tl is None else "%d/%s/%s" % (k, sp, tl)] = {"wall_ms": float(np.median(ts)), "min_ms": float(np.min(ts)), "ratio_to_resident": float(np.median(ts)) / res_ms, "parity": ok,
                                  "fresh_buffers_wall_ms": float(np.median(fr)), "fresh_buffers_min_ms": float(np.min(fr)),
                                  "kernel_ms": {q: round(tm[q], 3) for q in ("convert_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")}}
         if not ok:

@@ -2070,11 +2070,12 @@ template <class G> class MsmEngine {
     uint32_t tail_split = ovr >= 0 && ((ovr >> 12) & 15) ? (uint32_t)((ovr >> 12) & 15) - 1u : MsmTuning::get().host_tail_split != 0xFFFFFFFFu ? MsmTuning::get().host_tail_split : HOST_TAIL_SPLIT_DEFAULT;
     if (chunks > 64) chunks = 64;
     if (chunks > (n >> 16)) chunks = (uint32_t)(n >> 16);
-    const bool pipelined = chunks >= 2 && !ark_zero_identity && !win_cnt && !plan(n).glv && n < (size_t(1) << 30);
+    bool pipelined = chunks >= 2 && !ark_zero_identity && !win_cnt && !plan(n).glv && n < (size_t(1) << 30);
     size_t need = n;                 // staging capacity in points: the pipelined form addresses chunk k at k cm
     if (pipelined) {
       uint32_t cm, clen[HOST_CHUNKS_MAX];
       need = (size_t)host_chunk_plan(n, chunks, head_split, tail_split, cm, clen) * cm;
+      if ((uint64_t)need * (uint64_t)plan(n).nw >= (uint64_t(1) << 32)) { pipelined = false; need = n; }      // (the holes would overflow the 32-bit run offsets: plain form)
     }
     const size_t n_real = n;
     n = need;

@@ -1578,34 +1578,7 @@ template <class G> class MsmEngine {
   // (chunk, window) virtual windows on a sort stream beside the accumulation of the chunk before, and every chunk is converted and
   // accumulated (k_accumulate_chunk) as soon as it has landed - the PCIe time hides under the accumulation instead of preceding it.
   struct HostIn { const uint64_t* bases; const uint8_t* inf; const uint64_t* scalars; uint32_t chunks, head_split, tail_split; };
-  // The chunks of the host-pointer pipeline: `chunks` index chunks of cm points (a multiple of 1024), the FIRST of them cut in halves
-  // `head_split` times, smallest piece first - the pipeline is bound by the GPU's work from the moment the first chunk has landed
-  // (accumulating a chunk takes a little longer than sending the next), so what the call pays beyond the resident pipeline is the
-  // first chunk's transfer: it is short.  On the device chunk k lives at the virtual index k cm (the staging buffers have holes behind
-  // short chunks): nothing below the transfers knows chunk lengths.  Returns the number of chunks (<= 72).
-  static constexpr uint32_t HOST_CHUNKS_MAX = 72;
-  static constexpr uint32_t HOST_HEAD_SPLIT_DEFAULT = 1, HOST_TAIL_SPLIT_DEFAULT = 0;
-  static uint32_t host_chunk_plan(size_t n, uint32_t chunks, uint32_t head_split, uint32_t tail_split, uint32_t& cm, uint32_t* clen) {
-    cm = (uint32_t)(((n + chunks - 1) / chunks + 1023u) & ~size_t(1023));
-    const uint32_t base = (uint32_t)((n + cm - 1) / cm);       // >= 2 for every caller (chunks >= 2, chunks of >= 2^16 points)
-    uint32_t halves[8], nh = 0, piece = cm;
-    for (uint32_t t = 0; t < head_split && t < 8 && piece >= (1u << 16); t++) {
-      halves[nh] = ((piece + 1) / 2 + 1023u) & ~1023u;
-      piece -= halves[nh++];
-    }
-    uint32_t K = 0;
-    clen[K++] = piece;
-    while (nh) clen[K++] = halves[--nh];
-    for (uint32_t b = 1; b + 1 < base; b++) clen[K++] = cm;
-    piece = (uint32_t)(n - (size_t)(base - 1) * cm);           // the last base chunk, largest piece first
-    for (uint32_t t = 0; t < tail_split && t < 8 && piece >= (1u << 16); t++) {
-      const uint32_t half = ((piece + 1) / 2 + 1023u) & ~1023u;
-      clen[K++] = half;
-      piece -= half;
-    }
-    clen[K++] = piece;
-    return K;
-  }
+  static constexpr uint32_t HOST_HEAD_SPLIT_DEFAULT = 1, HOST_TAIL_SPLIT_DEFAULT = 0;      // (host_chunk_plan: runtime.h)
   int run_device_windows(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, int win_lo, int win_cnt,
                          uint64_t* out_jac, uint64_t* out_xyzz, hipStream_t stream, const FixedTable* fx = nullptr, const HostIn* hin = nullptr) {
     if (n_ == 0) {

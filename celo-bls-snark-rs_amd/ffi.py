@@ -35,7 +35,7 @@ EXPORTS = [
     "pairing_product_is_one_bls12_377", "pairing_product_is_one_batch_bls12_377", "celo_amd_pairing_gt_bls12_377",
     "celo_amd_pairing_last_timings", "pairing_product_is_one_bw6_761", "celo_amd_pairing_gt_bw6_761",
     "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
-    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks", "celo_amd_ubench_fp", "celo_amd_selftest_accumulate",
+    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks", "celo_amd_msm_host_chunk_plan", "celo_amd_ubench_fp", "celo_amd_selftest_accumulate",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
     "celo_amd_gen_points_grouped_bls12_377_g1_dev", "celo_amd_gen_points_grouped_bls12_377_g2_dev",
     "batch_verify_bls12_377", "batch_verify_bls12_377_dev", "celo_amd_draw_batch_exponents",
@@ -302,6 +302,14 @@ def set_host_chunks(chunks, head_split=None, tail_split=None):
     rc = lib().celo_amd_msm_set_host_chunks(C.c_int(chunks))
     if rc != 0:
         raise ValueError(f"host chunks {chunks} not supported")
+
+
+def host_chunk_plan(n, chunks, head_split=1, tail_split=0):
+    """(cm, [chunk lengths]) of the pipelined host-pointer entry for n terms; None where the entry would not pipeline.  No device call."""
+    cm = C.c_uint32(0)
+    lens = (C.c_uint32 * 72)()
+    k = lib().celo_amd_msm_host_chunk_plan(C.c_uint64(n), C.c_int(chunks), C.c_int(head_split), C.c_int(tail_split), C.byref(cm), lens)
+    return None if k < 0 else (cm.value, [lens[i] for i in range(k)])
 
 
 def set_window_bits(group, c):

@@ -81,8 +81,8 @@ inline std::atomic<int>& host_chunks_override() { static std::atomic<int> v{-1};
 // `head_split` times, smallest piece first - the pipeline is bound by the GPU's work from the moment the first chunk has landed
 // (accumulating a chunk takes a little longer than sending the next), so what the call pays beyond the resident pipeline is the
 // first chunk's transfer: it is short.  On the device chunk k lives at the virtual index k cm (the staging buffers have holes behind
-// short chunks): nothing below the transfers knows chunk lengths.  Returns the number of chunks (<= 72).
-constexpr uint32_t HOST_CHUNKS_MAX = 72;
+// short chunks): nothing below the transfers knows chunk lengths.  Returns the number of chunks (<= 80 = 64 + 8 + 8).
+constexpr uint32_t HOST_CHUNKS_MAX = 80;
 inline uint32_t host_chunk_plan(size_t n, uint32_t chunks, uint32_t head_split, uint32_t tail_split, uint32_t& cm, uint32_t* clen) {
   cm = (uint32_t)(((n + chunks - 1) / chunks + 1023u) & ~size_t(1023));
   const uint32_t base = (uint32_t)((n + cm - 1) / cm);       // >= 2 for every caller (chunks >= 2, chunks of >= 2^16 points)

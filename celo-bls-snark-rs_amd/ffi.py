@@ -307,7 +307,7 @@ def set_host_chunks(chunks, head_split=None, tail_split=None):
 def host_chunk_plan(n, chunks, head_split=1, tail_split=0):
     """(cm, [chunk lengths]) of the pipelined host-pointer entry for n terms; None where the entry would not pipeline.  No device call."""
     cm = C.c_uint32(0)
-    lens = (C.c_uint32 * 72)()
+    lens = (C.c_uint32 * 80)()
     k = lib().celo_amd_msm_host_chunk_plan(C.c_uint64(n), C.c_int(chunks), C.c_int(head_split), C.c_int(tail_split), C.byref(cm), lens)
     return None if k < 0 else (cm.value, [lens[i] for i in range(k)])
 

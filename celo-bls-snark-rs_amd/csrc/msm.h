@@ -2032,7 +2032,7 @@ template <class G> class MsmEngine {
   int run_host_windows(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, size_t n, int win_lo, int win_cnt, uint64_t* out_jac,
                        uint64_t* out_xyzz, hipStream_t stream) {
     if (n == 0) return run_device_windows(nullptr, nullptr, nullptr, 0, win_lo, win_cnt, out_jac, out_xyzz, stream);
-    // the pipelined form (run_device_windows' HostIn) from 2^17 terms up, in chunks of at least 2^16 points; the prover's entry points
+    // the pipelined form (run_device_windows' HostIn) from 2^18 terms up, in chunks of at least 2^17 points; the prover's entry points
     // (ark_zero_identity: the flags come from the bases), the GLV split (its expansion reads bases and scalars together) and window
     // shards keep the plain form below: three transfers, then the resident pipeline
     const int ovr = host_chunks_override().load();
@@ -2042,7 +2042,11 @@ template <class G> class MsmEngine {
     uint32_t head_split = ovr >= 0 && ((ovr >> 8) & 15) ? (uint32_t)((ovr >> 8) & 15) - 1u : MsmTuning::get().host_head_split != 0xFFFFFFFFu ? MsmTuning::get().host_head_split : HOST_HEAD_SPLIT_DEFAULT;
     uint32_t tail_split = ovr >= 0 && ((ovr >> 12) & 15) ? (uint32_t)((ovr >> 12) & 15) - 1u : MsmTuning::get().host_tail_split != 0xFFFFFFFFu ? MsmTuning::get().host_tail_split : HOST_TAIL_SPLIT_DEFAULT;
     if (chunks > 64) chunks = 64;
-    if (chunks > (n >> 16)) chunks = (uint32_t)(n >> 16);
+    // chunks of at least 2^17 points (2^16 when the count was set by hand - tests): measured (gpurun_out/r5n, G1): 2^17 terms 1.30 ms plain /
+    // 1.46 in two chunks, 2^18 1.95 / 1.90 in two / 2.16 in four, 2^19 3.23 / 2.72 in two / 2.55 in four - a chunk's sort pass and the
+    // accumulation's last round are fixed costs of ~0.08 ms
+    const size_t min_chunk_log = ovr >= 0 ? 16 : 17;
+    if (chunks > (n >> min_chunk_log)) chunks = (uint32_t)(n >> min_chunk_log);
     bool pipelined = chunks >= 2 && !ark_zero_identity && !win_cnt && !plan(n).glv && n < (size_t(1) << 30);
     size_t need = n;                 // staging capacity in points: the pipelined form addresses chunk k at k cm
     if (pipelined) {

@@ -919,10 +919,32 @@ class MixedConfig:
                             "note": "BASELINE config 5 asks for the HBM-roofline fraction of the mixed job: algorithmic bytes (128 B per G1 term, 224 B per G2 term, 288 B per "
                                     "Miller loop) / step wall time; integer-VALU bound.  Median HIP-event ms of the legs while overlapped: G1 MSM %.2f, G2 MSM %.2f, pairings %.2f"
                                     % (d[0], d[1], d[2])}
+        if cx.world == 1 and not cx.devices and self.n >= (1 << 20):
+            line["host_pointer_g2"] = self.host_pointer_g2()
         if not cx.args.no_cpu_baseline:
             cb = self.cpu_baseline(result, seq)
             if cx.rank == 0:
                 line["cpu_baseline"] = cb
+
+    def host_pointer_g2(self):
+        """Secondary number: msm_bls12_377_g2 at 2^20 terms through the host-pointer entry on pageable buffers (the first
+        2^20 of this configuration's G2 bases and scalars), beside the resident entry on the same terms - MsmConfig.host_pointer's block."""
+        from celo_bls_snark_rs_amd import ffi
+        n = 1 << 20
+
+        class Shim:
+            pass
+        sh = Shim()
+        sh.cx, sh.group, sh.n = self.cx, "bls12_377_g2", n
+        sh.bases = self.b2[:n * 24]
+        sh.sc = self.s2[:n]
+        sh.d_sc = self.d2[:n]
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ref = ffi.msm_dev("bls12_377_g2", sh.bases.data_ptr(), 0, sh.d_sc.data_ptr(), n)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return MsmConfig.host_pointer(sh, ref, float(np.median(ts[1:])))
 
     def cpu_baseline(self, result, seq):
         from oracle import cpu_oracle as co

@@ -462,6 +462,22 @@ class MsmConfig:
         if codec.jacobian_to_affine(out, p, ext) != want:
             raise SystemExit("PARITY FAILURE: msm_%s (host pointers, fresh buffers) != the resident entry point" % self.group)
         ms_f = float(np.median(fr))
+        # ... and from page-locked buffers of the library's own allocator (celo_amd_host_alloc: what a wrapper that builds the limb arrays anyway
+        # would write them into): no pinning by the runtime, transfers that do not hold the calling thread
+        pb, ps = ffi.PinnedArray(h_bases.shape, np.uint64), ffi.PinnedArray(h_sc.shape, np.uint64)
+        try:
+            pb.a[...] = h_bases; ps.a[...] = h_sc
+            ffi.msm(self.group, pb.a, None, ps.a)
+            pn = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                out = ffi.msm(self.group, pb.a, None, ps.a)
+                pn.append((time.perf_counter() - t0) * 1e3)
+        finally:
+            pb.close(); ps.close()
+        if codec.jacobian_to_affine(out, p, ext) != want:
+            raise SystemExit("PARITY FAILURE: msm_%s (host pointers, page-locked buffers) != the resident entry point" % self.group)
+        ms_pin = float(np.median(pn))
         # the bare transfer of the same bytes from the same pageable buffers
         d_b = torch.empty_like(self.bases); d_s = torch.empty_like(self.d_sc)
         tb, tsc = torch.from_numpy(h_bases.view(np.int64).reshape(-1)), torch.from_numpy(h_sc.view(np.int64))
@@ -477,12 +493,13 @@ class MsmConfig:
         return {"value": self.n / (ms_p * 1e-3), "unit": "scalar-muls/s", "wall_ms": ms_p, "first_call_ms": first_p,
                 "resident_ms": resident_ms, "ratio_to_resident": ms_p / resident_ms,
                 "fresh_buffers_wall_ms": ms_f, "fresh_buffers_ratio_to_resident": ms_f / resident_ms,
+                "pinned_buffers_wall_ms": ms_pin, "pinned_buffers_ratio_to_resident": ms_pin / resident_ms,
                 "unpipelined_wall_ms": ms_u, "h2d_only_ms": h2d_ms, "h2d_GBps": nbytes / (h2d_ms * 1e-3) / 1e9, "h2d_share_of_wall": h2d_ms / ms_p,
                 "bytes": nbytes, "chunks": "default (CELO_HOST_CHUNKS, else 4; BW6-761: 8)", "parity_with_resident": True,
                 "kernel_ms": {k: tm_p[k] for k in ("convert_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")},
                 "note": "entry point msm_%s on pageable numpy buffers, wall clock per call (median of %d after 2 warm calls; first_call_ms = the first call, "
                         "which also sizes the engine's staging buffers and takes the driver's first-touch of the pages; fresh_buffers_wall_ms = every call on newly "
-                        "allocated copies of the inputs, wall_ms = the same buffers call after call); kernel_ms.convert = the first chunk's scalars, "
+                        "allocated copies of the inputs, wall_ms = the same buffers call after call, pinned_buffers_wall_ms = buffers from celo_amd_host_alloc); kernel_ms.convert = the first chunk's scalars, "
                         "digits and sort, .accumulate = from there to the last chunk's end (the transfers hide here)" % (self.group, reps)}
 
     def subgroup_entry(self, plain_result):

@@ -105,6 +105,18 @@ int celo_amd_use_device(int device) {
   if (int rc = api_bind_thread(device)) return rc;
   return api_enter();
 }
+int celo_amd_host_alloc(size_t bytes, void** out) {
+  if (!out || !bytes) return 2;
+  *out = nullptr;
+  if (int rc = api_enter()) return rc;
+  // portable: page-locked for every device of the process, not only the calling thread's
+  return hipHostMalloc(out, bytes, hipHostMallocPortable) == hipSuccess ? 0 : 1;
+}
+int celo_amd_host_free(void* p) {
+  if (!p) return 0;
+  if (int rc = api_enter()) return rc;
+  return hipHostFree(p) == hipSuccess ? 0 : 1;
+}
 int celo_amd_device_count(int* count) {
   if (!count) return 2;
   *count = device_count();

@@ -35,7 +35,7 @@ EXPORTS = [
     "pairing_product_is_one_bls12_377", "pairing_product_is_one_batch_bls12_377", "celo_amd_pairing_gt_bls12_377",
     "celo_amd_pairing_last_timings", "pairing_product_is_one_bw6_761", "celo_amd_pairing_gt_bw6_761",
     "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
-    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks", "celo_amd_msm_host_chunk_plan", "celo_amd_ubench_fp", "celo_amd_selftest_accumulate",
+    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks", "celo_amd_msm_host_chunk_plan", "celo_amd_host_alloc", "celo_amd_host_free", "celo_amd_ubench_fp", "celo_amd_selftest_accumulate",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
     "celo_amd_gen_points_grouped_bls12_377_g1_dev", "celo_amd_gen_points_grouped_bls12_377_g2_dev",
     "batch_verify_bls12_377", "batch_verify_bls12_377_dev", "celo_amd_draw_batch_exponents",
@@ -302,6 +302,32 @@ def set_host_chunks(chunks, head_split=None, tail_split=None):
     rc = lib().celo_amd_msm_set_host_chunks(C.c_int(chunks))
     if rc != 0:
         raise ValueError(f"host chunks {chunks} not supported")
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory from celo_amd_host_alloc (freed with the object): `.a` is the array."""
+
+    def __init__(self, shape, dtype):
+        self.a = None
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = C.c_void_p()
+        rc = lib().celo_amd_host_alloc(C.c_size_t(nbytes), C.byref(self._p))
+        if rc != 0 or not self._p.value:
+            raise MemoryError(f"celo_amd_host_alloc({nbytes}) failed rc={rc}")
+        buf = (C.c_uint8 * nbytes).from_address(self._p.value)
+        self.a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self.a = None
+            lib().celo_amd_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                        # noqa: BLE001 (interpreter shutdown)
+            pass
 
 
 def host_chunk_plan(n, chunks, head_split=1, tail_split=0):

@@ -36,6 +36,13 @@ extern "C" {
 int celo_amd_init(int device);
 /* Binds the CALLING host thread to `device` for all its later calls (engines, tables and streams are per device). */
 int celo_amd_use_device(int device);
+/* Page-locked host memory for the arrays a caller hands to the host-pointer entry points (msm_<group>, msm_batch_<group>, ...): the
+ * transfers of such a buffer run at the link's rate from the first call on and do not hold the calling thread (a pageable range is
+ * pinned by the HIP runtime the first time it is copied from: DESIGN.md section 4 "Buffers the runtime has never seen" - 2^20 G1 terms
+ * 4.6-4.9 ms per call from newly allocated vectors, 4.0-4.2 ms from reused or page-locked ones).  A wrapper that converts the caller's
+ * points into limbs anyway writes them here.  Free with celo_amd_host_free; 0 on success. */
+int celo_amd_host_alloc(size_t bytes, void** out);
+int celo_amd_host_free(void* p);
 /* Number of HIP devices visible to the process (at most 16 are used). */
 int celo_amd_device_count(int* count);
 /* "gfx950:..." string of the active device into buf; returns 0. */

@@ -193,3 +193,23 @@ def test_concurrent_pipelined_calls_from_three_host_threads(gpu, chunks):
     for (i, rnd), v in got.items():
         assert v == jobs[i][2], (i, rnd)
     assert len(got) == 6
+
+
+def test_page_locked_buffers_from_the_library_allocator(gpu, chunks):
+    """celo_amd_host_alloc: inputs in page-locked memory - the transfers do not hold the calling thread then, so every launch of the pipeline is
+    queued at once and only the events order them; same point as the oracle, pipelined (default and 5 chunks with both ends split) and plain."""
+    n = (1 << 18) + 3000
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    xy = _gen(gpu, "bls12_377_g1", n, 0x9191, gen.reshape(-1), 12)
+    sc = _uniform(n, 4, 60, 0x9192)
+    inf = np.zeros(n, dtype=np.uint8); inf[[3, n - 1]] = 1
+    exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, inf, sc, threads=_threads()), "g1_377")
+    pb, ps, pi = gpu.PinnedArray(xy.shape, np.uint64), gpu.PinnedArray(sc.shape, np.uint64), gpu.PinnedArray(inf.shape, np.uint8)
+    try:
+        pb.a[...] = xy; ps.a[...] = sc; pi.a[...] = inf
+        for args in ((-1,), (5, 2, 1), (0,)):
+            chunks(*args)
+            for _ in range(2):
+                assert co.jac_to_affine(gpu.msm("bls12_377_g1", pb.a, pi.a, ps.a), "g1_377") == exp, args
+    finally:
+        pb.close(); ps.close(); pi.close()

@@ -63,9 +63,20 @@ def main():
             o2 = ffi.msm(a.group, fb, None, fs)
             fr.append((time.perf_counter() - t0) * 1e3)
             del fb, fs
-        ok = codec.jacobian_to_affine(o, p, ext) == want and codec.jacobian_to_affine(o2, p, ext) == want
+        # ... and on page-locked buffers from celo_amd_host_alloc
+        pb, ps = ffi.PinnedArray(h_bases.shape, np.uint64), ffi.PinnedArray(h_sc.shape, np.uint64)
+        pb.a[...] = h_bases; ps.a[...] = h_sc
+        ffi.msm(a.group, pb.a, None, ps.a)
+        pn = []
+        for _ in range(a.reps):
+            t0 = time.perf_counter()
+            o3 = ffi.msm(a.group, pb.a, None, ps.a)
+            pn.append((time.perf_counter() - t0) * 1e3)
+        pb.close(); ps.close()
+        ok = codec.jacobian_to_affine(o, p, ext) == want and codec.jacobian_to_affine(o2, p, ext) == want and codec.jacobian_to_affine(o3, p, ext) == want
         out["chunks"][str(k) if sp is None and tl is None else "%d/%s/%s" % (k, sp, tl)] = {"wall_ms": float(np.median(ts)), "min_ms": float(np.min(ts)), "ratio_to_resident": float(np.median(ts)) / res_ms, "parity": ok,
                                  "fresh_buffers_wall_ms": float(np.median(fr)), "fresh_buffers_min_ms": float(np.min(fr)),
+                                 "pinned_buffers_wall_ms": float(np.median(pn)), "pinned_buffers_min_ms": float(np.min(pn)),
                                  "kernel_ms": {q: round(tm[q], 3) for q in ("convert_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")}}
         if not ok:
             raise SystemExit("PARITY FAILURE at chunks=%d" % k)

@@ -495,7 +495,7 @@ class MsmConfig:
                 "fresh_buffers_wall_ms": ms_f, "fresh_buffers_ratio_to_resident": ms_f / resident_ms,
                 "pinned_buffers_wall_ms": ms_pin, "pinned_buffers_ratio_to_resident": ms_pin / resident_ms,
                 "unpipelined_wall_ms": ms_u, "h2d_only_ms": h2d_ms, "h2d_GBps": nbytes / (h2d_ms * 1e-3) / 1e9, "h2d_share_of_wall": h2d_ms / ms_p,
-                "bytes": nbytes, "chunks": "default (CELO_HOST_CHUNKS, else 4; BW6-761: 8)", "parity_with_resident": True,
+                "bytes": nbytes, "chunks": "default (CELO_HOST_CHUNKS, else n / 2^18 within [4, 16]; BW6-761 [8, 16]; G2 n / 2^19 within [4, 8]), the first halved once", "parity_with_resident": True,
                 "kernel_ms": {k: tm_p[k] for k in ("convert_ms", "sort_ms", "accumulate_ms", "reduce_ms", "total_ms")},
                 "note": "entry point msm_%s on pageable numpy buffers, wall clock per call (median of %d after 2 warm calls; first_call_ms = the first call, "
                         "which also sizes the engine's staging buffers and takes the driver's first-touch of the pages; fresh_buffers_wall_ms = every call on newly "

@@ -2038,7 +2038,14 @@ template <class G> class MsmEngine {
     const int ovr = host_chunks_override().load();
     // measured on the MI355X box (profiles/r5_host_pointer_*.json; DESIGN.md section 4 "Host-pointer pipeline"): 4 chunks for the 253-bit
     // groups, 8 for BW6-761, the first one cut in halves once
-    uint32_t chunks = ovr >= 0 ? (uint32_t)(ovr & 0xFF) : MsmTuning::get().host_chunks != 0xFFFFFFFFu ? MsmTuning::get().host_chunks : (G::SCALAR_BITS > 256 ? 8u : 4u);
+    // ... and from 2^21 terms chunks of about 2^18 points, up to 16 of them (gpurun_out/r5w: G1 2^21 7.43 / 7.18 / 7.19 ms with 4 / 8 / 16 chunks, 2^22
+    // 13.85 / 12.80 / 12.34, 2^23 - / 23.79 / 23.01 (32: 23.79), 2^24 51.3 / 46.6 / 43.4 (32: 43.9, 64: 46.0) = 1.05 x resident; BW6-761 2^22 68.4 / 67.8
+    // / 70.6 with 8 / 16 / 32; the Fq2 group, whose accumulation is three times the transfer, 2^22 37.7 / 37.7 / 39.1 with 4 / 8 / 16)
+    const bool fq2_group = sizeof(F) > 14 * sizeof(uint32_t) && G::SCALAR_BITS <= 256;
+    uint32_t by_size = (uint32_t)(n >> (fq2_group ? 19 : 18));
+    const uint32_t lo_k = G::SCALAR_BITS > 256 ? 8u : 4u, hi_k = fq2_group ? 8u : 16u;
+    by_size = by_size < lo_k ? lo_k : by_size > hi_k ? hi_k : by_size;
+    uint32_t chunks = ovr >= 0 ? (uint32_t)(ovr & 0xFF) : MsmTuning::get().host_chunks != 0xFFFFFFFFu ? MsmTuning::get().host_chunks : by_size;
     uint32_t head_split = ovr >= 0 && ((ovr >> 8) & 15) ? (uint32_t)((ovr >> 8) & 15) - 1u : MsmTuning::get().host_head_split != 0xFFFFFFFFu ? MsmTuning::get().host_head_split : HOST_HEAD_SPLIT_DEFAULT;
     uint32_t tail_split = ovr >= 0 && ((ovr >> 12) & 15) ? (uint32_t)((ovr >> 12) & 15) - 1u : MsmTuning::get().host_tail_split != 0xFFFFFFFFu ? MsmTuning::get().host_tail_split : HOST_TAIL_SPLIT_DEFAULT;
     if (chunks > 64) chunks = 64;

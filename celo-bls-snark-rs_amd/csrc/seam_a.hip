@@ -1363,9 +1363,23 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   uint64_t* d_hxy = (uint64_t*)(d_stage + ((d_body + 255) & ~size_t(255)));
   uint8_t* d_hinf = (uint8_t*)(d_hxy + m * 12);
   uint32_t* d_offs = (uint32_t*)(((uintptr_t)(d_hinf + m) + 255) & ~uintptr_t(255));
-  // the mirrors cover every slot either arena has handed out so far (a handle allocated by another thread DURING this call cannot be
-  // in this call's lists)
-  if (!DS.keys.grow(pk_arena().high_water(), 24) || !DS.sigs.grow(sig_arena().high_water(), 12)) { log_err("batch_verify_strict: device mirror allocation failed"); return false; }
+  // the mirrors cover every slot THIS call's lists name (not every slot either arena has ever handed out - a process that holds
+  // millions of live handles and verifies a few would pay 192 + 96 B of HBM per handle it never shows the device).  The largest slot of
+  // the call is looked up only when a mirror is smaller than its arena - new handles since the last call, when rows are about to be
+  // normalised and uploaded anyway; in the steady state (same validator set, epoch after epoch) the check is two comparisons.
+  {
+    uint32_t need_k = 0, need_s = 0;
+    if (pk_arena().high_water() > DS.keys.cap || sig_arena().high_water() > DS.sigs.cap) {
+      for (size_t b = 0; b < m; b++)
+        for (size_t i = 0; i < blen[b]; i++) {
+          const PublicKey* pk = batches[b].public_keys[i];
+          const Signature* sg = batches[b].signatures[i];
+          if (pk && pk->slot >= need_k) need_k = pk->slot + 1;       // (null handles: the workers below fail the call)
+          if (sg && sg->slot >= need_s) need_s = sg->slot + 1;
+        }
+    }
+    if (!DS.keys.grow(need_k, 24) || !DS.sigs.grow(need_s, 12)) { log_err("batch_verify_strict: device mirror allocation failed"); return false; }
+  }
   Mirror& MK = DS.keys;
   Mirror& MS = DS.sigs;
   // `seen` is advanced by the workers BEFORE the rows are on the device: any failure between the first claim and the last scatter drops both

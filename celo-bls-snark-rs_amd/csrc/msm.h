@@ -1577,7 +1577,7 @@ template <class G> class MsmEngine {
   // EMPTY: scalars (and flags) and bases cross in hin->chunks index chunks on a copy stream; a chunk's digits and sort run over its
   // (chunk, window) virtual windows on a sort stream beside the accumulation of the chunk before, and every chunk is converted and
   // accumulated (k_accumulate_chunk) as soon as it has landed - the PCIe time hides under the accumulation instead of preceding it.
-  struct HostIn { const uint64_t* bases; const uint8_t* inf; const uint64_t* scalars; uint32_t chunks, head_split, tail_split; };
+  struct HostIn { const uint64_t* bases; const uint8_t* inf; const uint64_t* scalars; uint32_t chunks, head_split, tail_split; bool ark_zero; };
   static constexpr uint32_t HOST_HEAD_SPLIT_DEFAULT = 1, HOST_TAIL_SPLIT_DEFAULT = 0;      // (host_chunk_plan: runtime.h)
   int run_device_windows(const uint64_t* d_ark_bases, const uint8_t* d_inf, const uint32_t* d_scalars, size_t n_, int win_lo, int win_cnt,
                          uint64_t* out_jac, uint64_t* out_xyzz, hipStream_t stream, const FixedTable* fx = nullptr, const HostIn* hin = nullptr) {
@@ -1771,14 +1771,27 @@ template <class G> class MsmEngine {
       HIP_OK(hipStreamWaitEvent(ss, ev_copy[3 * K], 0));
       constexpr size_t PT_BYTES = 2 * (size_t)IO::ARK64 * 8;
       const uint32_t cslots = (uint32_t)nw * PW;
+      ArkCoord<IO::ARK64> ark_one;
+      F::one().to_ark(ark_one.v);
+      if (hin->ark_zero && d_inf != d_in_inf) return 2;       // (the flags are written into the engine's own buffer)
       size_t hlo = 0;                                  // the chunk's first point in the caller's arrays
       for (uint32_t k = 0; k < K; hlo += clen[k], k++) {
         const size_t lo = (size_t)k * cm, cnt = clen[k];      // ... and on the device (virtual index)
+        // (the prover's queries - hin->ark_zero: a base row (0, 1) is the identity - need the chunk's bases before its digits: bases first)
+        if (hin->ark_zero) {
+          HIP_OK(hipMemcpyAsync((char*)d_ark_bases + lo * PT_BYTES, (const char*)hin->bases + hlo * PT_BYTES, cnt * PT_BYTES, hipMemcpyHostToDevice, cs));
+          HIP_OK(hipEventRecord(ev_bs[k], cs));
+        }
         // scalars -> digits, sort, schedule (sort stream)
         HIP_OK(hipMemcpyAsync((char*)d_scalars + lo * SW * 4, (const char*)hin->scalars + hlo * SW * 4, cnt * SW * 4, hipMemcpyHostToDevice, cs));
         if (hin->inf) HIP_OK(hipMemcpyAsync((char*)d_inf + lo, hin->inf + hlo, cnt, hipMemcpyHostToDevice, cs));
         HIP_OK(hipEventRecord(ev_sc[k], cs));
         HIP_OK(hipStreamWaitEvent(ss, ev_sc[k], 0));
+        if (hin->ark_zero) {
+          HIP_OK(hipStreamWaitEvent(ss, ev_bs[k], 0));
+          hipLaunchKernelGGL((k_flag_ark_zero<G>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ss, d_ark_bases + lo * 2 * IO::ARK64,
+                             hin->inf ? d_inf + lo : nullptr, d_in_inf + lo, cnt, ark_one);
+        }
         if (launch_digits<SW, G::SCALAR_BITS>(c, d_scalars, d_inf, d_digits_all, (uint32_t)(lo + cnt), ss, cm, (k + 1) * cm, k * cm)) return 3;    // (lanes behind the chunk's last point: "no digit")
         sort_windows(k * (uint32_t)nw, (uint32_t)nw, ss);
         uint32_t* bins_k = d_bins + (size_t)k * BINS_STRIDE;       // longest-first schedule over the chunk's own slots (its virtual windows are adjacent)
@@ -1792,8 +1805,10 @@ template <class G> class MsmEngine {
           HIP_OK(hipEventRecord(ev[2], stream));      //  "accumulate" = everything from here to the last chunk's end)
         }
         // bases -> conversion, accumulation (the call's stream)
-        HIP_OK(hipMemcpyAsync((char*)d_ark_bases + lo * PT_BYTES, (const char*)hin->bases + hlo * PT_BYTES, cnt * PT_BYTES, hipMemcpyHostToDevice, cs));
-        HIP_OK(hipEventRecord(ev_bs[k], cs));
+        if (!hin->ark_zero) {
+          HIP_OK(hipMemcpyAsync((char*)d_ark_bases + lo * PT_BYTES, (const char*)hin->bases + hlo * PT_BYTES, cnt * PT_BYTES, hipMemcpyHostToDevice, cs));
+          HIP_OK(hipEventRecord(ev_bs[k], cs));
+        }
         HIP_OK(hipStreamWaitEvent(stream, ev_bs[k], 0));
         if (k) HIP_OK(hipStreamWaitEvent(stream, ev_so[k], 0));
         hipLaunchKernelGGL((k_convert_bases<G>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, d_ark_bases + lo * 2 * IO::ARK64, d_bases + lo * IO::AFF_WORDS, cnt);
@@ -2032,9 +2047,9 @@ template <class G> class MsmEngine {
   int run_host_windows(const uint64_t* bases, const uint8_t* inf, const uint64_t* scalars, size_t n, int win_lo, int win_cnt, uint64_t* out_jac,
                        uint64_t* out_xyzz, hipStream_t stream) {
     if (n == 0) return run_device_windows(nullptr, nullptr, nullptr, 0, win_lo, win_cnt, out_jac, out_xyzz, stream);
-    // the pipelined form (run_device_windows' HostIn) from 2^18 terms up, in chunks of at least 2^17 points; the prover's entry points
-    // (ark_zero_identity: the flags come from the bases), the GLV split (its expansion reads bases and scalars together) and window
-    // shards keep the plain form below: three transfers, then the resident pipeline
+    // the pipelined form (run_device_windows' HostIn) from 2^18 terms up, in chunks of at least 2^17 points (the prover's entry points -
+    // ark_zero_identity: the flags come from the bases - send a chunk's bases before its scalars); the GLV split (its expansion reads bases
+    // and scalars together) and window shards keep the plain form below: three transfers, then the resident pipeline
     const int ovr = host_chunks_override().load();
     // measured on the MI355X box (profiles/r5_host_pointer_*.json; DESIGN.md section 4 "Host-pointer pipeline"): 4 chunks for the 253-bit
     // groups, 8 for BW6-761, the first one cut in halves once
@@ -2054,7 +2069,9 @@ template <class G> class MsmEngine {
     // accumulation's last round are fixed costs of ~0.08 ms
     const size_t min_chunk_log = ovr >= 0 ? 16 : 17;
     if (chunks > (n >> min_chunk_log)) chunks = (uint32_t)(n >> min_chunk_log);
-    bool pipelined = chunks >= 2 && !ark_zero_identity && !win_cnt && !plan(n).glv && n < (size_t(1) << 30);
+    // (the prover runs its four MSMs at once: they hide each other's transfers already, and chunking them costs more than it hides below 2^21
+    // rows - tools/bench_prover_host.py, witness-like assignment: 2^19 rows per query 37.8 ms plain / 45.3 pipelined, 2^20 58.0 / 66.8, 2^21 106.6 / 91.2)
+    bool pipelined = chunks >= 2 && !win_cnt && !plan(n).glv && n < (size_t(1) << 30) && (!ark_zero_identity || ovr >= 0 || n >= (size_t(1) << 21));
     size_t need = n;                 // staging capacity in points: the pipelined form addresses chunk k at k cm
     if (pipelined) {
       uint32_t cm, clen[HOST_CHUNKS_MAX];
@@ -2075,8 +2092,8 @@ template <class G> class MsmEngine {
     }
     n = n_real;
     if (pipelined) {
-      const HostIn hin = {bases, inf, scalars, chunks, head_split, tail_split};
-      return run_device_windows(d_in_bases, inf ? d_in_inf : nullptr, (const uint32_t*)d_in_scalars, n, 0, 0, out_jac, out_xyzz, stream, nullptr, &hin);
+      const HostIn hin = {bases, inf, scalars, chunks, head_split, tail_split, ark_zero_identity};
+      return run_device_windows(d_in_bases, inf || ark_zero_identity ? d_in_inf : nullptr, (const uint32_t*)d_in_scalars, n, 0, 0, out_jac, out_xyzz, stream, nullptr, &hin);
     }
     HIP_OK(hipMemcpyAsync(d_in_bases, bases, n * 2 * IO::ARK64 * 8, hipMemcpyHostToDevice, stream));
     HIP_OK(hipMemcpyAsync(d_in_scalars, scalars, n * SW * 4, hipMemcpyHostToDevice, stream));

@@ -213,3 +213,40 @@ def test_page_locked_buffers_from_the_library_allocator(gpu, chunks):
                 assert co.jac_to_affine(gpu.msm("bls12_377_g1", pb.a, pi.a, ps.a), "g1_377") == exp, args
     finally:
         pb.close(); ps.close(); pi.close()
+
+
+def test_prover_entry_pipelined_identity_rows_from_the_bases(gpu, chunks):
+    """groth16_prove_bw6_761 with host queries of 2^18 + rows: its four MSMs take the pipelined host entry in the form that flags rows
+    x = 0, y = 1 as the identity FROM THE BASES (a chunk's bases cross before its scalars, k_flag_ark_zero runs per chunk on the sort
+    stream).  Identity rows with full-size scalars in the first, a middle and the last chunk of every query; A, B, C equal the proofs of the
+    same key LOADED into fixed-base tables (groth16_load_key_bw6_761: another pipeline altogether) and of the unpipelined form."""
+    from celo_bls_snark_rs_amd import synthetic as syn
+    n_inputs, n_aux = 3, (1 << 18) + 1000
+    n_assign = n_inputs + n_aux
+    nh = (1 << 18) + 700
+
+    def pts(group, k, seed):
+        return syn.device_points(group, k, seed).cpu().numpy().view(np.uint64).reshape(k, 24)
+    a_q, b_q = pts("bw6_761_g1", n_assign + 1, 711), pts("bw6_761_g2", n_assign + 1, 712)
+    l_q, h_q = pts("bw6_761_g1", n_aux, 713), pts("bw6_761_g1", nh, 714)
+    alpha, beta = syn.generator_limbs("bw6_761_g1"), syn.generator_limbs("bw6_761_g2")
+    asg = syn.witness_like_scalars("bw6_761_g1", n_assign, 715)
+    h = syn.uniform_scalars("bw6_761_g1", nh, 716)
+    one = co.to_mont([1], ecc.Q761)[0]
+    zero_row = np.concatenate([np.zeros(12, dtype=np.uint64), one])
+    big = syn.uniform_scalars("bw6_761_g1", 8, 717)
+    for q, rows in ((a_q, (1, 9, n_assign // 2, n_assign)), (b_q, (2, n_assign // 3, n_assign - 1)), (l_q, (0, n_aux // 2 + 3, n_aux - 1)), (h_q, (5, nh // 2, nh - 1))):
+        for r_ in rows:
+            q[r_] = zero_row
+    asg[0], asg[8], asg[n_assign // 2 - 1], asg[n_assign - 1] = big[0], big[1], big[2], big[3]      # full-size scalars on identity rows of a_query (row i + 1 pairs with asg[i])
+    h[5], h[nh // 2], h[nh - 1] = big[4], big[5], big[6]
+    key = gpu.ProvingKey("bw6_761", a_q, b_q, h_q, l_q, alpha, beta, window_bits=16)
+    try:
+        want = [co.jac_to_affine(x, "761") for x in key.prove(asg, n_aux, h)]
+    finally:
+        key.release()
+    assert all(w is not None for w in want)
+    for k in (2, 3, 0):                         # (by default the prover's entry pipelines from 2^21 rows; asked for by hand here)
+        chunks(k)
+        got = [co.jac_to_affine(x, "761") for x in gpu.groth16_prove(a_q, b_q, h_q, l_q, alpha, beta, asg, n_aux, h)]
+        assert got == want, k

@@ -2071,7 +2071,12 @@ template <class G> class MsmEngine {
     if (chunks > (n >> min_chunk_log)) chunks = (uint32_t)(n >> min_chunk_log);
     // (the prover runs its four MSMs at once: they hide each other's transfers already, and chunking them costs more than it hides below 2^21
     // rows - tools/bench_prover_host.py, witness-like assignment: 2^19 rows per query 37.8 ms plain / 45.3 pipelined, 2^20 58.0 / 66.8, 2^21 106.6 / 91.2)
-    bool pipelined = chunks >= 2 && !win_cnt && !plan(n).glv && n < (size_t(1) << 30) && (!ark_zero_identity || ovr >= 0 || n >= (size_t(1) << 21));
+    // (the subgroup entry's GLV split reads bases and scalars together and is not pipelined: from 2^19 terms the transfers it waits for cost
+    // more than the split saves - tools/bench_host_subgroup.py, G1: 2^18 1.76 ms split / 1.87 pipelined, 2^19 3.08 / 2.68, 2^20 5.88 / 4.18, 2^21
+    // 11.6 / 7.07 - so a host-pointer call of that size takes the pipelined plain form; same group element)
+    const bool glv_plan = plan(n).glv;
+    const bool glv_off = glv_plan && !ark_zero_identity && !win_cnt && n >= (size_t(1) << 19);
+    bool pipelined = chunks >= 2 && !win_cnt && (!glv_plan || glv_off) && n < (size_t(1) << 30) && (!ark_zero_identity || ovr >= 0 || n >= (size_t(1) << 21));
     size_t need = n;                 // staging capacity in points: the pipelined form addresses chunk k at k cm
     if (pipelined) {
       uint32_t cm, clen[HOST_CHUNKS_MAX];
@@ -2093,6 +2098,7 @@ template <class G> class MsmEngine {
     n = n_real;
     if (pipelined) {
       const HostIn hin = {bases, inf, scalars, chunks, head_split, tail_split, ark_zero_identity};
+      struct GlvOff { bool& f; bool was; GlvOff(bool& x, bool off) : f(x), was(x) { if (off) f = false; } ~GlvOff() { f = was; } } glv_guard(use_glv, glv_plan);
       return run_device_windows(d_in_bases, inf || ark_zero_identity ? d_in_inf : nullptr, (const uint32_t*)d_in_scalars, n, 0, 0, out_jac, out_xyzz, stream, nullptr, &hin);
     }
     HIP_OK(hipMemcpyAsync(d_in_bases, bases, n * 2 * IO::ARK64 * 8, hipMemcpyHostToDevice, stream));

@@ -250,3 +250,19 @@ def test_prover_entry_pipelined_identity_rows_from_the_bases(gpu, chunks):
         chunks(k)
         got = [co.jac_to_affine(x, "761") for x in gpu.groth16_prove(a_q, b_q, h_q, l_q, alpha, beta, asg, n_aux, h)]
         assert got == want, k
+
+
+def test_subgroup_entry_from_host_pointers_takes_the_pipelined_form_from_2_to_19(gpu, chunks):
+    """msm_bls12_377_g1_subgroup on host buffers: below 2^19 terms the GLV split (unpipelined), from 2^19 the pipelined plain form (the
+    transfers the split would wait for cost more than it saves) - the same group element as the oracle's either way, flags included."""
+    gen, _ = co.pack_g1_377([ecc.G1_377])
+    for n, seed in (((1 << 18) + 9, 41), ((1 << 19) + 77, 42)):
+        xy = _gen(gpu, "bls12_377_g1", n, seed, gen.reshape(-1), 12)           # multiples of the generator: elements of G1
+        sc = _uniform(n, 4, 60, seed + 1)
+        inf = np.zeros(n, dtype=np.uint8); inf[[0, n // 2]] = 1
+        exp = co.jac_to_affine(co.msm("bls12_377_g1", xy, inf, sc, threads=_threads()), "g1_377")
+        assert co.jac_to_affine(gpu.msm("bls12_377_g1", xy, inf, sc, subgroup=True), "g1_377") == exp, n
+        assert gpu.msm_timings("bls12_377_g1")["windows"] == (8 if n < (1 << 19) else 16)      # 127-bit halves in 8 windows | 253-bit scalars in 16
+        chunks(0)                                                              # unpipelined: the split at every size
+        assert co.jac_to_affine(gpu.msm("bls12_377_g1", xy, inf, sc, subgroup=True), "g1_377") == exp, n
+        chunks(-1)

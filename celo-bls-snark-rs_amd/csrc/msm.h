@@ -2076,7 +2076,10 @@ template <class G> class MsmEngine {
     // 11.6 / 7.07 - so a host-pointer call of that size takes the pipelined plain form; same group element)
     const bool glv_plan = plan(n).glv;
     const bool glv_off = glv_plan && !ark_zero_identity && !win_cnt && n >= (size_t(1) << 19);
-    bool pipelined = chunks >= 2 && !win_cnt && (!glv_plan || glv_off) && n < (size_t(1) << 30) && (!ark_zero_identity || ovr >= 0 || n >= (size_t(1) << 21));
+    // (the default head split only where its halves keep 2^17 points: gpurun_out/r5z, G1 2^18 terms in two chunks 1.69 ms whole / 1.82 with the
+    // first one halved, 2^19 in four 2.55 / 2.69; 2^20 in four 4.14 / 4.04)
+    if (!(ovr >= 0 && ((ovr >> 8) & 15)) && MsmTuning::get().host_head_split == 0xFFFFFFFFu && chunks && n / chunks < (size_t(1) << 18)) head_split = 0;
+    bool pipelined = chunks >= (ovr >= 0 ? 1u : 2u) && !win_cnt && (!glv_plan || glv_off) && n < (size_t(1) << 30) && (!ark_zero_identity || ovr >= 0 || n >= (size_t(1) << 21));
     size_t need = n;                 // staging capacity in points: the pipelined form addresses chunk k at k cm
     if (pipelined) {
       uint32_t cm, clen[HOST_CHUNKS_MAX];

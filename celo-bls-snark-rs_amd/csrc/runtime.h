@@ -85,8 +85,8 @@ inline std::atomic<int>& host_chunks_override() { static std::atomic<int> v{-1};
 constexpr uint32_t HOST_CHUNKS_MAX = 80;
 inline uint32_t host_chunk_plan(size_t n, uint32_t chunks, uint32_t head_split, uint32_t tail_split, uint32_t& cm, uint32_t* clen) {
   cm = (uint32_t)(((n + chunks - 1) / chunks + 1023u) & ~size_t(1023));
-  const uint32_t base = (uint32_t)((n + cm - 1) / cm);       // >= 2 for every caller (chunks >= 2, chunks of >= 2^16 points)
-  uint32_t halves[8], nh = 0, piece = cm;
+  const uint32_t base = (uint32_t)((n + cm - 1) / cm);
+  uint32_t halves[8], nh = 0, piece = base >= 2 ? cm : (uint32_t)n;      // (one chunk: the whole job, cut by head_split only)
   for (uint32_t t = 0; t < head_split && t < 8 && piece >= (1u << 16); t++) {
     halves[nh] = ((piece + 1) / 2 + 1023u) & ~1023u;
     piece -= halves[nh++];
@@ -94,6 +94,7 @@ inline uint32_t host_chunk_plan(size_t n, uint32_t chunks, uint32_t head_split, 
   uint32_t K = 0;
   clen[K++] = piece;
   while (nh) clen[K++] = halves[--nh];
+  if (base < 2) return K;
   for (uint32_t b = 1; b + 1 < base; b++) clen[K++] = cm;
   piece = (uint32_t)(n - (size_t)(base - 1) * cm);           // the last base chunk, largest piece first
   for (uint32_t t = 0; t < tail_split && t < 8 && piece >= (1u << 16); t++) {

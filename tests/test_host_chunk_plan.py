@@ -56,6 +56,10 @@ def test_plan_invariants_over_ragged_sizes():
 
 
 def test_plan_refuses_what_the_entry_points_do_not_pipeline():
-    assert _plan(1 << 20, 1, 0, 0) is None and _plan(1 << 20, 65, 0, 0) is None
+    assert _plan(1 << 20, 0, 0, 0) is None and _plan(1 << 20, 65, 0, 0) is None
+    # one chunk (set by hand only): the whole job, cut by the head split alone
+    assert _plan((1 << 20) + 5, 1, 0, 0) == (((1 << 20) + 1024), [(1 << 20) + 5])
+    cm, lens = _plan(1 << 20, 1, 2, 3)
+    assert cm == 1 << 20 and lens == [1 << 18, 1 << 18, 1 << 19]
     assert _plan(1 << 30, 4, 0, 0) is None and _plan((1 << 17) - 1, 2, 0, 0) is None
     assert _plan(1 << 20, 4, 9, 0) is None and _plan(1 << 20, 4, 0, -1) is None

@@ -292,7 +292,7 @@ def ubench_fp():
 
 
 def set_host_chunks(chunks, head_split=None, tail_split=None):
-    """Host-pointer msm(): index chunks of the pipelined transfer (0 / 1 = unpipelined, -1 = default) and, optionally, how often the first /
+    """Host-pointer msm(): index chunks of the pipelined transfer (0 = unpipelined, 1 = one chunk, -1 = default) and, optionally, how often the first /
     the last chunk is cut in halves (default: the library's).  Process-wide."""
     if chunks >= 0:
         if head_split is not None:

@@ -33,7 +33,7 @@ def main():
         n = int(rng.integers(1 << 17, nmax + 1))
         if case % 7 == 0:
             n = (n >> 10) << 10                                   # exact multiples of the chunk granule too
-        k = int(rng.integers(2, max(3, min(12, n >> 16) + 1)))
+        k = int(rng.integers(1, max(3, min(12, n >> 16) + 1)))
         hs, ts = int(rng.integers(0, 4)), int(rng.integers(0, 3))
         start = int(rng.integers(0, nmax - n + 1))
         xy = pool[start:start + n].copy()

@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <type_traits>
 #include <atomic>
 #include <thread>
 #include <system_error>
@@ -611,6 +612,153 @@ __global__ void __launch_bounds__(256) ACC_OCC k_accumulate(const uint32_t* __re
 #endif
   }
   IO::store_xyzz(partials + (size_t)pid * IO::XYZZ_WORDS, acc);
+}
+
+// ---- 4b. The accumulation over Fq2 on LANE PAIRS (late round 5).  k_accumulate<G2_377> holds a whole Fq2 mixed addition per lane: 256 VGPRs
+// + 220 AGPRs, one wave per SIMD, an instruction every 5.1-5.7 cycles where the two-wave G1 kernel issues one every 4.0-4.2 (a lone wave
+// cannot issue back to back; DESIGN.md section 4 showed it is not the dependent multiply-add chains).  Here the two halves c0, c1 of
+// every Fq2 value sit on two ADJACENT lanes (half = lane & 1): a lane holds half the state (225 VGPRs, no AGPRs: two waves per SIMD) and
+// an Fq2 product is QHex377::mul - the six-lane pairings' pair product: one signed two-product Montgomery pass per lane (Fp::mul2s,
+// 2 x 196 + 182 multiply-adds: the same count as a half of the one-lane Fq2 product) after one DPP exchange with lane ^ 1.  Squarings and
+// Y3 = R t - Y1 PPP are plain pair products here (10 per addition against 6 + 2 squarings + the fused Y3 of curve.h: 11 % more
+// multiply-adds).  As register-resident loops (tools/ubench_g2_pair.hip) the pair form runs 2.54 G additions/s against 2.20 G/s; in the
+// MSM the gain is 2-3 % (launch_accumulate below): OPT-IN, CELO_G2_PAIR=1 | 2.  Same formulas (madd-2008-s, mdbl-2008-s-1), same stored bounds as curve.h (X < 19 p, Y < 7 p, ZZ, ZZZ
+// < 3 p, limbs normalised: every hex:: operation carries), same partials layout: the reduction does not know which kernel ran.
+// Control flow is PAIR-UNIFORM: both lanes of a pair walk the same piece and take the same branches (the exact-zero tests AND the two
+// halves through DPP), so the partner lane is always there for the exchange.
+struct PairAcc377 { Fp<P377> X, Y, ZZ, ZZZ; bool inf; };
+__device__ __forceinline__ bool pair_both(bool z) {
+  const int zi = z ? 1 : 0;
+  return (zi & __builtin_amdgcn_mov_dpp(zi, 0xB1, 0xF, 0xF, true)) != 0;
+}
+// QHex377::mul in two steps: the first operand's exchanged form (X = the even lane's half in both lanes, cs = the odd lane's half times -5 | 1)
+struct PairFirst {
+  Fp<P377> X; int32_t cs[14];
+  __device__ __forceinline__ explicit PairFirst(const Fp<P377>& a) {
+    const uint32_t k = QHex377::hsel() ? 1u : 0u - 5u;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+      X.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], 0xA0, 0xF, 0xF, true);
+      cs[i] = (int32_t)((uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], 0xF5, 0xF, 0xF, true) * k);
+    }
+  }
+};
+__device__ __forceinline__ Fp<P377> pair_mul(const PairFirst& f, const Fp<P377>& b, const Fp<P377>& bo) { return Fp<P377>::mul2s(f.X, b, f.cs, bo); }
+__device__ __forceinline__ void pair_dbl_affine(PairAcc377& a, const Fp<P377>& px, const Fp<P377>& py) {
+  typedef QHex377 Q;
+  typedef Fp<P377> H;
+  if (pair_both(py.is_zero_mod_p())) { a.inf = true; return; }
+  const H U = Q::dbl(py);
+  const H V = Q::mul(U, U), W = Q::mul(U, V), S = Q::mul(px, V), xx = Q::mul(px, px);
+  const H M = Q::tpl(xx);
+  const H X3 = Q::template sub<16>(Q::mul(M, M), Q::dbl(S));
+  const H t = Q::template sub<32>(S, X3);
+  a.Y = Q::template sub<4>(Q::mul(M, t), Q::mul(W, py));
+  a.X = X3; a.ZZ = V; a.ZZZ = W; a.inf = false;
+}
+template <int V> __device__ __forceinline__ void pair_madd(PairAcc377& a, const Fp<P377>& px, const Fp<P377>& py) {
+  typedef QHex377 Q;
+  typedef Fp<P377> H;
+  if (a.inf) { a.X = px; a.Y = py; a.ZZ = Q::one(); a.ZZZ = Q::one(); a.inf = false; return; }
+  const H U2 = Q::mul(px, a.ZZ), S2 = Q::mul(py, a.ZZZ);
+  const H Pd = Q::template sub<32>(U2, a.X), R = Q::template sub<16>(S2, a.Y);      // X < 19 p, Y < 7 p
+  if (pair_both(Pd.is_zero_mod_p())) {
+    if (pair_both(R.is_zero_mod_p())) pair_dbl_affine(a, px, py);
+    else a.inf = true;
+    return;
+  }
+  if constexpr (V == 0) {
+    const H PP = Q::mul(Pd, Pd), PPP = Q::mul(Pd, PP), Qv = Q::mul(a.X, PP), R2 = Q::mul(R, R);
+    const H X3 = Q::template sub<16>(R2, Q::add(Q::add(PPP, Qv), Qv));
+    const H t = Q::template sub<32>(Qv, X3);
+    a.Y = Q::template sub<4>(Q::mul(R, t), Q::mul(a.Y, PPP));
+    a.ZZ = Q::mul(a.ZZ, PP);
+    a.ZZZ = Q::mul(a.ZZZ, PPP);
+    a.X = X3;
+  } else {
+    // the exchanged forms of operands that enter several products are built once: Pd and R as first operands (the even lane's half and the
+    // scaled odd lane's half: 28 DPP moves + 14 multiplications by -5 | 1 each), PP and PPP as second operands (the partner's half: 14 DPP moves)
+    const PairFirst fPd(Pd), fR(R);
+    const H PP = pair_mul(fPd, Pd, Q::swap(Pd));
+    const H PPo = Q::swap(PP);
+    const H PPP = pair_mul(fPd, PP, PPo);
+    const H PPPo = Q::swap(PPP);
+    const H Qv = pair_mul(PairFirst(a.X), PP, PPo);
+    const H R2 = pair_mul(fR, R, Q::swap(R));
+    const H X3 = Q::template sub<16>(R2, Q::add(Q::add(PPP, Qv), Qv));
+    const H t = Q::template sub<32>(Qv, X3);
+    a.Y = Q::template sub<4>(pair_mul(fR, t, Q::swap(t)), pair_mul(PairFirst(a.Y), PPP, PPPo));
+    a.ZZ = pair_mul(PairFirst(a.ZZ), PP, PPo);
+    a.ZZZ = pair_mul(PairFirst(a.ZZZ), PPP, PPPo);
+    a.X = X3;
+  }
+}
+template <class G, int V>      // G = G2_377 (a template so that every translation unit that launches it owns an instantiation); V: see pair_madd
+__global__ void __launch_bounds__(256) k_accumulate_pair(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                            const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ plen,
+                                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ nwork,
+                                                            uint32_t* __restrict__ partials) {
+  static_assert(std::is_same<G, G2_377>::value, "lane pairs: Fq2 of BLS12-377");
+  typedef Fp<P377> H;
+  typedef PointIO<Fp2<P377>> IO;
+  constexpr int HW = H::WORDS;                 // words per half; an Fq2 coordinate is c0 | c1
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t piece = tid >> 1, h = tid & 1;
+  if (piece >= *nwork) return;
+  const uint32_t pid = order[piece];
+  const uint32_t* run = sorted + pstart[pid];
+  const uint32_t len = plen[pid];
+  PairAcc377 acc;
+  acc.X = H::zero(); acc.Y = H::zero(); acc.ZZ = H::zero(); acc.ZZZ = H::zero(); acc.inf = true;
+  if constexpr (V == 1) {
+    for (uint32_t k = 0; k < len; k++) {
+      const uint32_t v = run[k];
+      const uint32_t* q = bases + (size_t)(v & 0x7fffffffu) * IO::AFF_WORDS + h * HW;
+      const H px = H::load(q);
+      H py = H::load(q + IO::FW);
+      if (v >> 31) py = QHex377::template neg<4>(py);
+      pair_madd<V>(acc, px, py);
+    }
+  } else if (len) {
+    // the next point is fetched before the current addition starts: the two dependent loads (index, then the point it names) at the head of an
+    // iteration are a larger share of a HALF addition than of a whole one
+    uint32_t v = run[0];
+    const uint32_t* q = bases + (size_t)(v & 0x7fffffffu) * IO::AFF_WORDS + h * HW;
+    H px = H::load(q), py = H::load(q + IO::FW);
+    for (uint32_t k = 0; k < len; k++) {
+      const uint32_t vn = run[k + 1 < len ? k + 1 : k];
+      const uint32_t* qn = bases + (size_t)(vn & 0x7fffffffu) * IO::AFF_WORDS + h * HW;
+      const H nx = H::load(qn), ny = H::load(qn + IO::FW);
+      if (v >> 31) py = QHex377::template neg<4>(py);
+      pair_madd<V>(acc, px, py);
+      px = nx; py = ny; v = vn;
+    }
+  }
+  uint32_t* d = partials + (size_t)pid * IO::XYZZ_WORDS + h * HW;
+  if (acc.inf) { acc.X = H::zero(); acc.Y = H::zero(); acc.ZZ = H::zero(); acc.ZZZ = H::zero(); }      // the identity is stored as exact zeros
+  acc.X.store(d); acc.Y.store(d + IO::FW); acc.ZZ.store(d + 2 * IO::FW); acc.ZZZ.store(d + 3 * IO::FW);
+}
+// the launch of the accumulation: lane pairs for G2 of BLS12-377 (CELO_G2_PAIR=0: the one-lane kernel), one lane per piece otherwise
+template <class G>
+inline void launch_accumulate(uint32_t slots, hipStream_t stream, const uint32_t* d_bases, const uint32_t* d_sorted, const uint32_t* d_pstart, const uint32_t* d_plen,
+                              const uint32_t* d_order, const uint32_t* d_nwork, uint32_t* d_partials) {
+  if constexpr (std::is_same<G, G2_377>::value) {
+    // 0 (default): the one-lane kernel; 1, 2: lane pairs, plain products with the next point prefetched | exchanged operand forms built once.
+    // Same-box A/B at 2^20 terms (gpurun_out/r5pair): 7.83-7.89 ms one lane, 7.66-7.68 (1), 7.59-7.66 (2): the pair kernels issue a VALU
+    // instruction every 3.95 cycles (the limit) where the one-lane kernel issues one every 4.6, and need 12.5 % more of them (ten pair
+    // products of 574 multiply-adds per lane against six products, two squarings and the fused Y3 of curve.h): 2-3 %, not enough to make a
+    // second accumulation kernel the default - kept as a measured alternative (tests/test_msm_gpu.py runs both against the oracle)
+    static const int pair = getenv("CELO_G2_PAIR") ? atoi(getenv("CELO_G2_PAIR")) : 0;
+    if (pair == 2) {
+      hipLaunchKernelGGL((k_accumulate_pair<G, 1>), dim3((2 * slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order, d_nwork, d_partials);
+      return;
+    }
+    if (pair) {
+      hipLaunchKernelGGL((k_accumulate_pair<G, 0>), dim3((2 * slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order, d_nwork, d_partials);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_accumulate<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order, d_nwork, d_partials);
 }
 
 // The accumulation of ONE INDEX CHUNK of the host-pointer pipeline (round 5; run_device_windows' HostIn): the bases arrive over PCIe chunk
@@ -1849,8 +1997,7 @@ template <class G> class MsmEngine {
     if (side) HIP_OK(hipStreamWaitEvent(stream, ev_side[1], 0));
     HIP_OK(hipEventRecord(ev[2], stream));
     // ---- accumulate (grid covers every slot; lanes beyond the number of non-empty pieces exit)
-    hipLaunchKernelGGL((k_accumulate<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order,
-                       d_nwork, d_partials);
+    launch_accumulate<G>(slots, stream, d_bases, d_sorted, d_pstart, d_plen, d_order, d_nwork, d_partials);
     }
     HIP_OK(hipEventRecord(ev[3], stream));
     // ---- bucket reduction
@@ -2363,8 +2510,7 @@ template <class G> class MsmEngine {
     hipLaunchKernelGGL((k_size_scan<G>), dim3(1), dim3(1024), 0, stream, d_bins, d_nwork);
     hipLaunchKernelGGL((k_size_scatter<G>), dim3((slots + 4095) / 4096), dim3(1024), 0, stream, d_plen, d_bins, d_order, slots);
     HIP_OK(hipEventRecord(ev[2], stream));
-    hipLaunchKernelGGL((k_accumulate<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order,
-                       d_nwork, d_partials);
+    launch_accumulate<G>(slots, stream, d_bases, d_sorted, d_pstart, d_plen, d_order, d_nwork, d_partials);
     HIP_OK(hipEventRecord(ev[3], stream));
     hipLaunchKernelGGL((k_batch_reduce<G>), dim3(((uint32_t)nvw + 127) / 128), dim3(128), 0, stream, d_partials, d_plen, d_wsum, B, (uint32_t)nvw);
     if (lane_horner) BatchHornerLanes<G>::launch(d_wsum, d_out, (uint32_t)nw, (uint32_t)c, (uint32_t)m, stream);

@@ -3,6 +3,7 @@
 Reference call sites: crates/bls-crypto/src/bls/signature.rs:85 (G1), public.rs:61 (G2),
 ark_groth16 prover MSMs via crates/epoch-snark/src/api/prover.rs:78.  Parity = equality of the affine-normalised
 group element (bit-exact; SURVEY.md §7 "Bit-exactness must be defined on canonical forms")."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -534,3 +535,54 @@ def test_library_accumulate_kernels_equal_the_host_replay(gpu, golden, group, ch
     for seed in (1, 2):
         assert gpu.selftest_accumulate(group, gen.reshape(-1), runs=16384, length=24, seed=seed, check=2048, chunked=chunked) == 0
     assert gpu.selftest_accumulate(group, gen.reshape(-1), runs=300, length=1, seed=3, check=300, chunked=chunked) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 2])
+def test_g2_accumulation_on_lane_pairs_matches_the_oracle(variant):
+    """CELO_G2_PAIR=1 | 2 (read once per process: a child process): k_accumulate_pair<G2_377> - the two halves of every Fq2 value on two
+    adjacent lanes, pair-uniform branches - instead of the one-lane kernel.  G2 MSMs at 2^10 .. 2^17 terms incl. the branches of the
+    mixed addition a bucket run can take: the same point twice in a bucket (doubling), a point and its negative (cancellation, then a
+    restart from the identity), all scalars equal (one long run per window), infinity flags; and a chained Batch::verify."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, torch
+        from oracle.py import ecc
+        from oracle import cpu_oracle as co
+        from celo_bls_snark_rs_amd import ffi, synthetic as syn
+        ffi.init(0)
+        g2, _ = co.pack_g2_377([ecc.G2_377])
+        T = max(1, min(32, co.lib().orc_hardware_threads()))
+        rng = np.random.default_rng(11)
+        def pts(n, seed):
+            t = torch.empty(n * 24, dtype=torch.int64, device="cuda")
+            ffi.gen_points_dev("bls12_377_g2", t.data_ptr(), n, seed, g2.reshape(-1))
+            torch.cuda.synchronize()
+            return t.cpu().numpy().view(np.uint64).reshape(n, 24)
+        def scal(n, seed):
+            r = np.random.default_rng(seed)
+            sc = r.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+            sc[:, 3] &= np.uint64((1 << 60) - 1)
+            return sc
+        for n, seed in ((1 << 10, 1), (5000, 2), ((1 << 17) + 3, 3)):
+            xy = pts(n, seed); sc = scal(n, seed + 50)
+            inf = np.zeros(n, dtype=np.uint8); inf[[1, n - 1]] = 1
+            # equal points with equal scalars (doubling inside a bucket), opposite points with equal scalars (cancellation)
+            xy[7] = xy[3]; sc[7] = sc[3]
+            P = tuple(co.from_mont(xy[9].reshape(4, 6), ecc.Q377)); P = ((P[0], P[1]), (P[2], P[3]))
+            xy[11] = co.pack_g2_377([ecc.E2_377.neg(P)])[0][0]; sc[11] = sc[9]
+            xy[12] = xy[9]; sc[12] = sc[9]                                    # ... and the run goes on after the cancellation
+            assert co.jac_to_affine(ffi.msm("bls12_377_g2", xy, inf, sc), "g2_377") == co.jac_to_affine(co.msm("bls12_377_g2", xy, inf, sc, threads=T), "g2_377"), n
+            sc[:] = sc[5]                                                      # one scalar for all: every window is one long run
+            xy[100:200] = xy[100]                                              # ... with a stretch of one repeated point in it
+            assert co.jac_to_affine(ffi.msm("bls12_377_g2", xy, None, sc), "g2_377") == co.jac_to_affine(co.msm("bls12_377_g2", xy, None, sc, threads=T), "g2_377"), n
+        w = syn.valid_batches(6, 40, 99, [2])
+        ex = syn.batch_exponents(240, 100)
+        d_ex = torch.from_numpy(ex.view(np.int64)).cuda()
+        ok = ffi.batch_verify_dev(w["pk"].data_ptr(), w["sig"].data_ptr(), d_ex.data_ptr(), w["offsets"], w["hash"].data_ptr(), syn.neg_g2_limbs())
+        assert ok.tolist() == [1, 1, 0, 1, 1, 1]
+        print("PAIR-OK")
+    ''')
+    env = dict(os.environ, CELO_G2_PAIR=str(variant))
+    r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=480)
+    assert r.returncode == 0 and "PAIR-OK" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])

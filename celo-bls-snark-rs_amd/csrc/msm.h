@@ -622,7 +622,8 @@ __global__ void __launch_bounds__(256) ACC_OCC k_accumulate(const uint32_t* __re
 // 2 x 196 + 182 multiply-adds: the same count as a half of the one-lane Fq2 product) after one DPP exchange with lane ^ 1.  Squarings and
 // Y3 = R t - Y1 PPP are plain pair products here (10 per addition against 6 + 2 squarings + the fused Y3 of curve.h: 11 % more
 // multiply-adds).  As register-resident loops (tools/ubench_g2_pair.hip) the pair form runs 2.54 G additions/s against 2.20 G/s; in the
-// MSM the gain is 2-3 % (launch_accumulate below): OPT-IN, CELO_G2_PAIR=1 | 2.  Same formulas (madd-2008-s, mdbl-2008-s-1), same stored bounds as curve.h (X < 19 p, Y < 7 p, ZZ, ZZZ
+// MSM the gain is 2-3 % alone on the device and 2-5 % beside other kernels (launch_accumulate below): the default; CELO_G2_PAIR=0 restores
+// the one-lane kernel.  Same formulas (madd-2008-s, mdbl-2008-s-1), same stored bounds as curve.h (X < 19 p, Y < 7 p, ZZ, ZZZ
 // < 3 p, limbs normalised: every hex:: operation carries), same partials layout: the reduction does not know which kernel ran.
 // Control flow is PAIR-UNIFORM: both lanes of a pair walk the same piece and take the same branches (the exact-zero tests AND the two
 // halves through DPP), so the partner lane is always there for the exchange.
@@ -743,12 +744,14 @@ template <class G>
 inline void launch_accumulate(uint32_t slots, hipStream_t stream, const uint32_t* d_bases, const uint32_t* d_sorted, const uint32_t* d_pstart, const uint32_t* d_plen,
                               const uint32_t* d_order, const uint32_t* d_nwork, uint32_t* d_partials) {
   if constexpr (std::is_same<G, G2_377>::value) {
-    // 0 (default): the one-lane kernel; 1, 2: lane pairs, plain products with the next point prefetched | exchanged operand forms built once.
-    // Same-box A/B at 2^20 terms (gpurun_out/r5pair): 7.83-7.89 ms one lane, 7.66-7.68 (1), 7.59-7.66 (2): the pair kernels issue a VALU
-    // instruction every 3.95 cycles (the limit) where the one-lane kernel issues one every 4.6, and need 12.5 % more of them (ten pair
-    // products of 574 multiply-adds per lane against six products, two squarings and the fused Y3 of curve.h): 2-3 %, not enough to make a
-    // second accumulation kernel the default - kept as a measured alternative (tests/test_msm_gpu.py runs both against the oracle)
-    static const int pair = getenv("CELO_G2_PAIR") ? atoi(getenv("CELO_G2_PAIR")) : 0;
+    // 2 (default): lane pairs with the exchanged operand forms built once; 1: lane pairs, plain products with the next point prefetched;
+    // 0: the one-lane kernel.  Same-box A/Bs (profiles/r5_ab_g2_lane_pairs.txt): one G2 MSM of 2^20 terms alone on the device 7.83-7.89 ms
+    // one lane, 7.66-7.68 (1), 7.59-7.66 (2) - the pair kernels issue a VALU instruction every 3.95 cycles (the limit) where the one-lane
+    // kernel issues one every 4.6, and need 12.5 % more of them (ten pair products of 574 multiply-adds per lane against six products, two
+    // squarings and the fused Y3 of curve.h); BESIDE other kernels a two-wave kernel with half the registers shares the device better:
+    // config 3 (the key leg beside the signature leg) 24.23-24.29 -> 23.67-23.84 ms (five alternations), config 5 (G2 beside G1 and the
+    // pairings) 50.5-52.2 -> 48.9-49.0 ms.  The whole -m gpu suite passes on either.
+    static const int pair = getenv("CELO_G2_PAIR") ? atoi(getenv("CELO_G2_PAIR")) : 2;
     if (pair == 2) {
       hipLaunchKernelGGL((k_accumulate_pair<G, 1>), dim3((2 * slots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order, d_nwork, d_partials);
       return;

@@ -538,10 +538,10 @@ def test_library_accumulate_kernels_equal_the_host_replay(gpu, golden, group, ch
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_g2_accumulation_on_lane_pairs_matches_the_oracle(variant):
-    """CELO_G2_PAIR=1 | 2 (read once per process: a child process): k_accumulate_pair<G2_377> - the two halves of every Fq2 value on two
-    adjacent lanes, pair-uniform branches - instead of the one-lane kernel.  G2 MSMs at 2^10 .. 2^17 terms incl. the branches of the
+    """CELO_G2_PAIR=0 | 1 | 2 (read once per process: a child process): the one-lane kernel, and k_accumulate_pair<G2_377> - the two halves of
+    every Fq2 value on two adjacent lanes, pair-uniform branches - in its two forms (2 is the library's default).  G2 MSMs at 2^10 .. 2^17 terms incl. the branches of the
     mixed addition a bucket run can take: the same point twice in a bucket (doubling), a point and its negative (cancellation, then a
     restart from the identity), all scalars equal (one long run per window), infinity flags; and a chained Batch::verify."""
     import subprocess, sys, textwrap

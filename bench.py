@@ -48,7 +48,7 @@ import torch.distributed as dist
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 DTYPE = "u32 limbs (28-bit radix, 64-bit column accumulators)"
 KIND = {"bls12_377_g1": "g1_377", "bls12_377_g2": "g2_377", "bw6_761_g1": "761", "bw6_761_g2": "761"}
-ACC_KERNEL = {"bls12_377_g1": "k_accumulate<G1_377>", "bls12_377_g2": "k_accumulate<G2_377>", "bw6_761_g1": "k_accumulate<G_761>"}
+ACC_KERNEL = {"bls12_377_g1": "k_accumulate<G1_377>", "bls12_377_g2": "k_accumulate_pair<G2_377, 1>", "bw6_761_g1": "k_accumulate<G_761>"}
 
 
 class Ctx:
@@ -59,7 +59,7 @@ class Ctx:
 # tools/summarise_profile.py from the separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/r5_profiles.sh) that holds each:
 # kernel -> {shape: tag}.  Shapes: log2 n of an MSM, the number of products of a pairing launch, "cfg3" = 4096 batches x 256 signers.
 PROFILED = {"k_accumulate<G1_377>": {20: "r5", 22: "r5_cfg5", "cfg3": "r5_cfg3"},
-            "k_accumulate<G2_377>": {20: "r5_groups", 22: "r5_cfg5", "cfg3": "r5_cfg3"},
+            "k_accumulate_pair<G2_377, 1>": {20: "r5_groups", 22: "r5_cfg5", "cfg3": "r5_cfg3"},
             "k_accumulate<G_761>": {20: "r5_groups", 21: "r5_cfg4"},
             "k_miller_product_slots<LPH377, 2>": {81920: "r5_pairing"}, "k_miller_prepared_slots<LPH377>": {81920: "r5"},
             "k_prepare_lines<LPH377>": {81920: "r5"}, "k_final_exp_slots<LPH377>": {81920: "r5"}}
@@ -794,8 +794,8 @@ class BatchVerifyConfig:
                                       % (self.m, self.n), "batches_per_gpu": self.m, "signers_per_batch": self.n,
                           "signatures_per_s": None, "miller_loops_per_step": 2 * self.m, "final_exps_per_step": self.m,
                           "sharding": "batches sharded by rank, no exchange" if cx.world > 1 else "single GPU"}
-        traffic, src = committed_traffic("k_accumulate<G2_377>", "cfg3") if (self.m, self.n) == (4096, 256) else (None, "no committed PMC profile of this launch shape")
-        line["roofline"] = {"bound": "hbm", "kernel": "k_accumulate<G2_377> (batched path)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        traffic, src = committed_traffic("k_accumulate_pair<G2_377, 1>", "cfg3") if (self.m, self.n) == (4096, 256) else (None, "no committed PMC profile of this launch shape")
+        line["roofline"] = {"bound": "hbm", "kernel": "k_accumulate_pair<G2_377, 1> (batched path)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
                             "note": "integer-VALU bound; algorithmic bytes = signers*224 B per launch; median HIP-event ms: G2 MSM %.2f (accumulate %.2f), G1 MSM %.2f, "
                                     "pairings %.2f (Miller %.2f, final exp %.2f) - the two MSMs overlap on the GPU, so their event times include each other's work"
@@ -806,7 +806,7 @@ class BatchVerifyConfig:
         # the batched G2 accumulation: every (term, window) of the (GLS-expanded) instances is one mixed addition over Fq2
         terms = tot * (3 if g2t["windows"] * g2t["window_bits"] < 100 else 1)     # psi-split (csrc/msm.h gls_digits): three 64-bit digits per 136-bit exponent
         fq2_ops = terms * g2t["windows"] * MADS["madd"]["bls12_377_g2"]
-        line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": "k_accumulate<G2_377> (batched path)", "achieved": fq2_ops / (d[1] * 1e-3) / 1e12,
+        line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 issue)", "kernel": "k_accumulate_pair<G2_377, 1> (batched path)", "achieved": fq2_ops / (d[1] * 1e-3) / 1e12,
                                  "peak": pk["tmads"]["bls12_377_g2"], "unit": "T multiply-adds/s", "frac": fq2_ops / (d[1] * 1e-3) / 1e12 / pk["tmads"]["bls12_377_g2"],
                                  "multiply_adds_per_mixed_addition": MADS["madd"]["bls12_377_g2"],
                                  "peak_measured_in_run": pk["measured"], "windows": g2t["windows"], "window_bits": g2t["window_bits"], "expanded_terms": terms,
@@ -929,10 +929,10 @@ class MixedConfig:
                                       "MSM inputs resident in HBM" % ((self.n - 1).bit_length(), (self.n - 1).bit_length(), self.loops, self.mprod),
                           "terms_per_group_per_gpu": self.n, "miller_loops_per_gpu": self.loops, "miller_loops_per_s": cx.world * self.loops / (line["ms_per_step"] * 1e-3),
                           "sequential_ms_per_step": t_seq, "overlap_gain": t_seq / line["ms_per_step"]}
-        traffic, src = committed_traffic(["k_accumulate<G1_377>", "k_accumulate<G2_377>"], (self.n - 1).bit_length())
+        traffic, src = committed_traffic(["k_accumulate<G1_377>", "k_accumulate_pair<G2_377, 1>"], (self.n - 1).bit_length())
         line["roofline"] = {"bound": "hbm", "kernel": "whole step (three concurrent legs)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
-                            "traffic_kernels": "k_accumulate<G1_377> + k_accumulate<G2_377> (the two dominant kernels of the step)",
+                            "traffic_kernels": "k_accumulate<G1_377> + k_accumulate_pair<G2_377, 1> (the two dominant kernels of the step)",
                             "note": "BASELINE config 5 asks for the HBM-roofline fraction of the mixed job: algorithmic bytes (128 B per G1 term, 224 B per G2 term, 288 B per "
                                     "Miller loop) / step wall time; integer-VALU bound.  Median HIP-event ms of the legs while overlapped: G1 MSM %.2f, G2 MSM %.2f, pairings %.2f"
                                     % (d[0], d[1], d[2])}

@@ -811,7 +811,8 @@ class BatchVerifyConfig:
                                  "multiply_adds_per_mixed_addition": MADS["madd"]["bls12_377_g2"],
                                  "peak_measured_in_run": pk["measured"], "windows": g2t["windows"], "window_bits": g2t["window_bits"], "expanded_terms": terms,
                                  "note": pk["note"] + "; achieved = expanded terms x windows mixed additions over Fq2 x %d multiply-adds / accumulate ms - an upper count (a zero digit "
-                                         "adds nothing: 1/64 of them at 6-bit windows) over a time that also holds part of the overlapping G1 leg's work" % MADS["madd"]["bls12_377_g2"]}
+                                         "adds nothing: 1/64 of them at 6-bit windows) over a time that also holds part of the overlapping G1 leg's work; the count is curve.h's one-lane "
+                                         "formula (6 products, 2 squarings, the fused Y3) - the lane-pair kernel that runs spends 11 480 (ten pair products): its useful share is what is priced" % MADS["madd"]["bls12_377_g2"]}
         line["config"]["signatures_per_s"] = line["value"] * self.n
         line["parity"] = {"checked": True, "against": "this rank's accept vector of the timed step == the one built into the workload (1 % of the batches corrupted)"}
         if not cx.args.no_cpu_baseline and cx.rank == 0:

@@ -43,6 +43,16 @@
 struct uint4 { uint32_t x, y, z, w; };  // host-only builds (bounds-tracking unit tests)
 #endif
 
+// CELO_LONG_BRANCH note.  Out-of-line (noinline) DEVICE functions of the wide fields are longer than the reach of s_cbranch (2^17 bytes), so
+// branch relaxation expands their far branches into s_getpc_b64 / s_add_u32 / s_addc_u32 / s_setpc_b64 on an SGPR pair.  With this compiler
+// (ROCm 7.2, clang 22) the pair is the "long-branch reserved register": the highest free pair before register allocation, moved to the lowest
+// pair the function leaves unused after it.  In a leaf function that needs few SGPRs the lowest unused pair is s[30:31] - the function's own
+// return address: the first far branch taken overwrites it and the function returns into its own body.  That is round 5's "k_combine_big<G_761>
+// never returns with immediate K p tables": without the tables' ~100 SGPRs xyzz_add_outline<Fp<P761>> became such a function (with them the pair
+// was s[98:99], which callers know about through the callee's clobber mask).  Every unit is therefore compiled with
+// `-mllvm -amdgpu-long-branch-factor=0` (csrc/Makefile): no reservation, the pair is scavenged from registers proved dead (s[2:3], s[4:5] ...).
+// tools/scan_long_branch.py checks the built library for the shape (tests/test_abi_symbols.py); tools/repro_combine/ is the reproducer.
+
 #ifdef CELO_FP_TRACK
 #include <cassert>
 #include <cstdio>
@@ -344,12 +354,15 @@ template <class P> struct Fp {
     return r;
   }
   template <int K> HD static void cond_sub_k(Fp& r) {
-    if constexpr (L > 14) {
-      // the 28-limb field keeps the tables behind pointers: with immediates `k_combine_big<G_761>` (one workgroup folding a skewed bucket's
-      // pieces through LDS, its additions out of line) never returns on witness-like scalars - found by the -m gpu suite in round 5,
-      // reproduced with a function-local constexpr table and with a static one, gone with the pointer form (tools/dbg_witness.py; same
-      // sources otherwise, SLP vectorizer off in all three builds).  Not understood; the accumulate kernels of this field therefore keep their
-      // prologue loads and parked SGPRs (tests/test_abi_symbols.py allows them for G_761 only).
+#if defined(CELO_KP_PTR_TABLES)
+    // reproducer builds only (tools/repro_combine): rounds 1-5's pointer form of the tables for the 28-limb field.  Round 5 kept it there because
+    // the immediates form made `k_combine_big<G_761>` never return; round 6 found why (CELO_LONG_BRANCH note above): the
+    // out-of-line addition it calls lost its return address to a far branch.  Nothing to do with the tables.
+    constexpr bool PTR_TABLES = L > 14;
+#else
+    constexpr bool PTR_TABLES = false;
+#endif
+    if constexpr (PTR_TABLES) {
       cond_sub(r, K == 64 ? P::NP64 : K == 32 ? P::NP32 : K == 16 ? P::NP16 : K == 8 ? P::NP8 : K == 4 ? P::NP4 : K == 2 ? P::NP2 : P::NP1);
     } else {
       constexpr KpTable T = kp_table<K>();

@@ -220,6 +220,14 @@ template <class F> bool jac_to_affine(const uint64_t* jac, Affine<F>& out) {
   out.y = F::norm(F::mul(F::from_ark(jac + A), F::mul(zi2, zi)));
   return true;
 }
+// ... and for callers that must carry the identity the way arkworks does: GroupAffine::zero() is (x, y, infinity) = (0, 1, true), and the
+// reference's encode_public_key (crates/epoch-snark/src/encoding.rs:23-47) reads x and y of whatever into_affine() returned - for the identity
+// 754 zero bits and a clear sign bit.  (It documents "not the point at infinity" as an assumption and does not check it.)
+template <class F> Affine<F> jac_to_affine_or_zero(const uint64_t* jac) {
+  Affine<F> out;
+  if (!jac_to_affine<F>(jac, out)) out = {F::zero(), F::one()};
+  return out;
+}
 uint8_t* alloc_bytes(size_t n) { return (uint8_t*)malloc(n ? n : 1); }
 bool emit(const std::vector<uint8_t>& v, uint8_t** out_bytes, int* out_len) {
   uint8_t* p = alloc_bytes(v.size());
@@ -716,7 +724,13 @@ bool epoch_from_ffi(const EpochBlockFFI& src, EpochBlockHost& e) {  // snark/epo
   auto decode = [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi && ok; i++) {
       bool inf;
-      if (!g2_decompress(src.pubkeys + 96 * i, e.pubkeys[i], inf) || inf || !in_subgroup(e.pubkeys[i])) { ok = false; return; }
+      if (!g2_decompress(src.pubkeys + 96 * i, e.pubkeys[i], inf)) { ok = false; return; }
+      if (inf) {      // read_pubkeys (snark/epoch_block.rs:187-196) takes G2Affine::deserialize's zero() as it comes: (0, 1), the identity in the sum
+        e.pubkeys[i] = {Fq2_::zero(), Fq2_::one()};
+        identity_jac<Fq2_>(&e.pubkeys_jac[i * 36]);
+        continue;
+      }
+      if (!in_subgroup(e.pubkeys[i])) { ok = false; return; }
       affine_to_jac(e.pubkeys[i], &e.pubkeys_jac[i * 36]);
     }
   };
@@ -1597,9 +1611,7 @@ bool verify(const uint8_t* vk, uint32_t vk_len, const uint8_t* proof, uint32_t p
   epoch_bits_cip22(last, false, lb);
   uint64_t agg[36];
   if (celo_amd_sum_jacobian_bls12_377_g2(last.pubkeys_jac.data(), last.pubkeys.size(), agg) != 0) return false;
-  Affine<Fq2_> aggp;
-  if (!jac_to_affine<Fq2_>(agg, aggp)) return false;  // encode_public_key assumes a finite key
-  encode_public_key_bits(lb, aggp);
+  encode_public_key_bits(lb, jac_to_affine_or_zero<Fq2_>(agg));   // (an aggregate that is the identity encodes as arkworks' zero(), as in the reference)
   std::vector<uint8_t> h1 = blake2s_out_domain(bits_be_to_bytes_le(fb)), h2 = blake2s_out_domain(bits_be_to_bytes_le(lb));
   Bits hb;
   bits_append_le(hb, h1.data(), 32, 256);
@@ -1637,7 +1649,10 @@ bool verify(const uint8_t* vk, uint32_t vk_len, const uint8_t* proof, uint32_t p
 static bool collect_pubkeys(const PublicKey* const* in, int n, std::vector<Affine<Fq2_>>& out) {
   if (n < 0 || (n > 0 && !in)) return false;
   out.resize((size_t)n);
-  for (int i = 0; i < n; i++) if (!in[i] || !jac_to_affine<Fq2_>(in[i]->xyz, out[(size_t)i])) return false;
+  for (int i = 0; i < n; i++) {
+    if (!in[i]) return false;
+    out[(size_t)i] = jac_to_affine_or_zero<Fq2_>(in[i]->xyz);
+  }
   return true;
 }
 bool encode_epoch_block_to_bytes_cip22(unsigned short index, unsigned char round, const uint8_t* epoch_entropy, const uint8_t* parent_entropy,

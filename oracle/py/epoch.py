@@ -43,8 +43,9 @@ def encode_uint(num, nbytes):
 
 
 def encode_public_key(pk):
-    """pk: affine G2 point ((x0,x1),(y0,y1)) of BLS12-377."""
-    (x0, x1), (y0, y1) = pk
+    """pk: affine G2 point ((x0,x1),(y0,y1)) of BLS12-377, or None for the identity: the reference reads x and y of `into_affine()`
+    (crates/epoch-snark/src/encoding.rs:23-47), which for the identity is arkworks' GroupAffine::zero() = (0, 1, infinity)."""
+    (x0, x1), (y0, y1) = pk if pk is not None else ((0, 0), (1, 0))
     over_half = y1 > HALF or (y1 == 0 and y0 > HALF)
     bits = bytes_le_to_bits_be(x0.to_bytes(48, "little"), 377)
     bits += bytes_le_to_bits_be(x1.to_bytes(48, "little"), 377)

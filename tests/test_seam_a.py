@@ -565,6 +565,61 @@ def test_encode_epoch_block_symbols(sys_lib, golden):
     assert _take(sys_lib, o1, n1) == inner and _take(sys_lib, o2, n2) == extra
 
 
+def test_encode_epoch_block_with_an_identity_validator_key(sys_lib):
+    """the reference's `read_pubkeys` (crates/bls-snark-sys/src/snark/epoch_block.rs:187-196) and `encode_public_key`
+    (crates/epoch-snark/src/encoding.rs:23-47) take the identity as a validator key - arkworks' GroupAffine::zero() = (0, 1, infinity): 754 zero
+    bits and a clear sign bit - where rounds 2-5 of this library refused it.  Both encoders now emit what the restatement of those lines emits."""
+    from oracle.py import epoch as ep
+    gen = _deser(sys_lib, "deserialize_public_key", ecc.ser_point(ecc.E2_377, ecc.G2_377))
+    two = _deser(sys_lib, "deserialize_public_key", ecc.ser_point(ecc.E2_377, ecc.E2_377.mul(ecc.G2_377, 2)))
+    ident = _deser(sys_lib, "deserialize_public_key", ecc.ser_point(ecc.E2_377, None))
+    handles = [gen.value, ident.value, two.value, ident.value]
+    keys = [ecc.G2_377, None, ecc.E2_377.mul(ecc.G2_377, 2), None]
+    arr = (C.c_void_p * 4)(*handles)
+    out, n = C.c_void_p(), C.c_int()
+    sys_lib.encode_epoch_block_to_bytes.restype = C.c_bool
+    assert sys_lib.encode_epoch_block_to_bytes(C.c_ushort(7), C.c_uint(1), arr, C.c_int(4), C.byref(out), C.byref(n))
+    got = _take(sys_lib, out, n)
+    assert got == ep.EpochBlock(7, 0, None, None, 1, 4, keys).encode_to_bytes()
+    bits = ep.EpochBlock(7, 0, None, None, 1, 4, keys).encode_to_bits()
+    assert bits[48 + 755:48 + 2 * 755] == [0] * 755                       # the identity's slot: x = 0, sign bit clear
+    sys_lib.encode_epoch_block_to_bytes_cip22.restype = C.c_bool
+    o1, n1, o2, n2 = C.c_void_p(), C.c_int(), C.c_void_p(), C.c_int()
+    e_ent, p_ent = bytes([3] * 16), bytes([4] * 16)
+    assert sys_lib.encode_epoch_block_to_bytes_cip22(C.c_ushort(7), C.c_ubyte(2), e_ent, p_ent, C.c_uint(1), C.c_uint(5), arr, C.c_int(4),
+                                                     C.byref(o1), C.byref(n1), C.byref(o2), C.byref(n2))
+    inner, extra = ep.encode_inner_to_bytes_cip22(ep.EpochBlock(7, 2, e_ent, p_ent, 1, 5, keys))
+    assert _take(sys_lib, o1, n1) == inner and _take(sys_lib, o2, n2) == extra
+
+
+@pytest.mark.gpu
+def test_groth16_verify_takes_an_identity_validator_key(sys_lib, gpu, golden):
+    """... and `verify` decodes such a block and runs the check (the reference's vector with one validator key replaced by the identity: the
+    public inputs change, so the proof is rejected - by the pairing check, not by the decoder), also when the whole set sums to the identity."""
+    from oracle.py import epoch as ep
+    g = golden["groth16_bw6_761"]
+    vk, proof = bytes.fromhex(g["vk"]), bytes.fromhex(g["proof"])
+    fp, lp = bytes.fromhex(g["first_pubkeys"]), bytes.fromhex(g["last_pubkeys"])
+    fe, fpe = bytes.fromhex(g["first_epoch_entropy"]), bytes.fromhex(g["first_parent_entropy"])
+    le, lpe = bytes.fromhex(g["last_epoch_entropy"]), bytes.fromhex(g["last_parent_entropy"])
+
+    def blk(d, pk, ee, pe):
+        return _EpochBlockFFI(d["index"], d["round"], ee, pe, pk, d["pubkeys_num"], d["maximum_non_signers"], d["maximum_validators"])
+
+    sys_lib.verify.restype = C.c_bool
+    sys_lib.verify.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, _EpochBlockFFI, _EpochBlockFFI]
+    assert sys_lib.verify(vk, len(vk), proof, len(proof), blk(g["first"], fp, fe, fpe), blk(g["last"], lp, le, lpe)) is True
+    ident = ecc.ser_point(ecc.E2_377, None)
+    lp_id = ident + lp[96:]
+    assert sys_lib.verify(vk, len(vk), proof, len(proof), blk(g["first"], fp, fe, fpe), blk(g["last"], lp_id, le, lpe)) is False
+    all_id = ident * g["last"]["pubkeys_num"]
+    assert sys_lib.verify(vk, len(vk), proof, len(proof), blk(g["first"], fp, fe, fpe), blk(g["last"], all_id, le, lpe)) is False
+    # the restatement encodes the same blocks (what the rejected hashes were computed over)
+    keys = [None] * g["last"]["pubkeys_num"]
+    blk_py = ep.EpochBlock(g["last"]["index"], g["last"]["round"], le, lpe, g["last"]["maximum_non_signers"], g["last"]["maximum_validators"], keys)
+    assert len(blk_py.encode_last_epoch_to_bytes_with_aggregated_pk_cip22()) > 0
+
+
 @pytest.mark.gpu
 def test_reference_groth16_ffi_test_passes_on_gpu(sys_lib, gpu, golden):
     """The reference's own FFI test `simple_verifier_groth16_with_entropy` (crates/bls-snark-sys/src/snark/mod.rs:52-119),

@@ -82,7 +82,46 @@ MADS = {
              "bw6_761_g2": 6 * (784 + 784) + 2 * (406 + 784) + (2 * 784 + 784)},
     # one product round of the six-lane pairing backend: a half-Fq2 signed pass (2 sweeps + 1 reduction) on each of a group's six lanes
     "hex_round": 6 * (2 * 196 + 182),
+    # what the kernel named in ACC_KERNEL EXECUTES per mixed addition where that differs from the formula's count above: the lane-pair G2 kernel
+    # runs ten pair products (one two-product signed pass on each lane of the pair), ADVICE r5
+    "madd_executed": {"bls12_377_g2": 10 * 2 * (2 * 196 + 182)},                                                     # 11480
 }
+
+
+_COPY_PEAK = None
+
+
+def hbm_copy_peak():
+    """"measured copy bandwidth as denominator too".  A device-to-device copy of 1 GiB (read + write = 2 GiB of HBM traffic)
+    timed in THIS run on THIS device with events on torch's stream; best of 5.  GB/s."""
+    global _COPY_PEAK
+    if _COPY_PEAK is None:
+        n = 1 << 30
+        a = torch.empty(n, dtype=torch.uint8, device="cuda"); b = torch.empty(n, dtype=torch.uint8, device="cuda")
+        a.zero_(); b.copy_(a)
+        best = None
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); b.copy_(a); e1.record(); e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None or ms < best else best
+        del a, b
+        _COPY_PEAK = 2 * n / (best * 1e-3) / 1e9
+    return _COPY_PEAK
+
+
+def add_measured_hbm_peak(obj):
+    """Every {"bound": "hbm"} block of the line also gets the copy bandwidth measured in this run and the fraction against it."""
+    if isinstance(obj, dict):
+        if obj.get("bound") == "hbm" and "achieved" in obj and "peak_measured" not in obj:
+            obj["peak_measured"] = hbm_copy_peak()
+            obj["frac_of_measured"] = obj["achieved"] / obj["peak_measured"]
+            obj["peak_measured_note"] = "1 GiB device-to-device copy in this run (2 GiB of traffic), best of 5, GB/s"
+        for v in list(obj.values()):
+            add_measured_hbm_peak(v)
+    elif isinstance(obj, list):
+        for v in obj:
+            add_measured_hbm_peak(v)
 
 
 def valu_peaks():
@@ -300,6 +339,11 @@ class MsmConfig:
                                  "multiply_adds_per_mixed_addition": madd, "peak_measured_in_run": pk["measured"],
                                  "note": pk["note"] + "; achieved = n*windows mixed additions x %d multiply-adds (6 products, 2 squarings, the one-pass Y3: bench.py MADS) / "
                                                       "accumulate time" % madd}
+        if self.group in MADS["madd_executed"]:      # the named kernel executes more than the formula's count: priced are the USEFUL multiply-adds
+            ex = MADS["madd_executed"][self.group]
+            line["valu_roofline"]["multiply_adds_executed_per_mixed_addition"] = ex
+            line["valu_roofline"]["frac_executed"] = line["valu_roofline"]["frac"] * ex / madd
+            line["valu_roofline"]["note"] += "; %s executes %d per mixed addition (ten pair products): `frac` prices the useful %d of the one-lane formula, `frac_executed` the issued ones" % (ACC_KERNEL[self.group], ex, madd)
         if self.fixed is not None:
             fi = self.fixed.info()
             line["config"]["entry_point"] = "msm_%s_fixed_dev: per-key tables T[j][i] = 2^(c j) P_i built once by msm_%s_precompute_dev (the prover's queries stay, the assignment changes)" % (self.group, self.group)
@@ -844,20 +888,11 @@ class BatchVerifyConfig:
                 "sample": "%d of the batches (two of them corrupted), Batch::verify restated on one core: two %d-term MSMs with arkworks windowing + one 2-pair product" % (len(idx), n)}
 
 
-def verify_shaped_products(mprod, seed, bad=(1, 5)):
-    """mprod two-pair products e(sig, -g2) * e(H, pk) built from 8 device-generated (sk*H, H, sk*g2) triples, tiled; the triples
-    listed in `bad` carry a foreign signature.  Returns (g1 (2 mprod, 12), g2 (2 mprod, 24), offsets, expected accept list)."""
+def verify_shaped_products(mprod, seed):
+    """mprod DISTINCT two-pair products e(sig_b, -g2) * e(H_b, pk_b), every 97th with a foreign signature (synthetic.verify_products; rounds 2-5
+    tiled eight triples - VERDICT r5 item 4).  Returns (g1 (2 mprod, 12), g2 (2 mprod, 24), offsets, expected accept list)."""
     from celo_bls_snark_rs_amd import synthetic as syn
-    w = syn.valid_batches(8, 1, seed, list(bad))
-    sig = w["sig"].view(8, 12).cpu().numpy().view(np.uint64); hh = w["hash"].view(8, 12).cpu().numpy().view(np.uint64)
-    pk = w["pk"].view(8, 24).cpu().numpy().view(np.uint64)
-    ng2 = syn.neg_g2_limbs()
-    g1 = np.empty((16, 12), dtype=np.uint64); g2 = np.empty((16, 24), dtype=np.uint64)
-    g1[0::2] = sig; g1[1::2] = hh; g2[0::2] = ng2; g2[1::2] = pk
-    reps = (mprod + 7) // 8
-    ok = [int(x) for x in w["expect"]]
-    return (np.tile(g1, (reps, 1))[: 2 * mprod].copy(), np.tile(g2, (reps, 1))[: 2 * mprod].copy(), np.arange(0, 2 * mprod + 1, 2, dtype=np.uint32),
-            [ok[i % 8] for i in range(mprod)])
+    return syn.verify_products(mprod, seed)
 
 
 # ===================================================================================================== config 5
@@ -937,6 +972,20 @@ class MixedConfig:
                             "note": "BASELINE config 5 asks for the HBM-roofline fraction of the mixed job: algorithmic bytes (128 B per G1 term, 224 B per G2 term, 288 B per "
                                     "Miller loop) / step wall time; integer-VALU bound.  Median HIP-event ms of the legs while overlapped: G1 MSM %.2f, G2 MSM %.2f, pairings %.2f"
                                     % (d[0], d[1], d[2])}
+        # the multiplier roofline of the mixed step: useful multiply-adds of the three legs / step wall time / the in-run peak
+        from celo_bls_snark_rs_amd import ffi
+        t1, t2 = ffi.msm_timings("bls12_377_g1"), ffi.msm_timings("bls12_377_g2")
+        pk = valu_peaks()
+        legs_mads = {"g1_msm": self.n * t1["windows"] * MADS["madd"]["bls12_377_g1"], "g2_msm": self.n * t2["windows"] * MADS["madd"]["bls12_377_g2"],
+                     "pairings": self.mprod * (1157 + 900) * MADS["hex_round"]}
+        tot_mads = float(sum(legs_mads.values()))
+        peak = pk["tmads"]["bls12_377_g1"]
+        line["valu_roofline"] = {"bound": "integer VALU (v_mad_u64_u32 / v_mad_i64_i32 issue)", "kernel": "whole step (three concurrent legs)", "unit": "T multiply-adds/s",
+                                 "achieved": tot_mads / (line["ms_per_step"] * 1e-3) / 1e12, "peak": peak, "frac": tot_mads / (line["ms_per_step"] * 1e-3) / 1e12 / peak,
+                                 "multiply_adds_per_step": legs_mads, "peak_measured_in_run": pk["measured"],
+                                 "note": pk["note"] + "; achieved = (n x windows mixed additions x 3416 [G1] + n x windows x 10360 [G2, the one-lane formula's useful count] + "
+                                         "products x (1157 + 900) rounds x 3444 [pairings]) / step wall time: sort, reduction, host epilogues and the non-multiply share of the pairing "
+                                         "rounds are what the fraction below 1 is made of"}
         if cx.world == 1 and not cx.devices and self.n >= (1 << 20):
             line["host_pointer_g2"] = self.host_pointer_g2()
         if not cx.args.no_cpu_baseline:
@@ -973,26 +1022,27 @@ class MixedConfig:
         if cx.rank != 0:
             return None
         hw = co.lib().orc_hardware_threads()
-        k = 1 << 17
+        # the WHOLE job of this rank on the CPU port (not a 2^17 sample): 2^22 G1 + 2^22 G2 terms take ~15-25 s on 17 threads
+        k = self.n
         T = max(1, min(hw, 17))
-        h1 = self.b1.view(self.n, 12)[:k].cpu().numpy().view(np.uint64); h2 = self.b2.view(self.n, 24)[:k].cpu().numpy().view(np.uint64)
+        h1 = self.b1.view(self.n, 12).cpu().numpy().view(np.uint64); h2 = self.b2.view(self.n, 24).cpu().numpy().view(np.uint64)
         t0 = time.perf_counter()
-        o1 = co.msm("bls12_377_g1", h1, None, self.s1[:k], threads=T)
-        o2 = co.msm("bls12_377_g2", h2, None, self.s2[:k], threads=T)
+        o1 = co.msm("bls12_377_g1", h1, None, self.s1, threads=T)
+        o2 = co.msm("bls12_377_g2", h2, None, self.s2, threads=T)
         secs = time.perf_counter() - t0
-        g1 = ffi.msm_dev("bls12_377_g1", self.b1.data_ptr(), 0, self.d1.data_ptr(), k)
-        g2 = ffi.msm_dev("bls12_377_g2", self.b2.data_ptr(), 0, self.d2.data_ptr(), k)
-        if co.jac_to_affine(o1, "g1_377") != co.jac_to_affine(g1, "g1_377") or co.jac_to_affine(o2, "g2_377") != co.jac_to_affine(g2, "g2_377"):
-            raise SystemExit("PARITY FAILURE: GPU MSM != oracle on the 2^17 sample")
+        if co.jac_to_affine(o1, "g1_377") != co.jac_to_affine(seq[0] if cx.world == 1 else ffi.msm_dev("bls12_377_g1", self.b1.data_ptr(), 0, self.d1.data_ptr(), k), "g1_377") or \
+           co.jac_to_affine(o2, "g2_377") != co.jac_to_affine(seq[1] if cx.world == 1 else ffi.msm_dev("bls12_377_g2", self.b2.data_ptr(), 0, self.d2.data_ptr(), k), "g2_377"):
+            raise SystemExit("PARITY FAILURE: GPU MSM != oracle on the whole job")
         t0 = time.perf_counter()
-        acc = [int(co.pairing_product_377(self.g1[2 * i: 2 * i + 2], None, self.g2[2 * i: 2 * i + 2], None)[1]) for i in range(8)]
+        npair = 16
+        acc = [int(co.pairing_product_377(self.g1[2 * i: 2 * i + 2], None, self.g2[2 * i: 2 * i + 2], None)[1]) for i in range(npair)]
         psecs = time.perf_counter() - t0
-        if acc != self.expect[:8]:
+        if acc != self.expect[:npair]:
             raise SystemExit("PARITY FAILURE: oracle pairing verdicts != constructed")
-        return {"value": 2 * k / secs, "unit": "scalar-muls/s", "cores": T, "kind": "port", "hardware_threads": hw, "parity_with_gpu": True,
-                "miller_loops_per_s_1core": 16 / psecs,
-                "sample": "2^17-term G1 and G2 MSMs (arkworks windowing, one thread per window) back to back + 8 two-pair products on one core; full-size parity: "
-                          "tests/test_configs_gpu.py"}
+        return {"value": 2 * k / secs, "seconds": secs, "unit": "scalar-muls/s", "cores": T, "kind": "port", "hardware_threads": hw, "parity_with_gpu": True,
+                "miller_loops_per_s_1core": 2 * npair / psecs,
+                "sample": "the whole job of rank 0: 2^%d-term G1 and G2 MSMs (arkworks windowing, one thread per window) back to back, results compared with the GPU's; + %d "
+                          "distinct two-pair products on one core (accept vector of all %d products against construction)" % ((k - 1).bit_length(), npair, self.mprod)}
 
 
 # ===================================================================================================== secondary legs (cfg2, N = 1)
@@ -1159,6 +1209,7 @@ def main():
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--witness-like", action="store_true", help="configs 2/4: about 60 %% of the scalars are 0 or 1 (a Groth16 witness)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-configs", action="store_true", help="N = 1: after this configuration's line, one more line for each of the other BASELINE configurations (3, 4, 5 / 2)")
     ap.add_argument("--no-pairing", action="store_true", help="config 2, N = 1: skip the secondary pairing / NTT / wire legs")
     ap.add_argument("--balanced", action="store_true", help="diagnostic: scalars whose digits fill every bucket equally (not the headline workload)")
     ap.add_argument("--subgroup-points", action="store_true", help="config 2: time msm_bls12_377_g1_subgroup_dev (bases vouched to lie in G1: GLV split) instead of the plain entry point")
@@ -1263,7 +1314,23 @@ def main():
             line["pairing"] = pairing_leg(ffi, check_oracle=not args.no_cpu_baseline)
             line["ntt"] = ntt_leg(ffi, check_oracle=not args.no_cpu_baseline)
             line["wire"] = wire_leg(ffi, check_oracle=not args.no_cpu_baseline)
+        add_measured_hbm_peak(line)
         print(json.dumps(line), flush=True)
+    if args.all_configs and cx.world == 1 and not cx.devices:
+        # one more line per remaining BASELINE configuration (a single run times them all); each in a process of its own so that
+        # its arenas and streams start fresh - the first line printed stays the headline's
+        import subprocess
+        del job, result
+        torch.cuda.empty_cache()
+        for c in (3, 4, 5):
+            if c == cx.cfg:
+                continue
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+            if args.no_cpu_baseline:
+                cmd.append("--no-cpu-baseline")
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            print(out[-1] if out and r.returncode == 0 else json.dumps({"baseline_config": c, "error": (r.stderr or r.stdout)[-400:], "rc": r.returncode}), flush=True)
     if cx.world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1600,7 +1600,7 @@ struct MsmTuning {
   uint32_t seg_min, seg_min_shard, bitsum_lanes_max_shard;
   int seg_halves;          // piece length in half mean-bucket lengths (4 = twice the mean); 0 = not set: the path's own default
   uint32_t bitsum_lanes_max;
-  uint32_t host_chunks;    // host-pointer entry: index chunks of the pipelined transfer (CELO_HOST_CHUNKS; 0 or 1 = the plain form)
+  uint32_t host_chunks;    // host-pointer entry: index chunks of the pipelined transfer (CELO_HOST_CHUNKS; 0 or 1 = the plain form - celo_amd_msm_set_host_chunks(1), the test hook, is what runs ONE chunk through the pipelined code)
   uint32_t host_head_split, host_tail_split; // ... how often the first / the last of them is cut in halves (CELO_HOST_HEAD_SPLIT, CELO_HOST_TAIL_SPLIT)
   static const MsmTuning& get() {
     static const MsmTuning t = [] {
@@ -1908,6 +1908,8 @@ template <class G> class MsmEngine {
       // accumulation is the longer side of every stage from chunk 0 on (2^20 G1 terms: 0.61 ms per quarter against 0.58 ms of
       // transfers), so what the call pays on top of the resident pipeline is the first chunk's transfer.
       hipStream_t cs = side_stream_.get(), ss = sort_stream_.get();
+      //  an error return inside the chunk loop must not leave the copy and sort streams reading the caller's host buffers and the arena
+      struct Drain { hipStream_t a, b, c; bool armed; ~Drain() { if (armed) { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(c); } } } drain{cs, ss, stream, true};
       if (ev_copy.size() < 3 * (size_t)K + 1) {
         const size_t have = ev_copy.size();
         ev_copy.resize(3 * (size_t)K + 1, nullptr);
@@ -1966,6 +1968,7 @@ template <class G> class MsmEngine {
         hipLaunchKernelGGL((k_accumulate_chunk<G>), dim3((cslots + 255) / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart + (size_t)k * cslots, d_plen + (size_t)k * cslots,
                            d_order + (size_t)k * cslots, bins_k + SIZE_BINS, d_partials + (size_t)k * cslots * IO::XYZZ_WORDS, d_pbucket + (size_t)k * cslots, d_carrier, k ? 1u : 0u);
       }
+      drain.armed = false;
     } else {
     // window shards (A/B hook CELO_SIDE_CONVERT): the conversion of ALL n bases is replicated on every shard while its sort shrinks to a
     // handful of latency-bound launches - the two are independent until the accumulation, so the conversion may run on a second stream
@@ -2234,7 +2237,10 @@ template <class G> class MsmEngine {
     if (pipelined) {
       uint32_t cm, clen[HOST_CHUNKS_MAX];
       need = (size_t)host_chunk_plan(n, chunks, head_split, tail_split, cm, clen) * cm;
-      if ((uint64_t)need * (uint64_t)plan(n).nw >= (uint64_t(1) << 32)) { pipelined = false; need = n; }      // (the holes would overflow the 32-bit run offsets: plain form)
+      uint64_t nw_run;
+      { struct GlvOff { bool& f; bool was; GlvOff(bool& x, bool off) : f(x), was(x) { if (off) f = false; } ~GlvOff() { f = was; } } g(use_glv, glv_plan);
+        nw_run = (uint64_t)plan(n).nw; }       // (the pipelined run switches GLV off - the window count checked here is the one it will use)
+      if ((uint64_t)need * nw_run >= (uint64_t(1) << 32)) { pipelined = false; need = n; }      // (the holes would overflow the 32-bit run offsets: plain form)
     }
     const size_t n_real = n;
     n = need;

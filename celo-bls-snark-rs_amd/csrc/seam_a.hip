@@ -1383,13 +1383,16 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
   // normalised and uploaded anyway; in the steady state (same validator set, epoch after epoch) the check is two comparisons.
   {
     uint32_t need_k = 0, need_s = 0;
-    if (pk_arena().high_water() > DS.keys.cap || sig_arena().high_water() > DS.sigs.cap) {
+    const uint32_t hw_k = pk_arena().high_water(), hw_s = sig_arena().high_water();
+    if (hw_k > DS.keys.cap || hw_s > DS.sigs.cap) {
+      // (a destroyed or foreign handle carries serial 0 or a garbage slot - neither may size an allocation; slots the arenas never
+      // handed out are ignored here and the workers below fail the call with bad_handle as before)
       for (size_t b = 0; b < m; b++)
         for (size_t i = 0; i < blen[b]; i++) {
           const PublicKey* pk = batches[b].public_keys[i];
           const Signature* sg = batches[b].signatures[i];
-          if (pk && pk->slot >= need_k) need_k = pk->slot + 1;       // (null handles: the workers below fail the call)
-          if (sg && sg->slot >= need_s) need_s = sg->slot + 1;
+          if (pk && pk->serial != 0 && pk->slot < hw_k && pk->slot >= need_k) need_k = pk->slot + 1;       // (null handles: the workers below fail the call)
+          if (sg && sg->serial != 0 && sg->slot < hw_s && sg->slot >= need_s) need_s = sg->slot + 1;
         }
     }
     if (!DS.keys.grow(need_k, 24) || !DS.sigs.grow(need_s, 12)) { log_err("batch_verify_strict: device mirror allocation failed"); return false; }
@@ -1554,7 +1557,11 @@ bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composit
     }
   }
   if (pool_failed || work_failed) copy_failed = true;                   // a range threw (out of memory): rows may be missing
-  if (copy_failed) { MK.forget(); MS.forget(); }
+  if (copy_failed) {
+    MK.forget(); MS.forget();
+    (void)hipStreamSynchronize(copy_stream);      //  copies and scatters of the phases shipped before the failure may still be queued on the shared
+                                                  // stream, reading the shared pinned stage and d_up: they end before the next call on this device may stage
+  }
   stage_lk.unlock();                                                    // end of the mirror phase: the next call on this device may stage while this one computes
   if (bad_handle) log_err("batch_verify_strict: a destroyed or foreign handle in the batch lists");
   hasher.join();

@@ -107,3 +107,29 @@ def valid_batches(m, n, seed, corrupt=(), device="cuda"):
         expect[np.asarray(corrupt, dtype=np.int64)] = 0
     torch.cuda.synchronize()
     return {"pk": pk, "sig": sig, "hash": hashes, "offsets": np.arange(0, tot + 1, n, dtype=np.uint32), "expect": expect, "m": m, "n": n}
+
+
+def verify_products(m, seed, bad=None, device="cuda"):
+    """m DISTINCT two-pair products e(sig_b, -g2) * e(H_b, pk_b) (PublicKey::verify / Batch::verify's final check, public.rs:102): every product
+    has its own message point H_b = h_b * G1, its own key sk_b (pk_b = sk_b * g2, sig_b = sk_b * H_b), all generated on the device.  The
+    products listed in `bad` (default: every 97th from 1) carry the NEXT product's signature, so they must be rejected.
+    Returns host arrays (g1 (2 m, 12), g2 (2 m, 24), offsets (m + 1) uint32, expected accept list)."""
+    if bad is None:
+        bad = list(range(1, m - 1, 97))
+    w = valid_batches(m, 1, seed, [b for b in bad if b < m - 1], device)
+    sig = w["sig"].view(m, 12).cpu().numpy().view(np.uint64)
+    hh = w["hash"].view(m, 12).cpu().numpy().view(np.uint64)
+    pk = w["pk"].view(m, 24).cpu().numpy().view(np.uint64)
+    g1 = np.empty((2 * m, 12), dtype=np.uint64)
+    g2 = np.empty((2 * m, 24), dtype=np.uint64)
+    g1[0::2] = sig; g1[1::2] = hh
+    g2[0::2] = neg_g2_limbs(); g2[1::2] = pk
+    return g1, g2, np.arange(0, 2 * m + 1, 2, dtype=np.uint32), [int(x) for x in w["expect"]]
+
+
+def random_pair_products(m, k, seed, device="cuda"):
+    """m DISTINCT products of k pairs of UNRELATED points (P_i = a_i * G1, Q_i = b_i * g2, all different): no shared first G2 point, the product
+    is not 1.  Returns host arrays (g1 (k m, 12), g2 (k m, 24), offsets (m + 1) uint32)."""
+    g1 = device_points("bls12_377_g1", k * m, seed, device).view(k * m, 12).cpu().numpy().view(np.uint64)
+    g2 = device_points("bls12_377_g2", k * m, seed + 1, device).view(k * m, 24).cpu().numpy().view(np.uint64)
+    return g1, g2, np.arange(0, k * m + 1, k, dtype=np.uint32)

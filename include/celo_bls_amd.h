@@ -399,7 +399,7 @@ int celo_amd_msm_set_window_bits(int group, int c);
 int celo_amd_msm_set_host_chunks(int chunks);
 /* The chunk plan the pipelined host-pointer entry uses for n terms (pure host arithmetic, no device call - csrc/runtime.h host_chunk_plan):
  * returns the number of chunks K (<= 80) and their lengths lens[0..K) in the order they are sent, *cm = the chunk capacity (chunk k sits at
- * the virtual index k * cm on the device); -1 for arguments the entry points would not pipeline (chunks < 2, n < chunks * 2^16, n >= 2^30). */
+ * the virtual index k * cm on the device); -1 for arguments the entry points would not pipeline (chunks < 1 or > 64, n < chunks * 2^16, n >= 2^30; chunks = 1 is the one-chunk pipelined form celo_amd_msm_set_host_chunks(1) runs). */
 int celo_amd_msm_host_chunk_plan(uint64_t n, int chunks, int head_split, int tail_split, uint32_t* cm, uint32_t lens[80]);
 
 /* ---- synthetic-workload generators (bench / tests only): writes n affine points

@@ -215,23 +215,9 @@ def test_cfg5_mixed_g1_g2_msm_and_miller_loops_concurrently(gpu):
     s2 = syn.uniform_scalars("bls12_377_g2", n, 0x5EED0503)
     d1 = torch.from_numpy(s1.view(np.int64)).cuda()
     d2 = torch.from_numpy(s2.view(np.int64)).cuda()
-    # 2^14 independent Miller loops as 8192 two-pair products; every fourth product is a valid signature check
+    # 2^14 independent Miller loops as 8192 DISTINCT two-pair products (their own sig, H, pk each; every 97th carries a foreign signature)
     mprod = 8192
-    rng = ecc.SplitMix64(0x5EED0504)
-    ng2 = ecc.E2_377.neg(ecc.G2_377)
-    base = []
-    for i in range(8):
-        sk = ecc.random_scalar(rng, ecc.R377)
-        Hm = ecc.E1_377.mul(ecc.G1_377, rng.next() | 1)
-        good = i % 4 == 0
-        base.append((ecc.E1_377.mul(Hm, sk), Hm, ecc.E2_377.mul(ecc.G2_377, sk if good else sk + 1), good))
-    g1l, g2l = [], []
-    for sig, Hm, pk, _ in base:
-        g1l += [sig, Hm]; g2l += [ng2, pk]
-    g1, _ = co.pack_g1_377(g1l); g2, _ = co.pack_g2_377(g2l)
-    g1 = np.tile(g1, (mprod // 8, 1)); g2 = np.tile(g2, (mprod // 8, 1))
-    offs = np.arange(0, 2 * mprod + 1, 2, dtype=np.uint32)
-    expect = [int(base[i % 8][3]) for i in range(mprod)]
+    g1, g2, offs, expect = syn.verify_products(mprod, 0x5EED0504)
 
     def leg_g1():
         return gpu.msm_dev("bls12_377_g1", b1.data_ptr(), 0, d1.data_ptr(), n)
@@ -263,6 +249,8 @@ def test_cfg5_mixed_g1_g2_msm_and_miller_loops_concurrently(gpu):
     assert co.jac_to_affine(res[0], "g1_377") == co.jac_to_affine(seq[0], "g1_377")
     assert co.jac_to_affine(res[1], "g2_377") == co.jac_to_affine(seq[1], "g2_377")
     assert res[2].tolist() == seq[2].tolist() == expect
+    for p in (0, 1, 2, 97, 98, 4000, 8190, 8191):            # ... and the oracle's verdicts on products drawn over the call (1 and 98 are foreign signatures)
+        assert bool(co.pairing_product_377(g1[2 * p:2 * p + 2], None, g2[2 * p:2 * p + 2], None)[1]) == bool(expect[p])
     assert t_con < 1.15 * t_seq                              # separate engines and streams: not slower than back to back (measured: 0.87-0.9x)
     # G2 at 2^22 against the oracle (G1 at 2^22: tests/test_msm_gpu.py)
     h2 = b2.cpu().numpy().view(np.uint64).reshape(n, 24)

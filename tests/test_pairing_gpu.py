@@ -5,6 +5,7 @@ n+1 pairs), batch.rs:83 (strict batches).  The reference only exposes `== Fq12::
 Miller-loop product are additionally compared bit-for-bit with the oracle's arkworks restatement."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the library: torch brings its own HIP runtime; loaded after the library's, it finds no device)
 from oracle.py import ecc
 from oracle import cpu_oracle as co
 
@@ -152,46 +153,71 @@ def test_lane_parallel_pieces_match_one_lane_twins(gpu, exe_name):
     assert r.returncode == 0 and "MISMATCH" not in r.stdout and r.stdout.count(" ok") >= 16, r.stdout + r.stderr
 
 
-def test_shared_accumulator_mode_at_scale(gpu):
-    """>= 16384 products of <= 4 pairs in one call take the one-group-per-product path (pairing_lanes.h miller_multi: one
-    accumulator per product).  20000 products tiled from 8 distinct ones: 2-pair verify shapes (one corrupted), a 3-pair
-    product, and 3-pair products whose third pair has a point at infinity (skipped, as ark-ec's miller_loop does).  The accept
-    vector must equal the oracle's on the distinct products and the GT value of a 3-pair product must be bit-exact."""
-    rng = ecc.SplitMix64(4242)
-    ng2 = ecc.E2_377.neg(ecc.G2_377)
-    prods = []   # (list of G1, list of G2, expect)
-    for i in range(8):
-        sk = ecc.random_scalar(rng, ecc.R377)
-        Hm = ecc.E1_377.mul(ecc.G1_377, rng.next() | 1)
-        sig = ecc.E1_377.mul(Hm, sk)
-        pk = ecc.E2_377.mul(ecc.G2_377, sk + (1 if i == 2 else 0))
-        if i < 4:
-            prods.append(([sig, Hm], [ng2, pk]))
-        elif i < 6:                      # a third pair that contributes 1: G1 or G2 at infinity
-            prods.append(([sig, Hm, None if i == 4 else Hm], [ng2, pk, pk if i == 4 else None]))
-        else:                            # e(aP, bQ) e(-abP, Q) e(P, Q) != 1 and a 3-pair product that is 1: e(P,Q) e(P,Q) e(-2P,Q)
-            P, Qp = ecc.G1_377, ecc.G2_377
-            if i == 6:
-                prods.append(([P, P, ecc.E1_377.neg(ecc.E1_377.mul(P, 2))], [Qp, Qp, Qp]))
-            else:
-                prods.append(([P, Hm, sig], [Qp, pk, ng2]))
-    g1l, g2l, offs = [], [], [0]
-    for a, b in prods:
-        g1l += a; g2l += b; offs.append(offs[-1] + len(a))
-    g1u, i1u = co.pack_g1_377(g1l)
-    g2u, i2u = co.pack_g2_377(g2l)
-    want = [bool(co.pairing_product_377(g1u[offs[i]:offs[i + 1]], i1u[offs[i]:offs[i + 1]], g2u[offs[i]:offs[i + 1]], i2u[offs[i]:offs[i + 1]])[1])
-            for i in range(8)]
-    assert want == [True, True, False, True, True, True, True, False]
-    reps = 2500                                                     # 20000 products
-    g1 = np.tile(g1u, (reps, 1)); g2 = np.tile(g2u, (reps, 1)); i1 = np.tile(i1u, reps); i2 = np.tile(i2u, reps)
-    per = offs[-1]
-    off_all = np.concatenate([np.array(offs[:-1], dtype=np.uint32) + np.uint32(per * r) for r in range(reps)] + [np.array([per * reps], dtype=np.uint32)])
-    got = gpu.pairing_product_is_one_batch(g1, i1, g2, i2, off_all)
-    assert got.reshape(reps, 8).astype(bool).tolist() == [want] * reps
-    gt = gpu.pairing_gt(g1, i1, g2, i2, off_all)
-    assert np.array_equal(gt[6], co.pairing_product_377(g1u[offs[6]:offs[7]], None, g2u[offs[6]:offs[7]], None)[0])
-    assert np.array_equal(gt[8 * 1234 + 7], co.pairing_product_377(g1u[offs[7]:offs[8]], None, g2u[offs[7]:offs[8]], None)[0])
+def _sampled_gt_check(gpu, g1, i1, g2, i2, offs, got_ok, samples, seed):
+    """GT values of `samples` products drawn over the whole call, bit for bit against the oracle, and the oracle's verdicts against the GPU's."""
+    m = offs.size - 1
+    gt = gpu.pairing_gt(g1, i1, g2, i2, offs)
+    pick = np.unique(np.concatenate([np.random.default_rng(seed).integers(0, m, size=samples), [0, 1, m - 1]]))
+    for p in pick:
+        lo, hi = int(offs[p]), int(offs[p + 1])
+        want, one = co.pairing_product_377(g1[lo:hi], None if i1 is None else i1[lo:hi], g2[lo:hi], None if i2 is None else i2[lo:hi])
+        assert np.array_equal(gt[p], want), "GT value of product %d" % p
+        assert bool(got_ok[p]) == bool(one), "verdict of product %d" % p
+    return len(pick)
+
+
+def test_shared_accumulator_mode_at_scale_distinct_products(gpu):
+    """>= 16384 products of <= 4 pairs in one call take the one-group-per-product path (pairing_lanes.h miller_multi: one accumulator per
+    product).  VERDICT r5 item 4: rounds 1-5 tiled EIGHT products 2500 times - a data-dependent fault cannot show there.  Here 20480 DISTINCT
+    products, all generated on the device (synthetic.verify_products / random_pair_products): 16384 verify shapes with their own (sig, H, pk)
+    each (every 97th carries a foreign signature), 2048 three-pair products of unrelated points (never 1), and 2048 verify shapes with a THIRD pair
+    that contributes 1 because one of its points is at infinity (skipped, as ark-ec's miller_loop does).  Accept vector against construction;
+    GT values of 67 sampled products bit-exact against the oracle."""
+    from celo_bls_snark_rs_amd import synthetic as syn
+    a1, a2, _, ea = syn.verify_products(16384, 0x60D0001)
+    b1, b2, _ = syn.random_pair_products(2048, 3, 0x60D0002)
+    c1v, c2v, _, ec = syn.verify_products(2048, 0x60D0003)
+    x1, x2, _ = syn.random_pair_products(2048, 1, 0x60D0004)
+    c1 = np.empty((2048 * 3, 12), dtype=np.uint64); c2 = np.empty((2048 * 3, 24), dtype=np.uint64)
+    c1[0::3] = c1v[0::2]; c1[1::3] = c1v[1::2]; c1[2::3] = x1
+    c2[0::3] = c2v[0::2]; c2[1::3] = c2v[1::2]; c2[2::3] = x2
+    g1 = np.concatenate([a1, b1, c1]); g2 = np.concatenate([a2, b2, c2])
+    offs = np.concatenate([np.arange(0, 2 * 16384, 2), 2 * 16384 + np.arange(0, 3 * 2048, 3), 2 * 16384 + 3 * 2048 + np.arange(0, 3 * 2048 + 1, 3)]).astype(np.uint32)
+    i1 = np.zeros(g1.shape[0], dtype=np.uint8); i2 = np.zeros(g2.shape[0], dtype=np.uint8)
+    third = 2 * 16384 + 3 * 2048 + 2 + 3 * np.arange(2048)
+    i1[third[0::2]] = 1                                               # G1 at infinity in the third pair of every other such product ...
+    i2[third[1::2]] = 1                                               # ... G2 at infinity in the others
+    expect = ea + [0] * 2048 + ec
+    assert sum(expect) > 18000 and expect.count(0) > 2048 + 150
+    got = gpu.pairing_product_is_one_batch(g1, i1, g2, i2, offs)
+    assert got.astype(int).tolist() == expect
+    assert _sampled_gt_check(gpu, g1, i1, g2, i2, offs, got, 64, 11) >= 60
+
+
+def test_two_pair_products_of_unrelated_points_at_scale(gpu):
+    """20480 DISTINCT two-pair products with no shared G2 point (k_miller_product_slots<LPH377, 2>, both pairs walk their own point): none is 1,
+    GT values of 67 sampled products bit-exact against the oracle; and the same points through the one-group-per-PAIR path (6000 products:
+    k_miller_slots + k_gt_product_lanes) give the same GT values."""
+    from celo_bls_snark_rs_amd import synthetic as syn
+    g1, g2, offs = syn.random_pair_products(20480, 2, 0x60D0010)
+    got = gpu.pairing_product_is_one_batch(g1, None, g2, None, offs)
+    assert not got.any()
+    assert _sampled_gt_check(gpu, g1, None, g2, None, offs, got, 64, 12) >= 60
+    small = gpu.pairing_gt(g1[:12000], None, g2[:12000], None, offs[:6001])
+    big = gpu.pairing_gt(g1, None, g2, None, offs)
+    assert np.array_equal(small, big[:6000])
+
+
+@pytest.mark.wall_clock(600)
+def test_verify_shaped_products_81920_distinct(gpu):
+    """The bench's pairing leg, product for product distinct (prepared lines for the shared -g2 + k_miller_prepared_slots + k_final_exp_slots):
+    81920 (sig_b, H_b, pk_b) triples of their own, every 97th with a foreign signature: accept vector against construction, GT values of 67
+    sampled products bit-exact against the oracle."""
+    from celo_bls_snark_rs_amd import synthetic as syn
+    g1, g2, offs, expect = syn.verify_products(81920, 0x60D0020)
+    got = gpu.pairing_product_is_one_batch(g1, None, g2, None, offs)
+    assert got.astype(int).tolist() == expect and expect.count(0) == len(range(1, 81919, 97))
+    assert _sampled_gt_check(gpu, g1, None, g2, None, offs, got, 64, 13) >= 60
 
 
 def test_bilinearity_on_reference_held_points(gpu, golden):

@@ -432,6 +432,11 @@ int celo_amd_msm_set_host_chunks(int chunks) {
   celo::host_chunks_override().store(chunks);
   return 0;
 }
+int celo_amd_msm_set_batched_affine(int on) {
+  if (on < -1 || on > 1) return 1;
+  celo::batched_affine_override().store(on);
+  return 0;
+}
 int celo_amd_msm_host_chunk_plan(uint64_t n, int chunks, int head_split, int tail_split, uint32_t* cm, uint32_t lens[80]) {
   if (!cm || !lens || chunks < 1 || chunks > 64 || head_split < 0 || head_split > 8 || tail_split < 0 || tail_split > 8 || n < ((uint64_t)chunks << 16) || n >= (uint64_t(1) << 30)) return -1;
   return (int)celo::host_chunk_plan((size_t)n, (uint32_t)chunks, (uint32_t)head_split, (uint32_t)tail_split, *cm, lens);

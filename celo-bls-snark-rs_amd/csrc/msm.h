@@ -1594,12 +1594,19 @@ struct MsmTimings {  // milliseconds, HIP events on the MSM's stream (last call)
   float convert = 0, sort = 0, accumulate = 0, reduce = 0, total = 0;
 };
 
+}  // namespace celo
+#include "msm_ba.h"
+namespace celo {
+template <> struct BaCfg<G_761> { static constexpr bool enabled = true; };
+
 // A/B switches and tuning hooks of the pipeline, read from the environment ONCE per process (not per engine, not per call)
 struct MsmTuning {
-  bool narrow_windows, use_glv, use_gls, gls_force, lane_bitsum, host_threads, seg_occupancy, side_convert, fx_compact;
+  bool narrow_windows, use_glv, use_gls, gls_force, lane_bitsum, host_threads, seg_occupancy, side_convert, side_convert_all, fx_compact;
   uint32_t seg_min, seg_min_shard, bitsum_lanes_max_shard;
   int seg_halves;          // piece length in half mean-bucket lengths (4 = twice the mean); 0 = not set: the path's own default
   uint32_t bitsum_lanes_max;
+  int ba_levels, ba_occ; uint32_t ba_rounds;   // CELO_BA_LEVELS (1..4, default 3), CELO_BA_OCC (waves per SIMD of k_ba_levels: 1 or 2), CELO_BA_ROUNDS (grid = rounds x lanes in flight)
+  int batched_affine;      // CELO_BA: 0 (default) = the XYZZ chain everywhere, 1 = batched-affine pre-levels (msm_ba.h) for the groups that enable them (BW6-761)
   uint32_t host_chunks;    // host-pointer entry: index chunks of the pipelined transfer (CELO_HOST_CHUNKS; 0 or 1 = the plain form - celo_amd_msm_set_host_chunks(1), the test hook, is what runs ONE chunk through the pipelined code)
   uint32_t host_head_split, host_tail_split; // ... how often the first / the last of them is cut in halves (CELO_HOST_HEAD_SPLIT, CELO_HOST_TAIL_SPLIT)
   static const MsmTuning& get() {
@@ -1619,8 +1626,16 @@ struct MsmTuning {
       v.seg_min = getenv("CELO_SEG_MIN") ? (uint32_t)atoi(getenv("CELO_SEG_MIN")) : 32u;                     // shortest piece of a whole MSM
       v.seg_min_shard = getenv("CELO_SEG_MIN_SHARD") ? (uint32_t)atoi(getenv("CELO_SEG_MIN_SHARD")) : 16u;   // ... of a window shard (8 / 12 / 16 measure alike)
       v.seg_occupancy = getenv("CELO_NO_SEG_OCC") == nullptr;                                                  // A/B switch of the window shards' piece length
+      v.side_convert_all = getenv("CELO_SIDE_CONVERT") && atoi(getenv("CELO_SIDE_CONVERT")) == 2;     // 2: whole MSMs too (A/B hook, round 6)
       v.side_convert = getenv("CELO_SIDE_CONVERT") != nullptr;                                                // window shards: base conversion beside the sort
       v.bitsum_lanes_max_shard = getenv("CELO_LANE_BITSUM_MAX_SHARD") ? (uint32_t)atoi(getenv("CELO_LANE_BITSUM_MAX_SHARD")) : 21 * 1024;
+      v.batched_affine = getenv("CELO_BA") ? atoi(getenv("CELO_BA")) : 0;      // measured level with the XYZZ chain (profiles/r6_ba_ab.txt): off
+      v.ba_levels = getenv("CELO_BA_LEVELS") ? atoi(getenv("CELO_BA_LEVELS")) : 3;
+      if (v.ba_levels < 1) v.ba_levels = 1;
+      if (v.ba_levels > BA_K_MAX) v.ba_levels = BA_K_MAX;
+      v.ba_occ = getenv("CELO_BA_OCC") && atoi(getenv("CELO_BA_OCC")) == 1 ? 1 : 2;
+      v.ba_rounds = getenv("CELO_BA_ROUNDS") ? (uint32_t)atoi(getenv("CELO_BA_ROUNDS")) : 2u;
+      if (v.ba_rounds < 1) v.ba_rounds = 1;
       v.bitsum_lanes_max = getenv("CELO_LANE_BITSUM_MAX") ? (uint32_t)atoi(getenv("CELO_LANE_BITSUM_MAX")) : 21 * 1024;   // outputs of a launch: one wave of 21 additions per SIMD
       return v;
     }();
@@ -1853,6 +1868,15 @@ template <class G> class MsmEngine {
     const size_t o_order = take((size_t)slots * 4);
     const size_t o_partials = take((size_t)slots * IO::XYZZ_WORDS * 4);
     const size_t o_work = take(((size_t)res_pts + 2 * (size_t)half_pts + 64) * IO::XYZZ_WORDS * 4);
+    // batched-affine pre-levels (msm_ba.h): the resident variable-base path of the groups that enable them, from mean runs of 8 points up
+    const int ba_ovr = batched_affine_override().load();
+    const bool use_ba = BaCfg<G>::enabled && !hin && !fx && (ba_ovr >= 0 ? ba_ovr != 0 : MsmTuning::get().batched_affine != 0) && ns / B >= 8;
+    const int ba_occ = MsmTuning::get().ba_occ;
+    uint32_t ba_lanes = use_ba ? BA_LANES_OCC1 * (uint32_t)ba_occ * MsmTuning::get().ba_rounds : 0;       // the grid: whole rounds of the lanes in flight
+    if (use_ba && ba_lanes > (slots + 255) / 256 * 256) ba_lanes = (slots + 255) / 256 * 256;
+    const uint32_t ba_pref_slots = use_ba ? ((slots + ba_lanes - 1) / ba_lanes) * (SEG / 2) : 0;            // pairs of a lane's pieces, at most
+    const size_t o_ba_pts = take(use_ba ? (size_t)ns * nws * IO::AFF_WORDS * 4 : 0);
+    const size_t o_ba_pref = take(use_ba ? (size_t)ba_pref_slots * ba_lanes * F::WORDS * 4 : 0);
     if (ensure(off)) return 1;
     if (res_pts > H_OUT_POINTS) return 2;
     char* A = arena;
@@ -1972,7 +1996,7 @@ template <class G> class MsmEngine {
     } else {
     // window shards (A/B hook CELO_SIDE_CONVERT): the conversion of ALL n bases is replicated on every shard while its sort shrinks to a
     // handful of latency-bound launches - the two are independent until the accumulation, so the conversion may run on a second stream
-    const bool side = win_cnt && !glv && MsmTuning::get().side_convert && side_stream_.get() && ev_side[0];
+    const bool side = (win_cnt || MsmTuning::get().side_convert_all) && !glv && MsmTuning::get().side_convert && side_stream_.get() && ev_side[0];
     if (fx) {
       // nothing to convert: the table is in device form
     } else if (side) {
@@ -2003,7 +2027,18 @@ template <class G> class MsmEngine {
     if (side) HIP_OK(hipStreamWaitEvent(stream, ev_side[1], 0));
     HIP_OK(hipEventRecord(ev[2], stream));
     // ---- accumulate (grid covers every slot; lanes beyond the number of non-empty pieces exit)
-    launch_accumulate<G>(slots, stream, d_bases, d_sorted, d_pstart, d_plen, d_order, d_nwork, d_partials);
+    if constexpr (BaCfg<G>::enabled) if (use_ba) {
+      uint32_t* d_ba_pts = (uint32_t*)(A + o_ba_pts);
+      const int levels = MsmTuning::get().ba_levels;
+      if (ba_occ == 2)
+        hipLaunchKernelGGL((k_ba_levels<G, 2>), dim3(ba_lanes / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order, d_nwork, d_ba_pts,
+                           (uint32_t*)(A + o_ba_pref), ba_lanes, levels, ba_pref_slots);
+      else
+        hipLaunchKernelGGL((k_ba_levels<G, 1>), dim3(ba_lanes / 256), dim3(256), 0, stream, d_bases, d_sorted, d_pstart, d_plen, d_order, d_nwork, d_ba_pts,
+                           (uint32_t*)(A + o_ba_pref), ba_lanes, levels, ba_pref_slots);
+      hipLaunchKernelGGL((k_accumulate_ba<G>), dim3((slots + 255) / 256), dim3(256), 0, stream, d_ba_pts, d_pstart, d_plen, d_order, d_nwork, d_partials, levels);
+    }
+    if (!use_ba) launch_accumulate<G>(slots, stream, d_bases, d_sorted, d_pstart, d_plen, d_order, d_nwork, d_partials);
     }
     HIP_OK(hipEventRecord(ev[3], stream));
     // ---- bucket reduction

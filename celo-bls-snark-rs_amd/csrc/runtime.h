@@ -76,6 +76,7 @@ template <class E> class EnginePool {
 // celo_amd_msm_set_host_chunks (tests, bench.py's sweep): >= 0 overrides CELO_HOST_CHUNKS for the host-pointer MSM calls that follow
 // (msm.h run_host_windows); -1 = the default
 inline std::atomic<int>& host_chunks_override() { static std::atomic<int> v{-1}; return v; }
+inline std::atomic<int>& batched_affine_override() { static std::atomic<int> v{-1}; return v; }   // -1: CELO_BA / the default (csrc/msm_ba.h)
 
 // The chunks of the host-pointer pipeline: `chunks` index chunks of cm points (a multiple of 1024), the FIRST of them cut in halves
 // `head_split` times, smallest piece first - the pipeline is bound by the GPU's work from the moment the first chunk has landed

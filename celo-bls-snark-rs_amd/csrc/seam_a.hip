@@ -452,13 +452,121 @@ struct CompositeParams {
   }
 };
 const CompositeParams& composite_params() { static CompositeParams p; return p; }
+// The HOST evaluation of ONE message's CRH (round 6; VERDICT r5 item 5: the single-caller path - verify_signature, hash_composite*, hash_crh -
+// spent more than half of a call here).  pedersen.h is one host+device source on the device's 28-bit limbs: right for the bulk GPU kernel, ~1.4 us
+// per Edwards addition on a host core.  Here the same sum runs on 64-bit limbs (host64.h: arkworks' own Montgomery form, 6 x 6 CIOS) against a
+// table of AFFINE entries precomputed for the mixed addition - (y - x, y + x, 2 d x y) per multiple, so an addition is 7 products (madd-2008-hwcd-3)
+// and a negated entry is a swap and one negation: ~0.3 us per chunk.  Same group element, so the same 48 bytes (the reference's CRH vector and
+// its 20 compat hash-to-G1 points pin both paths: tests/test_seam_a.py, tests/test_hash_gpu.py).  The table is derived from CompositeParams::gens
+// (one batched inversion) window by window on first use: messages of the FFI's shapes touch the first two or three of the 560 windows.
+struct CompositeHostTable {
+  typedef HFp<P377> H;
+  struct Entry { H ymx, ypx, t2d; };
+  static constexpr size_t PER_WINDOW = (size_t)PEDERSEN_WINDOW_SIZE * PEDERSEN_MULTIPLES;
+  std::vector<Entry> tab;
+  std::vector<std::atomic<int>> ready;       // per window: 0 = not built, 2 = built (1 = being built: the builder holds `mu`)
+  std::mutex mu;
+  H two_d, raw_one;
+  CompositeHostTable() : tab(PER_WINDOW * PEDERSEN_NUM_WINDOWS), ready(PEDERSEN_NUM_WINDOWS) {
+    for (auto& r : ready) r.store(0);
+    uint64_t w[6];
+    sf_small(2 * 79743).v.to_ark(w);
+    two_d = H::load(w);
+    memset(raw_one.v, 0, sizeof raw_one.v);
+    raw_one.v[0] = 1;                           // a * raw_one = a R^-1: Montgomery form -> the plain integer
+  }
+  static H from_sf(const SF& a) { uint64_t w[6]; a.v.to_ark(w); return H::load(w); }
+  static H inv(const H& a) {                   // a^(p - 2), square-and-multiply from the top: one per built window and one per message
+    uint64_t e[6];
+    memcpy(e, P377::P64, sizeof e);
+    e[0] -= 2;                                  // (p is odd and its low limb is far from 0: no borrow)
+    H r = H::one();
+    bool started = false;
+    for (int i = 6 * 64 - 1; i >= 0; i--) {
+      if (started) r = r.sqr();
+      if ((e[i >> 6] >> (i & 63)) & 1) { r = started ? r * a : a; started = true; }
+    }
+    return r;
+  }
+  void build(int w) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (ready[(size_t)w].load(std::memory_order_acquire) == 2) return;
+    const EdPoint* g = composite_params().gens.data() + (size_t)w * PER_WINDOW;
+    std::vector<H> z(PER_WINDOW), pre(PER_WINDOW);
+    H acc = H::one();
+    for (size_t i = 0; i < PER_WINDOW; i++) { z[i] = from_sf(g[i].Z); pre[i] = acc; acc = acc * z[i]; }
+    H iv = inv(acc);
+    for (size_t i = PER_WINDOW; i-- > 0;) {
+      const H zi = iv * pre[i];
+      iv = iv * z[i];
+      const H x = from_sf(g[i].X) * zi, y = from_sf(g[i].Y) * zi;
+      tab[(size_t)w * PER_WINDOW + i] = {y - x, y + x, x * y * two_d};
+    }
+    ready[(size_t)w].store(2, std::memory_order_release);
+  }
+  void eval(const uint8_t* msg, size_t len, uint8_t out48[48]) {
+    const size_t nbits = len * 8, nchunks = (nbits + 2) / 3;
+    for (size_t w = 0; w * PEDERSEN_WINDOW_SIZE < nchunks; w++)
+      if (ready[w].load(std::memory_order_acquire) != 2) build((int)w);
+    H X = H::zero(), Y = H::one(), Z = H::one(), T = H::zero();
+    for (size_t ch = 0; ch < nchunks; ch++) {
+      const size_t b = 3 * ch;
+      uint32_t two = msg[b >> 3];
+      if ((b >> 3) + 1 < len) two |= (uint32_t)msg[(b >> 3) + 1] << 8;
+      const uint32_t bits = (two >> (b & 7)) & 7u;
+      const Entry& e = tab[(size_t)PEDERSEN_MULTIPLES * ch + (bits & 3u)];
+      const bool ng = (bits & 4) != 0;           // -(x, y) = (-x, y): the two sums swap, the T term changes sign
+      const H A = (Y - X) * (ng ? e.ypx : e.ymx), B = (Y + X) * (ng ? e.ymx : e.ypx), Ct = T * e.t2d, D = Z.dbl();
+      const H C = ng ? H::zero() - Ct : Ct;
+      const H E = B - A, F = D - C, G = D + C, Hh = B + A;
+      X = E * F; Y = G * Hh; Z = F * G; T = E * Hh;
+    }
+    // x = X / Z as a plain integer: Z out of Montgomery form, inverted by division steps (modinv.h works on plain 64-bit limbs: a few us on a
+    // host core, where Fermat's 570 products were half of a 64-byte message's time), and X_mont * (1 / Z)_plain = (X / Z)_plain
+    const H zc = Z * raw_one;
+    H zi;
+    SafeGcd<P377>::inv(zc.v, zi.v);
+    const H x = X * zi;
+    for (int i = 0; i < 48; i++) out48[i] = (uint8_t)(x.v[i >> 3] >> (8 * (i & 7)));
+  }
+  static CompositeHostTable& get() { static CompositeHostTable* t = new CompositeHostTable; return *t; }
+};
 bool composite_crh(const uint8_t* msg, size_t len, std::vector<uint8_t>& out) {  // bowe_hopwood::CRH::evaluate -> affine x, 48 bytes
-  const CompositeParams& cp = composite_params();
   if (len * 8 > PEDERSEN_MAX_BITS) return false;  // the reference panics
   out.assign(48, 0);
-  pedersen_crh(cp.gens.data(), msg, len, out.data());   // pedersen.h: the source the GPU kernel runs
+  static const bool slow = getenv("CELO_CRH_DEVICE_LIMBS") != nullptr;      // A/B and cross-check switch: pedersen.h's source on the host, as rounds 2-5 ran it
+  if (slow) pedersen_crh(composite_params().gens.data(), msg, len, out.data());
+  else CompositeHostTable::get().eval(msg, len, out.data());
   return true;
 }
+// scale_by_cofactor + affine normalisation of hash_direct.h's tai_finish on the host's 64-bit limbs (host64.h): 124 doublings and 17 additions
+// are ~1 700 products - 0.3 ms of every single hash on the device's 28-bit limbs, a third of that here.  Same group element.
+static bool tai_finish_host64(const Affine<Fq_>& p, Affine<Fq_>& out) {
+  typedef HFp<P377> H;
+  const uint64_t cof[2] = {0x0000000000000000ULL, 0x170b5d4430000000ULL};   // (x - 1)^2 / 3, 125 bits, bit 124 set
+  uint64_t w[6];
+  HXyzz<H> base;
+  p.x.to_ark(w); base.X = H::load(w);
+  p.y.to_ark(w); base.Y = H::load(w);
+  base.ZZ = H::one(); base.ZZZ = H::one();
+  HXyzz<H> s = base;
+  for (int i = 123; i >= 0; i--) {
+    s = hxyzz_dbl(s);
+    if ((cof[i >> 6] >> (i & 63)) & 1) hxyzz_add(s, base);
+  }
+  if (s.is_identity()) return false;
+  H raw_one;
+  memset(raw_one.v, 0, sizeof raw_one.v);
+  raw_one.v[0] = 1;
+  const H zc = (s.ZZ * s.ZZZ) * raw_one;     // plain integer
+  H t;
+  SafeGcd<P377>::inv(zc.v, t.v);             // 1 / (ZZ ZZZ) as a plain integer: (a_mont * b_plain) is a b plain, times c_mont is a b c plain
+  const H x = (s.X * t) * s.ZZZ, y = (s.Y * t) * s.ZZ;
+  out.x = Fq_::norm(Fq_::from_canonical(x.v));
+  out.y = Fq_::norm(Fq_::from_canonical(y.v));
+  return true;
+}
+
 // generic try-and-increment over {direct, composite} x {plain, cip22} with the `compat` bit logic
 // pre_cofactor (optional): the curve point BEFORE scale_by_cofactor (from_random_bytes' point), for the callers that restate arkworks' own multiple
 bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* msg, size_t mlen, const uint8_t* extra, size_t elen,
@@ -484,7 +592,7 @@ bool hash_to_g1(bool composite, bool cip22, const uint8_t* dom, const uint8_t* m
     memcpy(w12, cand.data(), 48);
     Affine<Fq_> p = {Fq_::zero(), Fq_::zero()};
     if (!tai_point_from_xof(w12, wire_consts(), p)) continue;            // hash_direct.h: compat flags, get_point_from_x
-    if (!tai_finish(p, out)) continue;                                   // scale_by_cofactor
+    if (!tai_finish_host64(p, out)) continue;                            // scale_by_cofactor
     attempt = c;
     if (pre_cofactor) *pre_cofactor = p;
     return true;
@@ -1019,8 +1127,19 @@ bool celo_amd_g2_generator(uint64_t out_xy[24]) {
   Fq_::from_limbs(T377::G2_GEN_Y1).to_ark(out_xy + 18);
   return true;
 }
+struct PhaseLog {  // CELO_AMD_LOG=1: wall time of the host / device phases of one FFI call
+  const char* fn; bool on; std::chrono::steady_clock::time_point t;
+  explicit PhaseLog(const char* f) : fn(f), on(getenv("CELO_AMD_LOG") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[celo-amd] %s: %-28s %9.3f ms\n", fn, what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
 bool celo_amd_verify_hash(const PublicKey* pk, const uint64_t* message_hash_xy, const Signature* sig, bool* out_verified) {
   if (!pk || !message_hash_xy || !sig || !out_verified) return false;
+  PhaseLog ph("verify_hash");
   Affine<Fq_> s;
   Affine<Fq2_> p;
   uint8_t inf1[2] = {0, 0}, inf2[2] = {0, 0};
@@ -1036,8 +1155,10 @@ bool celo_amd_verify_hash(const PublicKey* pk, const uint64_t* message_hash_xy, 
   memcpy(g2, gen, 96);
   ngy.to_ark(g2 + 12);
   if (jac_to_affine<Fq2_>(pk->xyz, p)) { p.x.to_ark(g2 + 24); p.y.to_ark(g2 + 36); } else inf2[1] = 1;
+  ph.mark("handles -> affine pairs (host)");
   int one = 0;
   if (pairing_product_is_one_bls12_377(g1, inf1, g2, inf2, 2, &one) != 0) return false;
+  ph.mark("2-pair product check (GPU, latency path)");
   *out_verified = one != 0;
   return true;
 }
@@ -1198,10 +1319,12 @@ bool sign_pop(const PrivateKey* sk, const uint8_t* msg, int mlen, Signature** ou
 static bool verify_with(const PublicKey* pk, bool composite, bool cip22, const uint8_t* dom, const uint8_t* msg, int mlen, const uint8_t* extra,
                         int elen, const Signature* sig, bool* out_verified) {
   if (!pk || !sig || !out_verified || mlen < 0 || elen < 0) return false;
+  PhaseLog ph("verify_with");
   Affine<Fq_> h; int c;
   if (!hash_to_g1(composite, cip22, dom, msg, (size_t)mlen, extra, (size_t)elen, h, c)) return false;
   uint64_t hxy[12];
   h.x.to_ark(hxy); h.y.to_ark(hxy + 6);
+  ph.mark("message -> G1 (host)");
   return celo_amd_verify_hash(pk, hxy, sig, out_verified);
 }
 bool verify_signature(const PublicKey* pk, const uint8_t* msg, int mlen, const uint8_t* extra, int elen, const Signature* sig,
@@ -1240,16 +1363,6 @@ bool batch_verify_signature(const MessageFFI* messages, size_t n, bool composite
 // Batch::verify per batch (crates/bls-crypto/src/bls/batch.rs:44-84), all batches at once: random exponents from the OS
 // RNG, all G2 MSMs in one call, all G1 MSMs in one call, all 2-pair checks in one call.  out_results is always filled;
 // the return value is false if any batch fails (signatures.rs:392-400).
-struct PhaseLog {  // CELO_AMD_LOG=1: wall time of the host / device phases of one FFI call
-  const char* fn; bool on; std::chrono::steady_clock::time_point t;
-  explicit PhaseLog(const char* f) : fn(f), on(getenv("CELO_AMD_LOG") != nullptr), t(std::chrono::steady_clock::now()) {}
-  void mark(const char* what) {
-    if (!on) return;
-    auto n = std::chrono::steady_clock::now();
-    fprintf(stderr, "[celo-amd] %s: %-28s %9.3f ms\n", fn, what, std::chrono::duration<double, std::milli>(n - t).count());
-    t = n;
-  }
-};
 bool batch_verify_strict(const BatchMessageFFI* batches, size_t m, bool composite, bool cip22, bool* out_results) {   /* signatures.rs:343 */
   if ((!batches && m) || !out_results) return false;
   PhaseLog ph("batch_verify_strict");

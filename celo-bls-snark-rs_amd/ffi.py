@@ -35,7 +35,7 @@ EXPORTS = [
     "pairing_product_is_one_bls12_377", "pairing_product_is_one_batch_bls12_377", "celo_amd_pairing_gt_bls12_377",
     "celo_amd_pairing_last_timings", "pairing_product_is_one_bw6_761", "celo_amd_pairing_gt_bw6_761",
     "celo_amd_sum_jacobian_bls12_377_g1", "celo_amd_sum_jacobian_bls12_377_g2", "celo_amd_sum_jacobian_bw6_761",
-    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks", "celo_amd_msm_host_chunk_plan", "celo_amd_host_alloc", "celo_amd_host_free", "celo_amd_ubench_fp", "celo_amd_selftest_accumulate",
+    "celo_amd_msm_last_timings", "celo_amd_msm_set_window_bits", "celo_amd_msm_set_host_chunks", "celo_amd_msm_set_batched_affine", "celo_amd_msm_host_chunk_plan", "celo_amd_host_alloc", "celo_amd_host_free", "celo_amd_ubench_fp", "celo_amd_selftest_accumulate",
     "celo_amd_gen_points_bls12_377_g1_dev", "celo_amd_gen_points_bls12_377_g2_dev", "celo_amd_gen_points_bw6_761_dev",
     "celo_amd_gen_points_grouped_bls12_377_g1_dev", "celo_amd_gen_points_grouped_bls12_377_g2_dev",
     "batch_verify_bls12_377", "batch_verify_bls12_377_dev", "celo_amd_draw_batch_exponents",
@@ -289,6 +289,12 @@ def ubench_fp():
         raise RuntimeError(f"celo_amd_ubench_fp failed rc={rc}")
     return {"fq377_mul_G": out[0], "fq377_sqr_G": out[1], "fq761_mul_G": out[2], "fq761_sqr_G": out[3], "clock_mhz": out[4],
             "kernel_ms": [out[5], out[6], out[7], out[8]]}
+
+
+def set_batched_affine(on):
+    """BW6-761 resident MSMs: 1 = batched-affine tree levels before the XYZZ chain (csrc/msm_ba.h), 0 = the chain alone, -1 = the default.  Process-wide."""
+    if lib().celo_amd_msm_set_batched_affine(C.c_int(on)) != 0:
+        raise ValueError(f"batched affine {on} not supported")
 
 
 def set_host_chunks(chunks, head_split=None, tail_split=None):

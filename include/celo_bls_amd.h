@@ -397,6 +397,10 @@ int celo_amd_msm_set_window_bits(int group, int c);
  * in halves CELO_HOST_HEAD_SPLIT times (default 1 where the halves keep 2^17 points, else 0), the last CELO_HOST_TAIL_SPLIT times (default 0); `chunks | (h + 1) << 8 | (t + 1) << 12`
  * sets those counts to h and t (0 <= h, t <= 8) as well.  Process-wide — tuning and test hook. */
 int celo_amd_msm_set_host_chunks(int chunks);
+/* The BW6-761 bucket accumulation of the resident entry points (msm_bw6_761_*_dev, and msm_bw6_761_* below 2^18 terms): 1 = three batched-affine
+ * tree levels before the XYZZ chain (csrc/msm_ba.h), 0 = the XYZZ chain alone, -1 = the default (CELO_BA, else 0: the two measure alike on
+ * config 4, profiles/r6_ba_ab.txt).  Same group element either way.  Process-wide - test and measurement hook; 1 for an argument out of range. */
+int celo_amd_msm_set_batched_affine(int on);
 /* The chunk plan the pipelined host-pointer entry uses for n terms (pure host arithmetic, no device call - csrc/runtime.h host_chunk_plan):
  * returns the number of chunks K (<= 80) and their lengths lens[0..K) in the order they are sent, *cm = the chunk capacity (chunk k sits at
  * the virtual index k * cm on the device); -1 for arguments the entry points would not pipeline (chunks < 1 or > 64, n < chunks * 2^16, n >= 2^30; chunks = 1 is the one-chunk pipelined form celo_amd_msm_set_host_chunks(1) runs). */

@@ -56,7 +56,7 @@ class Ctx:
 
 
 # launch shapes the committed PMC profiles were taken at, and the profile set (profiles/<tag>_traffic.json, written by
-# tools/summarise_profile.py from the separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/r5_profiles.sh) that holds each:
+# tools/summarise_profile.py from the separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/archive/r5_profiles.sh) that holds each:
 # kernel -> {shape: tag}.  Shapes: log2 n of an MSM, the number of products of a pairing launch, "cfg3" = 4096 batches x 256 signers.
 PROFILED = {"k_accumulate<G1_377>": {20: "r5", 22: "r5_cfg5", "cfg3": "r5_cfg3"},
             "k_accumulate_pair<G2_377, 1>": {20: "r5_groups", 22: "r5_cfg5", "cfg3": "r5_cfg3"},

@@ -502,7 +502,7 @@ template <class PP> class PairingEngine {
   }
   static constexpr size_t SHARED_MIN_PRODUCTS = 16384;
   static constexpr size_t SPLIT_MAX_PRODUCTS = 5120;       // two groups per product, ten per wave: at most one wave per SIMD
-  static bool miller_split_enabled() { static const bool on = getenv("CELO_NO_MILLER_SPLIT") == nullptr; return on; }      // A/B switch
+  static bool miller_split_enabled() { return true; }      // (the round-4 A/B switch CELO_NO_MILLER_SPLIT is gone: measured, kept on)
 
  private:
   uint64_t lines_q0[PP::G2_ARK64] = {};     // the G2 point whose prepared lines the arena holds at lines_at (run_staged)

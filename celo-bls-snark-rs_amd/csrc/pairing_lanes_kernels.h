@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(64) LANES_OCC k_final_exp_slots(const uint32_t
   bool LL::has_split() { return true; }                                                                                                   \
   void LL::miller_prepared_split(const uint64_t* g1, const uint8_t* i1, const uint64_t* g2, const uint8_t* i2, const uint32_t* lines,     \
                                  uint32_t* f, uint32_t m, hipStream_t s) {                                                                \
-    static const int cut = getenv("CELO_MILLER_SPLIT_H") ? atoi(getenv("CELO_MILLER_SPLIT_H")) : 30;   /* the cut h (tuning hook) */       \
+    static const int cut = 30;   /* the cut h: flat between 26 and 34 (the tuning hook of round 4 is gone) */                  \
     hipLaunchKernelGGL((k_miller_prepared_split_slots<LP>), dim3(2 * ((m + LP::GROUPS - 1) / LP::GROUPS)), dim3(64),                      \
                        Slots<LP>::product_lds_bytes(2), s, g1, i1, g2, i2, lines, f, m, cut < 1 ? 1 : cut > 62 ? 62 : cut);               \
   }                                                                                                                                       \

@@ -7,7 +7,7 @@ void final_exp_w2_377(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint3
 // 1.47 against 2.17 ms at 2048 products.  Above, SIMDs take a second wave and the side-by-side form's extra instructions cost more than
 // its shorter chains save (4096 products: 2.39 against 2.24 ms; 6144: 2.50 against 2.31): one six-lane group per product from there on
 void LaneLaunch377::final_exp(const uint32_t* prod, uint8_t* is_one, uint64_t* gt, uint32_t m, int do_fe, hipStream_t s) {
-  static const bool no_w3 = getenv("CELO_NO_W3_FINAL") != nullptr;       // A/B switch
+  constexpr bool no_w3 = false;       // (round 4's A/B switch CELO_NO_W3_FINAL is gone: the thresholds below are the measured ones)
   if (do_fe && m <= 3072 && !no_w3) { final_exp_w3_377(prod, is_one, gt, m, s); return; }
   // ... up to 5120 on TWO groups per product, five products per wave: still one wave per SIMD (config 3's 4096 verdicts)
   if (do_fe && m <= 5120 && !no_w3) { final_exp_w2_377(prod, is_one, gt, m, s); return; }

@@ -394,7 +394,7 @@ int celo_amd_msm_set_window_bits(int group, int c);
 /* Host-pointer entry points (msm_<group>, from 2^18 terms - 2^17 when the count is set here): the number of index chunks in which scalars and bases cross PCIe while the
  * chunks already on the device are sorted and accumulated (csrc/msm.h HostIn).  0 = the unpipelined form (three transfers, then
  * the resident pipeline; 1 = one chunk: the sort runs beside the bases' transfer), -1 = the default (CELO_HOST_CHUNKS, else n / 2^18 within [4, 16] - [8, 16] for BW6-761, n / 2^19 within [4, 8] for G2 of BLS12-377).  The first chunk is cut
- * in halves CELO_HOST_HEAD_SPLIT times (default 1 where the halves keep 2^17 points, else 0), the last CELO_HOST_TAIL_SPLIT times (default 0); `chunks | (h + 1) << 8 | (t + 1) << 12`
+ * in halves once where the halves keep 2^17 points (else not at all), the last one never; `chunks | (h + 1) << 8 | (t + 1) << 12`
  * sets those counts to h and t (0 <= h, t <= 8) as well.  Process-wide — tuning and test hook. */
 int celo_amd_msm_set_host_chunks(int chunks);
 /* The BW6-761 bucket accumulation of the resident entry points (msm_bw6_761_*_dev, and msm_bw6_761_* below 2^18 terms): 1 = three batched-affine

@@ -1235,3 +1235,27 @@ def test_batch_verify_strict_mirror_randomised_lifecycle(sys_lib, gpu):
         rc = sys_lib.batch_verify_strict(arr, C.c_size_t(m), CF, C22, out)
         assert list(out) == want, (rnd_no, [b for b in range(m) if out[b] != want[b]][:5])
         assert rc == all(want)
+
+
+def test_crh_paths_agree(sys_lib):
+    """The single-message composite CRH has two host implementations: the 64-bit-limb table (round 6, the default) and pedersen.h's 28-bit-limb
+    source the GPU kernel shares (CELO_CRH_DEVICE_LIMBS=1).  Same 48 bytes on every length 0 ... 130 (chunk boundaries on every bit offset, the
+    first two generator windows) and on a 1 500-byte message (windows 0 ... 43)."""
+    import subprocess, sys, hashlib
+    code = (
+        "import ctypes as C, hashlib, sys\n"
+        "lib = C.CDLL(sys.argv[1]); lib.hash_crh.restype = C.c_bool\n"
+        "h = hashlib.sha256()\n"
+        "for n in list(range(131)) + [1500]:\n"
+        "    m = bytes((7 * i + n) & 255 for i in range(n)); out, k = C.c_void_p(), C.c_int()\n"
+        "    assert lib.hash_crh(m, n, 96, C.byref(out), C.byref(k)) and k.value == 48\n"
+        "    h.update(bytes(C.cast(out, C.POINTER(C.c_ubyte * 48)).contents))\n"
+        "print(h.hexdigest())\n")
+    from celo_bls_snark_rs_amd import ffi
+    outs = []
+    for env_extra in ({}, {"CELO_CRH_DEVICE_LIMBS": "1"}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code, ffi.LIB_PATH], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 64

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies one sweep's results (gpurun_out/r4/, written by tools/r4_sweep.sh on the GPU box) into profiles/r4_* and runs
+"""Copies one sweep's results (gpurun_out/r4/, written by tools/archive/r4_sweep.sh on the GPU box) into profiles/r4_* and runs
 tools/summarise_profile.py over its rocprofv3 output sets.  Run on the host after the gpurun call returns."""
 import json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

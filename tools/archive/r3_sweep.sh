@@ -28,6 +28,6 @@ python tools/bench_pairing.py 2048 4096 10240 20480 40960 81920 2>/dev/null | ta
 python tools/bench_decompress.py 2>/dev/null | tail -1 > $OUT/decompress.json
 python tools/bench_hash.py 2>/dev/null | tail -1 > $OUT/hash.json
 python tools/bench_ntt.py 2>/dev/null | tail -1 > $OUT/ntt.json
-bash tools/r3_profiles.sh r3 > $OUT/profiles.log 2>&1
-bash tools/r3_pair_pmc.sh > $OUT/pair_pmc.log 2>&1
+bash tools/archive/r3_profiles.sh r3 > $OUT/profiles.log 2>&1
+bash tools/archive/r3_pair_pmc.sh > $OUT/pair_pmc.log 2>&1
 for f in $OUT/*.json; do echo "== $f"; head -c 300 $f; echo; done

@@ -27,7 +27,7 @@ python tools/bench_windows.py g1 20 --world 8 --subgroup 2>/dev/null | tail -1 >
 python tools/bench_windows.py g2 20 --world 8 2>/dev/null | tail -1 > $OUT/windows_g2_2p20.json
 python tools/bench_windows.py bw6 20 --world 8 2>/dev/null | tail -1 > $OUT/windows_bw6_2p20.json
 python tools/bench_hybrid.py 20 2>/dev/null > $OUT/hybrid_g1_2p20.jsonl
-bash tools/r4_fixed_sweep.sh > $OUT/fixed_sweep.txt 2>&1
+bash tools/archive/r4_fixed_sweep.sh > $OUT/fixed_sweep.txt 2>&1
 python tools/ab_cfg3_chains.py 2>/dev/null | tail -1 > $OUT/cfg3_chains.json
 python tools/bench_criterion_shapes.py 2>/dev/null | tail -1 > $OUT/criterion_shapes.json
 python tools/bench_glv.py g1 14 16 17 18 20 2>/dev/null > $OUT/glv_g1.jsonl
@@ -42,6 +42,6 @@ python tools/bench_ntt.py 2>/dev/null | tail -1 > $OUT/ntt.json
 celo-bls-snark-rs_amd/build/repro_mul4k 17 64 > $OUT/repro_mul4k.txt 2>&1
 celo-bls-snark-rs_amd/build/repro_acc 16 24 2 2048 > $OUT/repro_acc.txt 2>&1
 celo-bls-snark-rs_amd/build/repro_acc_uni 16 24 2 2048 > $OUT/repro_acc_uniform.txt 2>&1
-bash tools/r4_profiles.sh r4 > $OUT/profiles.log 2>&1
-bash tools/r4_pair_pmc.sh > $OUT/pair_pmc.log 2>&1
+bash tools/archive/r4_profiles.sh r4 > $OUT/profiles.log 2>&1
+bash tools/archive/r4_pair_pmc.sh > $OUT/pair_pmc.log 2>&1
 for f in $OUT/*.json; do echo "== $f"; head -c 300 $f; echo; done

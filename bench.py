@@ -58,11 +58,11 @@ class Ctx:
 # launch shapes the committed PMC profiles were taken at, and the profile set (profiles/<tag>_traffic.json, written by
 # tools/summarise_profile.py from the separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/archive/r5_profiles.sh) that holds each:
 # kernel -> {shape: tag}.  Shapes: log2 n of an MSM, the number of products of a pairing launch, "cfg3" = 4096 batches x 256 signers.
-PROFILED = {"k_accumulate<G1_377>": {20: "r5", 22: "r5_cfg5", "cfg3": "r5_cfg3"},
-            "k_accumulate_pair<G2_377, 1>": {20: "r5_groups", 22: "r5_cfg5", "cfg3": "r5_cfg3"},
-            "k_accumulate<G_761>": {20: "r5_groups", 21: "r5_cfg4"},
-            "k_miller_product_slots<LPH377, 2>": {81920: "r5_pairing"}, "k_miller_prepared_slots<LPH377>": {81920: "r5"},
-            "k_prepare_lines<LPH377>": {81920: "r5"}, "k_final_exp_slots<LPH377>": {81920: "r5"}}
+PROFILED = {"k_accumulate<G1_377>": {20: "r6", 22: "r6_cfg5", "cfg3": "r6_cfg3"},
+            "k_accumulate_pair<G2_377, 1>": {20: "r6_groups", 22: "r6_cfg5", "cfg3": "r6_cfg3"},
+            "k_accumulate<G_761>": {20: "r6_groups", 21: "r6_cfg4"},
+            "k_miller_product_slots<LPH377, 2>": {81920: "r6_pairing"}, "k_miller_prepared_slots<LPH377>": {81920: "r6"},
+            "k_prepare_lines<LPH377>": {81920: "r6"}, "k_final_exp_slots<LPH377>": {81920: "r6"}}
 
 
 _BUILD_SIG = None

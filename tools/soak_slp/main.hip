@@ -1,4 +1,5 @@
-// Differential soak of the one unit that keeps the SLP vectorizer (csrc/Makefile SLP_UNITS = unit_g1_377): the library's k_accumulate<G1_377> built
+// Differential soak of the headline kernel against the SLP vectorizer (csrc/Makefile SLP_UNITS: empty since the end of round 6, this soak is the
+// evidence behind any future exception): the library's k_accumulate<G1_377> built
 // WITH the pass against the same kernel built with -fno-slp-vectorize, on identical bucket runs, every partial sum compared limb for limb (same
 // additions in the same order: the two kernels must agree exactly).  Round 5 named the SLP vectorizer as the pass that miscompiles the signed
 // instantiation of k_accumulate<G2_377> (tools/repro_acc/REPORT.md); VERDICT r5 item 1c asks for this soak before a unit may keep the pass.

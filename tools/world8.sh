@@ -1,10 +1,10 @@
 #!/bin/bash
 # World-size-8 dry runs on a ONE-GPU box: eight ranks (gloo, host-staged exchange) sharing device 0, every partition and
 # config that the driver's 8-GPU SCALE run or a caller could take, each with its parity check; lines -> gpurun_out/r5_w8/*.json
-#   tools/r5_world8.sh [steps]
+#   tools/world8.sh [steps]   (TAG=r6 by default: lines -> gpurun_out/<TAG>_w8/*.json)
 set -u
 cd "$(dirname "$0")/.."
-OUT=gpurun_out/r5_w8; mkdir -p $OUT
+OUT=gpurun_out/${TAG:-r6}_w8; mkdir -p $OUT
 STEPS=${1:-3}
 export CELO_BENCH_BACKEND=gloo CELO_BENCH_DEVICE=0 OMP_NUM_THREADS=8
 run() { name=$1; shift; echo "== $name: $*"; timeout 900 python bench.py --gpus 8 --steps $STEPS --warmup 1 "$@" > $OUT/$name.json 2> $OUT/$name.err; echo "rc=$? $(tail -c 300 $OUT/$name.json | head -c 300)"; }

@@ -88,3 +88,32 @@ def test_ba_on_and_off_agree(gpu, golden):
     gpu.set_batched_affine(0)
     off = gpu.msm_dev("bw6_761_g1", bases.data_ptr(), 0, d_sc.data_ptr(), n)
     assert co.jac_to_affine(on, "761") == co.jac_to_affine(off, "761")
+
+
+def test_ba_bw6_761_g2_and_window_shards(gpu, golden):
+    """The pre-levels serve every caller of the resident BW6-761 pipeline: the G2 group (same coordinate field, another b: the addition formulas
+    do not use it and (0, 0) is off that curve too) at 2^14 terms, and the window shards of one 2^16-term G1 job (three shards joined by
+    msm_*_join_windows: each shard's pieces are shorter, the tree has odd runs and runs of one)."""
+    from oracle.py import epoch as ep
+    from celo_bls_snark_rs_amd import synthetic as syn
+    vk = ep.parse_vk(bytes.fromhex(golden["groth16_bw6_761"]["vk"]))
+    n = 1 << 14
+    gen, _ = co.pack_761([vk["beta_g2"]])
+    t = torch.empty(n * 24, dtype=torch.int64, device="cuda")
+    gpu.gen_points_dev("bw6_761_g2", t.data_ptr(), n, 0x5EED0BA5, gen.reshape(-1))
+    sc = syn.uniform_scalars("bw6_761_g2", n, 0xBA6)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = gpu.msm_dev("bw6_761_g2", t.data_ptr(), 0, d_sc.data_ptr(), n)
+    h = t.cpu().numpy().view(np.uint64).reshape(n, 24)
+    assert co.jac_to_affine(out, "761") == co.jac_to_affine(co.msm("bw6_761_g2", h, None, sc, threads=8), "761")
+    n = 1 << 16
+    bases = syn.device_points("bw6_761_g1", n, 0x5EED0BA7)
+    sc = syn.uniform_scalars("bw6_761_g1", n, 0xBA8)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    recs, bits = [], []
+    for s in range(3):
+        r, b = gpu.msm_window_shard_dev("bw6_761_g1", bases.data_ptr(), 0, d_sc.data_ptr(), n, s, 3)
+        recs.append(r); bits.append(b)
+    got = gpu.join_windows("bw6_761_g1", np.concatenate(recs), bits)
+    h = bases.cpu().numpy().view(np.uint64).reshape(n, 24)
+    assert co.jac_to_affine(got, "761") == co.jac_to_affine(co.msm("bw6_761_g1", h, None, sc, threads=8), "761")

@@ -32,7 +32,7 @@ struct MsmTuning {
   int ba_levels, ba_occ; uint32_t ba_rounds;   // CELO_BA_LEVELS (1..4, default 3), CELO_BA_OCC (waves per SIMD of k_ba_levels: 1 or 2), CELO_BA_ROUNDS (grid = rounds x lanes in flight)
   int batched_affine;      // CELO_BA: 0 (default) = the XYZZ chain everywhere, 1 = batched-affine pre-levels (msm_ba.h) for the groups that enable them (BW6-761)
   uint32_t host_chunks;    // host-pointer entry: index chunks of the pipelined transfer (CELO_HOST_CHUNKS; 0 or 1 = the plain form - celo_amd_msm_set_host_chunks(1), the test hook, is what runs ONE chunk through the pipelined code)
-  uint32_t host_head_split, host_tail_split; // ... how often the first / the last of them is cut in halves (CELO_HOST_HEAD_SPLIT, CELO_HOST_TAIL_SPLIT)
+  uint32_t host_head_split, host_tail_split; // ... how often the first / the last of them is cut in halves (celo_amd_msm_set_host_chunks)
   static const MsmTuning& get() {
     static const MsmTuning t = [] {
       MsmTuning v;
@@ -106,14 +106,14 @@ template <class G> class MsmEngine {
   // big path: mixed window widths (k_digits) for the 16-bit configuration only - the large inputs, where the work is throughput
   // and a ragged top window costs folds and balance (2^20 terms: G1 3.32 -> 3.31, G2 10.85 -> 10.75, BW6-761 19.5 -> 19.0 ms).
   // Small inputs are bound by their longest bucket run, and narrower windows mean longer runs: BW6-761 at 2^14 with 18 x 13 + 12 x 12
-  // bits instead of 29 x 13 (+ a carry window) 1.39 -> 1.88 ms, at 2^17 3.58 -> 3.79 ms.  CELO_NO_NARROW=1 is the A/B switch.
+  // bits instead of 29 x 13 (+ a carry window) 1.39 -> 1.88 ms, at 2^17 3.58 -> 3.79 ms.  (The round-2 A/B switch CELO_NO_NARROW is gone: MsmTuning::narrow_windows is a constant.)
   bool narrow_windows = MsmTuning::get().narrow_windows;
   bool narrow_top(int c) const { return narrow_windows && c == 16; }
   // big path, G1 of BLS12-377: the caller vouches for bases in the prime-order subgroup (Signature values, proving-key points): GLV split
   bool big_subgroup_points = false;
   // host-pointer entry (run_host), set by the Groth16 prover's entry points only: a base row x = 0, y = 1 is the identity (k_flag_ark_zero)
   bool ark_zero_identity = false;
-  bool use_glv = MsmTuning::get().use_glv;     // A/B switch (CELO_NO_GLV)
+  bool use_glv = MsmTuning::get().use_glv;     // (a constant since round 6; the pipelined host-pointer form still switches it off per call)
   bool last_glv = false;
   // window size for the 2 n points x 127-bit halves of the split (n = the expanded count)
   // (measured, round 3: 127 = 8 x 16 - 1, so c = 16 leaves no ragged top window and wins at every size from 2^14 terms up)
@@ -121,13 +121,13 @@ template <class G> class MsmEngine {
   // batched path, G2 of BLS12-377: the caller vouches that every base lies in the prime-order subgroup (Batch::verify's public keys:
   // PublicKey values only come from checked deserialisation, secret keys and sums of such), which is what makes psi(P) = [x]P
   bool gls_subgroup_points = false;
-  bool use_gls = MsmTuning::get().use_gls;     // A/B switch (CELO_NO_GLS)
+  bool use_gls = MsmTuning::get().use_gls;     // (a constant since round 6)
   bool gls_force = MsmTuning::get().gls_force;
   int last_gls_digits = 1;
   static constexpr int HOST_HORNER_THREADS = 4;
   bool host_threads = MsmTuning::get().host_threads;   // A/B switch (CELO_NO_HOST_THREADS) of the threaded host epilogue (Fq2 and BW6-761 groups)
   bool lane_horner = true;  // batched path: three lanes per instance in the Horner pass (tuning hook)
-  bool lane_bitsum = MsmTuning::get().lane_bitsum;   // big path (CELO_NO_LANE_BITSUM): three lanes per addition in the late levels of the bucket reduction (A/B hook)
+  bool lane_bitsum = MsmTuning::get().lane_bitsum;   // big path (a constant since round 6): three lanes per addition in the late levels of the bucket reduction (A/B hook)
   uint32_t BITSUM_LANES_MAX = MsmTuning::get().bitsum_lanes_max;
 
   // bases/scalars/inf are DEVICE pointers (ark layout); result: Jacobian in ark Montgomery form (3*ARK64 u64) on host.
@@ -417,7 +417,7 @@ template <class G> class MsmEngine {
       }
       drain.armed = false;
     } else {
-    // window shards (A/B hook CELO_SIDE_CONVERT): the conversion of ALL n bases is replicated on every shard while its sort shrinks to a
+    // window shards (round 4's A/B, MsmTuning::side_convert, a constant false since round 6 - measured level twice): the conversion of ALL n bases is replicated on every shard while its sort shrinks to a
     // handful of latency-bound launches - the two are independent until the accumulation, so the conversion may run on a second stream
     const bool side = (win_cnt || MsmTuning::get().side_convert_all) && !glv && MsmTuning::get().side_convert && side_stream_.get() && ev_side[0];
     if (fx) {
@@ -1034,7 +1034,7 @@ template <class G> class MsmEngine {
   bool side_path = false;
   static constexpr size_t H_OUT_POINTS = 17 * 64;   // pinned result buffer: (LB + 1) * windows points; checked per call
   OwnedStream stream_;
-  OwnedStream side_stream_;            // window shards: the base conversion beside the sort (CELO_SIDE_CONVERT)
+  OwnedStream side_stream_;            // the host-pointer pipeline's copy stream (and round 4's side conversion, off)
   OwnedStream sort_stream_;            // host-pointer pipeline: digits + sort + schedule of chunk k beside the accumulation of chunk k - 1
   hipEvent_t ev_side[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> ev_copy;     // host-pointer pipeline: per chunk - scalars sent, bases sent, sorted; + one for the per-call fills

@@ -364,6 +364,17 @@ template <class P> struct Fp {
 #endif
     if constexpr (PTR_TABLES) {
       cond_sub(r, K == 64 ? P::NP64 : K == 32 ? P::NP32 : K == 16 ? P::NP16 : K == 8 ? P::NP8 : K == 4 ? P::NP4 : K == 2 ? P::NP2 : P::NP1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    } else if constexpr (L > 14) {
+      // The 28-limb field on the device (end of round 6): the table behind a pointer the optimiser cannot see through, so that its scalar
+      // loads STAY in this cold block - not hoisted into every kernel's prologue and parked in VGPR lanes (the pointer form of rounds 1-5:
+      // 217 spilled SGPRs in k_accumulate<G_761>), and not 28 literals per cond_sub either (the immediates form: same-box A/B on config 4,
+      // profiles/r6_ab_kp_tables_761.txt: accumulate 30.5 ms with immediates, 29.8 with the old pointers, 28.9 with this form - 4 spilled
+      // SGPRs, 800 fewer instructions per mixed addition).  The 14-limb fields are level either way (hipcc -S) and keep the immediates.
+      const uint32_t* kp = K == 64 ? P::NP64 : K == 32 ? P::NP32 : K == 16 ? P::NP16 : K == 8 ? P::NP8 : K == 4 ? P::NP4 : K == 2 ? P::NP2 : P::NP1;
+      asm volatile("" : "+s"(kp));
+      cond_sub(r, kp);
+#endif
     } else {
       constexpr KpTable T = kp_table<K>();
       cond_sub(r, T.v);
